@@ -1,0 +1,137 @@
+"""Seeded synthetic workloads for BASELINE.json's configs (SURVEY.md 8(d) "Synthetic inputs").
+
+Produces the float32 ``[N, 56+4h]`` solver-input records (layout.py) plus the per-robot model
+constants, exactly as the reference's Python layer would marshal them at
+``ConvexMPCLocomotion.py:128-185`` for the sampled robot states.  Used by bench.py and the tests; it
+contains no solver code.
+"""
+import numpy as np
+
+from . import layout as L
+from .gait import mpc_table
+from .quadruped import (COL_ABAD, COL_HEIGHT, COL_HIP, COL_HIPLOC, COL_KNEE, COL_MU, ROBOT_TABLE, ROBOT_TABLE64,
+                        COL_MASS, COL_INERTIA, SIDE_SIGN, RobotType)
+
+# Parameters.py:25-33 (action -> weight rescale of the RL bridge)
+MPC_PARAM_SCALE = np.array([4, 4, 4, 20, 20, 20, 1, 1, 1, 1, 1, 1], dtype=np.float32)
+MPC_PARAM_CONST = np.array([5, 5, 5, 50, 50, 50, 1, 1, 1, 1, 1, 1], dtype=np.float32)
+
+
+def leg_fk(q, robot_type):
+    """Foot position in the hip frame, LegController.computeLegJacobianAndPosition (LegController.py:135-154).
+
+    q: [N,4,3] joint angles; robot_type: [N] int.  The reference evaluates this in Python floats
+    (double) and stores float32.
+    """
+    q = np.asarray(q, dtype=np.float64)
+    rt = np.asarray(robot_type)
+    dy = ROBOT_TABLE[rt, COL_ABAD].astype(np.float64)[:, None] * SIDE_SIGN[None, :].astype(np.float64)
+    dz1 = -ROBOT_TABLE[rt, COL_HIP].astype(np.float64)[:, None]
+    dz2 = -ROBOT_TABLE[rt, COL_KNEE].astype(np.float64)[:, None]
+    s1, s2, s3 = np.sin(q[..., 0]), np.sin(q[..., 1]), np.sin(q[..., 2])
+    c1, c2, c3 = np.cos(q[..., 0]), np.cos(q[..., 1]), np.cos(q[..., 2])
+    c23 = c2 * c3 - s2 * s3
+    s23 = s2 * c3 + c2 * s3
+    p = np.stack([dz2 * s23 + dz1 * s2,
+                  dy * c1 - dz1 * c2 * s1 - dz2 * s1 * c23,
+                  dy * s1 + dz1 * c1 * c2 + dz2 * c1 * c23], axis=-1)
+    return p.astype(np.float32)
+
+
+def hip_locations(robot_type):
+    """[N,4,3] float32 hip locations, Quadruped.getHipLocation (Quadruped.py:96-107)."""
+    rt = np.asarray(robot_type)
+    loc = ROBOT_TABLE[rt, COL_HIPLOC:COL_HIPLOC + 3]                  # [N,3]
+    sx = np.array([1, 1, -1, -1], dtype=np.float32)
+    sy = np.array([1, -1, 1, -1], dtype=np.float32)
+    out = np.empty((len(rt), 4, 3), dtype=np.float32)
+    out[..., 0] = loc[:, None, 0] * sx
+    out[..., 1] = loc[:, None, 1] * sy
+    out[..., 2] = loc[:, None, 2]
+    return out
+
+
+class Workload:
+    """Solver-boundary workload: records + per-robot model constants."""
+
+    def __init__(self, h, inputs, robot_type, gait_id, iteration_counter, dt_mpc, alpha):
+        self.h = h
+        self.inputs = inputs                  # float32 [N, 56+4h]
+        self.robot_type = robot_type          # int32 [N]
+        self.gait_id = gait_id                # int32 [N]
+        self.iteration_counter = iteration_counter
+        self.dt_mpc = dt_mpc
+        self.alpha = alpha
+        self.mass = ROBOT_TABLE64[robot_type, COL_MASS]                         # float64 [N]
+        self.inertia_diag = ROBOT_TABLE64[robot_type, COL_INERTIA:COL_INERTIA + 3]  # float64 [N,3]
+
+    @property
+    def n(self):
+        return self.inputs.shape[0]
+
+
+def make_solver_workload(n, h=10, seed=0, config=2, iterations_between_mpc=2, controller_dt=0.01,
+                         alpha=1e-5, step_index=0):
+    """per-robot random state -> the 13 arguments of compute_contact_forces.
+
+    config 1/2: Aliengo, trot, normal=(0,0,1).  config 3: robot type = idx mod 3 over
+    {Go1,A1,Aliengo}, gait = (idx div 3 + step_index div 50) mod 3 over {TROT,WALK,BOUND}.
+    config 4/5: Aliengo trot with random ground normals (use h=16 / h=20).
+    """
+    rng = np.random.default_rng(seed)
+    idx = np.arange(n)
+    if config == 3:
+        robot_type = np.array([RobotType.GO1, RobotType.A1, RobotType.ALIENGO], dtype=np.int32)[idx % 3]
+        gait_id = np.array([0, 6, 1], dtype=np.int32)[(idx // 3 + step_index // 50) % 3]
+    else:
+        robot_type = np.full(n, int(RobotType.ALIENGO), dtype=np.int32)
+        gait_id = np.zeros(n, dtype=np.int32)
+    H = ROBOT_TABLE[robot_type, COL_HEIGHT]
+
+    rpy = np.stack([rng.uniform(-0.15, 0.15, n), rng.uniform(-0.15, 0.15, n), rng.uniform(-np.pi, np.pi, n)], -1)
+    rpy = rpy.astype(np.float16).astype(np.float32)        # orientation_tools.py:13 -> float16 rpy
+    pos = np.zeros((n, 3), dtype=np.float32)
+    pos[:, 2] = H * rng.uniform(0.9, 1.05, n)
+    omega = rng.uniform(-0.5, 0.5, (n, 3)).astype(np.float32)
+    vel = np.stack([rng.uniform(-1.5, 1.5, n), rng.uniform(-0.5, 0.5, n), rng.uniform(-0.1, 0.1, n)], -1).astype(np.float32)
+    q = np.array([0.0, 0.8, -1.6])[None, None, :] + rng.uniform(-0.2, 0.2, (n, 4, 3))
+    foot = hip_locations(robot_type) + leg_fk(q, robot_type)          # ConvexMPCLocomotion.py:248-249
+    cmd = np.stack([rng.uniform(-2.5, 2.5, n), rng.uniform(-1, 1, n), rng.uniform(-2.5, 2.5, n)], -1).astype(np.float32)
+    w = np.zeros((n, 13), dtype=np.float32)
+    w[:, :12] = MPC_PARAM_CONST + rng.uniform(-1, 1, (n, 12)).astype(np.float32) * MPC_PARAM_SCALE
+    it = rng.integers(0, 2 * h, n).astype(np.int32)
+    if config in (4, 5):
+        nv = np.stack([rng.uniform(-0.3, 0.3, n), rng.uniform(-0.3, 0.3, n), np.ones(n)], -1)
+        normal = (nv / np.linalg.norm(nv, axis=1, keepdims=True)).astype(np.float32)
+    else:
+        normal = np.tile(np.array([0, 0, 1], dtype=np.float32), (n, 1))
+
+    rec = np.zeros((n, L.in_len(h)), dtype=np.float32)
+    rec[:, L.IN_WEIGHTS:L.IN_WEIGHTS + 13] = w
+    rec[:, L.IN_COM_POS:L.IN_COM_POS + 3] = pos
+    rec[:, L.IN_COM_VEL:L.IN_COM_VEL + 3] = vel
+    rec[:, L.IN_RPY:L.IN_RPY + 3] = rpy
+    rec[:, L.IN_NORMAL:L.IN_NORMAL + 3] = normal
+    rec[:, L.IN_ANGVEL:L.IN_ANGVEL + 3] = omega
+    rec[:, L.IN_CONTACT:L.IN_CONTACT + 4 * h] = mpc_table(gait_id, it, iterations_between_mpc, h)
+    rec[:, L.in_footpos(h):L.in_footpos(h) + 12] = foot.reshape(n, 12)
+    rec[:, L.in_friction(h):L.in_friction(h) + 4] = ROBOT_TABLE[robot_type, COL_MU][:, None]
+    rec[:, L.in_des_pos(h) + 2] = H                                   # ConvexMPCLocomotion.py:151
+    rec[:, L.in_des_vel(h):L.in_des_vel(h) + 2] = cmd[:, :2]          # :152
+    rec[:, L.in_des_angvel(h) + 2] = cmd[:, 2]                        # :154
+    return Workload(h, rec, robot_type, gait_id, it, controller_dt * iterations_between_mpc, alpha)
+
+
+def perturb_workload(wl, seed, scale=0.05):
+    """A follow-up solve for the same robots (exercises the warm-start path): advance the gait
+    counter by iterations_between_mpc and jitter the state a little."""
+    rng = np.random.default_rng(seed)
+    h, n = wl.h, wl.n
+    rec = wl.inputs.copy()
+    for off, k, s in ((L.IN_COM_VEL, 3, 0.1), (L.IN_ANGVEL, 3, 0.05), (L.in_footpos(h), 12, 0.01)):
+        rec[:, off:off + k] += (rng.standard_normal((n, k)) * s * scale / 0.05).astype(np.float32)
+    rpy = rec[:, L.IN_RPY:L.IN_RPY + 3] + (rng.standard_normal((n, 3)) * 0.01).astype(np.float32)
+    rec[:, L.IN_RPY:L.IN_RPY + 3] = rpy.astype(np.float16).astype(np.float32)
+    it = (wl.iteration_counter + 2).astype(np.int32)
+    rec[:, L.IN_CONTACT:L.IN_CONTACT + 4 * h] = mpc_table(wl.gait_id, it, 2, h)
+    return Workload(h, rec, wl.robot_type, wl.gait_id, it, wl.dt_mpc, wl.alpha)
