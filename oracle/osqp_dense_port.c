@@ -30,6 +30,7 @@
 #include <math.h>
 #include <pthread.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -567,6 +568,280 @@ static int polish(Port *s) {
   return ok;
 }
 
+
+/* ---- polish, literal form (polish.c:232-350): dense LU of the delta-regularised reduced KKT
+ * [[P + delta I, Ared^T], [Ared, -delta I]] + POLISH_REFINE_ITER = 3 refinement steps
+ * (polish.c:102-160).  O((n+mred)^3): checker only. */
+#define Q_DELTA 1e-6
+#define Q_POLISH_REFINE 3
+static void lu_factor(REAL *A, int *piv, int nn) {
+  for (int k = 0; k < nn; ++k) {
+    int p = k; REAL mx = fabs(A[(size_t)k * nn + k]);
+    for (int i = k + 1; i < nn; ++i) if (fabs(A[(size_t)i * nn + k]) > mx) { mx = fabs(A[(size_t)i * nn + k]); p = i; }
+    piv[k] = p;
+    if (p != k) for (int j = 0; j < nn; ++j) { REAL t = A[(size_t)k * nn + j]; A[(size_t)k * nn + j] = A[(size_t)p * nn + j]; A[(size_t)p * nn + j] = t; }
+    REAL d = A[(size_t)k * nn + k];
+    for (int i = k + 1; i < nn; ++i) {
+      REAL f = A[(size_t)i * nn + k] / d;
+      A[(size_t)i * nn + k] = f;
+      for (int j = k + 1; j < nn; ++j) A[(size_t)i * nn + j] -= f * A[(size_t)k * nn + j];
+    }
+  }
+}
+static void lu_solve(const REAL *A, const int *piv, int nn, REAL *b) {
+  for (int k = 0; k < nn; ++k) if (piv[k] != k) { REAL t = b[k]; b[k] = b[piv[k]]; b[piv[k]] = t; }
+  for (int k = 0; k < nn; ++k) for (int i = k + 1; i < nn; ++i) b[i] -= A[(size_t)i * nn + k] * b[k];
+  for (int i = nn - 1; i >= 0; --i) { REAL t = b[i]; for (int j = i + 1; j < nn; ++j) t -= A[(size_t)i * nn + j] * b[j]; b[i] = t / A[(size_t)i * nn + i]; }
+}
+static int polish_kkt(Port *s) {
+  const int n = s->n, m = s->m;
+  int *rows = (int *)malloc(sizeof(int) * 2 * m), *isup = (int *)malloc(sizeof(int) * 2 * m), mred = 0;
+  for (int i = 0; i < m; ++i) if (s->z[i] - s->ls[i] < -s->y[i]) { rows[mred] = i; isup[mred++] = 0; }
+  for (int i = 0; i < m; ++i) if (s->us[i] - s->z[i] < s->y[i]) { int dup = 0; for (int k = 0; k < mred; ++k) if (rows[k] == i) dup = 1; if (!dup) { rows[mred] = i; isup[mred++] = 1; } }
+  const int nn = n + mred;
+  REAL *K = ralloc((size_t)nn * nn), *Kr = ralloc((size_t)nn * nn), *rhs = ralloc(nn), *sol = ralloc(nn), *res = ralloc(nn);
+  int *piv = (int *)malloc(sizeof(int) * nn);
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) K[(size_t)i * nn + j] = s->Ps[(size_t)i * n + j];
+  for (int k = 0; k < mred; ++k) { int r = rows[k], f = r / 5, rr = r % 5;
+    for (int c = 0; c < 3; ++c) { REAL v = s->As[15 * f + 3 * rr + c]; K[(size_t)(n + k) * nn + 3 * f + c] = v; K[(size_t)(3 * f + c) * nn + n + k] = v; } }
+  memcpy(Kr, K, sizeof(REAL) * nn * nn);
+  for (int i = 0; i < n; ++i) Kr[(size_t)i * nn + i] += (REAL)Q_DELTA;
+  for (int k = 0; k < mred; ++k) Kr[(size_t)(n + k) * nn + n + k] -= (REAL)Q_DELTA;
+  lu_factor(Kr, piv, nn);
+  for (int i = 0; i < n; ++i) rhs[i] = -s->qs[i];
+  for (int k = 0; k < mred; ++k) rhs[n + k] = isup[k] ? s->us[rows[k]] : s->ls[rows[k]];
+  memcpy(sol, rhs, sizeof(REAL) * nn);
+  lu_solve(Kr, piv, nn, sol);
+  for (int it = 0; it < Q_POLISH_REFINE; ++it) {
+    for (int i = 0; i < nn; ++i) { REAL t = rhs[i]; for (int j = 0; j < nn; ++j) t -= K[(size_t)i * nn + j] * sol[j]; res[i] = t; }
+    lu_solve(Kr, piv, nn, res);
+    for (int i = 0; i < nn; ++i) sol[i] += res[i];
+  }
+  REAL *xpol = s->W, *ypol = xpol + n, *zpol = ypol + m;
+  memcpy(xpol, sol, sizeof(REAL) * n);
+  for (int i = 0; i < m; ++i) ypol[i] = 0;
+  for (int k = 0; k < mred; ++k) ypol[rows[k]] = sol[n + k];
+  mul_A(s, xpol, zpol);
+  for (int i = 0; i < m; ++i) { REAL t = zpol[i] + ypol[i]; REAL zc = t < s->ls[i] ? s->ls[i] : (t > s->us[i] ? s->us[i] : t); zpol[i] = zc; ypol[i] = t - zc; }
+  REAL pri, dua;
+  update_info(s, xpol, zpol, ypol, &pri, &dua);
+  int ok = (pri < s->pri_res && dua < s->dua_res) || (pri < s->pri_res && s->dua_res < (REAL)1e-10) || (dua < s->dua_res && s->pri_res < (REAL)1e-10);
+  if (ok) { s->pri_res = pri; s->dua_res = dua; memcpy(s->x, xpol, sizeof(REAL) * n); memcpy(s->z, zpol, sizeof(REAL) * m); memcpy(s->y, ypol, sizeof(REAL) * m); }
+  s->status_polish = ok ? 1 : -1;
+  s->nfact++;
+  free(rows); free(isup); free(K); free(Kr); free(rhs); free(sol); free(res); free(piv);
+  return ok;
+}
+
+
+/* ---- polish, reduced-coordinate form of the SAME delta-regularised iteration (the form the HIP
+ * kernel runs).  Per 5x3 block f with active rows A_f: Q_f = orthonormal basis of the active rows'
+ * span (rank r_f), N_f its complement, Gamma_f = pinv(A_f^T A_f) (3x3).  With block-diagonal
+ * Gamma, N and u = Gamma A^T r2, one application (x, y) = Kreg^{-1} (r1, r2) is, to O(delta^2):
+ *   tf  = Gamma (r1 - P u - delta u)
+ *   H_d = N^T (P + delta I - delta P Gamma P) N ;  w = H_d^{-1} N^T (r1 - P u - delta P tf)
+ *   xN  = N w ;  x = u + delta (tf - Gamma P xN) + xN
+ *   y   = A Gamma (r1 - P u - delta u - P xN)  -  (r2 - A u) / delta      (active rows only)
+ * followed by POLISH_REFINE_ITER refinement steps with the exact (unregularised) KKT residual. */
+typedef struct { REAL Q[9], N[9], G[9]; int r, nn, col0; } FootBasis;
+
+static void mul_gamma(const FootBasis *fb, int nf, const REAL *v, REAL *out) {
+  for (int f = 0; f < nf; ++f)
+    for (int a = 0; a < 3; ++a)
+      out[3 * f + a] = fb[f].G[a * 3] * v[3 * f] + fb[f].G[a * 3 + 1] * v[3 * f + 1] + fb[f].G[a * 3 + 2] * v[3 * f + 2];
+}
+/* out(n) = A_act^T y (active rows only) */
+static void mul_At_act(const Port *s, const int *act, const REAL *y, REAL *out) {
+  for (int f = 0; f < s->nf; ++f)
+    for (int c = 0; c < 3; ++c) {
+      REAL t = 0;
+      for (int r = 0; r < 5; ++r) if (act[5 * f + r]) t += s->As[15 * f + 3 * r + c] * y[5 * f + r];
+      out[3 * f + c] = t;
+    }
+}
+static void kreg_apply(Port *s, const FootBasis *fb, const int *act, const REAL *Hinv_chol, int nw, const REAL *r1,
+                       const REAL *r2, REAL *x, REAL *y, REAL *wk) {
+  const int n = s->n, m = s->m, nf = s->nf;
+  REAL *u = wk, *Pu = u + n, *tf = Pu + n, *v = tf + n, *Pv = v + n, *xN = Pv + n, *rw = xN + n, *Au = rw + n;
+  const REAL dl = (REAL)Q_DELTA;
+  mul_At_act(s, act, r2, v);
+  mul_gamma(fb, nf, v, u);                       /* u = Gamma A^T r2 */
+  mul_P(s, u, Pu);
+  for (int i = 0; i < n; ++i) v[i] = r1[i] - Pu[i] - dl * u[i];
+  mul_gamma(fb, nf, v, tf);                      /* tf */
+  mul_P(s, tf, Pv);
+  for (int i = 0; i < n; ++i) v[i] = r1[i] - Pu[i] - dl * Pv[i];
+  for (int f = 0; f < nf; ++f)
+    for (int k = 0; k < fb[f].nn; ++k)
+      rw[fb[f].col0 + k] = fb[f].N[3 * k] * v[3 * f] + fb[f].N[3 * k + 1] * v[3 * f + 1] + fb[f].N[3 * k + 2] * v[3 * f + 2];
+  chol_solve(Hinv_chol, nw, nw, rw);
+  for (int f = 0; f < nf; ++f)
+    for (int c = 0; c < 3; ++c) {
+      REAL t = 0;
+      for (int k = 0; k < fb[f].nn; ++k) t += fb[f].N[3 * k + c] * rw[fb[f].col0 + k];
+      xN[3 * f + c] = t;
+    }
+  mul_P(s, xN, Pv);                               /* P xN */
+  mul_gamma(fb, nf, Pv, v);                       /* Gamma P xN */
+  for (int i = 0; i < n; ++i) x[i] = u[i] + dl * (tf[i] - v[i]) + xN[i];
+  for (int i = 0; i < n; ++i) v[i] = r1[i] - Pu[i] - dl * u[i] - Pv[i];
+  mul_gamma(fb, nf, v, tf);                       /* reuse tf = Gamma(...) */
+  mul_A(s, tf, y);                                /* y = A Gamma(...) on all rows; mask below */
+  mul_A(s, u, Au);
+  for (int i = 0; i < m; ++i) y[i] = act[i] ? y[i] - (r2[i] - Au[i]) / dl : 0;
+}
+
+static int polish_reduced(Port *s) {
+  const int n = s->n, m = s->m, nf = s->nf;
+  const REAL dl = (REAL)Q_DELTA;
+  int *act = (int *)calloc(m, sizeof(int));
+  FootBasis *fb = (FootBasis *)calloc(nf, sizeof(FootBasis));
+  for (int i = 0; i < m; ++i) act[i] = (s->z[i] - s->ls[i] < -s->y[i]) ? -1 : ((s->us[i] - s->z[i] < s->y[i]) ? 1 : 0);
+  int nw = 0;
+  for (int f = 0; f < nf; ++f) {
+    const REAL *a = s->As + 15 * f;
+    FootBasis *b = &fb[f];
+    int r = 0;
+    for (int row = 0; row < 5 && r < 3; ++row) {
+      if (!act[5 * f + row]) continue;
+      REAL v[3] = {a[row * 3], a[row * 3 + 1], a[row * 3 + 2]};
+      REAL nrm0 = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+      for (int pass = 0; pass < 2; ++pass)
+        for (int k = 0; k < r; ++k) {
+          REAL d = v[0] * b->Q[3 * k] + v[1] * b->Q[3 * k + 1] + v[2] * b->Q[3 * k + 2];
+          v[0] -= d * b->Q[3 * k]; v[1] -= d * b->Q[3 * k + 1]; v[2] -= d * b->Q[3 * k + 2];
+        }
+      REAL nrm = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+      if (!(nrm > (REAL)1e-6 * nrm0)) continue;
+      b->Q[3 * r] = v[0] / nrm; b->Q[3 * r + 1] = v[1] / nrm; b->Q[3 * r + 2] = v[2] / nrm;
+      ++r;
+    }
+    b->r = r;
+    /* complement */
+    REAL *N = b->N, *Q = b->Q;
+    if (r == 0) { REAL I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; memcpy(N, I3, sizeof I3); }
+    else if (r == 1) {
+      int imin = fabs(Q[0]) <= fabs(Q[1]) ? (fabs(Q[0]) <= fabs(Q[2]) ? 0 : 2) : (fabs(Q[1]) <= fabs(Q[2]) ? 1 : 2);
+      REAL e[3] = {0, 0, 0}; e[imin] = 1;
+      REAL d = Q[imin], v[3] = {e[0] - d * Q[0], e[1] - d * Q[1], e[2] - d * Q[2]};
+      REAL nr = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+      N[0] = v[0] / nr; N[1] = v[1] / nr; N[2] = v[2] / nr;
+      N[3] = Q[1] * N[2] - Q[2] * N[1]; N[4] = Q[2] * N[0] - Q[0] * N[2]; N[5] = Q[0] * N[1] - Q[1] * N[0];
+    } else if (r == 2) {
+      N[0] = Q[1] * Q[5] - Q[2] * Q[4]; N[1] = Q[2] * Q[3] - Q[0] * Q[5]; N[2] = Q[0] * Q[4] - Q[1] * Q[3];
+      REAL nr = sqrt(N[0] * N[0] + N[1] * N[1] + N[2] * N[2]);
+      N[0] /= nr; N[1] /= nr; N[2] /= nr;
+    }
+    b->nn = 3 - r; b->col0 = nw; nw += b->nn;
+    /* Gamma = Q (Q^T B Q)^{-1} Q^T, B = A_act^T A_act */
+    REAL B[9] = {0}, G[9] = {0}, Gi[9] = {0};
+    for (int row = 0; row < 5; ++row) if (act[5 * f + row])
+      for (int c1 = 0; c1 < 3; ++c1) for (int c2 = 0; c2 < 3; ++c2) B[c1 * 3 + c2] += a[row * 3 + c1] * a[row * 3 + c2];
+    for (int k1 = 0; k1 < r; ++k1) for (int k2 = 0; k2 < r; ++k2) {
+      REAL t = 0;
+      for (int c1 = 0; c1 < 3; ++c1) for (int c2 = 0; c2 < 3; ++c2) t += Q[3 * k1 + c1] * B[c1 * 3 + c2] * Q[3 * k2 + c2];
+      G[k1 * 3 + k2] = t;
+    }
+    /* invert r x r SPD G by Gauss-Jordan */
+    REAL Mx[18];
+    for (int i = 0; i < r; ++i) for (int j = 0; j < r; ++j) { Mx[i * 6 + j] = G[i * 3 + j]; Mx[i * 6 + 3 + j] = (i == j); }
+    for (int p = 0; p < r; ++p) {
+      REAL d = Mx[p * 6 + p];
+      for (int j = 0; j < 6; ++j) Mx[p * 6 + j] /= d;
+      for (int i = 0; i < r; ++i) if (i != p) { REAL fct = Mx[i * 6 + p]; for (int j = 0; j < 6; ++j) Mx[i * 6 + j] -= fct * Mx[p * 6 + j]; }
+    }
+    for (int i = 0; i < r; ++i) for (int j = 0; j < r; ++j) Gi[i * 3 + j] = Mx[i * 6 + 3 + j];
+    for (int c1 = 0; c1 < 3; ++c1) for (int c2 = 0; c2 < 3; ++c2) {
+      REAL t = 0;
+      for (int k1 = 0; k1 < r; ++k1) for (int k2 = 0; k2 < r; ++k2) t += Q[3 * k1 + c1] * Gi[k1 * 3 + k2] * Q[3 * k2 + c2];
+      b->G[c1 * 3 + c2] = t;
+    }
+  }
+  /* W = P N (n x nw); H_d = N^T W + delta I - delta W^T Gamma W */
+  REAL *W = ralloc((size_t)n * (nw + 1)), *GW = ralloc((size_t)n * (nw + 1)), *Hd = ralloc((size_t)(nw + 1) * (nw + 1));
+  for (int i = 0; i < n; ++i)
+    for (int f = 0; f < nf; ++f)
+      for (int k = 0; k < fb[f].nn; ++k) {
+        const REAL *row = s->Ps + (size_t)i * n + 3 * f;
+        W[(size_t)i * nw + fb[f].col0 + k] = row[0] * fb[f].N[3 * k] + row[1] * fb[f].N[3 * k + 1] + row[2] * fb[f].N[3 * k + 2];
+      }
+  const int no_corr = getenv("PORT_POLISH_NOCORR") != 0;
+  for (int f = 0; f < nf; ++f)
+    for (int a = 0; a < 3; ++a)
+      for (int w2 = 0; w2 < nw; ++w2)
+        GW[(size_t)(3 * f + a) * nw + w2] = fb[f].G[a * 3] * W[(size_t)(3 * f) * nw + w2] + fb[f].G[a * 3 + 1] * W[(size_t)(3 * f + 1) * nw + w2] +
+                                            fb[f].G[a * 3 + 2] * W[(size_t)(3 * f + 2) * nw + w2];
+  for (int f1 = 0; f1 < nf; ++f1)
+    for (int k1 = 0; k1 < fb[f1].nn; ++k1) {
+      const int w1 = fb[f1].col0 + k1;
+      for (int w2 = 0; w2 < nw; ++w2) {
+        REAL t = fb[f1].N[3 * k1] * W[(size_t)(3 * f1) * nw + w2] + fb[f1].N[3 * k1 + 1] * W[(size_t)(3 * f1 + 1) * nw + w2] +
+                 fb[f1].N[3 * k1 + 2] * W[(size_t)(3 * f1 + 2) * nw + w2];
+        if (w1 == w2) t += dl;
+        if (!no_corr) { REAL c = 0; for (int i = 0; i < n; ++i) c += W[(size_t)i * nw + w1] * GW[(size_t)i * nw + w2]; t -= dl * c; }
+        Hd[(size_t)w1 * nw + w2] = t;
+      }
+    }
+  int bad = 0;
+  for (int j = 0; j < nw && !bad; ++j) {
+    REAL d = Hd[(size_t)j * nw + j];
+    for (int k = 0; k < j; ++k) d -= Hd[(size_t)j * nw + k] * Hd[(size_t)j * nw + k];
+    if (!(d > 0)) { bad = 1; break; }
+    d = sqrt(d); Hd[(size_t)j * nw + j] = d;
+    for (int i = j + 1; i < nw; ++i) {
+      REAL t = Hd[(size_t)i * nw + j];
+      for (int k = 0; k < j; ++k) t -= Hd[(size_t)i * nw + k] * Hd[(size_t)j * nw + k];
+      Hd[(size_t)i * nw + j] = t / d;
+    }
+  }
+  int ok = 0;
+  if (!bad) {
+    s->nfact++;
+    REAL *r1 = ralloc(n), *r2 = ralloc(m), *x = ralloc(n), *y = ralloc(m), *dx = ralloc(n), *dy = ralloc(m), *e1 = ralloc(n), *e2 = ralloc(m), *wk = ralloc(8 * n + m);
+    for (int i = 0; i < n; ++i) r1[i] = -s->qs[i];
+    for (int i = 0; i < m; ++i) r2[i] = act[i] < 0 ? s->ls[i] : (act[i] > 0 ? s->us[i] : 0);
+    if (getenv("PORT_POLISH_PROJ")) {
+      /* projected form: range part exact (u), iterative refinement only in the null space */
+      REAL *u = wk, *Pu = u + n, *g = Pu + n, *xN = g + n, *PxN = xN + n, *rw = PxN + n, *wv = rw + n, *v = wv + n;
+      mul_At_act(s, act, r2, v); mul_gamma(fb, nf, v, u); mul_P(s, u, Pu);
+      for (int i = 0; i < n; ++i) { g[i] = r1[i] - Pu[i]; xN[i] = 0; PxN[i] = 0; wv[i] = 0; }
+      for (int it = 0; it <= Q_POLISH_REFINE; ++it) {
+        for (int f = 0; f < nf; ++f) for (int k = 0; k < fb[f].nn; ++k) {
+          REAL t = 0; for (int c = 0; c < 3; ++c) t += fb[f].N[3 * k + c] * (g[3 * f + c] - PxN[3 * f + c]);
+          rw[fb[f].col0 + k] = t; }
+        chol_solve(Hd, nw, nw, rw);
+        for (int k = 0; k < nw; ++k) wv[k] += rw[k];
+        for (int f = 0; f < nf; ++f) for (int c = 0; c < 3; ++c) { REAL t = 0; for (int k = 0; k < fb[f].nn; ++k) t += fb[f].N[3 * k + c] * wv[fb[f].col0 + k]; xN[3 * f + c] = t; }
+        mul_P(s, xN, PxN);
+      }
+      for (int i = 0; i < n; ++i) { x[i] = u[i] + xN[i]; v[i] = g[i] - PxN[i]; }
+      mul_gamma(fb, nf, v, rw); mul_A(s, rw, y);
+      for (int i = 0; i < m; ++i) if (!act[i]) y[i] = 0;
+    } else {
+    kreg_apply(s, fb, act, Hd, nw, r1, r2, x, y, wk);
+    for (int it = 0; it < Q_POLISH_REFINE; ++it) {
+      mul_P(s, x, e1); mul_At_act(s, act, y, s->tn); mul_A(s, x, e2);
+      for (int i = 0; i < n; ++i) e1[i] = r1[i] - e1[i] - s->tn[i];
+      for (int i = 0; i < m; ++i) e2[i] = act[i] ? r2[i] - e2[i] : 0;
+      kreg_apply(s, fb, act, Hd, nw, e1, e2, dx, dy, wk);
+      for (int i = 0; i < n; ++i) x[i] += dx[i];
+      for (int i = 0; i < m; ++i) y[i] += dy[i];
+    }
+    }
+    REAL *zpol = e2;
+    mul_A(s, x, zpol);
+    for (int i = 0; i < m; ++i) { REAL t = zpol[i] + y[i]; REAL zc = t < s->ls[i] ? s->ls[i] : (t > s->us[i] ? s->us[i] : t); zpol[i] = zc; y[i] = t - zc; }
+    REAL pri, dua;
+    update_info(s, x, zpol, y, &pri, &dua);
+    ok = (pri < s->pri_res && dua < s->dua_res) || (pri < s->pri_res && s->dua_res < (REAL)1e-10) || (dua < s->dua_res && s->pri_res < (REAL)1e-10);
+    if (ok) { s->pri_res = pri; s->dua_res = dua; memcpy(s->x, x, sizeof(REAL) * n); memcpy(s->z, zpol, sizeof(REAL) * m); memcpy(s->y, y, sizeof(REAL) * m); }
+    free(r1); free(r2); free(x); free(y); free(dx); free(dy); free(e1); free(e2); free(wk);
+  }
+  s->status_polish = ok ? 1 : -1;
+  free(W); free(GW); free(Hd); free(act); free(fb);
+  return ok;
+}
+
 /*
  * One compute_contact_forces call.  in[] = flat record as doubles.  forces_out[12h] = -D x when
  * status == SOLVED (mpc_osqp.cc:788-790); returns 1 on success, 0 otherwise (reference returns []).
@@ -641,7 +916,18 @@ int port_solve(void *hd, const double *in, double *forces_out, int64_t *info, do
   }
   if (!checked) { update_info(s, s->x, s->z, s->y, &s->pri_res, &s->dua_res); s->iter = iter - 1; check_termination(s, 0); }
   if (s->status == ST_UNSOLVED && !check_termination(s, 1)) s->status = ST_MAX_ITER; /* osqp.c:564-568 */
-  if (s->status == ST_SOLVED) polish(s);
+  if (s->status == ST_SOLVED) {
+    if (getenv("PORT_POLISH_DEBUG")) {
+      REAL *sx = ralloc(n), *sz = ralloc(m), *sy = ralloc(m), *kx = ralloc(n); REAL p0 = s->pri_res, d0 = s->dua_res;
+      memcpy(sx, s->x, sizeof(REAL) * n); memcpy(sz, s->z, sizeof(REAL) * m); memcpy(sy, s->y, sizeof(REAL) * m);
+      int ok1 = polish_kkt(s); memcpy(kx, s->x, sizeof(REAL) * n); REAL p1 = s->pri_res, d1 = s->dua_res;
+      memcpy(s->x, sx, sizeof(REAL) * n); memcpy(s->z, sz, sizeof(REAL) * m); memcpy(s->y, sy, sizeof(REAL) * m); s->pri_res = p0; s->dua_res = d0;
+      int ok2 = polish(s);
+      REAL mx = 0, nx = 0; for (int i = 0; i < n; ++i) { REAL d = fabs(kx[i] - s->x[i]); if (d > mx) mx = d; if (fabs(s->x[i]) > nx) nx = fabs(s->x[i]); }
+      fprintf(stderr, "polish dbg: kkt ok=%d pri %.3e dua %.3e | ns ok=%d pri %.3e dua %.3e | admm pri %.3e dua %.3e | dx %.3e / %.3e\n", ok1, (double)p1, (double)d1, ok2, (double)s->pri_res, (double)s->dua_res, (double)p0, (double)d0, (double)mx, (double)nx);
+      free(sx); free(sz); free(sy); free(kx);
+    } else if (getenv("PORT_POLISH_KKT")) polish_kkt(s); else if (getenv("PORT_POLISH_RED")) polish_reduced(s); else polish(s);
+  }
   int has_sol = !(s->status == ST_PRIMAL_INF || s->status == ST_PRIMAL_INF_INACC || s->status == ST_DUAL_INF ||
                   s->status == ST_DUAL_INF_INACC || s->status == ST_NON_CVX);
   if (!has_sol) { /* auxil.c:558-560 cold start for the next run */

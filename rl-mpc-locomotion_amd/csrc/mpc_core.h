@@ -1,0 +1,894 @@
+// mpc_core.h -- one robot's convex-MPC contact-force solve, written once as a sequence of
+// barrier-separated phases over the threads of one workgroup.
+//
+//   Device build (mpc_batch.hip): Exec::par(f) = { f(thread); __syncthreads(); } -- the per-thread
+//   state lives in VGPRs, Shared<H> in LDS.
+//   Host emulation (tests/emu): Exec::par(f) runs f for every emulated thread (in forward or reverse
+//   order, to expose intra-phase races); used only by the CPU tests.
+//
+// What is computed (reference boundary: MPC_Controller/convex_MPC/mpc_osqp.cc:578-796,
+// ConvexMpc::ComputeContactForces, OSQP branch):
+//   1. single-rigid-body QP assembly (mpc_osqp.cc:606-688): x0, x_ref, A/B, exact exp, A^k B, q, P
+//      (P by cumulative diagonal sums = the reference's block recursion :387-434 in the same order)
+//   2. the OSQP 0.6.0 algorithm the reference calls on it (extern/osqp/src): Ruiz scaling
+//      (scaling.c:44-156), ADMM (auxil.c:164-228), residuals/termination (auxil.c:243-362,684-793),
+//      rho adaptation (auxil.c:13-77), polish (polish.c) -- restated for dense algebra:
+//        KKT solve      -> x~ = Kinv (sigma x - q + A^T(R z - y)),  K = P + sigma I + A^T R A,  z~ = A x~
+//        Kinv           -> explicit inverse by symmetric sweeps, one row slice per thread, in registers
+//        polish         -> delta-regularised refinement in the null space of the active rows
+//   All arithmetic is fp64: an fp32 ADMM does not reproduce OSQP's iterates (oracle/README).
+//
+// Thread layout: T = RP*S threads; thread tid owns row (tid / S), column slice
+// [part*CPT, (part+1)*CPT) with part = tid % S, of every n x n matrix (n = 12 H).
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MPC_HD __host__ __device__ __forceinline__
+#else
+#define MPC_HD inline
+#endif
+
+namespace mpc {
+
+// ---- OSQP constants (extern/osqp/include/constants.h:59-88) and the reference's settings -------
+constexpr double kRho0 = 0.1, kSigma = 1e-6, kAlphaRelax = 1.6;
+constexpr double kEpsAbs = 1e-3, kEpsRel = 1e-3;           // mpc_osqp.cc:711-712
+constexpr int kMaxIter = 4000, kCheck = 25;                // CHECK_TERMINATION; adaptive_rho_interval (mpc_osqp.cc:710)
+constexpr double kRhoMin = 1e-6, kRhoMax = 1e6, kRhoEqOverIneq = 1e3, kRhoTol = 1e-4;
+constexpr int kScalingIters = 10;
+constexpr double kMinScaling = 1e-4, kMaxScaling = 1e4, kAdaptTol = 5.0;
+constexpr double kInfty = 1e30, kDelta = 1e-6;
+constexpr int kPolishRefine = 3;
+constexpr double kGravity = 9.8, kMaxScale = 10.0, kMinScale = 0.1;  // mpc_osqp.cc:54-56
+
+// OSQP status values (constants.h:17-31)
+constexpr int kStSolved = 1, kStSolvedInaccurate = 2, kStMaxIter = -2, kStNonCvx = -7, kStUnsolved = -10;
+
+template <int H>
+struct Cfg {
+  static constexpr int N = 12 * H, M = 20 * H, NF = 4 * H;
+  static constexpr int S = (H <= 10) ? 2 : 4;            // threads per matrix row
+  static constexpr int CPT = N / S;                      // columns per thread (multiple of 3)
+  static constexpr int T = ((N * S + 63) / 64) * 64;     // workgroup size
+  static constexpr int RP = T / S;                       // padded rows
+  static constexpr int IN_LEN = 56 + 4 * H;
+  static constexpr int NTASK = 78 + (H - 1) * 144;       // P assembly tasks (d, a, b)
+  static_assert(N % S == 0 && CPT % 3 == 0, "column slice must hold whole feet");
+  static_assert(T >= M && T <= 1024, "workgroup must cover the constraint rows");
+};
+
+// Flat input record offsets (include/mpc_batch.h, layout.py)
+constexpr int IN_W = 0, IN_POS = 13, IN_VEL = 16, IN_RPY = 19, IN_NRM = 22, IN_ANG = 25, IN_CONTACT = 28;
+template <int H> constexpr int in_foot() { return 28 + 4 * H; }
+template <int H> constexpr int in_fric() { return 40 + 4 * H; }
+template <int H> constexpr int in_dpos() { return 44 + 4 * H; }
+template <int H> constexpr int in_dvel() { return 47 + 4 * H; }
+template <int H> constexpr int in_drpy() { return 50 + 4 * H; }
+template <int H> constexpr int in_dang() { return 53 + 4 * H; }
+
+// Per-robot persistent solver state in HBM (one contiguous record of doubles per robot):
+//   x[N] z[M] y[M] q_old[N] rho flags      flags: 0 = cold (next call is the "osqp_setup" call)
+template <int H> constexpr int state_len() { return 2 * Cfg<H>::N + 2 * Cfg<H>::M + 2; }
+
+// Per-robot info record (ints): iter, status, status_polish, rho_updates, n_factor, first_run, 0, 0
+constexpr int kInfoLen = 8;
+
+struct RobotModel {       // constructor arguments of ConvexMpc (mpc_osqp.cc:508-527)
+  double mass, inv_mass, inv_inertia[9], dt, alpha;
+};
+
+template <int H>
+struct Shared {
+  using C = Cfg<H>;
+  double in[C::IN_LEN];
+  // assembly
+  double x0[13], xref[13 * H], sdiff[13 * H], xk[13 * H];
+  double a_dt[169], b_dt[156], a_exp[169], b_exp[156], anb[H * 156];
+  double cone[15];
+  double q[C::N], l[C::M], u[C::M];                     // unscaled
+  // scaled problem
+  double qs[C::N], ls[C::M], us[C::M], As[C::NF * 15];
+  double D[C::N], Dinv[C::N], E[C::M], Einv[C::M], dt_[C::N], et_[C::M], cn_[C::N];
+  double c, cinv, rho;
+  double rho_vec[C::M], rho_inv[C::M];
+  int ctype[C::M];
+  // iterates and work vectors
+  double x[C::N], z[C::M], y[C::M], tm[C::M], rhs[C::N], xt[C::N], dx[C::N];
+  double Ax[C::M], Px[C::N], Aty[C::N], rp[C::M], rd[C::N];
+  double part[C::T];                                    // per-thread partial sums
+  double prow[2][C::N];                                 // sweep pivot row (double buffered)
+  double diag[C::N];                                    // diagonal of the matrix being swept
+  double piv[2];                                       // current pivot (double buffered)
+  unsigned long long red[16];                           // max-reductions (bit pattern of doubles >= 0)
+  // polish
+  int act[C::M];
+  double Nb[C::NF * 9], Gm[C::NF * 9];                  // per foot: null basis rows (3 x 3, zero padded), Gamma
+  int nnull[C::NF], isnull[C::N];
+  double u0[C::N], Pu[C::N], g[C::N], xN[C::N], PxN[C::N], wv[C::N], rw[C::N], ypol[C::M], zpol[C::M];
+  // control (uniform)
+  int first, iter, status, status_polish, rho_updates, nfact, done, bad;
+  double pri_res, dua_res, rho_new;
+};
+
+template <int H>
+struct Thread {
+  using C = Cfg<H>;
+  int tid, row, part;
+  double Mx[C::CPT];        // this thread's slice of the current n x n matrix (P_s, K, -Kinv, H, -Hinv)
+  double xprev, zprev;      // previous iterate of the vector element this thread owns
+};
+
+MPC_HD double limit_scaling(double v) {  // scaling.c:7-14
+  v = v < kMinScaling ? 1.0 : v;
+  return v > kMaxScaling ? kMaxScaling : v;
+}
+MPC_HD double dmax(double a, double b) { return a > b ? a : b; }
+MPC_HD double dmin(double a, double b) { return a < b ? a : b; }
+MPC_HD double clampd(double v, double lo, double hi) { return dmin(dmax(v, lo), hi); }
+
+MPC_HD unsigned long long dbits(double v) {
+  union { double d; unsigned long long u; } c;
+  c.d = v;
+  return c.u;
+}
+MPC_HD double bitsd(unsigned long long u) {
+  union { double d; unsigned long long u; } c;
+  c.u = u;
+  return c.d;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The solver.  `Exec` provides: par(f), amax(&slot, value) (LDS atomic max on a double >= 0).
+// `Pg` is this robot's n*n fp64 scratch in HBM (holds P, then the scaled P_s).
+// ------------------------------------------------------------------------------------------------
+template <int H, class Exec>
+struct Solver {
+  using C = Cfg<H>;
+  using Th = Thread<H>;
+  using Sh = Shared<H>;
+  static constexpr int N = C::N, M = C::M, NF = C::NF, S = C::S, CPT = C::CPT, T = C::T;
+
+  Exec &ex;
+  Sh &s;
+  const RobotModel &mdl;
+  const float *in;     // [IN_LEN]
+  double *state;       // [state_len<H>()]
+  double *Pg;          // [N*N]
+  double *forces;      // [N]   out: -D x (all horizon steps), untouched on failure
+  int *info;           // [kInfoLen]
+
+  // ---- helpers valid inside a phase ------------------------------------------------------------
+  static MPC_HD double a_row_dot(const Sh &s, int i, const double *v) {  // row i of scaled A times v
+    const int f = i / 5, r = i - 5 * f;
+    const double *a = s.As + 15 * f + 3 * r;
+    return a[0] * v[3 * f] + a[1] * v[3 * f + 1] + a[2] * v[3 * f + 2];
+  }
+  static MPC_HD double at_col_dot(const Sh &s, int j, const double *v) {  // column j of scaled A times v
+    const int f = j / 3, c = j - 3 * f;
+    const double *a = s.As + 15 * f + c;
+    double t = 0;
+    for (int r = 0; r < 5; ++r) t += a[3 * r] * v[5 * f + r];
+    return t;
+  }
+  // per-thread partial of (matrix row slice) . v
+  static MPC_HD double slice_dot(const Th &t, const double *v) {
+    double acc = 0;
+    const double *vv = v + t.part * CPT;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) acc += t.Mx[j] * vv[j];
+    return acc;
+  }
+  static MPC_HD double sum_parts(const Sh &s, int row) {
+    double acc = s.part[row * S];
+#pragma unroll
+    for (int p = 1; p < S; ++p) acc += s.part[row * S + p];
+    return acc;
+  }
+  static MPC_HD double max_parts(const Sh &s, int row) {
+    double acc = s.part[row * S];
+#pragma unroll
+    for (int p = 1; p < S; ++p) acc = dmax(acc, s.part[row * S + p]);
+    return acc;
+  }
+  MPC_HD void load_slice(Th &t, const double *G) {   // Mx <- G[row][slice]
+    if (t.row < N) {
+      const double *g = G + (size_t)t.row * N + t.part * CPT;
+#pragma unroll
+      for (int j = 0; j < CPT; ++j) t.Mx[j] = g[j];
+    }
+  }
+
+  // ================================ 1. assembly =================================================
+  MPC_HD void assemble() {
+    ex.par([&](Th &t) {
+      for (int i = t.tid; i < C::IN_LEN; i += T) s.in[i] = (double)in[i];
+      for (int i = t.tid; i < 169; i += T) s.a_dt[i] = 0;
+      for (int i = t.tid; i < 156; i += T) s.b_dt[i] = 0;
+      // warm-start state (scaled iterates of the previous call; zeros on the first call)
+      for (int i = t.tid; i < N; i += T) { s.x[i] = state[i]; s.rd[i] = state[N + 2 * M + i]; /* q_old */ }
+      for (int i = t.tid; i < M; i += T) { s.z[i] = state[N + i]; s.y[i] = state[N + M + i]; }
+      if (t.tid == 0) {
+        s.rho = state[2 * N + 2 * M];
+        s.first = state[2 * N + 2 * M + 1] == 0.0;
+        s.status = kStUnsolved; s.status_polish = 0; s.rho_updates = 0; s.nfact = 0; s.iter = 0; s.done = 0; s.bad = 0;
+      }
+    });
+    // A dt, B dt (mpc_osqp.cc:299-336, 606-617, 661-673) -- a few hundred flops, one thread
+    ex.par([&](Th &t) {
+      if (t.tid == 0) {
+        if (s.first) s.rho = kRho0;
+        const double *rpy = s.in + IN_RPY;
+        const double cr = cos(rpy[0]), sr = sin(rpy[0]), cp = cos(rpy[1]), sp = sin(rpy[1]), cy = cos(rpy[2]), sy = sin(rpy[2]);
+        const double rx[9] = {1, 0, 0, 0, cr, -sr, 0, sr, cr}, ry[9] = {cp, 0, sp, 0, 1, 0, -sp, 0, cp}, rz[9] = {cy, -sy, 0, sy, cy, 0, 0, 0, 1};
+        double tmp[9], rxyz[9], rzyx[9], iw[9], fw[12];
+        mat3(rx, ry, tmp); mat3(tmp, rz, rxyz);                        // feet: Rx Ry Rz (:606-609)
+        mat3(rz, ry, tmp); mat3(tmp, rx, rzyx);                        // inertia: Rz Ry Rx (:283-291)
+        const double *fb = s.in + in_foot<H>();
+        for (int i = 0; i < 4; ++i)
+          for (int r = 0; r < 3; ++r) fw[3 * i + r] = rxyz[3 * r] * fb[3 * i] + rxyz[3 * r + 1] * fb[3 * i + 1] + rxyz[3 * r + 2] * fb[3 * i + 2];
+        double rt[9];
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) rt[3 * r + c] = rzyx[3 * c + r];
+        mat3(rzyx, mdl.inv_inertia, tmp); mat3(tmp, rt, iw);           // :670-671
+        const double tp = tan(rpy[1]), dt = mdl.dt;
+        const double tm3[9] = {cy / cp, sy / cp, 0, -sy, cy, 0, cy * tp, sy * tp, 1};   // :311-312
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) s.a_dt[r * 13 + 6 + c] = tm3[3 * r + c] * dt;
+        s.a_dt[3 * 13 + 9] = dt; s.a_dt[4 * 13 + 10] = dt; s.a_dt[5 * 13 + 11] = dt;
+        for (int r = 0; r < 3; ++r) s.a_dt[(9 + r) * 13 + 12] = s.in[IN_NRM + r] * dt;
+        for (int i = 0; i < 4; ++i) {
+          const double *v = fw + 3 * i;
+          const double skew[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
+          double blk[9];
+          mat3(iw, skew, blk);
+          for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) s.b_dt[(6 + r) * 12 + 3 * i + c] = blk[3 * r + c] * dt;
+          for (int r = 0; r < 3; ++r) s.b_dt[(9 + r) * 12 + 3 * i + r] = mdl.inv_mass * dt;
+        }
+        const double *fr = s.in + in_fric<H>();
+        const double cb[15] = {-1, 0, fr[0], 1, 0, fr[1], 0, -1, fr[2], 0, 1, fr[3], 0, 0, 1};   // :437-447
+        for (int k = 0; k < 15; ++k) s.cone[k] = cb[k];
+      }
+      // x0 (:630-633)
+      if (t.tid < 13) {
+        const int i = t.tid;
+        s.x0[i] = i < 3 ? s.in[IN_RPY + i] : i < 6 ? s.in[IN_POS + i - 3] : i < 9 ? s.in[IN_ANG + i - 6] : i < 12 ? s.in[IN_VEL + i - 9] : -kGravity;
+      }
+      // x_ref (:635-659)
+      for (int k = t.tid; k < 13 * H; k += T) {
+        const int i = k / 13, r = k - 13 * i;
+        const double tt = mdl.dt * (i + 1);
+        const double *drpy = s.in + in_drpy<H>(), *dvel = s.in + in_dvel<H>(), *dang = s.in + in_dang<H>();
+        double v;
+        switch (r) {
+          case 0: v = drpy[0]; break;
+          case 1: v = drpy[1]; break;
+          case 2: v = s.in[IN_RPY + 2] + tt * dang[2]; break;
+          case 3: v = tt * dvel[0] + s.in[IN_POS]; break;
+          case 4: v = tt * dvel[1] + s.in[IN_POS + 1]; break;
+          case 5: v = s.in[in_dpos<H>() + 2]; break;
+          case 6: v = dang[0]; break;
+          case 7: v = dang[1]; break;
+          case 8: v = dang[2]; break;
+          case 9: v = dvel[0]; break;
+          case 10: v = dvel[1]; break;
+          case 11: v = 0; break;
+          default: v = -kGravity;
+        }
+        s.xref[k] = v;
+      }
+      // bounds (:449-477, 685-688, 720-721)
+      if (t.tid < M) {
+        const int i = t.tid, f = i / 5, r = i - 5 * f;
+        const double cst = s.in[IN_CONTACT + f];
+        const double fzmax = mdl.mass * kGravity * kMaxScale, fzmin = mdl.mass * kGravity * kMinScale;
+        const double mu0 = s.in[in_fric<H>()];
+        s.l[i] = dmax(r < 4 ? 0.0 : fzmin * cst, -kInfty);
+        s.u[i] = dmin(r < 4 ? (mu0 + 1) * fzmax * cst : fzmax * cst, kInfty);
+      }
+    });
+    // exact exponential (mpc_osqp.cc:338-351; M^3 = 0): A_exp = I + A dt + (A dt)^2/2, B_exp = B dt + (A dt)(B dt)/2
+    ex.par([&](Th &t) {
+      for (int k = t.tid; k < 169 + 156; k += T) {
+        if (k < 169) {
+          const int r = k / 13, c = k - 13 * r;
+          double acc = 0;
+          for (int j = 0; j < 13; ++j) acc += s.a_dt[r * 13 + j] * s.a_dt[j * 13 + c];
+          s.a_exp[k] = (r == c ? 1.0 : 0.0) + s.a_dt[k] + acc / 2;
+        } else {
+          const int kk = k - 169, r = kk / 12, c = kk - 12 * r;
+          double acc = 0;
+          for (int j = 0; j < 13; ++j) acc += s.a_dt[r * 13 + j] * s.b_dt[j * 12 + c];
+          s.b_exp[kk] = s.b_dt[kk] + acc / 2;
+          s.anb[kk] = s.b_exp[kk];
+        }
+      }
+    });
+    // A^k B (:368-373) and the free response A^{i+1} x0, i < H-1 (:360-364; the last A_qp block stays 0)
+    for (int k = 1; k < H; ++k) {
+      ex.par([&](Th &t) {
+        if (t.tid < 156) {
+          const int r = t.tid / 12, c = t.tid - 12 * r;
+          double acc = 0;
+          for (int j = 0; j < 13; ++j) acc += s.a_exp[r * 13 + j] * s.anb[(k - 1) * 156 + j * 12 + c];
+          s.anb[k * 156 + t.tid] = acc;
+        } else if (t.tid < 156 + 13) {
+          const int r = t.tid - 156;
+          const double *prev = (k == 1) ? s.x0 : s.xk + 13 * (k - 2);
+          double acc = 0;
+          for (int j = 0; j < 13; ++j) acc += s.a_exp[r * 13 + j] * prev[j];
+          s.xk[13 * (k - 1) + r] = acc;
+        }
+      });
+    }
+    ex.par([&](Th &t) {   // state_diff (:681)
+      for (int k = t.tid; k < 13 * H; k += T) s.sdiff[k] = (k < 13 * (H - 1) ? s.xk[k] : 0.0) - s.xref[k];
+    });
+    // q (:683) and P (:387-434) -> Pg (unscaled, full symmetric)
+    ex.par([&](Th &t) {
+      if (t.tid < N) {
+        const int j = t.tid / 12, c = t.tid - 12 * j;
+        double acc = 0;
+        for (int i = j; i < H; ++i) {
+          const double *bk = s.anb + (i - j) * 156;
+          for (int r = 0; r < 13; ++r) acc += bk[r * 12 + c] * (s.in[IN_W + r] * s.sdiff[13 * i + r]);
+        }
+        s.q[t.tid] = 2 * acc;
+      }
+      for (int task = t.tid; task < C::NTASK; task += T) {
+        int d, a, b;
+        if (task < 78) {          // diagonal blocks: a <= b only, mirrored
+          d = 0;
+          int k = task; a = 0;
+          while (k >= 12 - a) { k -= 12 - a; ++a; }
+          b = a + k;
+        } else {
+          const int k = task - 78;
+          d = 1 + k / 144;
+          const int ab = k - (d - 1) * 144;
+          a = ab / 12; b = ab - 12 * a;
+        }
+        double acc = 0;
+        for (int sidx = 0; sidx + d < H; ++sidx) {
+          const double *xa = s.anb + (sidx + d) * 156, *yb = s.anb + sidx * 156;
+          double tsum = 0;
+          for (int r = 0; r < 13; ++r) tsum += xa[r * 12 + a] * s.in[IN_W + r] * yb[r * 12 + b];
+          acc += tsum;
+          const int J = H - 1 - sidx, I = J - d;
+          const int ri = 12 * I + a, cj = 12 * J + b;
+          double v = 2.0 * acc;
+          if (ri == cj) v += mdl.alpha;
+          Pg[(size_t)ri * N + cj] = v;
+          if (ri != cj) Pg[(size_t)cj * N + ri] = v;
+        }
+      }
+    });
+  }
+  static MPC_HD void mat3(const double *a, const double *b, double *c) {
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) c[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+  }
+
+  // ================================ 2. scaling (scaling.c:44-156) ===============================
+  MPC_HD void scale() {
+    ex.par([&](Th &t) {
+      load_slice(t, Pg);
+      if (t.tid < N) {
+        s.qs[t.tid] = s.first ? s.q[t.tid] : s.rd[t.tid];   // osqp_update_P_A equilibrates with the PREVIOUS q
+        s.D[t.tid] = 1.0;
+      }
+      if (t.tid < M) s.E[t.tid] = 1.0;
+      for (int k = t.tid; k < NF * 15; k += T) s.As[k] = s.cone[k % 15];
+      if (t.tid == 0) s.c = 1.0;
+    });
+    for (int it = 0; it < kScalingIters; ++it) {
+      ex.par([&](Th &t) {   // row (= column) inf-norms of P, row norms of A
+        double mx = 0;
+        if (t.row < N) {
+#pragma unroll
+          for (int j = 0; j < CPT; ++j) mx = dmax(mx, fabs(t.Mx[j]));
+        }
+        s.part[t.tid] = mx;
+        if (t.tid < M) {
+          const double *a = s.As + 3 * t.tid;
+          s.et_[t.tid] = 1.0 / sqrt(limit_scaling(dmax(dmax(fabs(a[0]), fabs(a[1])), fabs(a[2]))));
+        }
+      });
+      ex.par([&](Th &t) {
+        if (t.part == 0 && t.row < N) {
+          const int j = t.row, f = j / 3, c = j - 3 * f;
+          double mx = max_parts(s, j);
+          for (int r = 0; r < 5; ++r) mx = dmax(mx, fabs(s.As[15 * f + 3 * r + c]));
+          s.dt_[j] = 1.0 / sqrt(limit_scaling(mx));
+        }
+      });
+      ex.par([&](Th &t) {   // P <- D P D, A <- E A D, q <- D q; then the new column norms of P
+        double mx = 0;
+        if (t.row < N) {
+          const double dr = s.dt_[t.row];
+          const double *dc = s.dt_ + t.part * CPT;
+#pragma unroll
+          for (int j = 0; j < CPT; ++j) { t.Mx[j] = (t.Mx[j] * dr) * dc[j]; mx = dmax(mx, fabs(t.Mx[j])); }
+        }
+        s.part[t.tid] = mx;
+        if (t.tid < M) {
+          const int f = t.tid / 5;
+          double *a = s.As + 3 * t.tid;
+          const double e = s.et_[t.tid];
+          a[0] = (a[0] * e) * s.dt_[3 * f]; a[1] = (a[1] * e) * s.dt_[3 * f + 1]; a[2] = (a[2] * e) * s.dt_[3 * f + 2];
+          s.E[t.tid] *= e;
+        }
+        if (t.tid < N) { s.qs[t.tid] *= s.dt_[t.tid]; s.D[t.tid] *= s.dt_[t.tid]; }
+      });
+      ex.par([&](Th &t) {
+        if (t.part == 0 && t.row < N) s.cn_[t.row] = max_parts(s, t.row);
+      });
+      ex.par([&](Th &t) {   // cost scaling (scaling.c:108-139); every thread derives the same c_temp
+        double mean = 0, nq = 0;
+        for (int j = 0; j < N; ++j) { mean += s.cn_[j]; nq = dmax(nq, fabs(s.qs[j])); }
+        mean /= N;
+        nq = limit_scaling(nq);
+        const double ct = 1.0 / limit_scaling(dmax(mean, nq));
+        t.xprev = ct;   // carried to the next phase in a register
+      });
+      ex.par([&](Th &t) {
+        const double ct = t.xprev;
+        if (t.row < N) {
+#pragma unroll
+          for (int j = 0; j < CPT; ++j) t.Mx[j] *= ct;
+        }
+        if (t.tid < N) s.qs[t.tid] *= ct;
+        if (t.tid == 0) s.c *= ct;
+      });
+    }
+    ex.par([&](Th &t) {
+      if (t.tid == 0) s.cinv = 1.0 / s.c;
+      if (t.tid < N) {
+        s.Dinv[t.tid] = 1.0 / s.D[t.tid];
+        if (!s.first) s.qs[t.tid] = (s.D[t.tid] * s.q[t.tid]) * s.c;     // osqp_update_lin_cost (osqp.c:765-770)
+      }
+      if (t.tid < M) {
+        const int i = t.tid;
+        s.Einv[i] = 1.0 / s.E[i];
+        s.ls[i] = s.E[i] * s.l[i];
+        s.us[i] = s.E[i] * s.u[i];
+        // set_rho_vec / update_rho_vec (auxil.c:79-141): rho_vec is a function of (type, rho) in both
+        const int ty = (s.ls[i] < -kInfty * kMinScaling && s.us[i] > kInfty * kMinScaling) ? -1 : (s.us[i] - s.ls[i] < kRhoTol ? 1 : 0);
+        s.ctype[i] = ty;
+      }
+      // keep P_s for residuals, re-factorisations and polish
+      if (t.row < N) {
+        double *g = Pg + (size_t)t.row * N + t.part * CPT;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) g[j] = t.Mx[j];
+      }
+    });
+  }
+
+  MPC_HD void set_rho_vec() {   // phase: rho_vec from (ctype, rho)  (auxil.c:79-96, osqp.c:1267-1310)
+    ex.par([&](Th &t) {
+      if (t.tid < M) {
+        const int ty = s.ctype[t.tid];
+        const double rv = ty == -1 ? kRhoMin : (ty == 1 ? kRhoEqOverIneq * s.rho : s.rho);
+        s.rho_vec[t.tid] = rv;
+        s.rho_inv[t.tid] = 1.0 / rv;
+      }
+    });
+  }
+
+  // ================================ 3. K = P_s + sigma I + A^T R A ; Mx <- -K^{-1} ==============
+  // Symmetric sweep: after sweeping every pivot the matrix equals -K^{-1}.  The matrix stays
+  // symmetric, so the multiplier of row i at pivot k is the pivot row's entry i (read from LDS).
+  // The diagonal lives in LDS (s.diag) while sweeping; the register copy of it is ignored.
+  MPC_HD void factor(bool reload) {
+    ex.par([&](Th &t) {
+      if (reload) load_slice(t, Pg);
+      if (t.row < N) {
+        const int f = t.row / 3, c1 = t.row - 3 * f;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+          const int col = t.part * CPT + j;
+          if (col / 3 == f) {
+            const int c2 = col - 3 * f;
+            double g = 0;
+            for (int r = 0; r < 5; ++r) g += s.As[15 * f + 3 * r + c1] * s.rho_vec[5 * f + r] * s.As[15 * f + 3 * r + c2];
+            t.Mx[j] += g;
+            if (col == t.row) { t.Mx[j] += kSigma; s.diag[t.row] = t.Mx[j]; }
+          }
+        }
+      }
+    });
+    sweep_all(false);
+    ex.par([&](Th &t) { if (t.tid == 0) s.nfact++; });
+  }
+
+  // Sweep all pivots (or only those with s.isnull[k] when masked).  On exit Mx (incl. the diagonal
+  // slot) holds minus the inverse (restricted to the swept pivots).
+  // Per step k:  p = a_kk;  a_ij -= a_ik a_kj / p (i,j != k);  a_ik -> a_ik / p;  a_kk -> -1/p.
+  // The published pivot row carries (p - 1) in slot k, which makes the generic update
+  //   a_ij -= (row_k[i] / p) * row_k[j]
+  // produce a_ik / p on column k and a_kj / p on row k without any per-element select.
+  MPC_HD void sweep_all(bool masked) {
+    int buf = 0;
+    int k0 = 0;
+    if (masked) while (k0 < N && !s.isnull[k0]) ++k0;
+    ex.par([&](Th &t) {   // publish the first pivot row and pivot
+      if (k0 < N && t.row == k0) publish_row(t, 0, k0, s.diag[k0]);
+    });
+    for (int k = k0; k < N;) {
+      int kn = k + 1;
+      if (masked) while (kn < N && !s.isnull[kn]) ++kn;
+      ex.par([&](Th &t) {
+        if (t.row < N) {
+          const double p = s.piv[buf];
+          const double pinv = 1.0 / p;
+          const double *pr = s.prow[buf];
+          const double f = pr[t.row];            // a_ik (or p - 1 on the pivot row)
+          const double g = f * pinv;
+          const double *prc = pr + t.part * CPT;
+#pragma unroll
+          for (int j = 0; j < CPT; ++j) t.Mx[j] -= g * prc[j];
+          double dnew = 0;
+          if (t.part == 0) {
+            dnew = (t.row == k) ? -pinv : s.diag[t.row] - f * g;
+            s.diag[t.row] = dnew;
+            if (t.row == k && !(p > 0)) s.bad = 1;   // not positive definite
+          }
+          if (kn < N && t.row == kn) publish_row(t, buf ^ 1, kn, dnew);
+        }
+      });
+      buf ^= 1;
+      k = kn;
+    }
+    ex.par([&](Th &t) {   // put the diagonal back into the register slice
+      if (t.row < N) {
+        const int dl = t.row - t.part * CPT;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) if (j == dl) t.Mx[j] = s.diag[t.row];
+      }
+    });
+  }
+  // Row `k`'s threads copy their slice to prow[b]; slot k itself gets (pivot - 1) and piv[b] the pivot
+  // (both written by the part-0 thread, which owns the LDS diagonal).
+  MPC_HD void publish_row(Th &t, int b, int k, double pivot) {
+    double *pn = s.prow[b] + t.part * CPT;
+    const int kloc = k - t.part * CPT;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) if (j != kloc) pn[j] = t.Mx[j];
+    if (t.part == 0) { s.prow[b][k] = pivot - 1.0; s.piv[b] = pivot; }
+  }
+
+  // ================================ 4. ADMM (auxil.c:164-228) ===================================
+  // pre: s.tm = R z - y for the current (z, y); thread-local xprev/zprev are set inside.
+  MPC_HD void admm_prepare() {
+    ex.par([&](Th &t) {
+      if (t.tid < M) s.tm[t.tid] = s.rho_vec[t.tid] * s.z[t.tid] - s.y[t.tid];
+    });
+  }
+  MPC_HD void admm_iter() {
+    ex.par([&](Th &t) {   // rhs = sigma x - q + A^T (R z - y)
+      if (t.tid < N) { t.xprev = s.x[t.tid]; s.rhs[t.tid] = kSigma * s.x[t.tid] - s.qs[t.tid] + at_col_dot(s, t.tid, s.tm); }
+    });
+    ex.par([&](Th &t) {   // x~ = K^{-1} rhs  (Mx = -K^{-1})
+      s.part[t.tid] = (t.row < N) ? -slice_dot(t, s.rhs) : 0.0;
+    });
+    ex.par([&](Th &t) {
+      if (t.tid < N) {
+        const double xt = sum_parts(s, t.tid);
+        s.xt[t.tid] = xt;
+        const double xn = kAlphaRelax * xt + (1.0 - kAlphaRelax) * t.xprev;
+        s.x[t.tid] = xn;
+        s.dx[t.tid] = xn - t.xprev;
+      }
+    });
+    ex.par([&](Th &t) {   // z~ = A x~ ; z, y updates; next iteration's R z - y
+      if (t.tid < M) {
+        const int i = t.tid;
+        const double zt = a_row_dot(s, i, s.xt);
+        const double zp = s.z[i], yv = s.y[i], rv = s.rho_vec[i];
+        const double zr = kAlphaRelax * zt + (1.0 - kAlphaRelax) * zp;
+        const double zn = clampd(zr + s.rho_inv[i] * yv, s.ls[i], s.us[i]);
+        const double yn = yv + rv * (zr - zn);
+        s.z[i] = zn;
+        s.y[i] = yn;
+        s.tm[i] = rv * zn - yn;
+      }
+    });
+  }
+
+  // P_s v -> out (P_s read from HBM scratch).  Two phases.
+  MPC_HD void mul_P(const double *v, double *out) {
+    ex.par([&](Th &t) {
+      double acc = 0;
+      if (t.row < N) {
+        const double *g = Pg + (size_t)t.row * N + t.part * CPT;
+        const double *vv = v + t.part * CPT;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) acc += g[j] * vv[j];
+      }
+      s.part[t.tid] = acc;
+    });
+    ex.par([&](Th &t) { if (t.tid < N) out[t.tid] = sum_parts(s, t.tid); });
+  }
+
+  // residuals of (x, z, y) (auxil.c:243-306, 563-629) + the norms termination and rho need.
+  // red[] slots: 0 pri_res 1 ||Einv z|| 2 ||Einv Ax|| 3 ||rp|| 4 ||z|| 5 ||Ax||
+  //              6 ||Dinv rd|| 7 ||Dinv q|| 8 ||Dinv Aty|| 9 ||Dinv Px|| 10 ||rd|| 11 ||q|| 12 ||Aty|| 13 ||Px||
+  MPC_HD void residuals(const double *x, const double *z, const double *y) {
+    ex.par([&](Th &t) { if (t.tid < 16) s.red[t.tid] = 0; });
+    mul_P(x, s.Px);
+    ex.par([&](Th &t) {
+      if (t.tid < M) {
+        const int i = t.tid;
+        const double ax = a_row_dot(s, i, x), r = ax - z[i], ei = s.Einv[i];
+        s.Ax[i] = ax; s.rp[i] = r;
+        ex.amax(&s.red[0], fabs(ei * r)); ex.amax(&s.red[1], fabs(ei * z[i])); ex.amax(&s.red[2], fabs(ei * ax));
+        ex.amax(&s.red[3], fabs(r)); ex.amax(&s.red[4], fabs(z[i])); ex.amax(&s.red[5], fabs(ax));
+      }
+      if (t.tid < N) {
+        const int j = t.tid;
+        const double aty = at_col_dot(s, j, y), px = s.Px[j], qv = s.qs[j], r = qv + px + aty, di = s.Dinv[j];
+        s.Aty[j] = aty; s.rd[j] = r;
+        ex.amax(&s.red[6], fabs(di * r)); ex.amax(&s.red[7], fabs(di * qv)); ex.amax(&s.red[8], fabs(di * aty));
+        ex.amax(&s.red[9], fabs(di * px)); ex.amax(&s.red[10], fabs(r)); ex.amax(&s.red[11], fabs(qv));
+        ex.amax(&s.red[12], fabs(aty)); ex.amax(&s.red[13], fabs(px));
+      }
+    });
+  }
+
+  // check_termination (auxil.c:684-793; infeasibility certificates not evaluated: the QP is always
+  // feasible and strictly convex) + adapt_rho decision (auxil.c:13-77).  One thread decides.
+  MPC_HD void check_and_adapt(int iter) {
+    ex.par([&](Th &t) {
+      if (t.tid == 0) {
+        const double pri = bitsd(s.red[0]), dua = s.cinv * bitsd(s.red[6]);
+        s.pri_res = pri; s.dua_res = dua; s.iter = iter; s.rho_new = 0;
+        if (pri > kInfty || dua > kInfty) { s.status = kStNonCvx; s.done = 1; }
+        else {
+          const double eps_prim = kEpsAbs + kEpsRel * dmax(bitsd(s.red[1]), bitsd(s.red[2]));
+          const double eps_dual = kEpsAbs + kEpsRel * s.cinv * dmax(dmax(bitsd(s.red[7]), bitsd(s.red[8])), bitsd(s.red[9]));
+          if (pri < eps_prim && dua < eps_dual) { s.status = kStSolved; s.done = 1; }
+          else {
+            double pr = bitsd(s.red[3]) / (dmax(bitsd(s.red[4]), bitsd(s.red[5])) + 1e-10);
+            double dr = bitsd(s.red[10]) / (dmax(dmax(bitsd(s.red[11]), bitsd(s.red[12])), bitsd(s.red[13])) + 1e-10);
+            double rn = s.rho * sqrt(pr / (dr + 1e-10));
+            rn = clampd(rn, kRhoMin, kRhoMax);
+            if (rn > s.rho * kAdaptTol || rn < s.rho / kAdaptTol) s.rho_new = rn;
+          }
+        }
+      }
+    });
+  }
+
+  // ================================ 5. polish (polish.c) ========================================
+  MPC_HD void polish() {
+    // active set (polish.c:36-52) and per-foot bases
+    ex.par([&](Th &t) {
+      if (t.tid < M) {
+        const int i = t.tid;
+        s.act[i] = (s.z[i] - s.ls[i] < -s.y[i]) ? -1 : ((s.us[i] - s.z[i] < s.y[i]) ? 1 : 0);
+      }
+    });
+    ex.par([&](Th &t) {
+      if (t.tid < NF) {
+        const int f = t.tid;
+        const double *a = s.As + 15 * f;
+        double Q[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Nn[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        int r = 0;
+        for (int row = 0; row < 5; ++row) {
+          if (r >= 3 || !s.act[5 * f + row]) continue;
+          double v[3] = {a[3 * row], a[3 * row + 1], a[3 * row + 2]};
+          const double n0 = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+          for (int pass = 0; pass < 2; ++pass)
+            for (int k = 0; k < 3; ++k) {
+              if (k >= r) break;
+              const double d = v[0] * Q[3 * k] + v[1] * Q[3 * k + 1] + v[2] * Q[3 * k + 2];
+              v[0] -= d * Q[3 * k]; v[1] -= d * Q[3 * k + 1]; v[2] -= d * Q[3 * k + 2];
+            }
+          const double nr = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+          if (!(nr > 1e-6 * n0)) continue;
+          Q[3 * r] = v[0] / nr; Q[3 * r + 1] = v[1] / nr; Q[3 * r + 2] = v[2] / nr;
+          ++r;
+        }
+        if (r == 0) { Nn[0] = 1; Nn[4] = 1; Nn[8] = 1; }
+        else if (r == 1) {
+          const int imin = fabs(Q[0]) <= fabs(Q[1]) ? (fabs(Q[0]) <= fabs(Q[2]) ? 0 : 2) : (fabs(Q[1]) <= fabs(Q[2]) ? 1 : 2);
+          double e[3] = {0, 0, 0};
+          e[imin] = 1;
+          const double d = Q[imin];
+          double v[3] = {e[0] - d * Q[0], e[1] - d * Q[1], e[2] - d * Q[2]};
+          const double nr = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+          Nn[0] = v[0] / nr; Nn[1] = v[1] / nr; Nn[2] = v[2] / nr;
+          Nn[3] = Q[1] * Nn[2] - Q[2] * Nn[1]; Nn[4] = Q[2] * Nn[0] - Q[0] * Nn[2]; Nn[5] = Q[0] * Nn[1] - Q[1] * Nn[0];
+        } else if (r == 2) {
+          Nn[0] = Q[1] * Q[5] - Q[2] * Q[4]; Nn[1] = Q[2] * Q[3] - Q[0] * Q[5]; Nn[2] = Q[0] * Q[4] - Q[1] * Q[3];
+          const double nr = sqrt(Nn[0] * Nn[0] + Nn[1] * Nn[1] + Nn[2] * Nn[2]);
+          Nn[0] /= nr; Nn[1] /= nr; Nn[2] /= nr;
+        }
+        const int nn = 3 - r;
+        s.nnull[f] = nn;
+        for (int k = 0; k < 9; ++k) s.Nb[9 * f + k] = Nn[k];          // row k (< nn) = null vector k
+        for (int k = 0; k < 3; ++k) s.isnull[3 * f + k] = k < nn;     // null coordinate (f, k) sits at index 3f+k
+        // Gamma = Q (Q^T B Q)^{-1} Q^T with B = A_act^T A_act
+        double B[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, G[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Gi[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        for (int row = 0; row < 5; ++row)
+          if (s.act[5 * f + row])
+            for (int c1 = 0; c1 < 3; ++c1) for (int c2 = 0; c2 < 3; ++c2) B[3 * c1 + c2] += a[3 * row + c1] * a[3 * row + c2];
+        for (int k1 = 0; k1 < 3; ++k1) for (int k2 = 0; k2 < 3; ++k2) {
+          if (k1 >= r || k2 >= r) continue;
+          double tt = 0;
+          for (int c1 = 0; c1 < 3; ++c1) for (int c2 = 0; c2 < 3; ++c2) tt += Q[3 * k1 + c1] * B[3 * c1 + c2] * Q[3 * k2 + c2];
+          G[3 * k1 + k2] = tt;
+        }
+        // Gauss-Jordan on the (identity padded) 3x3
+        for (int p = 0; p < 3; ++p) {
+          const double d = 1.0 / G[3 * p + p];
+          for (int j = 0; j < 3; ++j) { G[3 * p + j] *= d; Gi[3 * p + j] *= d; }
+          for (int i = 0; i < 3; ++i) {
+            if (i == p) continue;
+            const double fc = G[3 * i + p];
+            for (int j = 0; j < 3; ++j) { G[3 * i + j] -= fc * G[3 * p + j]; Gi[3 * i + j] -= fc * Gi[3 * p + j]; }
+          }
+        }
+        for (int c1 = 0; c1 < 3; ++c1) for (int c2 = 0; c2 < 3; ++c2) {
+          double tt = 0;
+          for (int k1 = 0; k1 < 3; ++k1) for (int k2 = 0; k2 < 3; ++k2) {
+            if (k1 >= r || k2 >= r) continue;
+            tt += Q[3 * k1 + c1] * Gi[3 * k1 + k2] * Q[3 * k2 + c2];
+          }
+          s.Gm[9 * f + 3 * c1 + c2] = tt;
+        }
+      }
+    });
+    // u = Gamma A_act^T b  (the point satisfying the active rows), g = -q - P u
+    ex.par([&](Th &t) {
+      if (t.tid < N) {
+        const int j = t.tid, f = j / 3;
+        double v[3];
+        for (int c = 0; c < 3; ++c) {
+          double tt = 0;
+          for (int r = 0; r < 5; ++r) {
+            const int i = 5 * f + r;
+            if (s.act[i]) tt += s.As[15 * f + 3 * r + c] * (s.act[i] < 0 ? s.ls[i] : s.us[i]);
+          }
+          v[c] = tt;
+        }
+        const double *G = s.Gm + 9 * f + 3 * (j - 3 * f);
+        s.u0[j] = G[0] * v[0] + G[1] * v[1] + G[2] * v[2];
+        s.xN[j] = 0; s.PxN[j] = 0; s.wv[j] = 0;
+      }
+    });
+    mul_P(s.u0, s.Pu);
+    // H = N~^T P N~ + delta I on the null coordinates, identity elsewhere; N~ = blockdiag([N_f | 0])
+    ex.par([&](Th &t) {
+      if (t.tid < N) s.g[t.tid] = -s.qs[t.tid] - s.Pu[t.tid];
+      if (t.row < N) {
+        const int f1 = t.row / 3, k1 = t.row - 3 * f1;
+        const double *n1 = s.Nb + 9 * f1 + 3 * k1;             // null vector k1 of foot f1 (zeros if k1 >= nn)
+        const bool rownull = k1 < s.nnull[f1];
+        const double *g0 = Pg + (size_t)(3 * f1) * N + t.part * CPT;
+#pragma unroll
+        for (int jf = 0; jf < CPT / 3; ++jf) {
+          const int f2 = (t.part * CPT) / 3 + jf;
+          double T1[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) T1[c] = n1[0] * g0[3 * jf + c] + n1[1] * g0[N + 3 * jf + c] + n1[2] * g0[2 * N + 3 * jf + c];
+          const int nn2 = s.nnull[f2];
+#pragma unroll
+          for (int k2 = 0; k2 < 3; ++k2) {
+            const int col = 3 * f2 + k2;
+            const double *n2 = s.Nb + 9 * f2 + 3 * k2;
+            double v = (rownull && k2 < nn2) ? (n2[0] * T1[0] + n2[1] * T1[1] + n2[2] * T1[2]) : 0.0;
+            if (col == t.row) { v = rownull ? v + kDelta : 1.0; s.diag[t.row] = v; }
+            t.Mx[3 * jf + k2] = v;
+          }
+        }
+      }
+    });
+    sweep_all(true);   // Mx <- -(H + delta I)^{-1} on the null coordinates
+    ex.par([&](Th &t) { if (t.tid == 0) s.nfact++; });
+    // iterative refinement in the null space (polish.c:102-160: 1 solve + 3 refinements)
+    for (int it = 0; it <= kPolishRefine; ++it) {
+      ex.par([&](Th &t) {   // rw = N~^T (g - P xN)
+        if (t.tid < N) {
+          const int j = t.tid, f = j / 3, k = j - 3 * f;
+          const double *nv = s.Nb + 9 * f + 3 * k;
+          s.rw[j] = (k < s.nnull[f]) ? nv[0] * (s.g[3 * f] - s.PxN[3 * f]) + nv[1] * (s.g[3 * f + 1] - s.PxN[3 * f + 1]) + nv[2] * (s.g[3 * f + 2] - s.PxN[3 * f + 2]) : 0.0;
+        }
+      });
+      ex.par([&](Th &t) { s.part[t.tid] = (t.row < N) ? -slice_dot(t, s.rw) : 0.0; });
+      ex.par([&](Th &t) { if (t.tid < N && s.isnull[t.tid]) s.wv[t.tid] += sum_parts(s, t.tid); });
+      ex.par([&](Th &t) {   // xN = N~ w
+        if (t.tid < N) {
+          const int j = t.tid, f = j / 3, c = j - 3 * f;
+          double v = 0;
+          for (int k = 0; k < 3; ++k) if (k < s.nnull[f]) v += s.Nb[9 * f + 3 * k + c] * s.wv[3 * f + k];
+          s.xN[j] = v;
+        }
+      });
+      mul_P(s.xN, s.PxN);
+    }
+    // x = u + xN ; y = A Gamma (g - P xN) on active rows ; z = A x ; normal-cone projection (proj.c:17-31)
+    ex.par([&](Th &t) {
+      if (t.tid < N) {
+        const int j = t.tid, f = j / 3;
+        s.xt[j] = s.u0[j] + s.xN[j];                                   // polished x (scaled)
+        const double *G = s.Gm + 9 * f + 3 * (j - 3 * f);
+        s.rw[j] = G[0] * (s.g[3 * f] - s.PxN[3 * f]) + G[1] * (s.g[3 * f + 1] - s.PxN[3 * f + 1]) + G[2] * (s.g[3 * f + 2] - s.PxN[3 * f + 2]);
+      }
+    });
+    ex.par([&](Th &t) {
+      if (t.tid < M) {
+        const int i = t.tid;
+        const double yv = s.act[i] ? a_row_dot(s, i, s.rw) : 0.0;
+        const double tt = a_row_dot(s, i, s.xt) + yv;
+        const double zc = clampd(tt, s.ls[i], s.us[i]);
+        s.zpol[i] = zc;
+        s.ypol[i] = tt - zc;
+      }
+    });
+    // residuals at the polished point, acceptance (polish.c:306-345)
+    const double pri0 = s.pri_res, dua0 = s.dua_res;
+    residuals(s.xt, s.zpol, s.ypol);
+    ex.par([&](Th &t) {
+      if (t.tid == 0) {
+        const double pri = bitsd(s.red[0]), dua = s.cinv * bitsd(s.red[6]);
+        const bool ok = !s.bad && ((pri < pri0 && dua < dua0) || (pri < pri0 && dua0 < 1e-10) || (dua < dua0 && pri0 < 1e-10));
+        s.status_polish = ok ? 1 : -1;
+        if (ok) { s.pri_res = pri; s.dua_res = dua; }
+      }
+    });
+    ex.par([&](Th &t) {
+      if (s.status_polish == 1) {
+        if (t.tid < N) s.x[t.tid] = s.xt[t.tid];
+        if (t.tid < M) { s.z[t.tid] = s.zpol[t.tid]; s.y[t.tid] = s.ypol[t.tid]; }
+      }
+    });
+  }
+
+  // ================================ driver ======================================================
+  MPC_HD void run() {
+    assemble();
+    scale();
+    set_rho_vec();
+    factor(false);
+    admm_prepare();
+    int iter = 0;
+    while (!s.done && !s.bad && iter < kMaxIter) {
+      ++iter;
+      admm_iter();
+      if (iter % kCheck == 0) {
+        residuals(s.x, s.z, s.y);
+        check_and_adapt(iter);
+        if (!s.done && s.rho_new > 0) {          // osqp_update_rho: new rho_vec, refactor
+          ex.par([&](Th &t) { if (t.tid == 0) { s.rho = s.rho_new; s.rho_updates++; } });
+          set_rho_vec();
+          factor(true);
+          admm_prepare();
+        }
+      }
+    }
+    if (!s.done && !s.bad) {   // max_iter reached (osqp.c:564-568): only SOLVED counts for the reference
+      ex.par([&](Th &t) { if (t.tid == 0) s.status = kStMaxIter; });
+    }
+    if (s.status == kStSolved && !s.bad) polish();
+    // outputs + persistent state (store_solution, auxil.c:528-561; mpc_osqp.cc:788-790: forces = -x)
+    ex.par([&](Th &t) {
+      const bool solved = s.status == kStSolved && !s.bad;
+      if (t.tid < N) {
+        if (solved) forces[t.tid] = -(s.D[t.tid] * s.x[t.tid]);
+        state[t.tid] = s.x[t.tid];
+        state[N + 2 * M + t.tid] = s.q[t.tid];
+      }
+      if (t.tid < M) { state[N + t.tid] = s.z[t.tid]; state[N + M + t.tid] = s.y[t.tid]; }
+      if (t.tid == 0) {
+        state[2 * N + 2 * M] = s.rho;
+        state[2 * N + 2 * M + 1] = 1.0;
+        info[0] = s.iter; info[1] = s.bad ? kStNonCvx : s.status; info[2] = s.status_polish; info[3] = s.rho_updates;
+        info[4] = s.nfact; info[5] = s.first; info[6] = 0; info[7] = 0;
+      }
+    });
+  }
+};
+
+}  // namespace mpc

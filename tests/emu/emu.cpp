@@ -1,0 +1,88 @@
+// tests/emu/emu.cpp -- HOST EMULATION of the device solver (TEST ONLY; never used by the product).
+// Compiles rl-mpc-locomotion_amd/csrc/mpc_core.h with g++ and runs each barrier-separated phase for
+// all emulated threads sequentially (forward or reverse order: identical results are required, which
+// exposes intra-phase races).  Lets the CPU test-suite check the kernel's algorithm against the
+// oracle without a GPU.
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "mpc_core.h"
+#include "mpc_model.h"
+
+using namespace mpc;
+
+template <int H>
+struct HostExec {
+  std::vector<Thread<H>> th;
+  bool reverse;
+  long phases = 0;
+  explicit HostExec(bool rev) : th(Cfg<H>::T), reverse(rev) {
+    for (int i = 0; i < Cfg<H>::T; ++i) {
+      th[i].tid = i; th[i].row = i / Cfg<H>::S; th[i].part = i % Cfg<H>::S; th[i].xprev = 0; th[i].zprev = 0;
+      for (int j = 0; j < Cfg<H>::CPT; ++j) th[i].Mx[j] = 0;
+    }
+  }
+  template <class F> void par(F &&f) {
+    ++phases;
+    if (!reverse) for (int i = 0; i < Cfg<H>::T; ++i) f(th[i]);
+    else for (int i = Cfg<H>::T - 1; i >= 0; --i) f(th[i]);
+  }
+  void amax(unsigned long long *slot, double v) {
+    const unsigned long long b = dbits(v);
+    if (b > *slot) *slot = b;
+  }
+};
+
+template <int H>
+static void solve_one(const RobotModel &mdl, const float *in, double *state, double *Pg, double *forces, int *info, bool reverse, long *phases) {
+  HostExec<H> ex(reverse);
+  Shared<H> *sh = new Shared<H>();
+  std::memset(sh, 0, sizeof(Shared<H>));
+  Solver<H, HostExec<H>> sv{ex, *sh, mdl, in, state, Pg, forces, info};
+  sv.run();
+  if (phases) *phases = ex.phases;
+  delete sh;
+}
+
+extern "C" {
+
+int emu_state_len(int h) { return 24 * h + 40 * h + 2; }
+int emu_shared_bytes(int h) { return h == 10 ? (int)sizeof(Shared<10>) : h == 16 ? (int)sizeof(Shared<16>) : h == 20 ? (int)sizeof(Shared<20>) : h == 6 ? (int)sizeof(Shared<6>) : -1; }
+
+// model: per robot {mass, inertia9[9]} (10 doubles); in: [n][56+4h] floats; state: [n][state_len];
+// forces: [n][12h]; info: [n][8].  Returns -1 for an unsupported horizon.
+int emu_batch_solve(int h, int n, const double *model, double dt, double alpha, const float *in, double *state,
+                    double *forces, int *info, int reverse, int nthreads, long *phases_out) {
+  if (h != 10 && h != 16 && h != 20 && h != 6) return -1;
+  const int N = 12 * h, inlen = 56 + 4 * h, sl = emu_state_len(h);
+  if (nthreads < 1) nthreads = 1;
+  std::vector<std::thread> pool;
+  auto work = [&](int lo, int hi) {
+    std::vector<double> Pg((size_t)N * N);
+    for (int r = lo; r < hi; ++r) {
+      RobotModel mdl = make_model(model[10 * r], model + 10 * r + 1, dt, alpha);
+      long ph = 0;
+      const float *ri = in + (size_t)r * inlen;
+      double *rs = state + (size_t)r * sl, *rf = forces + (size_t)r * N;
+      int *rinfo = info + (size_t)r * kInfoLen;
+      switch (h) {
+        case 6: solve_one<6>(mdl, ri, rs, Pg.data(), rf, rinfo, reverse, &ph); break;
+        case 10: solve_one<10>(mdl, ri, rs, Pg.data(), rf, rinfo, reverse, &ph); break;
+        case 16: solve_one<16>(mdl, ri, rs, Pg.data(), rf, rinfo, reverse, &ph); break;
+        case 20: solve_one<20>(mdl, ri, rs, Pg.data(), rf, rinfo, reverse, &ph); break;
+      }
+      if (phases_out) phases_out[r] = ph;
+    }
+  };
+  const int per = (n + nthreads - 1) / nthreads;
+  for (int t = 0; t < nthreads; ++t) {
+    const int lo = t * per, hi = std::min(n, (t + 1) * per);
+    if (lo >= hi) break;
+    if (nthreads == 1) work(lo, hi); else pool.emplace_back(work, lo, hi);
+  }
+  for (auto &t : pool) t.join();
+  return 0;
+}
+}

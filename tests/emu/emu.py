@@ -1,0 +1,42 @@
+"""ctypes wrapper of the host emulation of the device solver (TEST ONLY)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        subprocess.run(["make", "-C", _HERE], check=True, stdout=subprocess.DEVNULL)
+        _LIB = C.CDLL(os.path.join(_HERE, "_build", "libmpc_emu.so"))
+        _LIB.emu_batch_solve.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    return _LIB
+
+
+class EmuBatch:
+    def __init__(self, mass, inertia_diag, h, dt, alpha):
+        n = len(mass)
+        self.n, self.h, self.dt, self.alpha = n, h, dt, alpha
+        self.model = np.zeros((n, 10))
+        self.model[:, 0] = mass
+        self.model[:, 1] = inertia_diag[:, 0]
+        self.model[:, 5] = inertia_diag[:, 1]
+        self.model[:, 9] = inertia_diag[:, 2]
+        self.state = np.zeros((n, lib().emu_state_len(h)))
+        self.info = np.zeros((n, 8), dtype=np.int32)
+        self.phases = np.zeros(n, dtype=np.int64)
+
+    def solve(self, records, reverse=False, nthreads=8):
+        rec = np.ascontiguousarray(records, dtype=np.float32)
+        out = np.full((self.n, 12 * self.h), np.nan)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        rc = lib().emu_batch_solve(self.h, self.n, p(self.model), self.dt, self.alpha, p(rec), p(self.state), p(out),
+                                   p(self.info), int(reverse), nthreads, p(self.phases))
+        assert rc == 0
+        return out
