@@ -1,0 +1,169 @@
+#!/usr/bin/env python
+"""bench.py -- MPC control steps/s of the batched convex-MPC contact-force solve on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+A "step" = one pass of the hot path over one batch of synthetic input: every robot of the batch does
+one ``compute_contact_forces`` (QP build + OSQP-equivalent solve, mpc_osqp.cc:578-796) on the GPU.
+Workload at N=1: BASELINE.json configs[1] -- 4096 Aliengo, trot, horizon 10, flat terrain.  The K+W
+input batches are a seeded sequence: step 0 is the cold "osqp_setup" solve, the
+following ones advance the gait and perturb the state, so the timed steps are warm-started solves,
+as in the reference's control loop.  Inputs are resident in HBM before the timed region.
+Multi-GPU: robots shard across ranks (weak scaling, 4096 per GPU, no data-path collective).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (vector)"; SURVEY.md 8(d) prices against it
+FP64_VECTOR_PEAK_TFLOPS = 78.6    # datasheet fp64 vector rate (half the fp32 rate); the kernel computes in fp64
+
+
+def algorithmic_flops(h, contact, iters, nfact):
+    """SURVEY.md 8(d) minimal-algorithm flop count per control step, summed over the batch.
+    n_r = 3 * (stance leg-steps in the horizon); I = ADMM iterations executed; F = factorisations."""
+    n_r = 3.0 * contact.reshape(len(contact), -1).sum(1)
+    fixed = 4056.0 * (h - 1) + 3900.0 * h * (h + 1) / 2 + 2.0 * 13 * h * (13 + 12 * h)
+    per = fixed + nfact * n_r ** 3 / 3.0 + iters * (2.0 * n_r ** 2 + 40.0 * n_r)
+    return float(per.sum())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--robots", type=int, default=4096, help="robots per GPU")
+    ap.add_argument("--horizon", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import rl_mpc_locomotion_amd  # noqa: F401
+    from rl_mpc_locomotion_amd import layout as L
+    from rl_mpc_locomotion_amd.batched import BatchedConvexMpc
+    from rl_mpc_locomotion_amd.synthetic import make_solver_workload, perturb_workload
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+
+    n, h, K, W = args.robots, args.horizon, args.steps, args.warmup
+    # this rank's shard of the global batch: robots [rank*n, (rank+1)*n) of a world*n batch
+    wl = make_solver_workload(n, h=h, seed=1000 + rank, config=2)
+    batches = []
+    w = wl
+    for s in range(K + W):
+        batches.append(w.inputs)
+        w = perturb_workload(w, 7000 + 131 * s + rank)
+    d_in = [torch.from_numpy(b).to(dev) for b in batches]          # resident in HBM before timing
+    inertia9 = np.zeros((n, 9)); inertia9[:, 0], inertia9[:, 4], inertia9[:, 8] = wl.inertia_diag.T
+    solver = BatchedConvexMpc(wl.mass, inertia9, h, wl.dt_mpc, wl.alpha, device=dev)
+    infos = [torch.zeros((n, 8), dtype=torch.int32, device=dev) for _ in range(K)]
+
+    for s in range(W):
+        solver.solve(d_in[s])
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for s in range(K):
+        ev[s][0].record()                      # HIP events on the stream the kernel is launched on
+        solver.solve(d_in[W + s], info=infos[s])
+        ev[s][1].record()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernel_ms = np.array([a.elapsed_time(b) for a, b in ev])
+    info = torch.stack(infos).cpu().numpy()                         # [K, n, 8]
+    solved = int((info[..., 1] == 1).sum())
+    flops = 0.0
+    for s in range(K):
+        contact = batches[W + s][:, L.IN_CONTACT:L.IN_CONTACT + 4 * h]
+        flops += algorithmic_flops(h, contact, info[s, :, 0].astype(np.float64), info[s, :, 4].astype(np.float64))
+    flops_per_launch = flops / K
+    achieved_tflops = flops_per_launch / (kernel_ms.mean() * 1e-3) / 1e12
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    value = world * n * K / elapsed
+    out = {
+        "metric": "MPC control steps/sec (whole node) @ horizon=10, 4096 robots; max |GRF| err vs OSQP",
+        "value": value,
+        "unit": "control steps/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"{n} Aliengo/GPU, trot, horizon={h}, flat terrain, 1 compute_contact_forces per robot per step "
+                               "(BASELINE configs[1]); warm-started seeded sequence, SURVEY.md 8(d)",
+                   "robots_per_gpu": n, "horizon": h, "parallelism": f"robot-sharded x{world}"},
+        "solved_fraction": solved / float(K * n),
+        "mean_admm_iters": float(info[..., 0].mean()),
+        "mean_factorisations": float(info[..., 4].mean()),
+        "roofline": {"bound": "mfma", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": None,
+                     "note": "vector-FP bound, no MFMA/HBM roofline applies (SURVEY 8d): algorithmic flops (n_r formula) / "
+                             "mean kernel time from HIP events; kernel arithmetic is fp64 (peak 78.6 TF)",
+                     "kernel_ms": float(kernel_ms.mean()), "flops_per_launch": flops_per_launch,
+                     "frac_fp64_peak": achieved_tflops / FP64_VECTOR_PEAK_TFLOPS},
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(wl, batches, W, h)
+        out["max_grf_err_vs_osqp"] = out["cpu_baseline"].pop("_gpu_err", None)
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(wl, batches, W, h, sample=256, steps=4):
+    """The reference path (oracle/_ref: restated mpc_osqp.cc assembly + the vendored OSQP) timed on the
+    host cores on a bounded sample of the same workload: the first `sample` robots, cold solve +
+    `steps` timed warm solves (the same batches the GPU warmed up / timed on)."""
+    from oracle.refmpc import RefBatch
+    cores = len(os.sched_getaffinity(0))
+    ref = RefBatch(wl.mass[:sample], wl.inertia_diag[:sample], h, wl.dt_mpc, wl.alpha)
+    for s in range(W):
+        ref.solve(batches[s][:sample], nthreads=cores)
+    t0 = time.perf_counter()
+    for s in range(steps):
+        ref.solve(batches[W + s][:sample], nthreads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": sample * steps / dt, "unit": "control steps/s", "cores": cores, "kind": "reference",
+            "sample": f"first {sample} robots of the workload, {W} warm-up + {steps} timed warm-started solves each, "
+                      f"one OSQP workspace per robot, static partition over {cores} threads"}
+
+
+if __name__ == "__main__":
+    main()

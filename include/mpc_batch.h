@@ -1,0 +1,94 @@
+/*
+ * include/mpc_batch.h -- C ABI of the MI355X batched convex-MPC contact-force solver.
+ *
+ * Drop-in boundary.  Each entry point names the reference interface it replaces
+ * (paths relative to the reference repository, silvery107/rl-mpc-locomotion):
+ *
+ *   mpc_batch_create   <- mpc_osqp.ConvexMpc(mass, inertia[9], num_legs=4, planning_horizon, timestep,
+ *                         alpha, qp_solver_name)            MPC_Controller/convex_MPC/mpc_osqp.cc:508-574,
+ *                         call site ConvexMPCLocomotion.py:102-108 -- one object per robot there, one
+ *                         batch handle for N robots here.
+ *   mpc_batch_solve    <- ConvexMpc.compute_contact_forces(13 args) -> list[12 h]
+ *                                                           mpc_osqp.cc:578-796, call site
+ *                         ConvexMPCLocomotion.py:171-185, looped over robots at
+ *                         RL_Environment/tasks/aliengo.py:252-256.
+ *   mpc_batch_reset    <- the re-construction of ConvexMpc in ConvexMPCLocomotion.initialize
+ *                         (ConvexMPCLocomotion.py:89-108) reached from controllers[idx].reset(),
+ *                         RL_Environment/tasks/aliengo.py:333-334: the next solve of that robot is a cold
+ *                         "osqp_setup" solve (x = y = z = 0, rho = 0.1).
+ *   mpc_batch_destroy  <- ~ConvexMpc (osqp_cleanup), mpc_osqp.cc:192.
+ *
+ * Input record (float32, length 56 + 4 h per robot): the 13 positional arguments of
+ * compute_contact_forces concatenated in call order --
+ *   [0,13)  qp_weights             [13,16) com_position        [16,19) com_velocity
+ *   [19,22) com_roll_pitch_yaw     [22,25) ground_normal_vec   [25,28) com_angular_velocity
+ *   [28,28+4h) foot_contact_states, row-major [step][leg]
+ *   then foot_positions_body_frame[12] ([leg][xyz]), foot_friction_coeffs[4], desired_com_position[3],
+ *   desired_com_velocity[3], desired_com_roll_pitch_yaw[3], desired_com_angular_velocity[3].
+ * (The reference's Python passes float32 / float16 values; pybind11 widens them to double, which the
+ * kernel does as well.  All arithmetic is fp64.)
+ *
+ * Output: forces, fp64, 12 h per robot, [step][leg][xyz], already negated like mpc_osqp.cc:789-790.
+ * Error behaviour: the reference returns an EMPTY list unless OSQP reports OSQP_SOLVED
+ * (mpc_osqp.cc:781-794).  Here the robot's force row is left untouched and info[1] (status) != 1.
+ *
+ * info record (int32, 8 per robot): {iterations, osqp status_val, status_polish, rho_updates,
+ * factorisations, first_run, 0, 0}.
+ *
+ * All pointers named d_* are DEVICE pointers (HBM); `stream` is a hipStream_t (0 = default stream).
+ * Functions return 0 on success, a negative MPC_E_* code otherwise; mpc_last_error() gives the text.
+ */
+#ifndef MPC_BATCH_H
+#define MPC_BATCH_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mpc_batch mpc_batch;
+
+enum {
+  MPC_OK = 0,
+  MPC_E_ARG = -1,        /* bad argument (null pointer, n <= 0, ...) */
+  MPC_E_HORIZON = -2,    /* planning horizon not compiled in (supported: see mpc_supported_horizons) */
+  MPC_E_HIP = -3,        /* HIP runtime error */
+  MPC_E_NODEVICE = -4    /* no usable GPU */
+};
+
+#define MPC_INFO_LEN 8
+#define MPC_STATUS_SOLVED 1           /* OSQP_SOLVED */
+#define MPC_STATUS_MAX_ITER (-2)      /* OSQP_MAX_ITER_REACHED */
+#define MPC_STATUS_NON_CVX (-7)       /* OSQP_NON_CVX (also: KKT matrix not positive definite) */
+
+int mpc_input_len(int horizon);                       /* 56 + 4 h */
+int mpc_supported_horizons(int *out, int cap);        /* writes up to cap horizons, returns the count */
+
+/* mass[n], inertia9[n*9] (row-major 3x3 per robot) are HOST arrays. */
+int mpc_batch_create(mpc_batch **out, int n_robots, int horizon, double timestep, double alpha,
+                     const double *mass, const double *inertia9);
+void mpc_batch_destroy(mpc_batch *b);
+
+/* d_in: [n, 56+4h] float32; d_forces: [n, 12h] float64; d_info: [n, 8] int32 (may be NULL). */
+int mpc_batch_solve(mpc_batch *b, const float *d_in, double *d_forces, int *d_info, void *stream);
+
+/* Cold-start the listed robots (HOST array of indices); ids == NULL resets all. */
+int mpc_batch_reset(mpc_batch *b, const int *ids, int k, void *stream);
+
+/* Convenience for the per-robot plugin seam: host buffers, synchronous. */
+int mpc_batch_solve_host(mpc_batch *b, const float *h_in, double *h_forces, int *h_info);
+
+int mpc_batch_size(const mpc_batch *b);
+int mpc_batch_horizon(const mpc_batch *b);
+/* Bytes of HBM the handle owns (state + scratch + models). */
+long long mpc_batch_device_bytes(const mpc_batch *b);
+/* Warm-start state access (determinism tests / checkpointing): [n, 64 h + 2] float64. */
+int mpc_batch_state_len(const mpc_batch *b);
+int mpc_batch_get_state(mpc_batch *b, double *h_state);
+int mpc_batch_set_state(mpc_batch *b, const double *h_state);
+
+const char *mpc_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPC_BATCH_H */

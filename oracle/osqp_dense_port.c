@@ -765,7 +765,7 @@ static int polish_reduced(Port *s) {
         const REAL *row = s->Ps + (size_t)i * n + 3 * f;
         W[(size_t)i * nw + fb[f].col0 + k] = row[0] * fb[f].N[3 * k] + row[1] * fb[f].N[3 * k + 1] + row[2] * fb[f].N[3 * k + 2];
       }
-  const int no_corr = getenv("PORT_POLISH_NOCORR") != 0;
+  const int no_corr = getenv("PORT_POLISH_CORR") == 0;   /* the O(delta) Schur correction is not needed (tests) */
   for (int f = 0; f < nf; ++f)
     for (int a = 0; a < 3; ++a)
       for (int w2 = 0; w2 < nw; ++w2)
@@ -800,7 +800,7 @@ static int polish_reduced(Port *s) {
     REAL *r1 = ralloc(n), *r2 = ralloc(m), *x = ralloc(n), *y = ralloc(m), *dx = ralloc(n), *dy = ralloc(m), *e1 = ralloc(n), *e2 = ralloc(m), *wk = ralloc(8 * n + m);
     for (int i = 0; i < n; ++i) r1[i] = -s->qs[i];
     for (int i = 0; i < m; ++i) r2[i] = act[i] < 0 ? s->ls[i] : (act[i] > 0 ? s->us[i] : 0);
-    if (getenv("PORT_POLISH_PROJ")) {
+    if (!getenv("PORT_POLISH_FULL")) {
       /* projected form: range part exact (u), iterative refinement only in the null space */
       REAL *u = wk, *Pu = u + n, *g = Pu + n, *xN = g + n, *PxN = xN + n, *rw = PxN + n, *wv = rw + n, *v = wv + n;
       mul_At_act(s, act, r2, v); mul_gamma(fb, nf, v, u); mul_P(s, u, Pu);
@@ -926,7 +926,12 @@ int port_solve(void *hd, const double *in, double *forces_out, int64_t *info, do
       REAL mx = 0, nx = 0; for (int i = 0; i < n; ++i) { REAL d = fabs(kx[i] - s->x[i]); if (d > mx) mx = d; if (fabs(s->x[i]) > nx) nx = fabs(s->x[i]); }
       fprintf(stderr, "polish dbg: kkt ok=%d pri %.3e dua %.3e | ns ok=%d pri %.3e dua %.3e | admm pri %.3e dua %.3e | dx %.3e / %.3e\n", ok1, (double)p1, (double)d1, ok2, (double)s->pri_res, (double)s->dua_res, (double)p0, (double)d0, (double)mx, (double)nx);
       free(sx); free(sz); free(sy); free(kx);
-    } else if (getenv("PORT_POLISH_KKT")) polish_kkt(s); else if (getenv("PORT_POLISH_RED")) polish_reduced(s); else polish(s);
+    } else {
+      const char *pm = getenv("PORT_POLISH");   /* default: the form the HIP kernel runs */
+      if (pm && !strcmp(pm, "kkt")) polish_kkt(s);            /* literal polish.c (dense LU), checker of the reduced form */
+      else if (pm && !strcmp(pm, "exact")) polish(s);          /* delta -> 0 limit, for comparison only */
+      else polish_reduced(s);
+    }
   }
   int has_sol = !(s->status == ST_PRIMAL_INF || s->status == ST_PRIMAL_INF_INACC || s->status == ST_DUAL_INF ||
                   s->status == ST_DUAL_INF_INACC || s->status == ST_NON_CVX);

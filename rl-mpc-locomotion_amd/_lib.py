@@ -1,0 +1,52 @@
+"""ctypes loader of the C-ABI library (include/mpc_batch.h).  There is NO fallback: if the HIP
+library is missing or no GPU is usable, every entry point raises -- the product path never routes
+through a CPU implementation."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmpc_batch.so")
+_LIB = None
+
+MPC_OK = 0
+SYMBOLS = [
+    "mpc_input_len", "mpc_supported_horizons", "mpc_batch_create", "mpc_batch_destroy", "mpc_batch_solve",
+    "mpc_batch_reset", "mpc_batch_solve_host", "mpc_batch_size", "mpc_batch_horizon", "mpc_batch_device_bytes",
+    "mpc_batch_state_len", "mpc_batch_get_state", "mpc_batch_set_state", "mpc_last_error",
+]
+
+
+class MpcLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise MpcLibraryError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        vp, ci, cd = C.c_void_p, C.c_int, C.c_double
+        L.mpc_input_len.argtypes = [ci]; L.mpc_input_len.restype = ci
+        L.mpc_supported_horizons.argtypes = [vp, ci]; L.mpc_supported_horizons.restype = ci
+        L.mpc_batch_create.argtypes = [C.POINTER(vp), ci, ci, cd, cd, vp, vp]; L.mpc_batch_create.restype = ci
+        L.mpc_batch_destroy.argtypes = [vp]; L.mpc_batch_destroy.restype = None
+        L.mpc_batch_solve.argtypes = [vp, vp, vp, vp, vp]; L.mpc_batch_solve.restype = ci
+        L.mpc_batch_reset.argtypes = [vp, vp, ci, vp]; L.mpc_batch_reset.restype = ci
+        L.mpc_batch_solve_host.argtypes = [vp, vp, vp, vp]; L.mpc_batch_solve_host.restype = ci
+        L.mpc_batch_size.argtypes = [vp]; L.mpc_batch_size.restype = ci
+        L.mpc_batch_horizon.argtypes = [vp]; L.mpc_batch_horizon.restype = ci
+        L.mpc_batch_device_bytes.argtypes = [vp]; L.mpc_batch_device_bytes.restype = C.c_longlong
+        L.mpc_batch_state_len.argtypes = [vp]; L.mpc_batch_state_len.restype = ci
+        L.mpc_batch_get_state.argtypes = [vp, vp]; L.mpc_batch_get_state.restype = ci
+        L.mpc_batch_set_state.argtypes = [vp, vp]; L.mpc_batch_set_state.restype = ci
+        L.mpc_last_error.argtypes = []; L.mpc_last_error.restype = C.c_char_p
+        _LIB = L
+    return _LIB
+
+
+def check(rc, what):
+    if rc != MPC_OK:
+        raise MpcLibraryError(f"{what} failed ({rc}): {lib().mpc_last_error().decode()}")

@@ -1,0 +1,78 @@
+"""Batched contact-force solver: N robots' ``ConvexMpc`` objects behind one handle.
+
+Host-side mirror of the reference's per-robot plugin object (``mpc_osqp.ConvexMpc``,
+mpc_osqp.cc:952-983) for a whole batch: construction = N constructor calls
+(ConvexMPCLocomotion.py:102-108), ``solve`` = N ``compute_contact_forces`` calls
+(ConvexMPCLocomotion.py:171-185, looped at RL_Environment/tasks/aliengo.py:252-256),
+``reset(env_ids)`` = re-construction for those robots (aliengo.py:333-334).  torch is used for device
+memory and streams only.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .layout import in_len
+
+STATUS_SOLVED = 1
+
+
+class BatchedConvexMpc:
+    def __init__(self, mass, inertia9, planning_horizon, timestep, alpha=1e-5, device=None):
+        """mass: [N] floats; inertia9: [N, 9] row-major 3x3 body inertias (host arrays)."""
+        import torch
+        if not torch.cuda.is_available():
+            raise _lib.MpcLibraryError("BatchedConvexMpc needs a GPU (torch.cuda.is_available() is False); no CPU fallback")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        torch.cuda.set_device(self.device)
+        mass = np.ascontiguousarray(mass, dtype=np.float64).reshape(-1)
+        inertia9 = np.ascontiguousarray(inertia9, dtype=np.float64).reshape(len(mass), 9)
+        self.n, self.h = len(mass), int(planning_horizon)
+        self.in_len = in_len(self.h)
+        self._handle = C.c_void_p()
+        L = _lib.lib()
+        _lib.check(L.mpc_batch_create(C.byref(self._handle), self.n, self.h, float(timestep), float(alpha),
+                                      mass.ctypes.data, inertia9.ctypes.data), "mpc_batch_create")
+        self.forces = torch.zeros((self.n, 12 * self.h), dtype=torch.float64, device=self.device)
+        self.info = torch.zeros((self.n, 8), dtype=torch.int32, device=self.device)
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h:
+            _lib.lib().mpc_batch_destroy(h)
+            self._handle = None
+
+    def solve(self, inputs, forces=None, info=None):
+        """inputs: cuda float32 [N, 56+4h] (layout.py).  Returns (forces f64 [N,12h], info i32 [N,8]).
+        Rows whose info[:,1] != 1 (not OSQP_SOLVED) keep their previous forces (the reference returns
+        an empty list there, mpc_osqp.cc:781-794)."""
+        import torch
+        if inputs.dtype != torch.float32 or not inputs.is_cuda or not inputs.is_contiguous() or tuple(inputs.shape) != (self.n, self.in_len):
+            raise ValueError(f"inputs must be a contiguous cuda float32 tensor of shape {(self.n, self.in_len)}")
+        forces = self.forces if forces is None else forces
+        info = self.info if info is None else info
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.lib().mpc_batch_solve(self._handle, inputs.data_ptr(), forces.data_ptr(), info.data_ptr(), stream),
+                   "mpc_batch_solve")
+        return forces, info
+
+    def reset(self, env_ids=None):
+        import torch
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        if env_ids is None:
+            _lib.check(_lib.lib().mpc_batch_reset(self._handle, None, 0, stream), "mpc_batch_reset")
+            return
+        ids = np.ascontiguousarray(env_ids.detach().cpu().numpy() if hasattr(env_ids, "detach") else env_ids, dtype=np.int32)
+        _lib.check(_lib.lib().mpc_batch_reset(self._handle, ids.ctypes.data, len(ids), stream), "mpc_batch_reset")
+
+    def device_bytes(self):
+        return _lib.lib().mpc_batch_device_bytes(self._handle)
+
+    def get_state(self):
+        out = np.zeros((self.n, _lib.lib().mpc_batch_state_len(self._handle)))
+        _lib.check(_lib.lib().mpc_batch_get_state(self._handle, out.ctypes.data), "mpc_batch_get_state")
+        return out
+
+    def set_state(self, state):
+        st = np.ascontiguousarray(state, dtype=np.float64)
+        _lib.check(_lib.lib().mpc_batch_set_state(self._handle, st.ctypes.data), "mpc_batch_set_state")

@@ -1,0 +1,213 @@
+// mpc_batch.hip -- gfx950 kernels + the C ABI of include/mpc_batch.h.
+// One workgroup per robot; the algorithm itself is mpc_core.h (phase-structured, fp64).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mpc_batch.h"
+#include "mpc_core.h"
+#include "mpc_model.h"
+
+using namespace mpc;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) return fail(MPC_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+template <int H>
+struct DeviceExec {
+  Thread<H> &th;
+  template <class F>
+  __device__ __forceinline__ void par(F &&f) {
+    f(th);
+    __syncthreads();
+  }
+  __device__ __forceinline__ void amax(unsigned long long *slot, double v) { atomicMax(slot, dbits(v)); }
+};
+
+template <int H>
+__global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= 256 ? 2 : 1)) void mpc_solve_kernel(int n, const RobotModel *__restrict__ models,
+                                                               const float *__restrict__ in, double *__restrict__ state,
+                                                               double *__restrict__ scratch, double *__restrict__ forces,
+                                                               int *__restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Shared<H> &sh = *reinterpret_cast<Shared<H> *>(smem);
+  using C = Cfg<H>;
+  const int robot = blockIdx.x;
+  if (robot >= n) return;
+  Thread<H> th;
+  th.tid = threadIdx.x;
+  th.row = threadIdx.x / C::S;
+  th.part = threadIdx.x % C::S;
+  th.xprev = 0;
+  th.zprev = 0;
+#pragma unroll
+  for (int j = 0; j < C::CPT; ++j) th.Mx[j] = 0;
+  DeviceExec<H> ex{th};
+  const RobotModel mdl = models[robot];
+  Solver<H, DeviceExec<H>> sv{ex,
+                              sh,
+                              mdl,
+                              in + (size_t)robot * C::IN_LEN,
+                              state + (size_t)robot * state_len<H>(),
+                              scratch + (size_t)robot * C::N * C::N,
+                              forces + (size_t)robot * C::N,
+                              info + (size_t)robot * kInfoLen};
+  sv.run();
+}
+
+__global__ void reset_kernel(double *state, int state_len, const int *ids, int k, int n) {
+  const int r = blockIdx.x;
+  const int robot = ids ? ids[r] : r;
+  if (r >= k || robot < 0 || robot >= n) return;
+  for (int i = threadIdx.x; i < state_len; i += blockDim.x) state[(size_t)robot * state_len + i] = 0.0;
+}
+
+template <int H>
+int launch(int n, const RobotModel *models, const float *in, double *state, double *scratch, double *forces, int *info,
+           hipStream_t stream) {
+  static bool attr_set = false;
+  const size_t shbytes = sizeof(Shared<H>);
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(mpc_solve_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shbytes));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(mpc_solve_kernel<H>, dim3(n), dim3(Cfg<H>::T), shbytes, stream, n, models, in, state, scratch, forces, info);
+  HIP_TRY(hipGetLastError());
+  return MPC_OK;
+}
+
+}  // namespace
+
+struct mpc_batch {
+  int n = 0, h = 0;
+  int state_len = 0;
+  RobotModel *d_models = nullptr;
+  double *d_state = nullptr, *d_scratch = nullptr;
+  int *d_info = nullptr;   // used when the caller passes no info buffer
+  long long bytes = 0;
+};
+
+extern "C" {
+
+const char *mpc_last_error(void) { return g_err.c_str(); }
+int mpc_input_len(int horizon) { return 56 + 4 * horizon; }
+int mpc_supported_horizons(int *out, int cap) {
+  const int hs[] = {10, 16};
+  const int cnt = (int)(sizeof hs / sizeof *hs);
+  for (int i = 0; i < cnt && i < cap; ++i) out[i] = hs[i];
+  return cnt;
+}
+
+int mpc_batch_create(mpc_batch **out, int n, int horizon, double timestep, double alpha, const double *mass,
+                     const double *inertia9) {
+  if (!out || n <= 0 || !mass || !inertia9) return fail(MPC_E_ARG, "mpc_batch_create: bad argument");
+  if (horizon != 10 && horizon != 16) return fail(MPC_E_HORIZON, "mpc_batch_create: horizon not compiled in (10, 16)");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MPC_E_NODEVICE, "mpc_batch_create: no HIP device");
+  mpc_batch *b = new mpc_batch();
+  b->n = n;
+  b->h = horizon;
+  const size_t N = 12 * (size_t)horizon;
+  b->state_len = (int)(64 * horizon + 2);
+  std::vector<RobotModel> models(n);
+  for (int i = 0; i < n; ++i) models[i] = make_model(mass[i], inertia9 + 9 * (size_t)i, timestep, alpha);
+  auto cleanup = [&]() { mpc_batch_destroy(b); };
+  hipError_t e;
+  if ((e = hipMalloc(&b->d_models, sizeof(RobotModel) * n)) != hipSuccess ||
+      (e = hipMalloc(&b->d_state, sizeof(double) * (size_t)n * b->state_len)) != hipSuccess ||
+      (e = hipMalloc(&b->d_scratch, sizeof(double) * (size_t)n * N * N)) != hipSuccess ||
+      (e = hipMalloc(&b->d_info, sizeof(int) * (size_t)n * kInfoLen)) != hipSuccess ||
+      (e = hipMemcpy(b->d_models, models.data(), sizeof(RobotModel) * n, hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemset(b->d_state, 0, sizeof(double) * (size_t)n * b->state_len)) != hipSuccess) {
+    cleanup();
+    return fail(MPC_E_HIP, std::string("mpc_batch_create: ") + hipGetErrorString(e));
+  }
+  b->bytes = (long long)(sizeof(RobotModel) * n + sizeof(double) * (size_t)n * (b->state_len + N * N) + sizeof(int) * (size_t)n * kInfoLen);
+  *out = b;
+  return MPC_OK;
+}
+
+void mpc_batch_destroy(mpc_batch *b) {
+  if (!b) return;
+  if (b->d_models) (void)hipFree(b->d_models);
+  if (b->d_state) (void)hipFree(b->d_state);
+  if (b->d_scratch) (void)hipFree(b->d_scratch);
+  if (b->d_info) (void)hipFree(b->d_info);
+  delete b;
+}
+
+int mpc_batch_solve(mpc_batch *b, const float *d_in, double *d_forces, int *d_info, void *stream) {
+  if (!b || !d_in || !d_forces) return fail(MPC_E_ARG, "mpc_batch_solve: bad argument");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int *info = d_info ? d_info : b->d_info;
+  switch (b->h) {
+    case 10: return launch<10>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, d_forces, info, st);
+    case 16: return launch<16>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, d_forces, info, st);
+  }
+  return fail(MPC_E_HORIZON, "mpc_batch_solve: horizon not compiled in");
+}
+
+int mpc_batch_reset(mpc_batch *b, const int *ids, int k, void *stream) {
+  if (!b) return fail(MPC_E_ARG, "mpc_batch_reset: bad argument");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!ids) {
+    HIP_TRY(hipMemsetAsync(b->d_state, 0, sizeof(double) * (size_t)b->n * b->state_len, st));
+    return MPC_OK;
+  }
+  if (k <= 0) return MPC_OK;
+  int *d_ids = nullptr;
+  HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&d_ids), sizeof(int) * k, st));
+  HIP_TRY(hipMemcpyAsync(d_ids, ids, sizeof(int) * k, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(reset_kernel, dim3(k), dim3(256), 0, st, b->d_state, b->state_len, d_ids, k, b->n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipFreeAsync(d_ids, st));
+  return MPC_OK;
+}
+
+int mpc_batch_solve_host(mpc_batch *b, const float *h_in, double *h_forces, int *h_info) {
+  if (!b || !h_in || !h_forces) return fail(MPC_E_ARG, "mpc_batch_solve_host: bad argument");
+  const size_t inlen = 56 + 4 * (size_t)b->h, N = 12 * (size_t)b->h;
+  float *d_in = nullptr;
+  double *d_f = nullptr;
+  HIP_TRY(hipMalloc(&d_in, sizeof(float) * b->n * inlen));
+  HIP_TRY(hipMalloc(&d_f, sizeof(double) * b->n * N));
+  HIP_TRY(hipMemcpy(d_in, h_in, sizeof(float) * b->n * inlen, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_f, h_forces, sizeof(double) * b->n * N, hipMemcpyHostToDevice));
+  int rc = mpc_batch_solve(b, d_in, d_f, nullptr, nullptr);
+  if (rc == MPC_OK) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h_forces, d_f, sizeof(double) * b->n * N, hipMemcpyDeviceToHost));
+    if (h_info) HIP_TRY(hipMemcpy(h_info, b->d_info, sizeof(int) * b->n * kInfoLen, hipMemcpyDeviceToHost));
+  }
+  (void)hipFree(d_in);
+  (void)hipFree(d_f);
+  return rc;
+}
+
+int mpc_batch_size(const mpc_batch *b) { return b ? b->n : 0; }
+int mpc_batch_horizon(const mpc_batch *b) { return b ? b->h : 0; }
+long long mpc_batch_device_bytes(const mpc_batch *b) { return b ? b->bytes : 0; }
+int mpc_batch_state_len(const mpc_batch *b) { return b ? b->state_len : 0; }
+int mpc_batch_get_state(mpc_batch *b, double *h_state) {
+  if (!b || !h_state) return fail(MPC_E_ARG, "mpc_batch_get_state: bad argument");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(h_state, b->d_state, sizeof(double) * (size_t)b->n * b->state_len, hipMemcpyDeviceToHost));
+  return MPC_OK;
+}
+int mpc_batch_set_state(mpc_batch *b, const double *h_state) {
+  if (!b || !h_state) return fail(MPC_E_ARG, "mpc_batch_set_state: bad argument");
+  HIP_TRY(hipMemcpy(b->d_state, h_state, sizeof(double) * (size_t)b->n * b->state_len, hipMemcpyHostToDevice));
+  return MPC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,51 @@
+"""Generate the golden fixtures of tests/golden/ from the oracle (run in the build container, where
+/root/reference exists):   python tests/golden/make_golden.py
+
+Each fixture = a seeded synthetic workload pushed through
+oracle/_ref/libconvex_mpc_ref.so, i.e. oracle/convex_mpc_oracle.c (restated mpc_osqp.cc assembly)
+driving the reference's vendored OSQP 0.6.0 compiled from /root/reference/extern/osqp.
+Per solve step we store the inputs, the returned forces (NaN rows where the reference returns [])
+and OSQP's {iter, status_val, status_polish, rho_updates}.  The reference itself has no golden
+vectors for this path ("parity unpinned"); these pin the oracle and the HIP path to
+the vendored solver's behaviour.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import rl_mpc_locomotion_amd  # noqa: E402,F401
+from rl_mpc_locomotion_amd.synthetic import make_solver_workload, perturb_workload  # noqa: E402
+from oracle.refmpc import RefBatch  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+CASES = [  # name, n, h, config, seed, steps
+    ("solver_h10_cfg2", 48, 10, 2, 0, 3),      # Aliengo trot flat (BASELINE configs[1] shape)
+    ("solver_h10_cfg3", 48, 10, 3, 1, 3),      # Go1/A1/Aliengo x trot/walk/bound (configs[2])
+    ("solver_h16_cfg4", 12, 16, 4, 2, 2),      # h=16, random ground normals (configs[3])
+]
+
+
+def main():
+    for name, n, h, cfg, seed, steps in CASES:
+        wl = make_solver_workload(n, h=h, seed=seed, config=cfg)
+        ref = RefBatch(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
+        out = dict(h=h, config=cfg, seed=seed, dt_mpc=wl.dt_mpc, alpha=wl.alpha, mass=wl.mass,
+                   inertia_diag=wl.inertia_diag, robot_type=wl.robot_type, gait_id=wl.gait_id)
+        for s in range(steps):
+            f = ref.solve(wl.inputs, nthreads=4)
+            out[f"inputs_{s}"] = wl.inputs
+            out[f"forces_{s}"] = f
+            out[f"info_{s}"] = ref.info[:, :4].astype(np.int32)
+            wl = perturb_workload(wl, 1000 + s)
+        out["steps"] = steps
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, "written;", "polished:", [int((out[f'info_{s}'][:, 2] == 1).sum()) for s in range(steps)],
+              "iters:", [int(out[f'info_{s}'][:, 0].mean()) for s in range(steps)])
+
+
+if __name__ == "__main__":
+    main()

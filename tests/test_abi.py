@@ -1,0 +1,56 @@
+"""The C-ABI library builds, loads and exports exactly what include/mpc_batch.h declares (no compute)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import rl_mpc_locomotion_amd  # noqa: F401
+from rl_mpc_locomotion_amd import _lib
+from tests.helpers import ROOT
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "mpc_batch.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mpc_[a-z_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported():
+    import __graft_entry__ as g
+    g.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 13
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/mpc_batch.h but not exported"
+    assert sorted(_lib.SYMBOLS) == names
+
+
+def test_input_len_and_horizons():
+    L = _lib.lib()
+    assert L.mpc_input_len(10) == 96 and L.mpc_input_len(16) == 120
+    buf = (ctypes.c_int * 8)()
+    k = L.mpc_supported_horizons(buf, 8)
+    assert 10 in list(buf[:k])
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from rl_mpc_locomotion_amd.batched import BatchedConvexMpc
+    with pytest.raises(_lib.MpcLibraryError):
+        BatchedConvexMpc([18.0], [[0.03, 0, 0, 0, 0.16, 0, 0, 0, 0.17]], 10, 0.02)
+    from rl_mpc_locomotion_amd import mpc_osqp
+    with pytest.raises(_lib.MpcLibraryError):
+        mpc_osqp.ConvexMpc(18.0, [0.03, 0, 0, 0, 0.16, 0, 0, 0, 0.17], 4, 10, 0.02, 1e-5, mpc_osqp.QPOASES)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "rl-mpc-locomotion_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "oracle/" not in txt.replace("oracle/README", ""), f

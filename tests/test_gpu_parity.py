@@ -1,0 +1,110 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the committed golden
+vectors and against the live oracle (vendored OSQP) on seeded inputs."""
+import numpy as np
+import pytest
+
+import rl_mpc_locomotion_amd  # noqa: F401
+from rl_mpc_locomotion_amd.synthetic import make_solver_workload, perturb_workload
+from tests.helpers import GRF_RTOL, grf_relerr, inertia9_from_diag, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu(mass, inertia_diag, h, dt, alpha):
+    from rl_mpc_locomotion_amd.batched import BatchedConvexMpc
+    return BatchedConvexMpc(mass, inertia9_from_diag(inertia_diag), h, dt, alpha, device="cuda:0")
+
+
+def _solve(gpu, rec):
+    import torch
+    f, info = gpu.solve(torch.from_numpy(np.ascontiguousarray(rec, dtype=np.float32)).to("cuda:0"))
+    torch.cuda.synchronize()
+    return f.cpu().numpy().copy(), info.cpu().numpy().copy()
+
+
+@pytest.mark.parametrize("name", ["solver_h10_cfg2", "solver_h10_cfg3", "solver_h16_cfg4"])
+def test_hip_matches_golden(name):
+    g = load_golden(name)
+    gpu = _gpu(g["mass"], g["inertia_diag"], int(g["h"]), float(g["dt_mpc"]), float(g["alpha"]))
+    for s in range(int(g["steps"])):
+        f, info = _solve(gpu, g[f"inputs_{s}"])
+        assert np.array_equal(info[:, :4], g[f"info_{s}"]), f"step {s}: OSQP decisions differ"
+        assert grf_relerr(f, g[f"forces_{s}"], first_step_only=False).max() < GRF_RTOL
+
+
+@pytest.mark.parametrize("config,n", [(2, 1024), (3, 768)])
+def test_hip_matches_live_oracle(config, n):
+    from oracle.refmpc import RefBatch
+    h = 10
+    wl = make_solver_workload(n, h=h, seed=100 + config, config=config)
+    gpu = _gpu(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
+    ref = RefBatch(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
+    for s in range(3):
+        f, info = _solve(gpu, wl.inputs)
+        fr = ref.solve(wl.inputs, nthreads=8)
+        assert np.array_equal(info[:, :4], ref.info[:, :4].astype(np.int32))
+        ok = ref.info[:, 1] == 1
+        assert grf_relerr(f[ok], fr[ok]).max() < GRF_RTOL
+        wl = perturb_workload(wl, 500 + s)
+
+
+def test_full_size_properties_4096():
+    """BASELINE configs[1] at full size: size-independent properties instead of the (slow) oracle --
+    determinism across two handles, swing-leg forces vanish, stance forces inside the friction
+    pyramid and force limits, warm start not slower than cold."""
+    n, h = 4096, 10
+    wl = make_solver_workload(n, h=h, seed=0, config=2)
+    a = _gpu(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
+    b = _gpu(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
+    fa, ia = _solve(a, wl.inputs)
+    fb, ib = _solve(b, wl.inputs)
+    assert np.array_equal(fa, fb) and np.array_equal(ia, ib)          # bit-identical per robot
+    assert (ia[:, 1] == 1).all()
+    from rl_mpc_locomotion_amd import layout as L
+    c = wl.inputs[:, L.IN_CONTACT:L.IN_CONTACT + 4 * h].astype(bool)
+    f = -fa.reshape(n, 4 * h, 3)                                       # back to the QP variable x
+    fz_max = (wl.mass * 9.8 * 10)[:, None]
+    tol = 2e-3 * fz_max                                                 # eps_abs/rel = 1e-3 ADMM accuracy
+    assert (np.abs(f[~c]) < tol.max()).all()
+    mu = 0.4
+    assert ((np.abs(f[..., 0]) <= mu * f[..., 2] + tol) | ~c).all()
+    assert ((np.abs(f[..., 1]) <= mu * f[..., 2] + tol) | ~c).all()
+    assert ((f[..., 2] <= fz_max + tol) | ~c).all() and ((f[..., 2] >= 0.1 * fz_max / 10 - tol) | ~c).all()
+    wl2 = perturb_workload(wl, 1)
+    _, iw = _solve(a, wl2.inputs)
+    assert iw[:, 0].mean() < ia[:, 0].mean()
+
+
+def test_reset_subset_is_cold_start():
+    n, h = 64, 10
+    wl = make_solver_workload(n, h=h, seed=9, config=2)
+    gpu = _gpu(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
+    f0, i0 = _solve(gpu, wl.inputs)
+    wl2 = perturb_workload(wl, 2)
+    _solve(gpu, wl2.inputs)
+    ids = np.arange(0, n, 2, dtype=np.int32)
+    gpu.reset(ids)
+    f2, i2 = _solve(gpu, wl.inputs)
+    assert np.array_equal(f2[ids], f0[ids]) and np.array_equal(i2[ids], i0[ids])
+    assert (i2[1::2, 5] == 0).all() and (i2[ids, 5] == 1).all()      # first_run flag
+
+
+def test_mpc_osqp_shim_signature():
+    """The per-robot plugin seam: same 7 + 13 positional arguments as mpc_osqp.ConvexMpc."""
+    from rl_mpc_locomotion_amd import mpc_osqp as mpc
+    from rl_mpc_locomotion_amd import layout as L
+    g = load_golden("solver_h10_cfg2")
+    h = 10
+    d = g["inertia_diag"][0]
+    obj = mpc.ConvexMpc(float(g["mass"][0]), [d[0], 0, 0, 0, d[1], 0, 0, 0, d[2]], 4, h, float(g["dt_mpc"]),
+                        float(g["alpha"]), mpc.QPOASES)
+    r = g["inputs_0"][0]
+    out = obj.compute_contact_forces(
+        list(r[0:13]), r[13:16], r[16:19], r[19:22], r[22:25], r[25:28], r[28:28 + 4 * h],
+        r[L.in_footpos(h):L.in_footpos(h) + 12], r[L.in_friction(h):L.in_friction(h) + 4],
+        r[L.in_des_pos(h):L.in_des_pos(h) + 3], r[L.in_des_vel(h):L.in_des_vel(h) + 3],
+        r[L.in_des_rpy(h):L.in_des_rpy(h) + 3], r[L.in_des_angvel(h):L.in_des_angvel(h) + 3])
+    assert isinstance(out, list) and len(out) == 12 * h
+    ref = g["forces_0"][0]
+    assert np.abs(np.array(out) - ref).max() / max(np.abs(ref).max(), 1.0) < GRF_RTOL
+    assert mpc.TEST == 42 and mpc.OSQP == mpc.QPSolverName.OSQP
