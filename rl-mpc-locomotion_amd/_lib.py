@@ -5,14 +5,14 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmpc_batch.so")
+LIB_PATH = os.environ.get("MPC_LIB_PATH", os.path.join(_HERE, "csrc", "libmpc_batch.so"))   # override: kernel-variant experiments
 _LIB = None
 
 MPC_OK = 0
 SYMBOLS = [
     "mpc_input_len", "mpc_supported_horizons", "mpc_batch_create", "mpc_batch_destroy", "mpc_batch_solve",
     "mpc_batch_reset", "mpc_batch_solve_host", "mpc_batch_size", "mpc_batch_horizon", "mpc_batch_device_bytes",
-    "mpc_batch_state_len", "mpc_batch_get_state", "mpc_batch_set_state", "mpc_last_error",
+    "mpc_batch_state_len", "mpc_batch_get_state", "mpc_batch_set_state", "mpc_batch_get_profile", "mpc_last_error",
 ]
 
 
@@ -42,6 +42,7 @@ def lib():
         L.mpc_batch_state_len.argtypes = [vp]; L.mpc_batch_state_len.restype = ci
         L.mpc_batch_get_state.argtypes = [vp, vp]; L.mpc_batch_get_state.restype = ci
         L.mpc_batch_set_state.argtypes = [vp, vp]; L.mpc_batch_set_state.restype = ci
+        L.mpc_batch_get_profile.argtypes = [vp, vp]; L.mpc_batch_get_profile.restype = ci
         L.mpc_last_error.argtypes = []; L.mpc_last_error.restype = C.c_char_p
         _LIB = L
     return _LIB

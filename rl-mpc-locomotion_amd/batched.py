@@ -38,8 +38,8 @@ class BatchedConvexMpc:
 
     def __del__(self):
         h = getattr(self, "_handle", None)
-        if h:
-            _lib.lib().mpc_batch_destroy(h)
+        if h and _lib is not None and _lib._LIB is not None:   # module globals may be gone at interpreter exit
+            _lib._LIB.mpc_batch_destroy(h)
             self._handle = None
 
     def solve(self, inputs, forces=None, info=None):
@@ -71,6 +71,13 @@ class BatchedConvexMpc:
     def get_state(self):
         out = np.zeros((self.n, _lib.lib().mpc_batch_state_len(self._handle)))
         _lib.check(_lib.lib().mpc_batch_get_state(self._handle, out.ctypes.data), "mpc_batch_get_state")
+        return out
+
+    def get_profile(self):
+        """Shader-clock cycles of the last solve per robot: columns assemble, scale, factorise, admm,
+        residual+check, polish, total, 0."""
+        out = np.zeros((self.n, 8), dtype=np.int64)
+        _lib.check(_lib.lib().mpc_batch_get_profile(self._handle, out.ctypes.data), "mpc_batch_get_profile")
         return out
 
     def set_state(self, state):

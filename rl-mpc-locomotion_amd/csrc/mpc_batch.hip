@@ -13,6 +13,12 @@
 
 using namespace mpc;
 
+// minimum waves per SIMD the register allocator must leave room for (512-thread workgroups:
+// 2 -> one robot per CU, 4 -> two robots per CU)
+#ifndef MPC_MIN_WAVES
+#define MPC_MIN_WAVES 2
+#endif
+
 namespace {
 
 thread_local std::string g_err;
@@ -35,12 +41,13 @@ struct DeviceExec {
 };
 
 template <int H>
-__global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= 256 ? 2 : 1)) void mpc_solve_kernel(int n, const RobotModel *__restrict__ models,
+__global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= 512 ? MPC_MIN_WAVES : 1)) void mpc_solve_kernel(int n, const RobotModel *__restrict__ models,
                                                                const float *__restrict__ in, double *__restrict__ state,
                                                                double *__restrict__ scratch, double *__restrict__ forces,
-                                                               int *__restrict__ info) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  Shared<H> &sh = *reinterpret_cast<Shared<H> *>(smem);
+                                                               int *__restrict__ info, long long *__restrict__ prof) {
+  // static LDS: absolute addresses fold into the ds_* offset fields (a dynamic-LDS base costs an SGPR
+  // per array and the hot loops spill)
+  __shared__ __attribute__((aligned(16))) Shared<H> sh;
   using C = Cfg<H>;
   const int robot = blockIdx.x;
   if (robot >= n) return;
@@ -61,7 +68,8 @@ __global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= 256 ? 2 : 1)) void mpc_sol
                               state + (size_t)robot * state_len<H>(),
                               scratch + (size_t)robot * C::N * C::N,
                               forces + (size_t)robot * C::N,
-                              info + (size_t)robot * kInfoLen};
+                              info + (size_t)robot * kInfoLen,
+                              prof ? prof + (size_t)robot * kProfLen : nullptr};
   sv.run();
 }
 
@@ -74,14 +82,8 @@ __global__ void reset_kernel(double *state, int state_len, const int *ids, int k
 
 template <int H>
 int launch(int n, const RobotModel *models, const float *in, double *state, double *scratch, double *forces, int *info,
-           hipStream_t stream) {
-  static bool attr_set = false;
-  const size_t shbytes = sizeof(Shared<H>);
-  if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(mpc_solve_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shbytes));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(mpc_solve_kernel<H>, dim3(n), dim3(Cfg<H>::T), shbytes, stream, n, models, in, state, scratch, forces, info);
+           long long *prof, hipStream_t stream) {
+  hipLaunchKernelGGL(mpc_solve_kernel<H>, dim3(n), dim3(Cfg<H>::T), 0, stream, n, models, in, state, scratch, forces, info, prof);
   HIP_TRY(hipGetLastError());
   return MPC_OK;
 }
@@ -94,6 +96,7 @@ struct mpc_batch {
   RobotModel *d_models = nullptr;
   double *d_state = nullptr, *d_scratch = nullptr;
   int *d_info = nullptr;   // used when the caller passes no info buffer
+  long long *d_prof = nullptr;   // per-robot section cycle counts of the last solve
   long long bytes = 0;
 };
 
@@ -127,6 +130,7 @@ int mpc_batch_create(mpc_batch **out, int n, int horizon, double timestep, doubl
       (e = hipMalloc(&b->d_state, sizeof(double) * (size_t)n * b->state_len)) != hipSuccess ||
       (e = hipMalloc(&b->d_scratch, sizeof(double) * (size_t)n * N * N)) != hipSuccess ||
       (e = hipMalloc(&b->d_info, sizeof(int) * (size_t)n * kInfoLen)) != hipSuccess ||
+      (e = hipMalloc(&b->d_prof, sizeof(long long) * (size_t)n * kProfLen)) != hipSuccess ||
       (e = hipMemcpy(b->d_models, models.data(), sizeof(RobotModel) * n, hipMemcpyHostToDevice)) != hipSuccess ||
       (e = hipMemset(b->d_state, 0, sizeof(double) * (size_t)n * b->state_len)) != hipSuccess) {
     cleanup();
@@ -143,6 +147,7 @@ void mpc_batch_destroy(mpc_batch *b) {
   if (b->d_state) (void)hipFree(b->d_state);
   if (b->d_scratch) (void)hipFree(b->d_scratch);
   if (b->d_info) (void)hipFree(b->d_info);
+  if (b->d_prof) (void)hipFree(b->d_prof);
   delete b;
 }
 
@@ -151,8 +156,8 @@ int mpc_batch_solve(mpc_batch *b, const float *d_in, double *d_forces, int *d_in
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int *info = d_info ? d_info : b->d_info;
   switch (b->h) {
-    case 10: return launch<10>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, d_forces, info, st);
-    case 16: return launch<16>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, d_forces, info, st);
+    case 10: return launch<10>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, d_forces, info, b->d_prof, st);
+    case 16: return launch<16>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, d_forces, info, b->d_prof, st);
   }
   return fail(MPC_E_HORIZON, "mpc_batch_solve: horizon not compiled in");
 }
@@ -202,6 +207,12 @@ int mpc_batch_get_state(mpc_batch *b, double *h_state) {
   if (!b || !h_state) return fail(MPC_E_ARG, "mpc_batch_get_state: bad argument");
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(h_state, b->d_state, sizeof(double) * (size_t)b->n * b->state_len, hipMemcpyDeviceToHost));
+  return MPC_OK;
+}
+int mpc_batch_get_profile(mpc_batch *b, long long *h_prof) {
+  if (!b || !h_prof) return fail(MPC_E_ARG, "mpc_batch_get_profile: bad argument");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(h_prof, b->d_prof, sizeof(long long) * (size_t)b->n * kProfLen, hipMemcpyDeviceToHost));
   return MPC_OK;
 }
 int mpc_batch_set_state(mpc_batch *b, const double *h_state) {

@@ -30,6 +30,23 @@
 #else
 #define MPC_HD inline
 #endif
+// Opaque identity on an int: stops the optimiser from hoisting comparisons against it out of
+// unrolled loops (which would pin dozens of 64-bit lane masks in SGPRs).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MPC_LAUNDER(x) asm volatile("" : "+v"(x))
+// The slice loops are fully unrolled (static register indices); without a fence every few columns the
+// scheduler hoists all 60 LDS/HBM loads above the FMAs and the live set overflows the register file.
+#define MPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define MPC_LAUNDER(x) ((void)0)
+#define MPC_SCHED_FENCE() ((void)0)
+#endif
+#define MPC_CHUNK 10   // columns between scheduling fences
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MPC_CLOCK() ((long long)__builtin_readcyclecounter())
+#else
+#define MPC_CLOCK() (0LL)
+#endif
 
 namespace mpc {
 
@@ -50,7 +67,7 @@ constexpr int kStSolved = 1, kStSolvedInaccurate = 2, kStMaxIter = -2, kStNonCvx
 template <int H>
 struct Cfg {
   static constexpr int N = 12 * H, M = 20 * H, NF = 4 * H;
-  static constexpr int S = (H <= 10) ? 2 : 4;            // threads per matrix row
+  static constexpr int S = 4;                            // threads per matrix row
   static constexpr int CPT = N / S;                      // columns per thread (multiple of 3)
   static constexpr int T = ((N * S + 63) / 64) * 64;     // workgroup size
   static constexpr int RP = T / S;                       // padded rows
@@ -75,6 +92,8 @@ template <int H> constexpr int state_len() { return 2 * Cfg<H>::N + 2 * Cfg<H>::
 
 // Per-robot info record (ints): iter, status, status_polish, rho_updates, n_factor, first_run, 0, 0
 constexpr int kInfoLen = 8;
+// Per-robot profile record (shader cycles): assemble, scale, factor, admm, residual+check, polish, total, 0
+constexpr int kProfLen = 8;
 
 struct RobotModel {       // constructor arguments of ConvexMpc (mpc_osqp.cc:508-527)
   double mass, inv_mass, inv_inertia[9], dt, alpha;
@@ -83,34 +102,39 @@ struct RobotModel {       // constructor arguments of ConvexMpc (mpc_osqp.cc:508
 template <int H>
 struct Shared {
   using C = Cfg<H>;
-  double in[C::IN_LEN];
-  // assembly
-  double x0[13], xref[13 * H], sdiff[13 * H], xk[13 * H];
-  double a_dt[169], b_dt[156], a_exp[169], b_exp[156], anb[H * 156];
-  double cone[15];
-  double q[C::N], l[C::M], u[C::M];                     // unscaled
-  // scaled problem
-  double qs[C::N], ls[C::M], us[C::M], As[C::NF * 15];
-  double D[C::N], Dinv[C::N], E[C::M], Einv[C::M], dt_[C::N], et_[C::M], cn_[C::N];
+  // ---- alive for the whole solve -------------------------------------------------------------
+  double q[C::N];                                       // unscaled q (becomes q_old of the next call)
+  double qs[C::N], ls[C::M], us[C::M], As[C::NF * 15];   // scaled problem
+  double D[C::N], Dinv[C::N], E[C::M], Einv[C::M];
   double c, cinv, rho;
   double rho_vec[C::M], rho_inv[C::M];
   int ctype[C::M];
-  // iterates and work vectors
-  double x[C::N], z[C::M], y[C::M], tm[C::M], rhs[C::N], xt[C::N], dx[C::N];
-  double Ax[C::M], Px[C::N], Aty[C::N], rp[C::M], rd[C::N];
+  double x[C::N], z[C::M], y[C::M], tm[C::M], rhs[C::N], xt[C::N];
   double part[C::T];                                    // per-thread partial sums
   double prow[2][C::N];                                 // sweep pivot row (double buffered)
   double diag[C::N];                                    // diagonal of the matrix being swept
-  double piv[2];                                       // current pivot (double buffered)
+  double piv[2];                                        // current pivot (double buffered)
   unsigned long long red[16];                           // max-reductions (bit pattern of doubles >= 0)
-  // polish
-  int act[C::M];
-  double Nb[C::NF * 9], Gm[C::NF * 9];                  // per foot: null basis rows (3 x 3, zero padded), Gamma
-  int nnull[C::NF], isnull[C::N];
-  double u0[C::N], Pu[C::N], g[C::N], xN[C::N], PxN[C::N], wv[C::N], rw[C::N], ypol[C::M], zpol[C::M];
-  // control (uniform)
-  int first, iter, status, status_polish, rho_updates, nfact, done, bad;
+  int first, iter, status, status_polish, rho_updates, nfact, done, bad;   // control (uniform)
   double pri_res, dua_res, rho_new;
+  // ---- phase-local storage: assembly + scaling, then residuals + polish share the same LDS ------
+  union {
+    struct {
+      double in[C::IN_LEN];
+      double x0[13], xref[13 * H], sdiff[13 * H], xk[13 * H];
+      double a_dt[169], b_dt[156], a_exp[169], b_exp[156], anb[H * 156];
+      double cone[15];
+      double l[C::M], u[C::M];                          // unscaled bounds
+      double dt_[C::N], et_[C::M], cn_[C::N];           // Ruiz pass temporaries
+    };
+    struct {
+      double Ax[C::M], Px[C::N], Aty[C::N], rp[C::M], rd[C::N];
+      int act[C::M];
+      double Nb[C::NF * 9], Gm[C::NF * 9];              // per foot: null basis rows (3 x 3, zero padded), Gamma
+      int nnull[C::NF], isnull[C::N];
+      double u0[C::N], Pu[C::N], g[C::N], xN[C::N], PxN[C::N], wv[C::N], rw[C::N], ypol[C::M], zpol[C::M];
+    };
+  };
 };
 
 template <int H>
@@ -159,6 +183,7 @@ struct Solver {
   double *Pg;          // [N*N]
   double *forces;      // [N]   out: -D x (all horizon steps), untouched on failure
   int *info;           // [kInfoLen]
+  long long *prof;     // [kProfLen] shader-clock cycles per section (may be null)
 
   // ---- helpers valid inside a phase ------------------------------------------------------------
   static MPC_HD double a_row_dot(const Sh &s, int i, const double *v) {  // row i of scaled A times v
@@ -178,7 +203,10 @@ struct Solver {
     double acc = 0;
     const double *vv = v + t.part * CPT;
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) acc += t.Mx[j] * vv[j];
+    for (int j = 0; j < CPT; ++j) {
+      if (j % MPC_CHUNK == 0) MPC_SCHED_FENCE();
+      acc += t.Mx[j] * vv[j];
+    }
     return acc;
   }
   static MPC_HD double sum_parts(const Sh &s, int row) {
@@ -187,6 +215,8 @@ struct Solver {
     for (int p = 1; p < S; ++p) acc += s.part[row * S + p];
     return acc;
   }
+  // combine the partial products of (-Minv) v for a swept row: see sweep_all()
+  static MPC_HD double inv_combine(const Sh &s, int row, const double *v) { return sum_parts(s, row) + 2.0 * v[row]; }
   static MPC_HD double max_parts(const Sh &s, int row) {
     double acc = s.part[row * S];
 #pragma unroll
@@ -208,7 +238,7 @@ struct Solver {
       for (int i = t.tid; i < 169; i += T) s.a_dt[i] = 0;
       for (int i = t.tid; i < 156; i += T) s.b_dt[i] = 0;
       // warm-start state (scaled iterates of the previous call; zeros on the first call)
-      for (int i = t.tid; i < N; i += T) { s.x[i] = state[i]; s.rd[i] = state[N + 2 * M + i]; /* q_old */ }
+      for (int i = t.tid; i < N; i += T) { s.x[i] = state[i]; s.rhs[i] = state[N + 2 * M + i]; /* q_old */ }
       for (int i = t.tid; i < M; i += T) { s.z[i] = state[N + i]; s.y[i] = state[N + M + i]; }
       if (t.tid == 0) {
         s.rho = state[2 * N + 2 * M];
@@ -374,7 +404,7 @@ struct Solver {
     ex.par([&](Th &t) {
       load_slice(t, Pg);
       if (t.tid < N) {
-        s.qs[t.tid] = s.first ? s.q[t.tid] : s.rd[t.tid];   // osqp_update_P_A equilibrates with the PREVIOUS q
+        s.qs[t.tid] = s.first ? s.q[t.tid] : s.rhs[t.tid];   // osqp_update_P_A equilibrates with the PREVIOUS q
         s.D[t.tid] = 1.0;
       }
       if (t.tid < M) s.E[t.tid] = 1.0;
@@ -408,7 +438,11 @@ struct Solver {
           const double dr = s.dt_[t.row];
           const double *dc = s.dt_ + t.part * CPT;
 #pragma unroll
-          for (int j = 0; j < CPT; ++j) { t.Mx[j] = (t.Mx[j] * dr) * dc[j]; mx = dmax(mx, fabs(t.Mx[j])); }
+          for (int j = 0; j < CPT; ++j) {
+            if (j % MPC_CHUNK == 0) MPC_SCHED_FENCE();
+            t.Mx[j] = (t.Mx[j] * dr) * dc[j];
+            mx = dmax(mx, fabs(t.Mx[j]));
+          }
         }
         s.part[t.tid] = mx;
         if (t.tid < M) {
@@ -484,18 +518,27 @@ struct Solver {
     ex.par([&](Th &t) {
       if (reload) load_slice(t, Pg);
       if (t.row < N) {
+        // (A^T R A) is block diagonal: row `row` (foot f, coordinate c1) gets gv[c2] on columns 3f..3f+2.
         const int f = t.row / 3, c1 = t.row - 3 * f;
+        double gv[3];
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) {
-          const int col = t.part * CPT + j;
-          if (col / 3 == f) {
-            const int c2 = col - 3 * f;
-            double g = 0;
-            for (int r = 0; r < 5; ++r) g += s.As[15 * f + 3 * r + c1] * s.rho_vec[5 * f + r] * s.As[15 * f + 3 * r + c2];
-            t.Mx[j] += g;
-            if (col == t.row) { t.Mx[j] += kSigma; s.diag[t.row] = t.Mx[j]; }
-          }
+        for (int c2 = 0; c2 < 3; ++c2) {
+          double g = 0;
+          for (int r = 0; r < 5; ++r) g += s.As[15 * f + 3 * r + c1] * s.rho_vec[5 * f + r] * s.As[15 * f + 3 * r + c2];
+          gv[c2] = g + (c2 == c1 ? kSigma : 0.0);
         }
+        // value selects only (a conditional store would keep Mx out of registers); flocal is
+        // laundered per foot so the compiler does not hoist 20 lane masks out of the loop
+        int flocal = f - t.part * (CPT / 3);
+#pragma unroll
+        for (int jf = 0; jf < CPT / 3; ++jf) {
+          MPC_LAUNDER(flocal);
+          const bool hit = flocal == jf;
+          t.Mx[3 * jf] += hit ? gv[0] : 0.0;
+          t.Mx[3 * jf + 1] += hit ? gv[1] : 0.0;
+          t.Mx[3 * jf + 2] += hit ? gv[2] : 0.0;
+        }
+        if (t.part == 0) s.diag[t.row] = Pg[(size_t)t.row * N + t.row] + gv[c1];
       }
     });
     sweep_all(false);
@@ -527,7 +570,11 @@ struct Solver {
           const double g = f * pinv;
           const double *prc = pr + t.part * CPT;
 #pragma unroll
-          for (int j = 0; j < CPT; ++j) t.Mx[j] -= g * prc[j];
+          for (int j = 0; j < CPT; ++j) {
+            if (j % MPC_CHUNK == 0) MPC_SCHED_FENCE();
+            t.Mx[j] -= g * prc[j];
+          }
+          MPC_SCHED_FENCE();
           double dnew = 0;
           if (t.part == 0) {
             dnew = (t.row == k) ? -pinv : s.diag[t.row] - f * g;
@@ -540,13 +587,9 @@ struct Solver {
       buf ^= 1;
       k = kn;
     }
-    ex.par([&](Th &t) {   // put the diagonal back into the register slice
-      if (t.row < N) {
-        const int dl = t.row - t.part * CPT;
-#pragma unroll
-        for (int j = 0; j < CPT; ++j) if (j == dl) t.Mx[j] = s.diag[t.row];
-      }
-    });
+    // No fix-up of the register slice: its diagonal slot took the generic update, which leaves
+    // (true value + 2) on every swept row (2 - 1/p instead of -1/p at the row's own pivot, identical
+    // increments afterwards).  The matrix-vector products add the 2 v[row] back (inv_combine).
   }
   // Row `k`'s threads copy their slice to prow[b]; slot k itself gets (pivot - 1) and piv[b] the pivot
   // (both written by the part-0 thread, which owns the LDS diagonal).
@@ -554,7 +597,10 @@ struct Solver {
     double *pn = s.prow[b] + t.part * CPT;
     const int kloc = k - t.part * CPT;
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) if (j != kloc) pn[j] = t.Mx[j];
+    for (int j = 0; j < CPT; ++j) {
+      if (j % MPC_CHUNK == 0) MPC_SCHED_FENCE();
+      if (j != kloc) pn[j] = t.Mx[j];
+    }
     if (t.part == 0) { s.prow[b][k] = pivot - 1.0; s.piv[b] = pivot; }
   }
 
@@ -574,11 +620,10 @@ struct Solver {
     });
     ex.par([&](Th &t) {
       if (t.tid < N) {
-        const double xt = sum_parts(s, t.tid);
+        const double xt = inv_combine(s, t.tid, s.rhs);
         s.xt[t.tid] = xt;
         const double xn = kAlphaRelax * xt + (1.0 - kAlphaRelax) * t.xprev;
         s.x[t.tid] = xn;
-        s.dx[t.tid] = xn - t.xprev;
       }
     });
     ex.par([&](Th &t) {   // z~ = A x~ ; z, y updates; next iteration's R z - y
@@ -604,7 +649,10 @@ struct Solver {
         const double *g = Pg + (size_t)t.row * N + t.part * CPT;
         const double *vv = v + t.part * CPT;
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) acc += g[j] * vv[j];
+        for (int j = 0; j < CPT; ++j) {
+          if (j % MPC_CHUNK == 0) MPC_SCHED_FENCE();
+          acc += g[j] * vv[j];
+        }
       }
       s.part[t.tid] = acc;
     });
@@ -767,6 +815,8 @@ struct Solver {
         const double *n1 = s.Nb + 9 * f1 + 3 * k1;             // null vector k1 of foot f1 (zeros if k1 >= nn)
         const bool rownull = k1 < s.nnull[f1];
         const double *g0 = Pg + (size_t)(3 * f1) * N + t.part * CPT;
+        double dval = 0;
+        int rowl = t.row;
 #pragma unroll
         for (int jf = 0; jf < CPT / 3; ++jf) {
           const int f2 = (t.part * CPT) / 3 + jf;
@@ -779,10 +829,15 @@ struct Solver {
             const int col = 3 * f2 + k2;
             const double *n2 = s.Nb + 9 * f2 + 3 * k2;
             double v = (rownull && k2 < nn2) ? (n2[0] * T1[0] + n2[1] * T1[1] + n2[2] * T1[2]) : 0.0;
-            if (col == t.row) { v = rownull ? v + kDelta : 1.0; s.diag[t.row] = v; }
+            MPC_LAUNDER(rowl);
+            const bool isd = col == rowl;
+            v = isd ? (rownull ? v + kDelta : 1.0) : v;
+            dval = isd ? v : dval;
             t.Mx[3 * jf + k2] = v;
           }
         }
+        const int jd = t.row - t.part * CPT;
+        if (jd >= 0 && jd < CPT) s.diag[t.row] = dval;
       }
     });
     sweep_all(true);   // Mx <- -(H + delta I)^{-1} on the null coordinates
@@ -797,7 +852,7 @@ struct Solver {
         }
       });
       ex.par([&](Th &t) { s.part[t.tid] = (t.row < N) ? -slice_dot(t, s.rw) : 0.0; });
-      ex.par([&](Th &t) { if (t.tid < N && s.isnull[t.tid]) s.wv[t.tid] += sum_parts(s, t.tid); });
+      ex.par([&](Th &t) { if (t.tid < N && s.isnull[t.tid]) s.wv[t.tid] += inv_combine(s, t.tid, s.rw); });
       ex.par([&](Th &t) {   // xN = N~ w
         if (t.tid < N) {
           const int j = t.tid, f = j / 3, c = j - 3 * f;
@@ -848,30 +903,44 @@ struct Solver {
 
   // ================================ driver ======================================================
   MPC_HD void run() {
+    long long tc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long t0 = MPC_CLOCK();
+    long long ta = t0, tb;
+#define MPC_LAP(k) { tb = MPC_CLOCK(); tc[k] += tb - ta; ta = tb; }
     assemble();
+    MPC_LAP(0)
     scale();
+    MPC_LAP(1)
     set_rho_vec();
     factor(false);
+    MPC_LAP(2)
     admm_prepare();
     int iter = 0;
     while (!s.done && !s.bad && iter < kMaxIter) {
       ++iter;
       admm_iter();
       if (iter % kCheck == 0) {
+        MPC_LAP(3)
         residuals(s.x, s.z, s.y);
         check_and_adapt(iter);
+        MPC_LAP(4)
         if (!s.done && s.rho_new > 0) {          // osqp_update_rho: new rho_vec, refactor
           ex.par([&](Th &t) { if (t.tid == 0) { s.rho = s.rho_new; s.rho_updates++; } });
           set_rho_vec();
           factor(true);
           admm_prepare();
+          MPC_LAP(2)
         }
       }
     }
+    MPC_LAP(3)
     if (!s.done && !s.bad) {   // max_iter reached (osqp.c:564-568): only SOLVED counts for the reference
       ex.par([&](Th &t) { if (t.tid == 0) s.status = kStMaxIter; });
     }
     if (s.status == kStSolved && !s.bad) polish();
+    MPC_LAP(5)
+#undef MPC_LAP
+    tc[6] = MPC_CLOCK() - t0;
     // outputs + persistent state (store_solution, auxil.c:528-561; mpc_osqp.cc:788-790: forces = -x)
     ex.par([&](Th &t) {
       const bool solved = s.status == kStSolved && !s.bad;
@@ -886,6 +955,7 @@ struct Solver {
         state[2 * N + 2 * M + 1] = 1.0;
         info[0] = s.iter; info[1] = s.bad ? kStNonCvx : s.status; info[2] = s.status_polish; info[3] = s.rho_updates;
         info[4] = s.nfact; info[5] = s.first; info[6] = 0; info[7] = 0;
+        if (prof) for (int k = 0; k < kProfLen; ++k) prof[k] = tc[k];
       }
     });
   }

@@ -40,7 +40,7 @@ static void solve_one(const RobotModel &mdl, const float *in, double *state, dou
   HostExec<H> ex(reverse);
   Shared<H> *sh = new Shared<H>();
   std::memset(sh, 0, sizeof(Shared<H>));
-  Solver<H, HostExec<H>> sv{ex, *sh, mdl, in, state, Pg, forces, info};
+  Solver<H, HostExec<H>> sv{ex, *sh, mdl, in, state, Pg, forces, info, nullptr};
   sv.run();
   if (phases) *phases = ex.phases;
   delete sh;
