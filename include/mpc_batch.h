@@ -85,8 +85,7 @@ long long mpc_batch_device_bytes(const mpc_batch *b);
 int mpc_batch_state_len(const mpc_batch *b);
 int mpc_batch_get_state(mpc_batch *b, double *h_state);
 int mpc_batch_set_state(mpc_batch *b, const double *h_state);
-/* Shader-clock cycles the last solve spent per section, [n, 8] int64:
- * {assemble, scale, factorise, admm, residual+check, polish, total, 0}. */
+/* Shader-clock cycles the last solve spent per section, [n, 16] int64 (sections: csrc/mpc_core.h kProfLen). */
 int mpc_batch_get_profile(mpc_batch *b, long long *h_prof);
 
 const char *mpc_last_error(void);

@@ -74,9 +74,8 @@ class BatchedConvexMpc:
         return out
 
     def get_profile(self):
-        """Shader-clock cycles of the last solve per robot: columns assemble, scale, factorise, admm,
-        residual+check, polish, total, 0."""
-        out = np.zeros((self.n, 8), dtype=np.int64)
+        """Shader-clock cycles of the last solve per robot, 16 sections (csrc/mpc_core.h kProfLen)."""
+        out = np.zeros((self.n, 16), dtype=np.int64)
         _lib.check(_lib.lib().mpc_batch_get_profile(self._handle, out.ctypes.data), "mpc_batch_get_profile")
         return out
 

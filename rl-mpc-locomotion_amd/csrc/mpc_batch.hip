@@ -13,8 +13,8 @@
 
 using namespace mpc;
 
-// minimum waves per SIMD the register allocator must leave room for (512-thread workgroups:
-// 2 -> one robot per CU, 4 -> two robots per CU)
+// minimum waves per SIMD the register allocator must leave room for (256-thread workgroups:
+// 2 -> two robots per CU)
 #ifndef MPC_MIN_WAVES
 #define MPC_MIN_WAVES 2
 #endif
@@ -41,7 +41,7 @@ struct DeviceExec {
 };
 
 template <int H>
-__global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= 512 ? MPC_MIN_WAVES : 1)) void mpc_solve_kernel(int n, const RobotModel *__restrict__ models,
+__global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= 256 ? MPC_MIN_WAVES : 1)) void mpc_solve_kernel(int n, const RobotModel *__restrict__ models,
                                                                const float *__restrict__ in, double *__restrict__ state,
                                                                double *__restrict__ scratch, double *__restrict__ forces,
                                                                int *__restrict__ info, long long *__restrict__ prof) {
@@ -52,13 +52,9 @@ __global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= 512 ? MPC_MIN_WAVES : 1)) 
   const int robot = blockIdx.x;
   if (robot >= n) return;
   Thread<H> th;
-  th.tid = threadIdx.x;
-  th.row = threadIdx.x / C::S;
-  th.part = threadIdx.x % C::S;
-  th.xprev = 0;
-  th.zprev = 0;
+  th.init(threadIdx.x);
 #pragma unroll
-  for (int j = 0; j < C::CPT; ++j) th.Mx[j] = 0;
+  for (int j = 0; j < C::TE; ++j) th.Mx[j] = 0;
   DeviceExec<H> ex{th};
   const RobotModel mdl = models[robot];
   Solver<H, DeviceExec<H>> sv{ex,

@@ -18,8 +18,10 @@
 //        polish         -> delta-regularised refinement in the null space of the active rows
 //   All arithmetic is fp64: an fp32 ADMM does not reproduce OSQP's iterates (oracle/README).
 //
-// Thread layout: T = RP*S threads; thread tid owns row (tid / S), column slice
-// [part*CPT, (part+1)*CPT) with part = tid % S, of every n x n matrix (n = 12 H).
+// Thread layout: every n x n matrix (n = 12 H) is held as 6 x 12 register tiles (2 feet x 4 feet), one
+// per thread: thread tid < 2H*H owns rows [6 ti, 6 ti + 6), columns [12 tj, 12 tj + 12) with
+// ti = tid / H, tj = tid % H.  A rank-1 update then costs 18 LDS reads per 72 FMAs (a row-slice
+// layout needs one LDS read per FMA and is LDS-bandwidth bound).  Vector phases use tid < n / tid < m.
 #pragma once
 
 #include <math.h>
@@ -67,14 +69,15 @@ constexpr int kStSolved = 1, kStSolvedInaccurate = 2, kStMaxIter = -2, kStNonCvx
 template <int H>
 struct Cfg {
   static constexpr int N = 12 * H, M = 20 * H, NF = 4 * H;
-  static constexpr int S = 4;                            // threads per matrix row
-  static constexpr int CPT = N / S;                      // columns per thread (multiple of 3)
-  static constexpr int T = ((N * S + 63) / 64) * 64;     // workgroup size
-  static constexpr int RP = T / S;                       // padded rows
+  static constexpr int TR = 6, TC = 12;                  // register tile (rows x cols), multiples of 3
+  static constexpr int GR = N / TR, GC = N / TC;         // tile grid: 2H x H
+  static constexpr int MT = GR * GC;                     // threads that hold a tile
+  static constexpr int TE = TR * TC;                     // tile elements per thread
+  static constexpr int T = (((MT > M ? MT : M) + 63) / 64) * 64;   // workgroup size
   static constexpr int IN_LEN = 56 + 4 * H;
   static constexpr int NTASK = 78 + (H - 1) * 144;       // P assembly tasks (d, a, b)
-  static_assert(N % S == 0 && CPT % 3 == 0, "column slice must hold whole feet");
-  static_assert(T >= M && T <= 1024, "workgroup must cover the constraint rows");
+  static_assert(T <= 1024, "workgroup too large");
+  static constexpr int PARTLEN = (N * GC > 14 * 64) ? N * GC : 14 * 64;   // part[] doubles as the reduction scratch
 };
 
 // Flat input record offsets (include/mpc_batch.h, layout.py)
@@ -92,8 +95,9 @@ template <int H> constexpr int state_len() { return 2 * Cfg<H>::N + 2 * Cfg<H>::
 
 // Per-robot info record (ints): iter, status, status_polish, rho_updates, n_factor, first_run, 0, 0
 constexpr int kInfoLen = 8;
-// Per-robot profile record (shader cycles): assemble, scale, factor, admm, residual+check, polish, total, 0
-constexpr int kProfLen = 8;
+// Per-robot profile record (shader cycles), 16 sections: 0 load 1 dynamics 2 q+P 3 scale-load 4 scale-loop 5 scale-store
+// 6 K-form 7 sweep 8 admm 9 resid-mulP 10 resid-rest+check 11 polish-setup 12 polish-H 13 polish-refine 14 polish-finish 15 total
+constexpr int kProfLen = 16;
 
 struct RobotModel {       // constructor arguments of ConvexMpc (mpc_osqp.cc:508-527)
   double mass, inv_mass, inv_inertia[9], dt, alpha;
@@ -106,14 +110,15 @@ struct Shared {
   double q[C::N];                                       // unscaled q (becomes q_old of the next call)
   double qs[C::N], ls[C::M], us[C::M], As[C::NF * 15];   // scaled problem
   double D[C::N], Dinv[C::N], E[C::M], Einv[C::M];
-  double c, cinv, rho;
+  double c, cinv, rho, ctmp;
   double rho_vec[C::M], rho_inv[C::M];
   int ctype[C::M];
-  double x[C::N], z[C::M], y[C::M], tm[C::M], rhs[C::N], xt[C::N];
-  double part[C::T];                                    // per-thread partial sums
+  double x[C::N], xt[C::N];
+  double zz[2][C::M], yy[2][C::M], rr[2][C::N];          // z, y, rhs: ping-pong buffered across ADMM iterations
+  double part[C::PARTLEN];                              // per (row, column-tile) partial sums / maxima
   double prow[2][C::N];                                 // sweep pivot row (double buffered)
   double diag[C::N];                                    // diagonal of the matrix being swept
-  double piv[2];                                        // current pivot (double buffered)
+  double piv[2][2];                                     // current pivot and its reciprocal (double buffered)
   unsigned long long red[16];                           // max-reductions (bit pattern of doubles >= 0)
   int first, iter, status, status_polish, rho_updates, nfact, done, bad;   // control (uniform)
   double pri_res, dua_res, rho_new;
@@ -140,9 +145,13 @@ struct Shared {
 template <int H>
 struct Thread {
   using C = Cfg<H>;
-  int tid, row, part;
-  double Mx[C::CPT];        // this thread's slice of the current n x n matrix (P_s, K, -Kinv, H, -Hinv)
-  double xprev, zprev;      // previous iterate of the vector element this thread owns
+  int tid, ti, tj;          // thread id; tile row / tile column
+  bool mact;                // holds a matrix tile (tid < MT)
+  double Mx[C::TE];         // tile of the current n x n matrix (P_s, K, -Kinv, H, -Hinv), row-major 6 x 12
+  double xprev, zprev;      // carried scalars
+  MPC_HD void init(int id) {
+    tid = id; ti = id / C::GC; tj = id - ti * C::GC; mact = id < C::MT; xprev = 0; zprev = 0;
+  }
 };
 
 MPC_HD double limit_scaling(double v) {  // scaling.c:7-14
@@ -173,7 +182,7 @@ struct Solver {
   using C = Cfg<H>;
   using Th = Thread<H>;
   using Sh = Shared<H>;
-  static constexpr int N = C::N, M = C::M, NF = C::NF, S = C::S, CPT = C::CPT, T = C::T;
+  static constexpr int N = C::N, M = C::M, NF = C::NF, T = C::T, TR = C::TR, TC = C::TC, GC = C::GC, TE = C::TE;
 
   Exec &ex;
   Sh &s;
@@ -184,6 +193,13 @@ struct Solver {
   double *forces;      // [N]   out: -D x (all horizon steps), untouched on failure
   int *info;           // [kInfoLen]
   long long *prof;     // [kProfLen] shader-clock cycles per section (may be null)
+  int pp = 0;          // which half of the z / y / rhs ping-pong buffers is current (uniform)
+  MPC_HD double *cz() { return s.zz[pp]; }
+  MPC_HD double *cy() { return s.yy[pp]; }
+  MPC_HD double *crhs() { return s.rr[pp]; }
+  long long tc[kProfLen] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = 0;
+  MPC_HD void lap(int k) { const long long now = MPC_CLOCK(); tc[k] += now - tlast; tlast = now; }
 
   // ---- helpers valid inside a phase ------------------------------------------------------------
   static MPC_HD double a_row_dot(const Sh &s, int i, const double *v) {  // row i of scaled A times v
@@ -198,36 +214,63 @@ struct Solver {
     for (int r = 0; r < 5; ++r) t += a[3 * r] * v[5 * f + r];
     return t;
   }
-  // per-thread partial of (matrix row slice) . v
-  static MPC_HD double slice_dot(const Th &t, const double *v) {
-    double acc = 0;
-    const double *vv = v + t.part * CPT;
+  // part[row * GC + tj] <- -(tile row) . v[my columns]   (partial products of (-Mx) v)
+  MPC_HD void tile_matvec_neg(const Th &t, const double *v) {
+    const double *vv = v + TC * t.tj;
+    double vr[TC];
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) {
-      if (j % MPC_CHUNK == 0) MPC_SCHED_FENCE();
-      acc += t.Mx[j] * vv[j];
+    for (int b = 0; b < TC; ++b) vr[b] = vv[b];
+    double acc[TR];
+#pragma unroll
+    for (int a = 0; a < TR; ++a) acc[a] = 0;
+#pragma unroll
+    for (int b = 0; b < TC; ++b) {   // six independent accumulation chains (fp64 FMA latency)
+#pragma unroll
+      for (int a = 0; a < TR; ++a) acc[a] += t.Mx[a * TC + b] * vr[b];
+      if (b % 4 == 3) MPC_SCHED_FENCE();
     }
-    return acc;
+#pragma unroll
+    for (int a = 0; a < TR; ++a) s.part[(TR * t.ti + a) * GC + t.tj] = -acc[a];
   }
   static MPC_HD double sum_parts(const Sh &s, int row) {
-    double acc = s.part[row * S];
+    const double *p = s.part + row * GC;
+    double acc = p[0];
 #pragma unroll
-    for (int p = 1; p < S; ++p) acc += s.part[row * S + p];
+    for (int k = 1; k < GC; ++k) acc += p[k];
     return acc;
   }
   // combine the partial products of (-Minv) v for a swept row: see sweep_all()
   static MPC_HD double inv_combine(const Sh &s, int row, const double *v) { return sum_parts(s, row) + 2.0 * v[row]; }
   static MPC_HD double max_parts(const Sh &s, int row) {
-    double acc = s.part[row * S];
+    const double *p = s.part + row * GC;
+    double acc = p[0];
 #pragma unroll
-    for (int p = 1; p < S; ++p) acc = dmax(acc, s.part[row * S + p]);
+    for (int k = 1; k < GC; ++k) acc = dmax(acc, p[k]);
     return acc;
   }
-  MPC_HD void load_slice(Th &t, const double *G) {   // Mx <- G[row][slice]
-    if (t.row < N) {
-      const double *g = G + (size_t)t.row * N + t.part * CPT;
+  MPC_HD void tile_rowmax(const Th &t) {   // part[row * GC + tj] <- max_b |tile row|
 #pragma unroll
-      for (int j = 0; j < CPT; ++j) t.Mx[j] = g[j];
+    for (int a = 0; a < TR; ++a) {
+      double mx = 0;
+#pragma unroll
+      for (int b = 0; b < TC; ++b) mx = dmax(mx, fabs(t.Mx[a * TC + b]));
+      s.part[(TR * t.ti + a) * GC + t.tj] = mx;
+    }
+  }
+  MPC_HD void load_tile(Th &t, const double *G) {   // Mx <- G[my rows][my columns]
+#pragma unroll
+    for (int a = 0; a < TR; ++a) {
+      const double *g = G + (size_t)(TR * t.ti + a) * N + TC * t.tj;
+#pragma unroll
+      for (int b = 0; b < TC; ++b) t.Mx[a * TC + b] = g[b];
+    }
+  }
+  MPC_HD void store_tile(const Th &t, double *G) {
+#pragma unroll
+    for (int a = 0; a < TR; ++a) {
+      double *g = G + (size_t)(TR * t.ti + a) * N + TC * t.tj;
+#pragma unroll
+      for (int b = 0; b < TC; ++b) g[b] = t.Mx[a * TC + b];
     }
   }
 
@@ -238,14 +281,15 @@ struct Solver {
       for (int i = t.tid; i < 169; i += T) s.a_dt[i] = 0;
       for (int i = t.tid; i < 156; i += T) s.b_dt[i] = 0;
       // warm-start state (scaled iterates of the previous call; zeros on the first call)
-      for (int i = t.tid; i < N; i += T) { s.x[i] = state[i]; s.rhs[i] = state[N + 2 * M + i]; /* q_old */ }
-      for (int i = t.tid; i < M; i += T) { s.z[i] = state[N + i]; s.y[i] = state[N + M + i]; }
+      for (int i = t.tid; i < N; i += T) { s.x[i] = state[i]; s.xt[i] = state[N + 2 * M + i]; /* q_old */ }
+      for (int i = t.tid; i < M; i += T) { s.zz[0][i] = state[N + i]; s.yy[0][i] = state[N + M + i]; }
       if (t.tid == 0) {
         s.rho = state[2 * N + 2 * M];
         s.first = state[2 * N + 2 * M + 1] == 0.0;
         s.status = kStUnsolved; s.status_polish = 0; s.rho_updates = 0; s.nfact = 0; s.iter = 0; s.done = 0; s.bad = 0;
       }
     });
+    lap(0);
     // A dt, B dt (mpc_osqp.cc:299-336, 606-617, 661-673) -- a few hundred flops, one thread
     ex.par([&](Th &t) {
       if (t.tid == 0) {
@@ -354,6 +398,7 @@ struct Solver {
     ex.par([&](Th &t) {   // state_diff (:681)
       for (int k = t.tid; k < 13 * H; k += T) s.sdiff[k] = (k < 13 * (H - 1) ? s.xk[k] : 0.0) - s.xref[k];
     });
+    lap(1);
     // q (:683) and P (:387-434) -> Pg (unscaled, full symmetric)
     ex.par([&](Th &t) {
       if (t.tid < N) {
@@ -394,6 +439,7 @@ struct Solver {
       }
     });
   }
+  // (lap(2) is taken at the start of scale())
   static MPC_HD void mat3(const double *a, const double *b, double *c) {
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) c[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
@@ -401,50 +447,48 @@ struct Solver {
 
   // ================================ 2. scaling (scaling.c:44-156) ===============================
   MPC_HD void scale() {
+    lap(2);
     ex.par([&](Th &t) {
-      load_slice(t, Pg);
+      if (t.mact) load_tile(t, Pg);
       if (t.tid < N) {
-        s.qs[t.tid] = s.first ? s.q[t.tid] : s.rhs[t.tid];   // osqp_update_P_A equilibrates with the PREVIOUS q
+        s.qs[t.tid] = s.first ? s.q[t.tid] : s.xt[t.tid];   // osqp_update_P_A equilibrates with the PREVIOUS q
         s.D[t.tid] = 1.0;
       }
       if (t.tid < M) s.E[t.tid] = 1.0;
       for (int k = t.tid; k < NF * 15; k += T) s.As[k] = s.cone[k % 15];
       if (t.tid == 0) s.c = 1.0;
     });
+    lap(3);
     for (int it = 0; it < kScalingIters; ++it) {
       ex.par([&](Th &t) {   // row (= column) inf-norms of P, row norms of A
-        double mx = 0;
-        if (t.row < N) {
-#pragma unroll
-          for (int j = 0; j < CPT; ++j) mx = dmax(mx, fabs(t.Mx[j]));
-        }
-        s.part[t.tid] = mx;
+        if (t.mact) tile_rowmax(t);
         if (t.tid < M) {
           const double *a = s.As + 3 * t.tid;
           s.et_[t.tid] = 1.0 / sqrt(limit_scaling(dmax(dmax(fabs(a[0]), fabs(a[1])), fabs(a[2]))));
         }
       });
       ex.par([&](Th &t) {
-        if (t.part == 0 && t.row < N) {
-          const int j = t.row, f = j / 3, c = j - 3 * f;
+        if (t.tid < N) {
+          const int j = t.tid, f = j / 3, c = j - 3 * f;
           double mx = max_parts(s, j);
           for (int r = 0; r < 5; ++r) mx = dmax(mx, fabs(s.As[15 * f + 3 * r + c]));
           s.dt_[j] = 1.0 / sqrt(limit_scaling(mx));
         }
       });
       ex.par([&](Th &t) {   // P <- D P D, A <- E A D, q <- D q; then the new column norms of P
-        double mx = 0;
-        if (t.row < N) {
-          const double dr = s.dt_[t.row];
-          const double *dc = s.dt_ + t.part * CPT;
+        if (t.mact) {
+          const double *dr = s.dt_ + TR * t.ti, *dc = s.dt_ + TC * t.tj;
+          double dcv[TC];
 #pragma unroll
-          for (int j = 0; j < CPT; ++j) {
-            if (j % MPC_CHUNK == 0) MPC_SCHED_FENCE();
-            t.Mx[j] = (t.Mx[j] * dr) * dc[j];
-            mx = dmax(mx, fabs(t.Mx[j]));
+          for (int b = 0; b < TC; ++b) dcv[b] = dc[b];
+#pragma unroll
+          for (int a = 0; a < TR; ++a) {
+            const double da = dr[a];
+#pragma unroll
+            for (int b = 0; b < TC; ++b) t.Mx[a * TC + b] = (t.Mx[a * TC + b] * da) * dcv[b];
           }
+          tile_rowmax(t);
         }
-        s.part[t.tid] = mx;
         if (t.tid < M) {
           const int f = t.tid / 5;
           double *a = s.As + 3 * t.tid;
@@ -455,26 +499,35 @@ struct Solver {
         if (t.tid < N) { s.qs[t.tid] *= s.dt_[t.tid]; s.D[t.tid] *= s.dt_[t.tid]; }
       });
       ex.par([&](Th &t) {
-        if (t.part == 0 && t.row < N) s.cn_[t.row] = max_parts(s, t.row);
+        if (t.tid < N) s.cn_[t.tid] = max_parts(s, t.tid);
       });
-      ex.par([&](Th &t) {   // cost scaling (scaling.c:108-139); every thread derives the same c_temp
-        double mean = 0, nq = 0;
-        for (int j = 0; j < N; ++j) { mean += s.cn_[j]; nq = dmax(nq, fabs(s.qs[j])); }
-        mean /= N;
-        nq = limit_scaling(nq);
-        const double ct = 1.0 / limit_scaling(dmax(mean, nq));
-        t.xprev = ct;   // carried to the next phase in a register
+      ex.par([&](Th &t) {   // cost scaling (scaling.c:108-139), two-level: 12 x 3 foot-sized chunks...
+        if (t.tid < NF) {
+          const int f = t.tid;
+          s.et_[f] = (s.cn_[3 * f] + s.cn_[3 * f + 1]) + s.cn_[3 * f + 2];                  // partial sum of column norms
+          s.et_[NF + f] = dmax(dmax(fabs(s.qs[3 * f]), fabs(s.qs[3 * f + 1])), fabs(s.qs[3 * f + 2]));   // partial ||q||_inf
+        }
+      });
+      ex.par([&](Th &t) {   // ...then one thread combines the NF partials
+        if (t.tid == 0) {
+          double mean = 0, nq = 0;
+          for (int f = 0; f < NF; ++f) { mean += s.et_[f]; nq = dmax(nq, s.et_[NF + f]); }
+          mean /= N;
+          nq = limit_scaling(nq);
+          s.ctmp = 1.0 / limit_scaling(dmax(mean, nq));
+        }
       });
       ex.par([&](Th &t) {
-        const double ct = t.xprev;
-        if (t.row < N) {
+        const double ct = s.ctmp;
+        if (t.mact) {
 #pragma unroll
-          for (int j = 0; j < CPT; ++j) t.Mx[j] *= ct;
+          for (int e = 0; e < TE; ++e) t.Mx[e] *= ct;
         }
         if (t.tid < N) s.qs[t.tid] *= ct;
         if (t.tid == 0) s.c *= ct;
       });
     }
+    lap(4);
     ex.par([&](Th &t) {
       if (t.tid == 0) s.cinv = 1.0 / s.c;
       if (t.tid < N) {
@@ -490,13 +543,9 @@ struct Solver {
         const int ty = (s.ls[i] < -kInfty * kMinScaling && s.us[i] > kInfty * kMinScaling) ? -1 : (s.us[i] - s.ls[i] < kRhoTol ? 1 : 0);
         s.ctype[i] = ty;
       }
-      // keep P_s for residuals, re-factorisations and polish
-      if (t.row < N) {
-        double *g = Pg + (size_t)t.row * N + t.part * CPT;
-#pragma unroll
-        for (int j = 0; j < CPT; ++j) g[j] = t.Mx[j];
-      }
+      if (t.mact) store_tile(t, Pg);   // keep P_s for residuals, re-factorisations and polish
     });
+    lap(5);
   }
 
   MPC_HD void set_rho_vec() {   // phase: rho_vec from (ctype, rho)  (auxil.c:79-96, osqp.c:1267-1310)
@@ -511,150 +560,229 @@ struct Solver {
   }
 
   // ================================ 3. K = P_s + sigma I + A^T R A ; Mx <- -K^{-1} ==============
-  // Symmetric sweep: after sweeping every pivot the matrix equals -K^{-1}.  The matrix stays
-  // symmetric, so the multiplier of row i at pivot k is the pivot row's entry i (read from LDS).
-  // The diagonal lives in LDS (s.diag) while sweeping; the register copy of it is ignored.
+  // A^T R A is block diagonal (3 x 3 per foot); a tile holds 2 row feet x 4 column feet.
   MPC_HD void factor(bool reload) {
     ex.par([&](Th &t) {
-      if (reload) load_slice(t, Pg);
-      if (t.row < N) {
-        // (A^T R A) is block diagonal: row `row` (foot f, coordinate c1) gets gv[c2] on columns 3f..3f+2.
-        const int f = t.row / 3, c1 = t.row - 3 * f;
-        double gv[3];
+      if (t.mact) {
+        if (reload) load_tile(t, Pg);
 #pragma unroll
-        for (int c2 = 0; c2 < 3; ++c2) {
-          double g = 0;
-          for (int r = 0; r < 5; ++r) g += s.As[15 * f + 3 * r + c1] * s.rho_vec[5 * f + r] * s.As[15 * f + 3 * r + c2];
-          gv[c2] = g + (c2 == c1 ? kSigma : 0.0);
-        }
-        // value selects only (a conditional store would keep Mx out of registers); flocal is
-        // laundered per foot so the compiler does not hoist 20 lane masks out of the loop
-        int flocal = f - t.part * (CPT / 3);
+        for (int fr = 0; fr < 2; ++fr)
 #pragma unroll
-        for (int jf = 0; jf < CPT / 3; ++jf) {
-          MPC_LAUNDER(flocal);
-          const bool hit = flocal == jf;
-          t.Mx[3 * jf] += hit ? gv[0] : 0.0;
-          t.Mx[3 * jf + 1] += hit ? gv[1] : 0.0;
-          t.Mx[3 * jf + 2] += hit ? gv[2] : 0.0;
-        }
-        if (t.part == 0) s.diag[t.row] = Pg[(size_t)t.row * N + t.row] + gv[c1];
+          for (int fc = 0; fc < 4; ++fc) {
+            const int f = 2 * t.ti + fr;
+            if (f == 4 * t.tj + fc) {      // this 3x3 sub-block sits on the block diagonal
+              const double *a = s.As + 15 * f, *rv = s.rho_vec + 5 * f;
+#pragma unroll
+              for (int c1 = 0; c1 < 3; ++c1)
+#pragma unroll
+                for (int c2 = 0; c2 < 3; ++c2) {
+                  double g = 0;
+                  for (int r = 0; r < 5; ++r) g += a[3 * r + c1] * rv[r] * a[3 * r + c2];
+                  if (c1 == c2) g += kSigma;
+                  t.Mx[(3 * fr + c1) * TC + 3 * fc + c2] += g;
+                }
+#pragma unroll
+              for (int c1 = 0; c1 < 3; ++c1) s.diag[3 * f + c1] = t.Mx[(3 * fr + c1) * TC + 3 * fc + c1];
+            }
+          }
       }
     });
+    lap(6);
     sweep_all(false);
     ex.par([&](Th &t) { if (t.tid == 0) s.nfact++; });
+    lap(7);
   }
 
-  // Sweep all pivots (or only those with s.isnull[k] when masked).  On exit Mx (incl. the diagonal
-  // slot) holds minus the inverse (restricted to the swept pivots).
-  // Per step k:  p = a_kk;  a_ij -= a_ik a_kj / p (i,j != k);  a_ik -> a_ik / p;  a_kk -> -1/p.
-  // The published pivot row carries (p - 1) in slot k, which makes the generic update
+  // Symmetric sweep of every pivot (masked: the update is skipped for pivots with !isnull[k]).  After
+  // all pivots the matrix equals -inverse.  Per step k:  p = a_kk;  a_ij -= a_ik a_kj / p (i,j != k);
+  // a_ik -> a_ik / p;  a_kk -> -1/p.  The matrix stays symmetric, so a_ik is read from the published
+  // pivot row.  That row carries (p - 1) in slot k, which makes the generic update
   //   a_ij -= (row_k[i] / p) * row_k[j]
-  // produce a_ik / p on column k and a_kj / p on row k without any per-element select.
+  // produce a_ik / p on column k and a_kj / p on row k with no per-element select.  The true diagonal
+  // lives in LDS (s.diag); the register copy of a diagonal element takes the generic update and ends
+  // up as (true value + 2) on every swept row -- the matrix-vector products add 2 v[row] back.
+  // The pivot loop is unrolled by TC = 12 so that the pivot row's position inside its tile is static.
   MPC_HD void sweep_all(bool masked) {
     int buf = 0;
-    int k0 = 0;
-    if (masked) while (k0 < N && !s.isnull[k0]) ++k0;
-    ex.par([&](Th &t) {   // publish the first pivot row and pivot
-      if (k0 < N && t.row == k0) publish_row(t, 0, k0, s.diag[k0]);
+    ex.par([&](Th &t) {   // publish pivot row 0
+      if (t.mact && t.ti == 0) publish_row<0, 0>(t, 0, 0, 0, s.diag[0]);
     });
-    for (int k = k0; k < N;) {
-      int kn = k + 1;
-      if (masked) while (kn < N && !s.isnull[kn]) ++kn;
-      ex.par([&](Th &t) {
-        if (t.row < N) {
-          const double p = s.piv[buf];
-          const double pinv = 1.0 / p;
-          const double *pr = s.prow[buf];
-          const double f = pr[t.row];            // a_ik (or p - 1 on the pivot row)
-          const double g = f * pinv;
-          const double *prc = pr + t.part * CPT;
-#pragma unroll
-          for (int j = 0; j < CPT; ++j) {
-            if (j % MPC_CHUNK == 0) MPC_SCHED_FENCE();
-            t.Mx[j] -= g * prc[j];
-          }
-          MPC_SCHED_FENCE();
-          double dnew = 0;
-          if (t.part == 0) {
-            dnew = (t.row == k) ? -pinv : s.diag[t.row] - f * g;
-            s.diag[t.row] = dnew;
-            if (t.row == k && !(p > 0)) s.bad = 1;   // not positive definite
-          }
-          if (kn < N && t.row == kn) publish_row(t, buf ^ 1, kn, dnew);
-        }
-      });
-      buf ^= 1;
-      k = kn;
-    }
-    // No fix-up of the register slice: its diagonal slot took the generic update, which leaves
-    // (true value + 2) on every swept row (2 - 1/p instead of -1/p at the row's own pivot, identical
-    // increments afterwards).  The matrix-vector products add the 2 v[row] back (inv_combine).
+    for (int kb = 0; kb < GC; ++kb) sweep_steps<0>(masked, kb, buf);
   }
-  // Row `k`'s threads copy their slice to prow[b]; slot k itself gets (pivot - 1) and piv[b] the pivot
-  // (both written by the part-0 thread, which owns the LDS diagonal).
-  MPC_HD void publish_row(Th &t, int b, int k, double pivot) {
-    double *pn = s.prow[b] + t.part * CPT;
-    const int kloc = k - t.part * CPT;
-#pragma unroll
-    for (int j = 0; j < CPT; ++j) {
-      if (j % MPC_CHUNK == 0) MPC_SCHED_FENCE();
-      if (j != kloc) pn[j] = t.Mx[j];
+  template <int KK>
+  MPC_HD void sweep_steps(bool masked, int kb, int &buf) {
+    if constexpr (KK < TC) {
+      sweep_step<KK>(masked, kb, buf);
+      buf ^= 1;
+      sweep_steps<KK + 1>(masked, kb, buf);
     }
-    if (t.part == 0) { s.prow[b][k] = pivot - 1.0; s.piv[b] = pivot; }
+  }
+  // Pivot step k = 12 kb + KK.  Order inside the phase: the tile row that holds pivot row k+1 is
+  // updated first, then the LDS diagonal, then row k+1 is published -- so that the LDS stores and the
+  // reciprocal are in flight while the other five tile rows take their update.
+  template <int KK>
+  MPC_HD void sweep_step(bool masked, int kb, int buf) {
+    constexpr int A = KK % TR;                       // pivot row's position inside its tile
+    constexpr int KN = KK + 1;                       // next pivot, relative to 12 kb
+    constexpr int AN = KN % TR, BN = KN % TC;
+    const int k = TC * kb + KK;
+    const int tik = 2 * kb + KK / TR;
+    const int kn = k + 1;
+    const int tikn = (KN < TC) ? 2 * kb + KN / TR : 2 * (kb + 1);
+    const int tjkn = (KN < TC) ? kb : kb + 1;
+    const bool active = !masked || s.isnull[k];      // uniform
+    const bool pub = kn < N && (!masked || s.isnull[kn]);   // the next pivot row is only needed if that pivot is used
+    if (!active && !pub) return;
+    ex.par([&](Th &t) {
+      if (t.mact) {
+        double g[TR], pc[TC], dnext = 0;
+        if (active) {
+          const double p = s.piv[buf][0], pinv = s.piv[buf][1];
+          const double *pr = s.prow[buf];
+          double f[TR];
+#pragma unroll
+          for (int a = 0; a < TR; ++a) { f[a] = pr[TR * t.ti + a]; g[a] = f[a] * pinv; }
+#pragma unroll
+          for (int b = 0; b < TC; ++b) pc[b] = pr[TC * t.tj + b];
+#pragma unroll
+          for (int b = 0; b < TC; ++b) t.Mx[AN * TC + b] -= g[AN] * pc[b];
+          if (t.tj == 0) {
+#pragma unroll
+            for (int a = 0; a < TR; ++a) {
+              const int row = TR * t.ti + a;
+              const double dn = (a == A && t.ti == tik) ? -pinv : s.diag[row] - f[a] * g[a];
+              s.diag[row] = dn;
+              if (a == AN) dnext = dn;
+            }
+            if (t.ti == tik && !(p > 0)) s.bad = 1;   // not positive definite
+          }
+        } else if (t.tj == 0 && t.ti == tikn) {
+          dnext = s.diag[kn];
+        }
+        if (pub && t.ti == tikn) publish_row<AN, BN>(t, buf ^ 1, kn, tjkn, dnext);
+        MPC_SCHED_FENCE();
+        if (active) {
+#pragma unroll
+          for (int a = 0; a < TR; ++a) {
+            if (a == AN) continue;
+#pragma unroll
+            for (int b = 0; b < TC; ++b) t.Mx[a * TC + b] -= g[a] * pc[b];
+          }
+        }
+      }
+    });
+  }
+  // The threads of tile row (k / 6) copy row k of their tiles to prow[b]; slot k itself gets
+  // (pivot - 1) and piv[b] = {pivot, 1/pivot}, written by the tj == 0 thread (owner of the LDS diagonal).
+  template <int A, int B>
+  MPC_HD void publish_row(Th &t, int b, int k, int tjk, double pivot) {
+    double *pn = s.prow[b] + TC * t.tj;
+#pragma unroll
+    for (int bb = 0; bb < TC; ++bb)
+      if (!(bb == B && t.tj == tjk)) pn[bb] = t.Mx[A * TC + bb];
+    if (t.tj == 0) {
+      s.prow[b][k] = pivot - 1.0;
+      s.piv[b][0] = pivot;
+      s.piv[b][1] = fast_recip(pivot);
+    }
+  }
+  static MPC_HD double fast_recip(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(d);            // v_rcp_f64 + two Newton steps (full double accuracy, not IEEE-rounded)
+    r = r * (2.0 - d * r);
+    r = r * (2.0 - d * r);
+    return r;
+#else
+    return 1.0 / d;
+#endif
   }
 
   // ================================ 4. ADMM (auxil.c:164-228) ===================================
-  // pre: s.tm = R z - y for the current (z, y); thread-local xprev/zprev are set inside.
-  MPC_HD void admm_prepare() {
+  // Two phases per iteration:
+  //   M: part <- (-Mx) rhs                       (tile threads; Mx = -K^{-1} + 2 I on the diagonal slots)
+  //   V: one thread per foot finishes the iteration for its 3 variables and 5 constraint rows
+  //      (x~ from the partials, x, z~ = A x~, z, y) and forms the next right-hand side
+  //      rhs = sigma x - q + A^T (R z - y).
+  MPC_HD void admm_prepare() {   // rhs for the first iteration / after a rho update
     ex.par([&](Th &t) {
-      if (t.tid < M) s.tm[t.tid] = s.rho_vec[t.tid] * s.z[t.tid] - s.y[t.tid];
+      if (t.tid < NF) {
+        const int f = t.tid;
+        const double *a = s.As + 15 * f;
+        double tm[5];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) tm[r] = s.rho_vec[5 * f + r] * cz()[5 * f + r] - cy()[5 * f + r];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          double acc = 0;
+#pragma unroll
+          for (int r = 0; r < 5; ++r) acc += a[3 * r + c] * tm[r];
+          crhs()[3 * f + c] = kSigma * s.x[3 * f + c] - s.qs[3 * f + c] + acc;
+        }
+      }
     });
   }
   MPC_HD void admm_iter() {
-    ex.par([&](Th &t) {   // rhs = sigma x - q + A^T (R z - y)
-      if (t.tid < N) { t.xprev = s.x[t.tid]; s.rhs[t.tid] = kSigma * s.x[t.tid] - s.qs[t.tid] + at_col_dot(s, t.tid, s.tm); }
-    });
-    ex.par([&](Th &t) {   // x~ = K^{-1} rhs  (Mx = -K^{-1})
-      s.part[t.tid] = (t.row < N) ? -slice_dot(t, s.rhs) : 0.0;
+    ex.par([&](Th &t) {
+      if (t.mact) tile_matvec_neg(t, crhs());
     });
     ex.par([&](Th &t) {
+      // Three threads per foot (tid = 3 f + c), each redoing the foot's 3 x~ and 5 row updates -- the
+      // five rows are independent chains, which hides the fp64 latency a single thread would expose.
+      // Thread c stores x[3f+c], rhs[3f+c] and rows c, c+3.  z, y and rhs are ping-pong buffered
+      // (siblings read the old values while others already store the new ones).
       if (t.tid < N) {
-        const double xt = inv_combine(s, t.tid, s.rhs);
-        s.xt[t.tid] = xt;
-        const double xn = kAlphaRelax * xt + (1.0 - kAlphaRelax) * t.xprev;
+        const int f = t.tid / 3, c0 = t.tid - 3 * f;
+        const double *a = s.As + 15 * f;
+        const double *zc = s.zz[pp], *yc = s.yy[pp], *rc = s.rr[pp];
+        double xt[3], tm[5], zk0 = 0, yk0 = 0, zk1 = 0, yk1 = 0;
+        // scheduling fences keep the live set small: the tile already occupies 144 of the 256 VGPRs
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { xt[c] = inv_combine(s, 3 * f + c, rc); MPC_SCHED_FENCE(); }
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+          const int i = 5 * f + r;
+          const double zt = a[3 * r] * xt[0] + a[3 * r + 1] * xt[1] + a[3 * r + 2] * xt[2];
+          const double zp = zc[i], yv = yc[i], rv = s.rho_vec[i];
+          const double zr = kAlphaRelax * zt + (1.0 - kAlphaRelax) * zp;
+          const double znr = clampd(zr + s.rho_inv[i] * yv, s.ls[i], s.us[i]);
+          const double ynr = yv + rv * (zr - znr);
+          tm[r] = rv * znr - ynr;
+          if (r < 3) { zk0 = (r == c0) ? znr : zk0; yk0 = (r == c0) ? ynr : yk0; }      // rows c0 ...
+          else { zk1 = (r == c0 + 3) ? znr : zk1; yk1 = (r == c0 + 3) ? ynr : yk1; }     // ... and c0 + 3
+          MPC_SCHED_FENCE();
+        }
+        double xtc = xt[0], acc = 0;
+        xtc = (c0 == 1) ? xt[1] : xtc;
+        xtc = (c0 == 2) ? xt[2] : xtc;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) acc += a[3 * r + c0] * tm[r];
+        const double xn = kAlphaRelax * xtc + (1.0 - kAlphaRelax) * s.x[t.tid];
         s.x[t.tid] = xn;
+        s.rr[pp ^ 1][t.tid] = kSigma * xn - s.qs[t.tid] + acc;
+        s.zz[pp ^ 1][5 * f + c0] = zk0; s.yy[pp ^ 1][5 * f + c0] = yk0;
+        if (c0 < 2) { s.zz[pp ^ 1][5 * f + c0 + 3] = zk1; s.yy[pp ^ 1][5 * f + c0 + 3] = yk1; }
       }
     });
-    ex.par([&](Th &t) {   // z~ = A x~ ; z, y updates; next iteration's R z - y
-      if (t.tid < M) {
-        const int i = t.tid;
-        const double zt = a_row_dot(s, i, s.xt);
-        const double zp = s.z[i], yv = s.y[i], rv = s.rho_vec[i];
-        const double zr = kAlphaRelax * zt + (1.0 - kAlphaRelax) * zp;
-        const double zn = clampd(zr + s.rho_inv[i] * yv, s.ls[i], s.us[i]);
-        const double yn = yv + rv * (zr - zn);
-        s.z[i] = zn;
-        s.y[i] = yn;
-        s.tm[i] = rv * zn - yn;
-      }
-    });
+    pp ^= 1;
   }
 
-  // P_s v -> out (P_s read from HBM scratch).  Two phases.
+  // P_s v -> out (P_s tiles read from HBM scratch).  Two phases.
   MPC_HD void mul_P(const double *v, double *out) {
     ex.par([&](Th &t) {
-      double acc = 0;
-      if (t.row < N) {
-        const double *g = Pg + (size_t)t.row * N + t.part * CPT;
-        const double *vv = v + t.part * CPT;
+      if (t.mact) {
+        const double *vv = v + TC * t.tj;
+        double vr[TC];
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) {
-          if (j % MPC_CHUNK == 0) MPC_SCHED_FENCE();
-          acc += g[j] * vv[j];
+        for (int b = 0; b < TC; ++b) vr[b] = vv[b];
+#pragma unroll
+        for (int a = 0; a < TR; ++a) {
+          const double *g = Pg + (size_t)(TR * t.ti + a) * N + TC * t.tj;
+          double acc = 0;
+#pragma unroll
+          for (int b = 0; b < TC; ++b) acc += g[b] * vr[b];
+          s.part[(TR * t.ti + a) * GC + t.tj] = acc;
         }
       }
-      s.part[t.tid] = acc;
     });
     ex.par([&](Th &t) { if (t.tid < N) out[t.tid] = sum_parts(s, t.tid); });
   }
@@ -662,24 +790,39 @@ struct Solver {
   // residuals of (x, z, y) (auxil.c:243-306, 563-629) + the norms termination and rho need.
   // red[] slots: 0 pri_res 1 ||Einv z|| 2 ||Einv Ax|| 3 ||rp|| 4 ||z|| 5 ||Ax||
   //              6 ||Dinv rd|| 7 ||Dinv q|| 8 ||Dinv Aty|| 9 ||Dinv Px|| 10 ||rd|| 11 ||q|| 12 ||Aty|| 13 ||Px||
+  // 64 threads stride over the rows and keep running maxima in registers; 14 threads finish.
+  static constexpr int kRedW = 64;
   MPC_HD void residuals(const double *x, const double *z, const double *y) {
-    ex.par([&](Th &t) { if (t.tid < 16) s.red[t.tid] = 0; });
     mul_P(x, s.Px);
+    lap(9);
     ex.par([&](Th &t) {
-      if (t.tid < M) {
-        const int i = t.tid;
-        const double ax = a_row_dot(s, i, x), r = ax - z[i], ei = s.Einv[i];
-        s.Ax[i] = ax; s.rp[i] = r;
-        ex.amax(&s.red[0], fabs(ei * r)); ex.amax(&s.red[1], fabs(ei * z[i])); ex.amax(&s.red[2], fabs(ei * ax));
-        ex.amax(&s.red[3], fabs(r)); ex.amax(&s.red[4], fabs(z[i])); ex.amax(&s.red[5], fabs(ax));
+      if (t.tid < kRedW) {
+        double mx[14];
+#pragma unroll
+        for (int k = 0; k < 14; ++k) mx[k] = 0;
+        for (int i = t.tid; i < M; i += kRedW) {
+          const double ax = a_row_dot(s, i, x), r = ax - z[i], ei = s.Einv[i];
+          s.Ax[i] = ax; s.rp[i] = r;
+          mx[0] = dmax(mx[0], fabs(ei * r)); mx[1] = dmax(mx[1], fabs(ei * z[i])); mx[2] = dmax(mx[2], fabs(ei * ax));
+          mx[3] = dmax(mx[3], fabs(r)); mx[4] = dmax(mx[4], fabs(z[i])); mx[5] = dmax(mx[5], fabs(ax));
+        }
+        for (int j = t.tid; j < N; j += kRedW) {
+          const double aty = at_col_dot(s, j, y), px = s.Px[j], qv = s.qs[j], r = qv + px + aty, di = s.Dinv[j];
+          s.Aty[j] = aty; s.rd[j] = r;
+          mx[6] = dmax(mx[6], fabs(di * r)); mx[7] = dmax(mx[7], fabs(di * qv)); mx[8] = dmax(mx[8], fabs(di * aty));
+          mx[9] = dmax(mx[9], fabs(di * px)); mx[10] = dmax(mx[10], fabs(r)); mx[11] = dmax(mx[11], fabs(qv));
+          mx[12] = dmax(mx[12], fabs(aty)); mx[13] = dmax(mx[13], fabs(px));
+        }
+#pragma unroll
+        for (int k = 0; k < 14; ++k) s.part[k * kRedW + t.tid] = mx[k];
       }
-      if (t.tid < N) {
-        const int j = t.tid;
-        const double aty = at_col_dot(s, j, y), px = s.Px[j], qv = s.qs[j], r = qv + px + aty, di = s.Dinv[j];
-        s.Aty[j] = aty; s.rd[j] = r;
-        ex.amax(&s.red[6], fabs(di * r)); ex.amax(&s.red[7], fabs(di * qv)); ex.amax(&s.red[8], fabs(di * aty));
-        ex.amax(&s.red[9], fabs(di * px)); ex.amax(&s.red[10], fabs(r)); ex.amax(&s.red[11], fabs(qv));
-        ex.amax(&s.red[12], fabs(aty)); ex.amax(&s.red[13], fabs(px));
+    });
+    ex.par([&](Th &t) {
+      if (t.tid < 14) {
+        const double *p = s.part + t.tid * kRedW;
+        double m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+        for (int k = 0; k < kRedW; k += 4) { m0 = dmax(m0, p[k]); m1 = dmax(m1, p[k + 1]); m2 = dmax(m2, p[k + 2]); m3 = dmax(m3, p[k + 3]); }
+        s.red[t.tid] = dbits(dmax(dmax(m0, m1), dmax(m2, m3)));
       }
     });
   }
@@ -714,7 +857,7 @@ struct Solver {
     ex.par([&](Th &t) {
       if (t.tid < M) {
         const int i = t.tid;
-        s.act[i] = (s.z[i] - s.ls[i] < -s.y[i]) ? -1 : ((s.us[i] - s.z[i] < s.y[i]) ? 1 : 0);
+        s.act[i] = (cz()[i] - s.ls[i] < -cy()[i]) ? -1 : ((s.us[i] - cz()[i] < cy()[i]) ? 1 : 0);
       }
     });
     ex.par([&](Th &t) {
@@ -807,41 +950,44 @@ struct Solver {
       }
     });
     mul_P(s.u0, s.Pu);
-    // H = N~^T P N~ + delta I on the null coordinates, identity elsewhere; N~ = blockdiag([N_f | 0])
+    lap(11);
+    // H = N~^T P N~ + delta I on the null coordinates, identity elsewhere; N~ = blockdiag([N_f | 0]).
+    // Tile-local: 2 row feet x 4 column feet of 3 x 3 blocks, all register indices static.
     ex.par([&](Th &t) {
       if (t.tid < N) s.g[t.tid] = -s.qs[t.tid] - s.Pu[t.tid];
-      if (t.row < N) {
-        const int f1 = t.row / 3, k1 = t.row - 3 * f1;
-        const double *n1 = s.Nb + 9 * f1 + 3 * k1;             // null vector k1 of foot f1 (zeros if k1 >= nn)
-        const bool rownull = k1 < s.nnull[f1];
-        const double *g0 = Pg + (size_t)(3 * f1) * N + t.part * CPT;
-        double dval = 0;
-        int rowl = t.row;
+      if (t.mact) {
+        load_tile(t, Pg);
 #pragma unroll
-        for (int jf = 0; jf < CPT / 3; ++jf) {
-          const int f2 = (t.part * CPT) / 3 + jf;
-          double T1[3];
+        for (int fr = 0; fr < 2; ++fr)
 #pragma unroll
-          for (int c = 0; c < 3; ++c) T1[c] = n1[0] * g0[3 * jf + c] + n1[1] * g0[N + 3 * jf + c] + n1[2] * g0[2 * N + 3 * jf + c];
-          const int nn2 = s.nnull[f2];
+          for (int fc = 0; fc < 4; ++fc) {
+            const int rf = 2 * t.ti + fr, cf = 4 * t.tj + fc;
+            const double *nr = s.Nb + 9 * rf, *nc = s.Nb + 9 * cf;   // row k = null vector k (zero rows beyond nnull)
+            const int nnr = s.nnull[rf], nnc = s.nnull[cf];
+            double T1[9];
 #pragma unroll
-          for (int k2 = 0; k2 < 3; ++k2) {
-            const int col = 3 * f2 + k2;
-            const double *n2 = s.Nb + 9 * f2 + 3 * k2;
-            double v = (rownull && k2 < nn2) ? (n2[0] * T1[0] + n2[1] * T1[1] + n2[2] * T1[2]) : 0.0;
-            MPC_LAUNDER(rowl);
-            const bool isd = col == rowl;
-            v = isd ? (rownull ? v + kDelta : 1.0) : v;
-            dval = isd ? v : dval;
-            t.Mx[3 * jf + k2] = v;
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+              for (int k2 = 0; k2 < 3; ++k2)
+                T1[3 * r + k2] = t.Mx[(3 * fr + r) * TC + 3 * fc] * nc[3 * k2] + t.Mx[(3 * fr + r) * TC + 3 * fc + 1] * nc[3 * k2 + 1] +
+                                 t.Mx[(3 * fr + r) * TC + 3 * fc + 2] * nc[3 * k2 + 2];
+#pragma unroll
+            for (int k1 = 0; k1 < 3; ++k1)
+#pragma unroll
+              for (int k2 = 0; k2 < 3; ++k2) {
+                double v = (k1 < nnr && k2 < nnc) ? nr[3 * k1] * T1[k2] + nr[3 * k1 + 1] * T1[3 + k2] + nr[3 * k1 + 2] * T1[6 + k2] : 0.0;
+                if (k1 == k2 && rf == cf) {
+                  v = (k1 < nnr) ? v + kDelta : 1.0;
+                  s.diag[3 * rf + k1] = v;
+                }
+                t.Mx[(3 * fr + k1) * TC + 3 * fc + k2] = v;
+              }
           }
-        }
-        const int jd = t.row - t.part * CPT;
-        if (jd >= 0 && jd < CPT) s.diag[t.row] = dval;
       }
     });
     sweep_all(true);   // Mx <- -(H + delta I)^{-1} on the null coordinates
     ex.par([&](Th &t) { if (t.tid == 0) s.nfact++; });
+    lap(12);
     // iterative refinement in the null space (polish.c:102-160: 1 solve + 3 refinements)
     for (int it = 0; it <= kPolishRefine; ++it) {
       ex.par([&](Th &t) {   // rw = N~^T (g - P xN)
@@ -851,7 +997,7 @@ struct Solver {
           s.rw[j] = (k < s.nnull[f]) ? nv[0] * (s.g[3 * f] - s.PxN[3 * f]) + nv[1] * (s.g[3 * f + 1] - s.PxN[3 * f + 1]) + nv[2] * (s.g[3 * f + 2] - s.PxN[3 * f + 2]) : 0.0;
         }
       });
-      ex.par([&](Th &t) { s.part[t.tid] = (t.row < N) ? -slice_dot(t, s.rw) : 0.0; });
+      ex.par([&](Th &t) { if (t.mact) tile_matvec_neg(t, s.rw); });
       ex.par([&](Th &t) { if (t.tid < N && s.isnull[t.tid]) s.wv[t.tid] += inv_combine(s, t.tid, s.rw); });
       ex.par([&](Th &t) {   // xN = N~ w
         if (t.tid < N) {
@@ -863,6 +1009,7 @@ struct Solver {
       });
       mul_P(s.xN, s.PxN);
     }
+    lap(13);
     // x = u + xN ; y = A Gamma (g - P xN) on active rows ; z = A x ; normal-cone projection (proj.c:17-31)
     ex.par([&](Th &t) {
       if (t.tid < N) {
@@ -896,51 +1043,46 @@ struct Solver {
     ex.par([&](Th &t) {
       if (s.status_polish == 1) {
         if (t.tid < N) s.x[t.tid] = s.xt[t.tid];
-        if (t.tid < M) { s.z[t.tid] = s.zpol[t.tid]; s.y[t.tid] = s.ypol[t.tid]; }
+        if (t.tid < M) { cz()[t.tid] = s.zpol[t.tid]; cy()[t.tid] = s.ypol[t.tid]; }
       }
     });
   }
 
   // ================================ driver ======================================================
   MPC_HD void run() {
-    long long tc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const long long t0 = MPC_CLOCK();
-    long long ta = t0, tb;
-#define MPC_LAP(k) { tb = MPC_CLOCK(); tc[k] += tb - ta; ta = tb; }
+    tlast = t0;
     assemble();
-    MPC_LAP(0)
     scale();
-    MPC_LAP(1)
     set_rho_vec();
     factor(false);
-    MPC_LAP(2)
     admm_prepare();
+    lap(8);
     int iter = 0;
     while (!s.done && !s.bad && iter < kMaxIter) {
       ++iter;
       admm_iter();
       if (iter % kCheck == 0) {
-        MPC_LAP(3)
-        residuals(s.x, s.z, s.y);
+        lap(8);
+        residuals(s.x, cz(), cy());
         check_and_adapt(iter);
-        MPC_LAP(4)
+        lap(10);
         if (!s.done && s.rho_new > 0) {          // osqp_update_rho: new rho_vec, refactor
           ex.par([&](Th &t) { if (t.tid == 0) { s.rho = s.rho_new; s.rho_updates++; } });
           set_rho_vec();
           factor(true);
           admm_prepare();
-          MPC_LAP(2)
+          lap(8);
         }
       }
     }
-    MPC_LAP(3)
+    lap(8);
     if (!s.done && !s.bad) {   // max_iter reached (osqp.c:564-568): only SOLVED counts for the reference
       ex.par([&](Th &t) { if (t.tid == 0) s.status = kStMaxIter; });
     }
     if (s.status == kStSolved && !s.bad) polish();
-    MPC_LAP(5)
-#undef MPC_LAP
-    tc[6] = MPC_CLOCK() - t0;
+    lap(14);
+    tc[15] = MPC_CLOCK() - t0;
     // outputs + persistent state (store_solution, auxil.c:528-561; mpc_osqp.cc:788-790: forces = -x)
     ex.par([&](Th &t) {
       const bool solved = s.status == kStSolved && !s.bad;
@@ -949,7 +1091,7 @@ struct Solver {
         state[t.tid] = s.x[t.tid];
         state[N + 2 * M + t.tid] = s.q[t.tid];
       }
-      if (t.tid < M) { state[N + t.tid] = s.z[t.tid]; state[N + M + t.tid] = s.y[t.tid]; }
+      if (t.tid < M) { state[N + t.tid] = cz()[t.tid]; state[N + M + t.tid] = cy()[t.tid]; }
       if (t.tid == 0) {
         state[2 * N + 2 * M] = s.rho;
         state[2 * N + 2 * M + 1] = 1.0;

@@ -20,8 +20,8 @@ struct HostExec {
   long phases = 0;
   explicit HostExec(bool rev) : th(Cfg<H>::T), reverse(rev) {
     for (int i = 0; i < Cfg<H>::T; ++i) {
-      th[i].tid = i; th[i].row = i / Cfg<H>::S; th[i].part = i % Cfg<H>::S; th[i].xprev = 0; th[i].zprev = 0;
-      for (int j = 0; j < Cfg<H>::CPT; ++j) th[i].Mx[j] = 0;
+      th[i].init(i);
+      for (int j = 0; j < Cfg<H>::TE; ++j) th[i].Mx[j] = 0;
     }
   }
   template <class F> void par(F &&f) {

@@ -11,7 +11,7 @@ n, h = int(sys.argv[1]) if len(sys.argv) > 1 else 4096, 10
 wl = make_solver_workload(n, h=h, seed=1000, config=2)
 inertia9 = np.zeros((n, 9)); inertia9[:, 0], inertia9[:, 4], inertia9[:, 8] = wl.inertia_diag.T
 sv = BatchedConvexMpc(wl.mass, inertia9, h, wl.dt_mpc, wl.alpha)
-names = ["assemble", "scale", "factor", "admm", "resid", "polish", "total"]
+names = ["load", "dyn", "qP", "sc-load", "sc-loop", "sc-store", "Kform", "sweep", "admm", "r-mulP", "r-rest", "p-setup", "p-H", "p-refine", "p-fin", "total"]
 w = wl
 for step in range(4):
     d = torch.from_numpy(w.inputs).cuda()
@@ -21,5 +21,5 @@ for step in range(4):
     p = sv.get_profile().astype(np.float64); i = info.cpu().numpy()
     print(f"step {step}: {dt*1e3:.2f} ms  iters {i[:,0].mean():.1f} nfact {i[:,4].mean():.2f} | mean kcycles/robot: " +
           " ".join(f"{nm}={p[:,k].mean()/1e3:.0f}" for k, nm in enumerate(names)) +
-          f" | per-iter admm {p[:,3].sum()/i[:,0].sum():.0f} cyc, per-factor {p[:,2].sum()/np.maximum(i[:,4]-1,1).sum():.0f} cyc")
+          f" | per-iter admm {p[:,8].sum()/i[:,0].sum():.0f} cyc, per-sweep {p[:,7].sum()/np.maximum(i[:,4]-1,1).sum():.0f} cyc")
     w = perturb_workload(w, 7000 + step)
