@@ -149,12 +149,25 @@ def main():
         dist.destroy_process_group()
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota
+    (the GPU boxes expose 256 logical CPUs but grant a 16-CPU quota)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(round(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(wl, batches, W, h, sample=2048, steps=4, gpu_first_forces=None):
     """The reference path (oracle/_ref: restated mpc_osqp.cc assembly + the vendored OSQP) timed on the
     host cores on a bounded sample of the same workload: the first `sample` robots, cold solve +
     `steps` timed warm solves (the same batches the GPU warmed up / timed on)."""
     from oracle.refmpc import RefBatch
-    cores = len(os.sched_getaffinity(0))
+    cores = usable_cores()
     sample = min(sample, len(wl.mass))
     ref = RefBatch(wl.mass[:sample], wl.inertia_diag[:sample], h, wl.dt_mpc, wl.alpha)
     for s in range(W):
