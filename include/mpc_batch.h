@@ -88,6 +88,38 @@ int mpc_batch_set_state(mpc_batch *b, const double *h_state);
 /* Shader-clock cycles the last solve spent per section, [n, 16] int64 (sections: csrc/mpc_core.h kProfLen). */
 int mpc_batch_get_profile(mpc_batch *b, long long *h_prof);
 
+/* ---- per-tick controller (the rest of the hot path around the solve) -------------------------------
+ *
+ *   mpc_ctrl_create  <- RobotRunnerMin.init (robot_runner/RobotRunnerMin.py:14-47) for N robots: Quadruped,
+ *                       LegController, ConvexMPCLocomotion(dt, 27/(1000 dt)) and its ConvexMpc object.
+ *   mpc_ctrl_step    <- the part of RobotRunnerMin.run (RobotRunnerMin.py:54-75) after StateEstimator.update:
+ *                       LegController.updateData (LegController.py:89-106), ConvexMPCLocomotion.run
+ *                       (ConvexMPCLocomotion.py:222-378: gait, estimator sub-steps, foot placement, the MPC solve
+ *                       every iterationsBetweenMPC-th tick, swing Bezier, leg commands) and
+ *                       LegController.updateCommand (LegController.py:108-132) -> 12 joint torques per robot.
+ *   mpc_ctrl_reset   <- RobotRunnerMin.reset (RobotRunnerMin.py:49-52), RL_Environment/tasks/aliengo.py:333-334.
+ *   mpc_ctrl_set_gait<- the process-global Parameters.cmpc_gait (Parameters.py:17), per robot here.
+ *
+ * d_dof:  [n, 12, 2] float32 (pos, vel; legs FL FR RL RR)         = dof_states of controller.run
+ * d_est:  [n, 18]    float32 StateEstimator.update outputs: vBody[3], omegaBody[3], rpyBody[3] (float16
+ *                    valued), ground_R_body_frame[9] (float16 valued, row-major)
+ * d_cmd:  [n, 16]    float32 vx, vy, yaw_rate, 13 MPC weights      = commands of controller.run
+ * d_torques: [n, 12] float32, FL FR RL RR x (hip, thigh, calf)
+ * robot_table: [n_types, 25] float64 rows {abad, hip, knee link lengths, abad location xyz, mass, inertia
+ *   diag xyz, body height, mu, 13 default weights} (MPC_Controller/common/Quadruped.py:16-92);
+ * gait_off / gait_dur: [8, 4] int32 offsets / durations in MPC segments per gait id
+ *   (ConvexMPCLocomotion.py:30-56), horizon segments per cycle.
+ */
+typedef struct mpc_ctrl mpc_ctrl;
+int mpc_ctrl_create(mpc_ctrl **out, int n_robots, int horizon, double controller_dt, int iterations_between_mpc,
+                    double alpha, int flat_ground, const int *robot_type, const int *gait_id, int n_types,
+                    const double *robot_table, const int *gait_off, const int *gait_dur);
+void mpc_ctrl_destroy(mpc_ctrl *c);
+int mpc_ctrl_step(mpc_ctrl *c, const float *d_dof, const float *d_est, const float *d_cmd, float *d_torques, void *stream);
+int mpc_ctrl_reset(mpc_ctrl *c, const int *ids, int k, void *stream);      /* HOST ids; NULL = all */
+int mpc_ctrl_set_gait(mpc_ctrl *c, const int *gait_id, void *stream);       /* HOST [n] */
+int mpc_ctrl_solver_info(mpc_ctrl *c, int *h_info);                          /* [n, 8] of the last solves */
+
 const char *mpc_last_error(void);
 
 #ifdef __cplusplus

@@ -1,0 +1,347 @@
+// controller.h -- the per-tick controller around the contact-force solve, one robot per thread.
+//
+// Restates, in the reference's own arithmetic types (numpy float32 "f", Python float "d"), what
+//   MPC_Controller/common/LegController.py:89-106,135-171   updateData (leg FK, Jacobian, foot velocity)
+//   MPC_Controller/convex_MPC/ConvexMPCLocomotion.py:222-378 run (gait, estimator sub-steps, foot placement,
+//                                                            MPC marshalling, swing / stance leg commands)
+//   MPC_Controller/convex_MPC/Gait.py:26-93                   OffsetDurationGait
+//   MPC_Controller/common/FootSwingTrajectory.py:54-70, math_utils/interplation.py:4-26   swing Bezier
+//   MPC_Controller/common/StateEstimator.py:99-143            contact history, CoM height, ground normal
+//   MPC_Controller/common/LegController.py:108-132            updateCommand (12 joint torques)
+// do for one robot and one control tick.  Split in two halves around the solver launch:
+//   ctrl_pre  : everything up to the call of compute_contact_forces (writes the solver input record)
+//   ctrl_post : f_ff <- first-step forces, leg commands, torques
+// StateEstimator.update (quaternion -> body-frame velocities, float16 rpy) runs before this stage; its
+// outputs arrive in the `est` record.
+#pragma once
+
+#include <math.h>
+
+#include "mpc_core.h"
+
+namespace mpc {
+
+constexpr int kEstLen = 18;     // vBody[3] omegaBody[3] rpyBody[3] ground_R_body_frame[9] (fp16-valued)
+constexpr int kNumGaitIds = 8;
+
+struct RobotConst {   // MPC_Controller/common/Quadruped.py:16-92 (one row per robot type)
+  double abad, hip, knee;        // link lengths (Python floats)
+  float hiploc[3];               // _abadLocation (float32)
+  double body_height;
+  float mu;
+  float weights[13];
+};
+
+struct GaitTable {    // ConvexMPCLocomotion.py:30-56 rescaled to n_seg segments (gait.py)
+  int n_seg;
+  float offsets[kNumGaitIds][4], durations[kNumGaitIds][4];
+};
+
+struct CtrlParams {
+  double dt;                     // Parameters.controller_dt                       (Parameters.py:44)
+  int iters_between_mpc;         // int(27 / (1000 dt)) = 2                        (RobotRunnerMin.py:21-22)
+  double dt_mpc;                 // dt * iterationsBetweenMPC                      (ConvexMPCLocomotion.py:58)
+  int horizon;
+  int flat_ground;               // Parameters.flat_ground                          (Parameters.py:21)
+};
+
+struct CtrlState {    // per-robot persistent controller state
+  int iter, first_run, first_swing[4];
+  int gait_id, robot_type;
+  double swing_time_remaining[4];
+  float swing_times[4];
+  float f_ff[12];
+  float p0[12], pf[12], tp[12], tv[12];          // FootSwingTrajectory _p0 _pf _p _v per foot
+  float pos_z, normal[3], contact_phase[4], hist[12];
+  // scratch carried from ctrl_pre to ctrl_post within one tick
+  float q[12], qd[12], p[12], v[12], J[36];
+  float foot_positions[12], pfoot[12];
+  float contact_states[4], swing_states[4];
+  float vbody[3], posz_tick;
+  int do_solve;
+};
+
+// RobotRunnerMin.reset (RobotRunnerMin.py:49-52): cMPC.initialize (ConvexMPCLocomotion.py:89-114) resets
+// the counter and the firstRun / firstSwing flags, StateEstimator.reset (:41-48) the estimate.  f_ff and the
+// swing trajectories' last p / v are NOT touched by the reference's reset -- kept here as well.
+MPC_HD void ctrl_reset(CtrlState &s, const RobotConst &rc) {
+  s.iter = 0; s.first_run = 1;
+  for (int i = 0; i < 4; ++i) { s.first_swing[i] = 1; s.contact_phase[i] = 0.f; }
+  for (int i = 0; i < 12; ++i) s.hist[i] = 0.f;
+  s.pos_z = (float)rc.body_height;                             // StateEstimator.py:39
+  s.normal[0] = 0.f; s.normal[1] = 0.f; s.normal[2] = 1.f;     // StateEstimator.py:21-22
+  s.do_solve = 0;
+}
+// RobotRunnerMin.init: fresh objects (zeros everywhere)
+MPC_HD void ctrl_init(CtrlState &s, const RobotConst &rc, int robot_type, int gait_id) {
+  for (int i = 0; i < 4; ++i) { s.swing_time_remaining[i] = 0.0; s.swing_times[i] = 0.f; s.contact_states[i] = s.swing_states[i] = 0.f; }
+  for (int i = 0; i < 12; ++i) { s.f_ff[i] = 0.f; s.p0[i] = s.pf[i] = s.tp[i] = s.tv[i] = 0.f; s.q[i] = s.qd[i] = s.p[i] = s.v[i] = 0.f; s.foot_positions[i] = s.pfoot[i] = 0.f; }
+  for (int i = 0; i < 36; ++i) s.J[i] = 0.f;
+  s.vbody[0] = s.vbody[1] = s.vbody[2] = 0.f; s.posz_tick = 0.f;
+  s.gait_id = gait_id; s.robot_type = robot_type;
+  ctrl_reset(s, rc);
+}
+
+// LegController.computeLegJacobianAndPosition (LegController.py:135-171): Python-float math, float32 storage.
+MPC_HD void leg_kinematics(const RobotConst &rc, int leg, const float *q, float *p, float *J) {
+  const double side = (leg == 0 || leg == 2) ? 1.0 : -1.0;      // utils.py:7 SIDE_SIGN
+  const double dy = rc.abad * side, dz1 = -rc.hip, dz2 = -rc.knee;
+  const double s1 = sin((double)q[0]), s2 = sin((double)q[1]), s3 = sin((double)q[2]);
+  const double c1 = cos((double)q[0]), c2 = cos((double)q[1]), c3 = cos((double)q[2]);
+  const double c23 = c2 * c3 - s2 * s3, s23 = s2 * c3 + c2 * s3;
+  p[0] = (float)(dz2 * s23 + dz1 * s2);
+  p[1] = (float)(dy * c1 - dz1 * c2 * s1 - dz2 * s1 * c23);
+  p[2] = (float)(dy * s1 + dz1 * c1 * c2 + dz2 * c1 * c23);
+  J[0] = 0.f;
+  J[3] = (float)(-dy * s1 - dz2 * c1 * c23 - dz1 * c1 * c2);
+  J[6] = (float)(-dz2 * s1 * c23 + dy * c1 - dz1 * c2 * s1);
+  J[1] = (float)(dz2 * c23 + dz1 * c2);
+  J[4] = (float)(dz2 * s1 * s23 + dz1 * s1 * s2);
+  J[7] = (float)(-dz2 * c1 * s23 - dz1 * c1 * s2);
+  J[2] = (float)(dz2 * c23);
+  J[5] = (float)(dz2 * s1 * s23);
+  J[8] = (float)(-dz2 * c1 * s23);
+}
+
+MPC_HD float round_to_half(float x) {   // numpy float16 rounding (round-to-nearest-even), returned as float
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (float)(_Float16)x;
+#else
+  union { float f; unsigned u; } c;
+  c.f = x;
+  const unsigned ex = (c.u >> 23) & 0xffu;
+  if (ex == 255u) return x;
+  const int e = (int)ex - 127;
+  if (e >= -14) {                       // normal half (or overflow): round the 13 dropped mantissa bits to nearest even
+    c.u += 0xFFFu + ((c.u >> 13) & 1u);
+    c.u &= ~0x1FFFu;
+    if (fabsf(c.f) > 65504.f) return c.f > 0 ? INFINITY : -INFINITY;
+    return c.f;
+  }
+  return nearbyintf(x * 16777216.f) / 16777216.f;   // subnormal half: multiples of 2^-24
+#endif
+}
+
+MPC_HD void hip_location(const RobotConst &rc, int leg, float *h) {   // Quadruped.getHipLocation (Quadruped.py:96-107)
+  h[0] = (leg == 0 || leg == 1) ? rc.hiploc[0] : -rc.hiploc[0];
+  h[1] = (leg == 0 || leg == 2) ? rc.hiploc[1] : -rc.hiploc[1];
+  h[2] = rc.hiploc[2];
+}
+
+// ---- first half of the tick -----------------------------------------------------------------
+// dof: [12][2] (pos, vel) leg-major; est: kEstLen floats; cmd: 16 floats (vx vy yaw_rate w[13]).
+// rec: solver input record [56 + 4h] (written only when s.do_solve).
+MPC_HD void ctrl_pre(CtrlState &s, const RobotConst &rc, const GaitTable &gt, const CtrlParams &cp, const float *dof,
+                     const float *est, const float *cmd, float *rec) {
+  const int nseg = gt.n_seg;
+  // LegController.updateData (LegController.py:89-106)
+  for (int leg = 0; leg < 4; ++leg) {
+    for (int j = 0; j < 3; ++j) { s.q[3 * leg + j] = dof[2 * (3 * leg + j)]; s.qd[3 * leg + j] = dof[2 * (3 * leg + j) + 1]; }
+    leg_kinematics(rc, leg, s.q + 3 * leg, s.p + 3 * leg, s.J + 9 * leg);
+    for (int r = 0; r < 3; ++r) {
+      const float *Jr = s.J + 9 * leg + 3 * r, *qd = s.qd + 3 * leg;
+      s.v[3 * leg + r] = Jr[0] * qd[0] + Jr[1] * qd[1] + Jr[2] * qd[2];
+    }
+  }
+  const float *vBody = est, *omegaBody = est + 3, *rpyBody = est + 6, *gRb = est + 9;
+  const float x_vel_des = cmd[0], y_vel_des = cmd[1], yaw_rate = cmd[2];   // ConvexMPCLocomotion.py:119-126
+  const float *off = gt.offsets[s.gait_id], *dur = gt.durations[s.gait_id];
+  // Gait.setIterations (Gait.py:26-28), called with the counter BEFORE the increment
+  const int per = cp.iters_between_mpc * nseg;
+  const double iteration = fmod((double)s.iter / (double)cp.iters_between_mpc, (double)nseg);
+  const double phase = (double)(s.iter % per) / (double)per;
+
+  // foot positions (ConvexMPCLocomotion.py:248-250)
+  for (int i = 0; i < 4; ++i) {
+    float h[3];
+    hip_location(rc, i, h);
+    for (int c = 0; c < 3; ++c) s.foot_positions[3 * i + c] = h[c] + s.p[3 * i + c];
+    s.pfoot[3 * i] = s.foot_positions[3 * i] + 0.f;
+    s.pfoot[3 * i + 1] = s.foot_positions[3 * i + 1] + 0.f;
+    s.pfoot[3 * i + 2] = s.foot_positions[3 * i + 2] + s.pos_z;
+  }
+  if (s.first_run) {   // :257-263
+    s.first_run = 0;
+    for (int i = 0; i < 4; ++i) {
+      s.hist[3 * i] = s.foot_positions[3 * i]; s.hist[3 * i + 1] = s.foot_positions[3 * i + 1];
+      s.hist[3 * i + 2] = (float)(-rc.body_height);                     // StateEstimator.py:99-101
+      for (int c = 0; c < 3; ++c) { s.p0[3 * i + c] = s.pfoot[3 * i + c]; s.pf[3 * i + c] = s.pfoot[3 * i + c]; }
+    }
+  }
+  // StateEstimator._update_com_position_ground_frame (StateEstimator.py:109-118)
+  {
+    const float *cph = s.contact_phase;
+    const float csum = ((cph[0] + cph[1]) + cph[2]) + cph[3];
+    if (csum != 0.f) {
+      float acc = 0.f;
+      for (int i = 0; i < 4; ++i) {
+        const float *fp = s.foot_positions + 3 * i;
+        const float z = fp[0] * gRb[6] + fp[1] * gRb[7] + fp[2] * gRb[8];   // (foot . gRb^T)[:, 2]
+        acc = (i == 0) ? (-z) * cph[0] : acc + (-z) * cph[i];
+      }
+      s.pos_z = acc / csum;
+    }
+  }
+  if (!cp.flat_ground) {   // _compute_ground_normal_and_com_position (StateEstimator.py:120-143)
+    for (int i = 0; i < 4; ++i)
+      if (s.contact_phase[i] != 0.f)
+        for (int c = 0; c < 3; ++c) s.hist[3 * i + c] = s.foot_positions[3 * i + c];
+    // least squares H n = 1 (scipy lstsq / LAPACK sgelsd there; normal equations in double here)
+    double AtA[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Atb[3] = {0, 0, 0};
+    for (int i = 0; i < 4; ++i)
+      for (int r = 0; r < 3; ++r) {
+        Atb[r] += (double)s.hist[3 * i + r];
+        for (int c = 0; c < 3; ++c) AtA[3 * r + c] += (double)s.hist[3 * i + r] * (double)s.hist[3 * i + c];
+      }
+    const double c00 = AtA[4] * AtA[8] - AtA[5] * AtA[7], c01 = AtA[5] * AtA[6] - AtA[3] * AtA[8], c02 = AtA[3] * AtA[7] - AtA[4] * AtA[6];
+    const double det = AtA[0] * c00 + AtA[1] * c01 + AtA[2] * c02;
+    double nv[3];
+    nv[0] = (c00 * Atb[0] + (AtA[2] * AtA[7] - AtA[1] * AtA[8]) * Atb[1] + (AtA[1] * AtA[5] - AtA[2] * AtA[4]) * Atb[2]) / det;
+    nv[1] = (c01 * Atb[0] + (AtA[0] * AtA[8] - AtA[2] * AtA[6]) * Atb[1] + (AtA[2] * AtA[3] - AtA[0] * AtA[5]) * Atb[2]) / det;
+    nv[2] = (c02 * Atb[0] + (AtA[1] * AtA[6] - AtA[0] * AtA[7]) * Atb[1] + (AtA[0] * AtA[4] - AtA[1] * AtA[3]) * Atb[2]) / det;
+    float n[3] = {(float)nv[0], (float)nv[1], (float)nv[2]};
+    for (int pass = 0; pass < 2; ++pass) {           // normalised twice (StateEstimator.py:134,140)
+      const float nn = sqrtf((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2]);
+      n[0] /= nn; n[1] /= nn; n[2] /= nn;
+      if (pass == 0 && n[2] < 0.f) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+    }
+    s.normal[0] = n[0]; s.normal[1] = n[1]; s.normal[2] = n[2];
+  }
+
+  // foot placement (ConvexMPCLocomotion.py:270-311)
+  const float swing_seg = (float)nseg - dur[0], stance_seg = dur[0];        // Gait.py:22-23
+  const float swing_time = (float)cp.dt_mpc * swing_seg;                      // getCurrentSwingTime
+  const float stance_time = (float)cp.dt_mpc * stance_seg;                    // getCurrentStanceTime
+  for (int l = 0; l < 4; ++l) s.swing_times[l] = swing_time;
+  const float posz = s.pos_z;
+  for (int i = 0; i < 4; ++i) {
+    if (s.first_swing[i]) s.swing_time_remaining[i] = (double)s.swing_times[i];
+    else s.swing_time_remaining[i] -= cp.dt;
+    const float side = (i == 0 || i == 2) ? 1.f : -1.f;
+    float pr[3];
+    hip_location(rc, i, pr);
+    pr[1] = pr[1] + (float)((double)side * rc.abad);
+    // coordinateRotation(Z, -yaw_rate * stance_time / 2): float16 matrix (orientation_tools.py:13,20-37)
+    const float theta = -yaw_rate * stance_time / 2.f;
+    const float cz = round_to_half((float)cos((double)theta)), sz = round_to_half((float)sin((double)theta));
+    const float msz = round_to_half((float)(-sin((double)theta)));
+    const float pyc[3] = {cz * pr[0] + sz * pr[1] + 0.f * pr[2], msz * pr[0] + cz * pr[1] + 0.f * pr[2], 0.f * pr[0] + 0.f * pr[1] + 1.f * pr[2]};
+    const float str = (float)s.swing_time_remaining[i];
+    float Pf[3] = {0.f + (pyc[0] + x_vel_des * str), 0.f + (pyc[1] + y_vel_des * str), posz + (pyc[2] + 0.f * str)};
+    float pfx = vBody[0] * 0.5f * stance_time + 0.03f * (vBody[0] - x_vel_des) + (0.5f * posz / 9.81f) * (vBody[1] * yaw_rate);
+    float pfy = vBody[1] * 0.5f * stance_time * (float)cp.dt_mpc + 0.03f * (vBody[1] - y_vel_des) + (0.5f * posz / 9.81f) * (-vBody[0] * yaw_rate);
+    pfx = fminf(fmaxf(pfx, -0.3f), 0.3f);
+    pfy = fminf(fmaxf(pfy, -0.3f), 0.3f);
+    Pf[0] += pfx; Pf[1] += pfy; Pf[2] = -0.003f;
+    s.pf[3 * i] = Pf[0]; s.pf[3 * i + 1] = Pf[1]; s.pf[3 * i + 2] = Pf[2];
+  }
+  s.iter += 1;   // :314
+
+  // gait states (Gait.py:30-67) -- phase set before the increment
+  for (int i = 0; i < 4; ++i) {
+    const float offf = off[i] / (float)nseg, durf = dur[i] / (float)nseg;
+    float pc = (float)phase - offf;
+    if (pc < 0.f) pc += 1.0f;
+    s.contact_states[i] = (pc > durf) ? 0.f : pc / durf;
+    float so = offf + durf;
+    if (so > 1.f) so -= 1.0f;
+    const float sd = 1.f - durf;
+    float ps = (float)phase - so;
+    if (ps < 0.f) ps += 1.0f;
+    s.swing_states[i] = (ps > sd) ? 0.f : (sd == 0.f ? 0.f : ps / sd);
+  }
+  s.vbody[0] = vBody[0]; s.vbody[1] = vBody[1]; s.vbody[2] = vBody[2];
+  s.posz_tick = s.pos_z;
+
+  // updateMPCIfNeeded / solveDenseMPC marshalling (ConvexMPCLocomotion.py:128-185, 217-220)
+  s.do_solve = (s.iter % cp.iters_between_mpc) == 0;
+  if (s.do_solve) {
+    const int h = cp.horizon;
+    for (int k = 0; k < 13; ++k) rec[IN_W + k] = cmd[3 + k];                 // weights from the command (DesiredStateCommand.py:26-30)
+    rec[IN_POS] = 0.f; rec[IN_POS + 1] = 0.f; rec[IN_POS + 2] = s.pos_z;
+    for (int k = 0; k < 3; ++k) {
+      rec[IN_VEL + k] = vBody[k];
+      rec[IN_RPY + k] = rpyBody[k];
+      rec[IN_NRM + k] = cp.flat_ground ? (k == 2 ? 1.f : 0.f) : s.normal[k];
+      rec[IN_ANG + k] = omegaBody[k];
+    }
+    for (int i = 0; i < h; ++i) {                                             // Gait.getMpcTable (Gait.py:69-84)
+      const double it = fmod((double)i + iteration + 1.0, (double)nseg);
+      for (int j = 0; j < 4; ++j) {
+        float pg = (float)it - off[j];
+        if (pg < 0.f) pg += (float)nseg;
+        rec[IN_CONTACT + 4 * i + j] = (pg < dur[j]) ? 1.f : 0.f;
+      }
+    }
+    const int o_foot = 28 + 4 * h, o_fric = 40 + 4 * h, o_dpos = 44 + 4 * h, o_dvel = 47 + 4 * h, o_drpy = 50 + 4 * h, o_dang = 53 + 4 * h;
+    for (int k = 0; k < 12; ++k) rec[o_foot + k] = s.foot_positions[k];
+    for (int k = 0; k < 4; ++k) rec[o_fric + k] = rc.mu;
+    rec[o_dpos] = 0.f; rec[o_dpos + 1] = 0.f; rec[o_dpos + 2] = (float)rc.body_height;
+    rec[o_dvel] = x_vel_des; rec[o_dvel + 1] = y_vel_des; rec[o_dvel + 2] = 0.f;
+    rec[o_drpy] = rec[o_drpy + 1] = rec[o_drpy + 2] = 0.f;
+    rec[o_dang] = 0.f; rec[o_dang + 1] = 0.f; rec[o_dang + 2] = yaw_rate;
+  }
+}
+
+// interplation.py:4-26
+MPC_HD float bez(float x) { return x * x * x + 3.0f * (x * x * (1.0f - x)); }
+MPC_HD float bez_d(float x) { return 6.0f * x * (1.0f - x); }
+
+// ---- second half of the tick ------------------------------------------------------------------
+// forces: this robot's solver output (fp64 [12h], first 12 used) -- read only when the solve ran and
+// reported OSQP_SOLVED.  torques: 12 floats, FL FR RL RR x (hip, thigh, calf).
+MPC_HD void ctrl_post(CtrlState &s, const RobotConst &rc, const double *forces, int solved, float *torques) {
+  if (s.do_solve && solved)
+    for (int k = 0; k < 12; ++k) s.f_ff[k] = (float)forces[k];                // ConvexMPCLocomotion.py:186-187
+  const float height = (float)(rc.body_height / 3.0);                          // :287
+  for (int foot = 0; foot < 4; ++foot) {
+    const float swing = s.swing_states[foot];
+    float hloc[3];
+    hip_location(rc, foot, hloc);
+    float kp[3] = {0.f, 0.f, 0.f}, kd[3] = {7.f, 7.f, 7.f}, ff[3] = {0.f, 0.f, 0.f}, kdj = 0.f;
+    if (swing > 0.f) {   // :327-348
+      if (s.first_swing[foot]) {
+        s.first_swing[foot] = 0;
+        for (int c = 0; c < 3; ++c) s.p0[3 * foot + c] = s.pfoot[3 * foot + c];
+      }
+      const float T = (float)(double)s.swing_times[foot];                       // swingTimes[foot].item()
+      const float *p0 = s.p0 + 3 * foot, *pf = s.pf + 3 * foot;
+      float *tp = s.tp + 3 * foot, *tv = s.tv + 3 * foot;
+      const float b = bez(swing), bd = bez_d(swing);
+      for (int c = 0; c < 3; ++c) { tp[c] = p0[c] + b * (pf[c] - p0[c]); tv[c] = bd * (pf[c] - p0[c]) / T; }
+      if (swing < 0.5f) {   // FootSwingTrajectory.py:59-62
+        const float x = swing * 2.f, top = p0[2] + height;
+        tp[2] = p0[2] + bez(x) * (top - p0[2]);
+        tv[2] = bez_d(x) * (top - p0[2]) * 2.f / T;
+      } else {
+        const float x = swing * 2.f - 1.f, top = p0[2] + height;
+        tp[2] = top + bez(x) * (pf[2] - top);
+        tv[2] = bez_d(x) * (pf[2] - top) * 2.f / T;
+      }
+      kp[0] = 700.f; kp[1] = 700.f; kp[2] = 150.f;                            // :82-83
+      s.contact_phase[foot] = 0.f;
+    } else {             // stance :350-376
+      s.first_swing[foot] = 1;
+      for (int c = 0; c < 3; ++c) ff[c] = s.f_ff[3 * foot + c];
+      kdj = 0.2f;
+      s.contact_phase[foot] = s.contact_states[foot];                          // setContactPhase (:378)
+    }
+    // pDesLeg = (pDesFoot - position) - hip ; vDesLeg = vDesFoot - vBody
+    float pdes[3], vdes[3];
+    const float pos[3] = {0.f, 0.f, s.posz_tick};
+    for (int c = 0; c < 3; ++c) { pdes[c] = (s.tp[3 * foot + c] - pos[c]) - hloc[c]; vdes[c] = s.tv[3 * foot + c] - s.vbody[c]; }
+    // LegController.updateCommand (LegController.py:108-132)
+    float force[3];
+    for (int c = 0; c < 3; ++c)
+      force[c] = ff[c] + kp[c] * (pdes[c] - s.p[3 * foot + c]) + kd[c] * (vdes[c] - s.v[3 * foot + c]);
+    const float *J = s.J + 9 * foot;
+    for (int j = 0; j < 3; ++j) {
+      float tau = 0.f + (J[j] * force[0] + J[3 + j] * force[1] + J[6 + j] * force[2]);   // tauFeedForward + J^T f
+      tau += 0.f * (0.f - s.q[3 * foot + j]);                                              // kpJoint = 0
+      tau += kdj * (0.f - s.qd[3 * foot + j]);                                             // kdJoint (qdDes = 0)
+      torques[3 * foot + j] = tau;
+    }
+  }
+}
+
+}  // namespace mpc

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/mpc_batch.h"
+#include "controller.h"
 #include "mpc_core.h"
 #include "mpc_model.h"
 
@@ -44,13 +45,15 @@ template <int H>
 __global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= 256 ? MPC_MIN_WAVES : 1)) void mpc_solve_kernel(int n, const RobotModel *__restrict__ models,
                                                                const float *__restrict__ in, double *__restrict__ state,
                                                                double *__restrict__ scratch, double *__restrict__ forces,
-                                                               int *__restrict__ info, long long *__restrict__ prof) {
+                                                               int *__restrict__ info, long long *__restrict__ prof,
+                                                               const int *__restrict__ active) {
   // static LDS: absolute addresses fold into the ds_* offset fields (a dynamic-LDS base costs an SGPR
   // per array and the hot loops spill)
   __shared__ __attribute__((aligned(16))) Shared<H> sh;
   using C = Cfg<H>;
   const int robot = blockIdx.x;
   if (robot >= n) return;
+  if (active && !active[robot]) return;   // robots whose controller is between two MPC updates
   Thread<H> th;
   th.init(threadIdx.x);
 #pragma unroll
@@ -78,8 +81,8 @@ __global__ void reset_kernel(double *state, int state_len, const int *ids, int k
 
 template <int H>
 int launch(int n, const RobotModel *models, const float *in, double *state, double *scratch, double *forces, int *info,
-           long long *prof, hipStream_t stream) {
-  hipLaunchKernelGGL(mpc_solve_kernel<H>, dim3(n), dim3(Cfg<H>::T), 0, stream, n, models, in, state, scratch, forces, info, prof);
+           long long *prof, const int *active, hipStream_t stream) {
+  hipLaunchKernelGGL(mpc_solve_kernel<H>, dim3(n), dim3(Cfg<H>::T), 0, stream, n, models, in, state, scratch, forces, info, prof, active);
   HIP_TRY(hipGetLastError());
   return MPC_OK;
 }
@@ -152,8 +155,8 @@ int mpc_batch_solve(mpc_batch *b, const float *d_in, double *d_forces, int *d_in
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int *info = d_info ? d_info : b->d_info;
   switch (b->h) {
-    case 10: return launch<10>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, d_forces, info, b->d_prof, st);
-    case 16: return launch<16>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, d_forces, info, b->d_prof, st);
+    case 10: return launch<10>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, d_forces, info, b->d_prof, nullptr, st);
+    case 16: return launch<16>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, d_forces, info, b->d_prof, nullptr, st);
   }
   return fail(MPC_E_HORIZON, "mpc_batch_solve: horizon not compiled in");
 }
@@ -214,6 +217,175 @@ int mpc_batch_get_profile(mpc_batch *b, long long *h_prof) {
 int mpc_batch_set_state(mpc_batch *b, const double *h_state) {
   if (!b || !h_state) return fail(MPC_E_ARG, "mpc_batch_set_state: bad argument");
   HIP_TRY(hipMemcpy(b->d_state, h_state, sizeof(double) * (size_t)b->n * b->state_len, hipMemcpyHostToDevice));
+  return MPC_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Per-tick controller (controller.h): one thread per robot before and after the solve.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ void ctrl_init_kernel(int n, CtrlState *st, const RobotConst *rc, const int *robot_type, const int *gait_id) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) ctrl_init(st[r], rc[robot_type[r]], robot_type[r], gait_id[r]);
+}
+__global__ void ctrl_reset_kernel(int n, CtrlState *st, const RobotConst *rc, const int *ids, int k) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k) return;
+  const int r = ids ? ids[i] : i;
+  if (r >= 0 && r < n) ctrl_reset(st[r], rc[st[r].robot_type]);
+}
+__global__ void ctrl_set_gait_kernel(int n, CtrlState *st, const int *gait_id) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) st[r].gait_id = gait_id[r];
+}
+__global__ void ctrl_pre_kernel(int n, CtrlState *st, const RobotConst *rc, GaitTable gt, CtrlParams cp, const float *dof,
+                                const float *est, const float *cmd, float *rec, int *active) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  CtrlState s = st[r];
+  ctrl_pre(s, rc[s.robot_type], gt, cp, dof + (size_t)r * 24, est + (size_t)r * kEstLen, cmd + (size_t)r * 16,
+           rec + (size_t)r * (56 + 4 * cp.horizon));
+  active[r] = s.do_solve;
+  st[r] = s;
+}
+__global__ void ctrl_post_kernel(int n, CtrlState *st, const RobotConst *rc, int horizon, const double *forces, const int *info,
+                                 float *torques) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  CtrlState s = st[r];
+  ctrl_post(s, rc[s.robot_type], forces + (size_t)r * 12 * horizon, info[(size_t)r * kInfoLen + 1] == kStSolved, torques + (size_t)r * 12);
+  st[r] = s;
+}
+
+}  // namespace
+
+struct mpc_ctrl {
+  int n = 0;
+  mpc_batch *solver = nullptr;
+  CtrlState *d_state = nullptr;
+  RobotConst *d_rc = nullptr;
+  int *d_robot_type = nullptr, *d_gait = nullptr, *d_active = nullptr, *d_info = nullptr;
+  float *d_rec = nullptr;
+  double *d_forces = nullptr;
+  GaitTable gt;
+  CtrlParams cp;
+};
+
+extern "C" {
+
+void mpc_ctrl_destroy(mpc_ctrl *c) {
+  if (!c) return;
+  mpc_batch_destroy(c->solver);
+  void *ptrs[] = {c->d_state, c->d_rc, c->d_robot_type, c->d_gait, c->d_active, c->d_info, c->d_rec, c->d_forces};
+  for (void *p : ptrs) if (p) (void)hipFree(p);
+  delete c;
+}
+
+int mpc_ctrl_create(mpc_ctrl **out, int n, int horizon, double controller_dt, int iters_between_mpc, double alpha, int flat_ground,
+                    const int *robot_type, const int *gait_id, int n_types, const double *robot_table, const int *gait_off,
+                    const int *gait_dur) {
+  if (!out || n <= 0 || !robot_type || !gait_id || n_types <= 0 || !robot_table || !gait_off || !gait_dur || iters_between_mpc <= 0)
+    return fail(MPC_E_ARG, "mpc_ctrl_create: bad argument");
+  std::vector<double> mass(n), inertia((size_t)n * 9, 0.0);
+  for (int r = 0; r < n; ++r) {
+    if (robot_type[r] < 0 || robot_type[r] >= n_types || gait_id[r] < 0 || gait_id[r] >= kNumGaitIds) return fail(MPC_E_ARG, "mpc_ctrl_create: robot_type / gait_id out of range");
+    const double *row = robot_table + 25 * robot_type[r];
+    mass[r] = row[6];
+    inertia[9 * (size_t)r] = row[7]; inertia[9 * (size_t)r + 4] = row[8]; inertia[9 * (size_t)r + 8] = row[9];
+  }
+  mpc_ctrl *c = new mpc_ctrl();
+  c->n = n;
+  const double dt_mpc = controller_dt * iters_between_mpc;
+  int rc0 = mpc_batch_create(&c->solver, n, horizon, dt_mpc, alpha, mass.data(), inertia.data());
+  if (rc0 != MPC_OK) { delete c; return rc0; }
+  c->cp = CtrlParams{controller_dt, iters_between_mpc, dt_mpc, horizon, flat_ground};
+  c->gt.n_seg = horizon;
+  for (int g = 0; g < kNumGaitIds; ++g)
+    for (int j = 0; j < 4; ++j) { c->gt.offsets[g][j] = (float)gait_off[4 * g + j]; c->gt.durations[g][j] = (float)gait_dur[4 * g + j]; }
+  std::vector<RobotConst> rcs(n_types);
+  for (int t = 0; t < n_types; ++t) {
+    const double *row = robot_table + 25 * t;
+    rcs[t].abad = row[0]; rcs[t].hip = row[1]; rcs[t].knee = row[2];
+    for (int k = 0; k < 3; ++k) rcs[t].hiploc[k] = (float)row[3 + k];
+    rcs[t].body_height = row[10]; rcs[t].mu = (float)row[11];
+    for (int k = 0; k < 13; ++k) rcs[t].weights[k] = (float)row[12 + k];
+  }
+  const size_t inlen = 56 + 4 * (size_t)horizon;
+  hipError_t e;
+  if ((e = hipMalloc(&c->d_state, sizeof(CtrlState) * n)) != hipSuccess || (e = hipMalloc(&c->d_rc, sizeof(RobotConst) * n_types)) != hipSuccess ||
+      (e = hipMalloc(&c->d_robot_type, sizeof(int) * n)) != hipSuccess || (e = hipMalloc(&c->d_gait, sizeof(int) * n)) != hipSuccess ||
+      (e = hipMalloc(&c->d_active, sizeof(int) * n)) != hipSuccess || (e = hipMalloc(&c->d_info, sizeof(int) * (size_t)n * kInfoLen)) != hipSuccess ||
+      (e = hipMalloc(&c->d_rec, sizeof(float) * n * inlen)) != hipSuccess || (e = hipMalloc(&c->d_forces, sizeof(double) * (size_t)n * 12 * horizon)) != hipSuccess ||
+      (e = hipMemcpy(c->d_rc, rcs.data(), sizeof(RobotConst) * n_types, hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemcpy(c->d_robot_type, robot_type, sizeof(int) * n, hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemcpy(c->d_gait, gait_id, sizeof(int) * n, hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemset(c->d_info, 0, sizeof(int) * (size_t)n * kInfoLen)) != hipSuccess ||
+      (e = hipMemset(c->d_rec, 0, sizeof(float) * n * inlen)) != hipSuccess ||
+      (e = hipMemset(c->d_forces, 0, sizeof(double) * (size_t)n * 12 * horizon)) != hipSuccess) {
+    mpc_ctrl_destroy(c);
+    return fail(MPC_E_HIP, std::string("mpc_ctrl_create: ") + hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(ctrl_init_kernel, dim3((n + 127) / 128), dim3(128), 0, nullptr, n, c->d_state, c->d_rc, c->d_robot_type, c->d_gait);
+  if ((e = hipDeviceSynchronize()) != hipSuccess) { mpc_ctrl_destroy(c); return fail(MPC_E_HIP, std::string("mpc_ctrl_create: ") + hipGetErrorString(e)); }
+  *out = c;
+  return MPC_OK;
+}
+
+int mpc_ctrl_step(mpc_ctrl *c, const float *d_dof, const float *d_est, const float *d_cmd, float *d_torques, void *stream) {
+  if (!c || !d_dof || !d_est || !d_cmd || !d_torques) return fail(MPC_E_ARG, "mpc_ctrl_step: bad argument");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int n = c->n, blocks = (n + 127) / 128;
+  hipLaunchKernelGGL(ctrl_pre_kernel, dim3(blocks), dim3(128), 0, st, n, c->d_state, c->d_rc, c->gt, c->cp, d_dof, d_est, d_cmd, c->d_rec, c->d_active);
+  HIP_TRY(hipGetLastError());
+  mpc_batch *b = c->solver;
+  int rc = MPC_E_HORIZON;
+  switch (b->h) {
+    case 10: rc = launch<10>(b->n, b->d_models, c->d_rec, b->d_state, b->d_scratch, c->d_forces, c->d_info, b->d_prof, c->d_active, st); break;
+    case 16: rc = launch<16>(b->n, b->d_models, c->d_rec, b->d_state, b->d_scratch, c->d_forces, c->d_info, b->d_prof, c->d_active, st); break;
+  }
+  if (rc != MPC_OK) return rc;
+  hipLaunchKernelGGL(ctrl_post_kernel, dim3(blocks), dim3(128), 0, st, n, c->d_state, c->d_rc, c->cp.horizon, c->d_forces, c->d_info, d_torques);
+  HIP_TRY(hipGetLastError());
+  return MPC_OK;
+}
+
+int mpc_ctrl_reset(mpc_ctrl *c, const int *ids, int k, void *stream) {
+  if (!c) return fail(MPC_E_ARG, "mpc_ctrl_reset: bad argument");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int rc = mpc_batch_reset(c->solver, ids, k, stream);   // new ConvexMpc object = cold solver (ConvexMPCLocomotion.py:102-108)
+  if (rc != MPC_OK) return rc;
+  if (!ids) {
+    hipLaunchKernelGGL(ctrl_reset_kernel, dim3((c->n + 127) / 128), dim3(128), 0, st, c->n, c->d_state, c->d_rc, (const int *)nullptr, c->n);
+    HIP_TRY(hipGetLastError());
+    return MPC_OK;
+  }
+  if (k <= 0) return MPC_OK;
+  int *d_ids = nullptr;
+  HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&d_ids), sizeof(int) * k, st));
+  HIP_TRY(hipMemcpyAsync(d_ids, ids, sizeof(int) * k, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(ctrl_reset_kernel, dim3((k + 127) / 128), dim3(128), 0, st, c->n, c->d_state, c->d_rc, d_ids, k);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipFreeAsync(d_ids, st));
+  return MPC_OK;
+}
+
+int mpc_ctrl_set_gait(mpc_ctrl *c, const int *gait_id, void *stream) {
+  if (!c || !gait_id) return fail(MPC_E_ARG, "mpc_ctrl_set_gait: bad argument");
+  for (int r = 0; r < c->n; ++r) if (gait_id[r] < 0 || gait_id[r] >= kNumGaitIds) return fail(MPC_E_ARG, "mpc_ctrl_set_gait: gait id out of range");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  HIP_TRY(hipMemcpyAsync(c->d_gait, gait_id, sizeof(int) * c->n, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(ctrl_set_gait_kernel, dim3((c->n + 127) / 128), dim3(128), 0, st, c->n, c->d_state, c->d_gait);
+  HIP_TRY(hipGetLastError());
+  return MPC_OK;
+}
+
+int mpc_ctrl_solver_info(mpc_ctrl *c, int *h_info) {
+  if (!c || !h_info) return fail(MPC_E_ARG, "mpc_ctrl_solver_info: bad argument");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(h_info, c->d_info, sizeof(int) * (size_t)c->n * kInfoLen, hipMemcpyDeviceToHost));
   return MPC_OK;
 }
 

@@ -1,0 +1,78 @@
+"""Batched per-tick controller: N ``RobotRunnerMin``-style controllers behind one handle.
+
+Host-side mirror of the reference's runner for the part of ``RobotRunnerMin.run``
+(robot_runner/RobotRunnerMin.py:54-75) that follows ``StateEstimator.update``:
+``LegController.updateData`` -> ``ConvexMPCLocomotion.run`` (with the MPC solve every
+``iterationsBetweenMPC``-th tick) -> ``LegController.updateCommand``.  Per-robot gait and robot type replace
+the process-global ``Parameters.cmpc_gait`` / one-runner-per-type of the reference.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .gait import gait_arrays
+from .quadruped import ROBOT_TABLE64
+
+
+class BatchedLocomotion:
+    def __init__(self, robot_type, gait_id, horizon=10, controller_dt=0.01, alpha=1e-5, flat_ground=False, device=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise _lib.MpcLibraryError("BatchedLocomotion needs a GPU (torch.cuda.is_available() is False); no CPU fallback")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        torch.cuda.set_device(self.device)
+        rt = np.ascontiguousarray(robot_type, dtype=np.int32)
+        gi = np.ascontiguousarray(gait_id, dtype=np.int32)
+        self.n, self.h = len(rt), int(horizon)
+        iters = int(27 / (1000.0 * controller_dt))                    # RobotRunnerMin.py:21-22
+        off, dur = gait_arrays(self.h)
+        off = np.ascontiguousarray(off, dtype=np.int32); dur = np.ascontiguousarray(dur, dtype=np.int32)
+        tab = np.ascontiguousarray(ROBOT_TABLE64, dtype=np.float64)
+        self._handle = C.c_void_p()
+        _lib.check(_lib.lib().mpc_ctrl_create(C.byref(self._handle), self.n, self.h, float(controller_dt), iters, float(alpha),
+                                              int(bool(flat_ground)), rt.ctypes.data, gi.ctypes.data, tab.shape[0], tab.ctypes.data,
+                                              off.ctypes.data, dur.ctypes.data), "mpc_ctrl_create")
+        self.torques = torch.zeros((self.n, 12), dtype=torch.float32, device=self.device)
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h and _lib is not None and _lib._LIB is not None:
+            _lib._LIB.mpc_ctrl_destroy(h)
+            self._handle = None
+
+    def step(self, dof_states, est, commands, torques=None):
+        """dof_states [N,12,2] (or [N*12,2]), est [N,18], commands [N,16]: contiguous cuda float32.
+        Returns torques [N,12] float32 (FL FR RL RR x hip, thigh, calf)."""
+        import torch
+        for name, t, numel in (("dof_states", dof_states, self.n * 24), ("est", est, self.n * 18), ("commands", commands, self.n * 16)):
+            if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or t.numel() != numel:
+                raise ValueError(f"{name} must be a contiguous cuda float32 tensor with {numel} elements")
+        torques = self.torques if torques is None else torques
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.lib().mpc_ctrl_step(self._handle, dof_states.data_ptr(), est.data_ptr(), commands.data_ptr(),
+                                            torques.data_ptr(), stream), "mpc_ctrl_step")
+        return torques
+
+    def reset(self, env_ids=None):
+        import torch
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        if env_ids is None:
+            _lib.check(_lib.lib().mpc_ctrl_reset(self._handle, None, 0, stream), "mpc_ctrl_reset")
+            return
+        ids = np.ascontiguousarray(env_ids.detach().cpu().numpy() if hasattr(env_ids, "detach") else env_ids, dtype=np.int32)
+        _lib.check(_lib.lib().mpc_ctrl_reset(self._handle, ids.ctypes.data, len(ids), stream), "mpc_ctrl_reset")
+
+    def set_gait(self, gait_id):
+        import torch
+        gi = np.ascontiguousarray(gait_id, dtype=np.int32)
+        if len(gi) != self.n:
+            raise ValueError("gait_id must have one entry per robot")
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.lib().mpc_ctrl_set_gait(self._handle, gi.ctypes.data, stream), "mpc_ctrl_set_gait")
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def solver_info(self):
+        out = np.zeros((self.n, 8), dtype=np.int32)
+        _lib.check(_lib.lib().mpc_ctrl_solver_info(self._handle, out.ctypes.data), "mpc_ctrl_solver_info")
+        return out

@@ -25,9 +25,9 @@ def leg_fk(q, robot_type):
     """
     q = np.asarray(q, dtype=np.float64)
     rt = np.asarray(robot_type)
-    dy = ROBOT_TABLE[rt, COL_ABAD].astype(np.float64)[:, None] * SIDE_SIGN[None, :].astype(np.float64)
-    dz1 = -ROBOT_TABLE[rt, COL_HIP].astype(np.float64)[:, None]
-    dz2 = -ROBOT_TABLE[rt, COL_KNEE].astype(np.float64)[:, None]
+    dy = ROBOT_TABLE64[rt, COL_ABAD][:, None] * SIDE_SIGN[None, :].astype(np.float64)   # link lengths are Python floats there
+    dz1 = -ROBOT_TABLE64[rt, COL_HIP][:, None]
+    dz2 = -ROBOT_TABLE64[rt, COL_KNEE][:, None]
     s1, s2, s3 = np.sin(q[..., 0]), np.sin(q[..., 1]), np.sin(q[..., 2])
     c1, c2, c3 = np.cos(q[..., 0]), np.cos(q[..., 1]), np.cos(q[..., 2])
     c23 = c2 * c3 - s2 * s3

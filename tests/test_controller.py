@@ -1,0 +1,109 @@
+"""Per-tick controller (ctrl_pre -> solve -> ctrl_post) against golden torques recorded from the UNMODIFIED
+reference Python (tests/golden/make_golden_controller.py).  CPU: host emulation; GPU: the HIP kernels
+through the C ABI."""
+import numpy as np
+import pytest
+
+import rl_mpc_locomotion_amd  # noqa: F401
+from tests.helpers import load_golden
+
+# float32 controller arithmetic + the ground-normal least squares (LAPACK sgelsd in the reference, fp64 normal
+# equations here): observed <= 5e-6 relative to max(|tau|_inf, 1 Nm)
+TAU_RTOL = 5e-5
+
+
+def _relerr(a, b):
+    return np.abs(a - b).max(-1) / np.maximum(np.abs(b).max(-1), 1.0)
+
+
+@pytest.mark.parametrize("name", ["controller_h10_flat", "controller_h10_slope"])
+def test_emulated_controller_matches_reference_python(name):
+    from tests.emu.emu import ctrl_replay
+    g = load_golden(name)
+    tau, rec, fff = ctrl_replay(g["robot_type"], g["gait_id"], int(g["flat_ground"]), g["dof"], g["est"], g["cmd"])
+    assert _relerr(tau, g["torque"]).max() < TAU_RTOL
+    assert _relerr(fff, g["f_ff"]).max() < TAU_RTOL
+    # the MPC ran on every second tick (iterationsBetweenMPC = 2, ConvexMPCLocomotion.py:217-220)
+    ran = np.abs(rec).sum(-1) > 0
+    assert np.array_equal(ran, g["solved"].astype(bool))
+
+
+def test_gait_tables_match_reference_definition():
+    """gait.py's tables against ConvexMPCLocomotion.py:30-56 (restated literally here)."""
+    from rl_mpc_locomotion_amd.gait import GAIT_TABLE_10, gait_arrays, mpc_table
+    ref = {0: ([0, 5, 5, 0], [5] * 4), 1: ([5, 5, 0, 0], [4] * 4), 2: ([0] * 4, [4] * 4), 3: ([5, 0, 5, 0], [5] * 4),
+           5: ([0, 2, 7, 9], [4] * 4), 6: ([0, 3, 5, 8], [5] * 4), 7: ([0, 5, 5, 0], [4] * 4)}
+    assert GAIT_TABLE_10 == ref
+    off, dur = gait_arrays(16)
+    assert off[0].tolist() == [0, 8, 8, 0] and dur[0].tolist() == [8] * 4
+    t = mpc_table([0], [0], 2, 10).reshape(10, 4)
+    assert t[:, 0].tolist() == [1, 1, 1, 1, 0, 0, 0, 0, 0, 1]                    # trot, leg FL, counter 0
+
+
+@pytest.mark.reference
+def test_gait_and_fk_match_reference_modules():
+    import os
+    import sys
+    if not os.path.isdir("/root/reference/MPC_Controller"):
+        pytest.skip("reference not mounted")
+    sys.path.insert(0, "/root/reference")
+    from MPC_Controller.convex_MPC.Gait import OffsetDurationGait
+    from MPC_Controller.common.Quadruped import Quadruped, RobotType as RefType
+    from MPC_Controller.common.LegController import LegController
+    from rl_mpc_locomotion_amd.gait import GAIT_TABLE_10, mpc_table
+    from rl_mpc_locomotion_amd.synthetic import leg_fk
+    for gid, (o, d) in GAIT_TABLE_10.items():
+        g = OffsetDurationGait(10, np.array(o, dtype=np.float32), np.array(d, dtype=np.float32), "x")
+        for it in range(0, 23):
+            g.setIterations(2, it)
+            assert np.array_equal(np.array(g.getMpcTable(), dtype=np.float32), mpc_table([gid], [it], 2, 10)[0])
+    rng = np.random.default_rng(0)
+    for ours, ref in ((0, RefType.ALIENGO), (1, RefType.A1), (2, RefType.GO1)):
+        lc = LegController(Quadruped(ref))
+        q = rng.uniform(-1, 1, (4, 3))
+        for leg in range(4):
+            lc.datas[leg].q[:, 0] = q[leg]
+            lc.computeLegJacobianAndPosition(leg)
+            assert np.array_equal(lc.datas[leg].p[:, 0], leg_fk(q[None].astype(np.float32), [ours])[0, leg])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["controller_h10_flat", "controller_h10_slope"])
+def test_hip_controller_matches_reference_python(name):
+    import torch
+    from rl_mpc_locomotion_amd.locomotion import BatchedLocomotion
+    g = load_golden(name)
+    T, n = g["dof"].shape[:2]
+    ctl = BatchedLocomotion(g["robot_type"], g["gait_id"], horizon=10, flat_ground=bool(g["flat_ground"]), device="cuda:0")
+    worst = 0.0
+    for k in range(T):
+        tau = ctl.step(torch.from_numpy(g["dof"][k]).cuda(), torch.from_numpy(g["est"][k]).cuda(), torch.from_numpy(g["cmd"][k]).cuda())
+        torch.cuda.synchronize()
+        worst = max(worst, float(_relerr(tau.cpu().numpy(), g["torque"][k]).max()))
+        if (k + 1) % 2 == 0:
+            assert (ctl.solver_info()[:, 1] == 1).all()
+    assert worst < TAU_RTOL
+
+
+@pytest.mark.gpu
+def test_hip_controller_reset_and_gait_switch():
+    import torch
+    from rl_mpc_locomotion_amd.locomotion import BatchedLocomotion
+    g = load_golden("controller_h10_flat")
+    T, n = g["dof"].shape[:2]
+    a = BatchedLocomotion(g["robot_type"], g["gait_id"], flat_ground=True, device="cuda:0")
+    run = lambda ctl, k: ctl.step(torch.from_numpy(g["dof"][k]).cuda(), torch.from_numpy(g["est"][k]).cuda(), torch.from_numpy(g["cmd"][k]).cuda()).cpu().numpy().copy()
+    first = [run(a, k) for k in range(6)]
+    a.reset(np.array([0, 2], dtype=np.int32))          # robots 0 and 2 start over, the others continue
+    again = [run(a, k) for k in range(6)]
+    b = BatchedLocomotion(g["robot_type"], g["gait_id"], flat_ground=True, device="cuda:0")
+    cont = [run(b, k) for k in range(6)] + [run(b, k) for k in range(6)]
+    for k in range(6):
+        # reset robots: same as a fresh controller except for the carried f_ff / last swing p, v (reference semantics),
+        # which only matter before the first solve / first swing -> compare from the first MPC tick on
+        if k >= 1:
+            np.testing.assert_allclose(again[k][[0, 2]], first[k][[0, 2]], rtol=0, atol=2e-3 * np.abs(first[k]).max())
+        np.testing.assert_array_equal(again[k][[1, 3, 4, 5]], cont[6 + k][[1, 3, 4, 5]])
+    a.set_gait(np.full(n, 1, dtype=np.int32))
+    out = run(a, 6)
+    assert np.isfinite(out).all()
