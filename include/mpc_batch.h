@@ -116,6 +116,11 @@ int mpc_ctrl_create(mpc_ctrl **out, int n_robots, int horizon, double controller
                     const double *robot_table, const int *gait_off, const int *gait_dur);
 void mpc_ctrl_destroy(mpc_ctrl *c);
 int mpc_ctrl_step(mpc_ctrl *c, const float *d_dof, const float *d_est, const float *d_cmd, float *d_torques, void *stream);
+/* The whole controller.run(dof_states, body_states, commands) -> torques of RobotRunnerMin.run
+ * (robot_runner/RobotRunnerMin.py:54-75, looped at RL_Environment/tasks/aliengo.py:252-256):
+ * StateEstimator.update (common/StateEstimator.py:57-97, with its float16 / float32 arithmetic) then mpc_ctrl_step.
+ * d_body: [n, 13] float32 = pos3, quat xyzw, linear velocity (world), angular velocity (world). */
+int mpc_ctrl_run(mpc_ctrl *c, const float *d_dof, const float *d_body, const float *d_cmd, float *d_torques, void *stream);
 int mpc_ctrl_reset(mpc_ctrl *c, const int *ids, int k, void *stream);      /* HOST ids; NULL = all */
 int mpc_ctrl_set_gait(mpc_ctrl *c, const int *gait_id, void *stream);       /* HOST [n] */
 int mpc_ctrl_solver_info(mpc_ctrl *c, int *h_info);                          /* [n, 8] of the last solves */

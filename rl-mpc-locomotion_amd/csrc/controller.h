@@ -128,11 +128,132 @@ MPC_HD void hip_location(const RobotConst &rc, int leg, float *h) {   // Quadrup
   h[2] = rc.hiploc[2];
 }
 
+
+// ================================================================================================
+// StateEstimator.update (MPC_Controller/common/StateEstimator.py:57-97) with the arithmetic types the
+// reference's numpy code really uses (numpy 2, NEP 50): the quaternion fields are np.float32 scalars, so
+// quat_to_rot / quat_to_rpy (math_utils/orientation_tools.py:120-149) evaluate in float32 and store
+// float16; rot_to_quat (:159-196) mixes Python floats with np.float16 scalars, which demotes every
+// mixed operation to float16.  A float16 value is carried as a float here; hadd/hsub/hmul/hdiv round each
+// operation to half like numpy's half loops (compute in float, round to half).
+// ================================================================================================
+MPC_HD float round_to_half_d(double d) {   // Python float -> np.float16 (one rounding, ties to even)
+  if (!(d == d) || d == 0.0) return (float)d;
+  const double ad = fabs(d);
+  if (ad >= 65520.0) return d > 0 ? INFINITY : -INFINITY;
+  int e = ilogb(ad);
+  if (e < -14) e = -14;                       // subnormal halfs share the quantum 2^-24
+  const double scale = ldexp(1.0, 10 - e);
+  return (float)(nearbyint(d * scale) / scale);
+}
+MPC_HD float hadd(float a, float b) { return round_to_half(a + b); }
+MPC_HD float hsub(float a, float b) { return round_to_half(a - b); }
+MPC_HD float hmul(float a, float b) { return round_to_half(a * b); }
+MPC_HD float hdiv(float a, float b) { return round_to_half(a / b); }
+
+struct PyOrHalf {   // a quaternion component that is either a Python float or an np.float16 scalar
+  double py; float h; bool is_py;
+};
+MPC_HD float as_half(const PyOrHalf &v) { return v.is_py ? round_to_half_d(v.py) : v.h; }
+MPC_HD PyOrHalf qmul(const PyOrHalf &a, const PyOrHalf &b) {
+  PyOrHalf r;
+  if (a.is_py && b.is_py) { r.is_py = true; r.py = a.py * b.py; r.h = 0.f; }
+  else { r.is_py = false; r.py = 0.0; r.h = hmul(as_half(a), as_half(b)); }
+  return r;
+}
+MPC_HD float qadd(const PyOrHalf &a, const PyOrHalf &b) { return hadd(as_half(a), as_half(b)); }   // at most one side is Python
+MPC_HD float qsub(const PyOrHalf &a, const PyOrHalf &b) { return hsub(as_half(a), as_half(b)); }
+MPC_HD PyOrHalf from_half(float h) { PyOrHalf r; r.is_py = false; r.py = 0.0; r.h = h; return r; }
+
+// 3x3 float16 matmul: float accumulation, one rounding to half (numpy HALF matmul)
+MPC_HD void hmatmul(const float *A, const float *B, float *C) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) C[3 * i + j] = round_to_half((A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j]) + A[3 * i + 2] * B[6 + j]);
+}
+
+// body: 13 floats (pos3, quat xyzw, lin vel world 3, ang vel world 3); normal: ground_normal_yaw of the
+// previous tick; est out: vBody[3], omegaBody[3], rpyBody[3] (half valued), ground_R_body_frame[9].
+MPC_HD void estimator_update(const float *body, const float *normal, float *est) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  const float x = body[3], y = body[4], z = body[5], w = body[6];
+  const float e0 = w, e1 = x, e2 = y, e3 = z;
+  // quat_to_rot (orientation_tools.py:135-149): listed row-major, then transposed
+  float Ml[9];
+  Ml[0] = round_to_half(1.f - 2.f * (e2 * e2 + e3 * e3)); Ml[1] = round_to_half(2.f * (e1 * e2 - e0 * e3)); Ml[2] = round_to_half(2.f * (e1 * e3 + e0 * e2));
+  Ml[3] = round_to_half(2.f * (e1 * e2 + e0 * e3)); Ml[4] = round_to_half(1.f - 2.f * (e1 * e1 + e3 * e3)); Ml[5] = round_to_half(2.f * (e2 * e3 - e0 * e1));
+  Ml[6] = round_to_half(2.f * (e1 * e3 - e0 * e2)); Ml[7] = round_to_half(2.f * (e2 * e3 + e0 * e1)); Ml[8] = round_to_half(1.f - 2.f * (e1 * e1 + e2 * e2));
+  float R[9];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[3 * i + j] = Ml[3 * j + i];
+  for (int i = 0; i < 3; ++i) {   // float16 matrix @ float32 vector -> float32 (BLAS there; +-1 ulp)
+    est[i] = (R[3 * i] * body[7] + R[3 * i + 1] * body[8]) + R[3 * i + 2] * body[9];
+    est[3 + i] = (R[3 * i] * body[10] + R[3 * i + 1] * body[11]) + R[3 * i + 2] * body[12];
+  }
+  // quat_to_rpy (:120-133) -- only the yaw of the world-frame rpy is used
+  const float yaw = round_to_half(atan2f(2.f * (x * y + w * z), w * w + x * x - y * y - z * z));
+  const double th = (double)yaw;
+  const float cz = round_to_half_d(cos(th)), sz = round_to_half_d(sin(th));
+  const float ZT[9] = {cz, -sz, 0.f, sz, cz, 0.f, 0.f, 0.f, 1.f};          // world_R_yaw_frame^T
+  // get_rot_from_normals / axis_angle_to_rot (:88-107), axis un-normalised, zz term uses k1*k1 (as written there)
+  const float k0 = 0.f * normal[2] - 1.f * normal[1], k1 = 1.f * normal[0] - 0.f * normal[2], k2 = 0.f * normal[1] - 0.f * normal[0];
+  const float theta = acosf((0.f * normal[0] + 0.f * normal[1]) + 1.f * normal[2]);
+  const float c_t = (float)cos((double)theta), s_t = (float)sin((double)theta), v_t = (float)(1.0 - cos((double)theta));
+  float E[9];   // R_axis_angle as listed (= yaw_R_ground_frame^T)
+  E[0] = round_to_half(k0 * k0 * v_t + c_t); E[1] = round_to_half(k0 * k1 * v_t - k2 * s_t); E[2] = round_to_half(k0 * k2 * v_t + k1 * s_t);
+  E[3] = round_to_half(k0 * k1 * v_t + k2 * s_t); E[4] = round_to_half(k1 * k1 * v_t + c_t); E[5] = round_to_half(k1 * k2 * v_t - k0 * s_t);
+  E[6] = round_to_half(k0 * k2 * v_t - k1 * s_t); E[7] = round_to_half(k1 * k2 * v_t + k0 * s_t); E[8] = round_to_half(k1 * k1 * v_t + c_t);
+  float T1[9], G[9];
+  hmatmul(R, ZT, T1);
+  hmatmul(T1, E, G);            // ground_R_body_frame
+  for (int k = 0; k < 9; ++k) est[9 + k] = G[k];
+  // rot_to_rpy = quat_to_rpy(rot_to_quat(G))  (:159-199)
+  float r[9];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r[3 * i + j] = G[3 * j + i];   // r = rot.T
+  const float tr = round_to_half((r[0] + r[4]) + r[8]);
+  PyOrHalf qw, qx, qy, qz;
+  double S;
+  if (tr > 0.f) {
+    S = sqrt((double)hadd(tr, 1.f)) * 2.0;
+    const float Sh = round_to_half_d(S);
+    qw.is_py = true; qw.py = 0.25 * S; qw.h = 0.f;
+    qx = from_half(hdiv(hsub(r[7], r[5]), Sh)); qy = from_half(hdiv(hsub(r[2], r[6]), Sh)); qz = from_half(hdiv(hsub(r[3], r[1]), Sh));
+  } else if (r[0] > r[4] && r[0] > r[8]) {
+    S = sqrt((double)hsub(hsub(hadd(1.f, r[0]), r[4]), r[8])) * 2.0;
+    const float Sh = round_to_half_d(S);
+    qw = from_half(hdiv(hsub(r[7], r[5]), Sh));
+    qx.is_py = true; qx.py = 0.25 * S; qx.h = 0.f;
+    qy = from_half(hdiv(hadd(r[1], r[3]), Sh)); qz = from_half(hdiv(hadd(r[2], r[6]), Sh));
+  } else if (r[4] > r[8]) {
+    S = sqrt((double)hsub(hsub(hadd(1.f, r[4]), r[0]), r[8])) * 2.0;
+    const float Sh = round_to_half_d(S);
+    qw = from_half(hdiv(hsub(r[2], r[6]), Sh)); qx = from_half(hdiv(hadd(r[1], r[3]), Sh));
+    qy.is_py = true; qy.py = 0.25 * S; qy.h = 0.f;
+    qz = from_half(hdiv(hadd(r[5], r[7]), Sh));
+  } else {
+    S = sqrt((double)hsub(hsub(hadd(1.f, r[8]), r[0]), r[4])) * 2.0;
+    const float Sh = round_to_half_d(S);
+    qw = from_half(hdiv(hsub(r[3], r[1]), Sh)); qx = from_half(hdiv(hadd(r[2], r[6]), Sh)); qy = from_half(hdiv(hadd(r[5], r[7]), Sh));
+    qz.is_py = true; qz.py = 0.25 * S; qz.h = 0.f;
+  }
+  const float as_h = hmul(-2.f, qsub(qmul(qx, qz), qmul(qw, qy)));
+  const double as_ = fmin((double)as_h, 0.99999);
+  const float roll = round_to_half(atan2f(hmul(2.f, qadd(qmul(qy, qz), qmul(qw, qx))),
+                                          hadd(hsub(qsub(qmul(qw, qw), qmul(qx, qx)), as_half(qmul(qy, qy))), as_half(qmul(qz, qz)))));
+  const float pitch = round_to_half_d(asin(as_));
+  const float yawb = round_to_half(atan2f(hmul(2.f, qadd(qmul(qx, qy), qmul(qw, qz))),
+                                          hsub(hsub(qadd(qmul(qw, qw), qmul(qx, qx)), as_half(qmul(qy, qy))), as_half(qmul(qz, qz)))));
+  est[6] = roll; est[7] = pitch; est[8] = yawb;
+}
+
 // ---- first half of the tick -----------------------------------------------------------------
 // dof: [12][2] (pos, vel) leg-major; est: kEstLen floats; cmd: 16 floats (vx vy yaw_rate w[13]).
 // rec: solver input record [56 + 4h] (written only when s.do_solve).
 MPC_HD void ctrl_pre(CtrlState &s, const RobotConst &rc, const GaitTable &gt, const CtrlParams &cp, const float *dof,
                      const float *est, const float *cmd, float *rec) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
   const int nseg = gt.n_seg;
   // LegController.updateData (LegController.py:89-106)
   for (int leg = 0; leg < 4; ++leg) {
@@ -291,6 +412,9 @@ MPC_HD float bez_d(float x) { return 6.0f * x * (1.0f - x); }
 // forces: this robot's solver output (fp64 [12h], first 12 used) -- read only when the solve ran and
 // reported OSQP_SOLVED.  torques: 12 floats, FL FR RL RR x (hip, thigh, calf).
 MPC_HD void ctrl_post(CtrlState &s, const RobotConst &rc, const double *forces, int solved, float *torques) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
   if (s.do_solve && solved)
     for (int k = 0; k < 12; ++k) s.f_ff[k] = (float)forces[k];                // ConvexMPCLocomotion.py:186-187
   const float height = (float)(rc.body_height / 3.0);                          // :287

@@ -251,6 +251,14 @@ __global__ void ctrl_pre_kernel(int n, CtrlState *st, const RobotConst *rc, Gait
   active[r] = s.do_solve;
   st[r] = s;
 }
+__global__ void estimator_kernel(int n, const CtrlState *st, const float *body, float *est) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const float nrm[3] = {st[r].normal[0], st[r].normal[1], st[r].normal[2]};
+  float e[kEstLen];
+  estimator_update(body + (size_t)r * 13, nrm, e);
+  for (int k = 0; k < kEstLen; ++k) est[(size_t)r * kEstLen + k] = e[k];
+}
 __global__ void ctrl_post_kernel(int n, CtrlState *st, const RobotConst *rc, int horizon, const double *forces, const int *info,
                                  float *torques) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -268,7 +276,7 @@ struct mpc_ctrl {
   CtrlState *d_state = nullptr;
   RobotConst *d_rc = nullptr;
   int *d_robot_type = nullptr, *d_gait = nullptr, *d_active = nullptr, *d_info = nullptr;
-  float *d_rec = nullptr;
+  float *d_rec = nullptr, *d_est = nullptr;
   double *d_forces = nullptr;
   GaitTable gt;
   CtrlParams cp;
@@ -279,7 +287,7 @@ extern "C" {
 void mpc_ctrl_destroy(mpc_ctrl *c) {
   if (!c) return;
   mpc_batch_destroy(c->solver);
-  void *ptrs[] = {c->d_state, c->d_rc, c->d_robot_type, c->d_gait, c->d_active, c->d_info, c->d_rec, c->d_forces};
+  void *ptrs[] = {c->d_state, c->d_rc, c->d_robot_type, c->d_gait, c->d_active, c->d_info, c->d_rec, c->d_est, c->d_forces};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   delete c;
 }
@@ -318,7 +326,7 @@ int mpc_ctrl_create(mpc_ctrl **out, int n, int horizon, double controller_dt, in
   if ((e = hipMalloc(&c->d_state, sizeof(CtrlState) * n)) != hipSuccess || (e = hipMalloc(&c->d_rc, sizeof(RobotConst) * n_types)) != hipSuccess ||
       (e = hipMalloc(&c->d_robot_type, sizeof(int) * n)) != hipSuccess || (e = hipMalloc(&c->d_gait, sizeof(int) * n)) != hipSuccess ||
       (e = hipMalloc(&c->d_active, sizeof(int) * n)) != hipSuccess || (e = hipMalloc(&c->d_info, sizeof(int) * (size_t)n * kInfoLen)) != hipSuccess ||
-      (e = hipMalloc(&c->d_rec, sizeof(float) * n * inlen)) != hipSuccess || (e = hipMalloc(&c->d_forces, sizeof(double) * (size_t)n * 12 * horizon)) != hipSuccess ||
+      (e = hipMalloc(&c->d_rec, sizeof(float) * n * inlen)) != hipSuccess || (e = hipMalloc(&c->d_est, sizeof(float) * (size_t)n * kEstLen)) != hipSuccess || (e = hipMalloc(&c->d_forces, sizeof(double) * (size_t)n * 12 * horizon)) != hipSuccess ||
       (e = hipMemcpy(c->d_rc, rcs.data(), sizeof(RobotConst) * n_types, hipMemcpyHostToDevice)) != hipSuccess ||
       (e = hipMemcpy(c->d_robot_type, robot_type, sizeof(int) * n, hipMemcpyHostToDevice)) != hipSuccess ||
       (e = hipMemcpy(c->d_gait, gait_id, sizeof(int) * n, hipMemcpyHostToDevice)) != hipSuccess ||
@@ -350,6 +358,14 @@ int mpc_ctrl_step(mpc_ctrl *c, const float *d_dof, const float *d_est, const flo
   hipLaunchKernelGGL(ctrl_post_kernel, dim3(blocks), dim3(128), 0, st, n, c->d_state, c->d_rc, c->cp.horizon, c->d_forces, c->d_info, d_torques);
   HIP_TRY(hipGetLastError());
   return MPC_OK;
+}
+
+int mpc_ctrl_run(mpc_ctrl *c, const float *d_dof, const float *d_body, const float *d_cmd, float *d_torques, void *stream) {
+  if (!c || !d_dof || !d_body || !d_cmd || !d_torques) return fail(MPC_E_ARG, "mpc_ctrl_run: bad argument");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(estimator_kernel, dim3((c->n + 127) / 128), dim3(128), 0, st, c->n, c->d_state, d_body, c->d_est);
+  HIP_TRY(hipGetLastError());
+  return mpc_ctrl_step(c, d_dof, c->d_est, d_cmd, d_torques, stream);
 }
 
 int mpc_ctrl_reset(mpc_ctrl *c, const int *ids, int k, void *stream) {

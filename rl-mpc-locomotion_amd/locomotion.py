@@ -54,6 +54,20 @@ class BatchedLocomotion:
                                             torques.data_ptr(), stream), "mpc_ctrl_step")
         return torques
 
+    def run(self, dof_states, body_states, commands, torques=None):
+        """The batched ``controller.run(dof_states, body_states, commands)`` of the reference loop
+        (RL_Environment/tasks/aliengo.py:252-256): dof_states [N,12,2], body_states [N,13] (pos3, quat xyzw,
+        lin vel3, ang vel3, world frame), commands [N,16]; returns torques [N,12]."""
+        import torch
+        for name, t, numel in (("dof_states", dof_states, self.n * 24), ("body_states", body_states, self.n * 13), ("commands", commands, self.n * 16)):
+            if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or t.numel() != numel:
+                raise ValueError(f"{name} must be a contiguous cuda float32 tensor with {numel} elements")
+        torques = self.torques if torques is None else torques
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.lib().mpc_ctrl_run(self._handle, dof_states.data_ptr(), body_states.data_ptr(), commands.data_ptr(),
+                                           torques.data_ptr(), stream), "mpc_ctrl_run")
+        return torques
+
     def reset(self, env_ids=None):
         import torch
         stream = torch.cuda.current_stream(self.device).cuda_stream

@@ -89,6 +89,12 @@ int emu_ctrl_replay(int n, int ticks, const double *robot_table, const int *robo
   return 0;
 }
 
+// StateEstimator.update restatement: body [n][13], normal [n][3] -> est [n][18]
+int emu_estimator_update(int n, const float *body, const float *normal, float *est) {
+  for (int r = 0; r < n; ++r) estimator_update(body + 13 * r, normal + 3 * r, est + kEstLen * r);
+  return 0;
+}
+
 int emu_state_len(int h) { return 24 * h + 40 * h + 2; }
 int emu_shared_bytes(int h) { return h == 10 ? (int)sizeof(Shared<10>) : h == 16 ? (int)sizeof(Shared<16>) : h == 20 ? (int)sizeof(Shared<20>) : h == 6 ? (int)sizeof(Shared<6>) : -1; }
 

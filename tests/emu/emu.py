@@ -60,3 +60,14 @@ def ctrl_replay(robot_type, gait_id, flat_ground, dof, est, cmd, dt=0.01, iters_
                            p(dof), p(est), p(cmd), p(tau), p(rec), p(fff))
     assert rc == 0
     return tau, rec, fff
+
+
+def estimator_update(body, normal):
+    L = lib()
+    body = np.ascontiguousarray(body, dtype=np.float32); normal = np.ascontiguousarray(normal, dtype=np.float32)
+    n = body.shape[0]
+    est = np.zeros((n, 18), np.float32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    L.emu_estimator_update.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.emu_estimator_update(n, p(body), p(normal), p(est))
+    return est

@@ -28,6 +28,20 @@ def test_emulated_controller_matches_reference_python(name):
     assert np.array_equal(ran, g["solved"].astype(bool))
 
 
+@pytest.mark.parametrize("name", ["controller_h10_flat", "controller_h10_slope"])
+def test_emulated_estimator_matches_reference_python(name):
+    """StateEstimator.update restated with explicit float16/float32 semantics: the float16 outputs (rpyBody,
+    ground_R_body_frame) must be bit-identical to the reference's, the float32 ones within an ulp or two
+    (numpy's float16 @ float32 product goes through BLAS there)."""
+    from tests.emu.emu import estimator_update
+    g = load_golden(name)
+    T, n = g["body"].shape[:2]
+    normal_prev = np.concatenate([np.tile(np.array([0, 0, 1], np.float32), (1, n, 1)), g["normal"][:-1]], axis=0)   # estimate of the previous tick
+    est = estimator_update(g["body"].reshape(T * n, 13), normal_prev.reshape(T * n, 3)).reshape(T, n, 18)
+    assert np.array_equal(est[..., 6:], g["est"][..., 6:])
+    np.testing.assert_allclose(est[..., :6], g["est"][..., :6], rtol=3e-7, atol=1e-7)
+
+
 def test_gait_tables_match_reference_definition():
     """gait.py's tables against ConvexMPCLocomotion.py:30-56 (restated literally here)."""
     from rl_mpc_locomotion_amd.gait import GAIT_TABLE_10, gait_arrays, mpc_table
@@ -83,6 +97,27 @@ def test_hip_controller_matches_reference_python(name):
         if (k + 1) % 2 == 0:
             assert (ctl.solver_info()[:, 1] == 1).all()
     assert worst < TAU_RTOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["controller_h10_flat", "controller_h10_slope"])
+def test_hip_full_run_matches_reference_python(name):
+    """The complete controller.run seam (estimator + controller + solve) on the GPU against the reference's
+    torques.  vBody / omegaBody can differ from numpy's by a float32 ulp, which on rare ticks moves a solver
+    input across a float16 rounding or an OSQP decision: require 99 % of the (tick, robot) samples inside
+    TAU_RTOL and all of them inside 2 %."""
+    import torch
+    from rl_mpc_locomotion_amd.locomotion import BatchedLocomotion
+    g = load_golden(name)
+    T, n = g["dof"].shape[:2]
+    ctl = BatchedLocomotion(g["robot_type"], g["gait_id"], horizon=10, flat_ground=bool(g["flat_ground"]), device="cuda:0")
+    errs = []
+    for k in range(T):
+        tau = ctl.run(torch.from_numpy(g["dof"][k]).cuda(), torch.from_numpy(g["body"][k]).cuda(), torch.from_numpy(g["cmd"][k]).cuda())
+        torch.cuda.synchronize()
+        errs.append(_relerr(tau.cpu().numpy(), g["torque"][k]))
+    errs = np.concatenate(errs)
+    assert (errs < TAU_RTOL).mean() >= 0.99 and errs.max() < 2e-2, (float((errs < TAU_RTOL).mean()), float(errs.max()))
 
 
 @pytest.mark.gpu
