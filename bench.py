@@ -94,9 +94,8 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        from rl_mpc_locomotion_amd.sharding import max_over_ranks
+        elapsed = max_over_ranks(elapsed, dev)
 
     kernel_ms = np.array([a.elapsed_time(b) for a, b in ev])
     first_forces = first_out.cpu().numpy()
@@ -141,12 +140,37 @@ def main():
                      "kernel_ms": float(kernel_ms.mean()), "flops_per_launch": flops_per_launch,
                      "frac_fp64_peak": achieved_tflops / FP64_VECTOR_PEAK_TFLOPS},
     }
+    out["control_loop"] = control_loop_leg(n, h, dev)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, batches, W, h, gpu_first_forces=first_forces)
         out["max_grf_err_vs_osqp"] = out["cpu_baseline"].pop("_gpu_err", None)
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def control_loop_leg(n, h, dev, ticks=40, warm=10):
+    """Secondary figure (NOT `value`): robot-ticks/s of the whole controller.run seam on device tensors --
+    state estimator + leg kinematics + gait / foot placement + the MPC solve on every second tick (the
+    reference's cadence, RobotRunnerMin.py:21-22) + swing / stance commands + joint torques."""
+    import torch
+    from rl_mpc_locomotion_amd.locomotion import BatchedLocomotion
+    from rl_mpc_locomotion_amd.synthetic import TickStream
+    ts = TickStream(n, seed=4242, config=2)
+    ctl = BatchedLocomotion(ts.robot_type, ts.gait_id, horizon=h, device=dev)
+    ins = [tuple(torch.from_numpy(a).to(dev) for a in ts.tick(k)) for k in range(warm + ticks)]
+    for k in range(warm):
+        ctl.run(*ins[k])
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(warm, warm + ticks):
+        ctl.run(*ins[k])
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    solved = float((ctl.solver_info()[:, 1] == 1).mean())
+    return {"robot_ticks_per_s": n * ticks / dt, "ms_per_tick": dt / ticks * 1e3, "ticks": ticks, "mpc_every_n_ticks": 2,
+            "solved_fraction_last_mpc": solved,
+            "note": "controller.run for every robot per tick; the MPC solve runs on every 2nd tick, so this is ~2x the control-step rate by construction"}
 
 
 def usable_cores():

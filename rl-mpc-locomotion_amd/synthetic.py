@@ -135,3 +135,48 @@ def perturb_workload(wl, seed, scale=0.05):
     it = (wl.iteration_counter + 2).astype(np.int32)
     rec[:, L.IN_CONTACT:L.IN_CONTACT + 4 * h] = mpc_table(wl.gait_id, it, 2, h)
     return Workload(h, rec, wl.robot_type, wl.gait_id, it, wl.dt_mpc, wl.alpha)
+
+
+class TickStream:
+    """Seeded, smooth open-loop (dof_states, body_states, commands) signals for N robots, shaped like the RL
+    bridge's per-tick inputs (RL_Environment/tasks/aliengo.py:246-256).  Same construction as
+    tests/golden/make_golden_controller.py, vectorised."""
+
+    def __init__(self, n, seed=0, config=2):
+        rng = np.random.default_rng(seed)
+        idx = np.arange(n)
+        if config == 3:
+            self.robot_type = np.array([RobotType.GO1, RobotType.A1, RobotType.ALIENGO], dtype=np.int32)[idx % 3]
+            self.gait_id = np.array([0, 6, 1], dtype=np.int32)[(idx // 3) % 3]
+        else:
+            self.robot_type = np.full(n, int(RobotType.ALIENGO), dtype=np.int32)
+            self.gait_id = np.zeros(n, dtype=np.int32)
+        self.n = n
+        self.phase = rng.uniform(0, 2 * np.pi, (n, 21))
+        self.amp = rng.uniform(0.02, 0.15, (n, 21))
+        self.yaw0 = rng.uniform(-3, 3, n)
+        self.H = ROBOT_TABLE[self.robot_type, COL_HEIGHT] * rng.uniform(0.9, 1.05, n)
+        self.v0 = rng.uniform(-0.5, 0.5, (n, 3)) * np.array([1, 0.4, 0.1])
+        self.cmd = np.stack([rng.uniform(-1.5, 1.5, n), rng.uniform(-0.5, 0.5, n), rng.uniform(-1.0, 1.0, n)], -1)
+        self.w = MPC_PARAM_CONST + rng.uniform(-1, 1, (n, 12)).astype(np.float32) * MPC_PARAM_SCALE
+
+    def tick(self, k, dt=0.01):
+        t, ph, amp, n = dt * k, self.phase, self.amp, self.n
+        q = np.tile([0.0, 0.8, -1.6], 4)[None] + amp[:, :12] * np.sin(2 * np.pi * 1.3 * t + ph[:, :12])
+        qd = amp[:, :12] * 2 * np.pi * 1.3 * np.cos(2 * np.pi * 1.3 * t + ph[:, :12])
+        dof = np.stack([q, qd], axis=2).astype(np.float32)
+        rpy = 0.12 * np.sin(2 * np.pi * 0.7 * t + ph[:, 12:15])
+        rpy[:, 2] += self.yaw0 + 0.4 * t
+        cy, sy, cp, sp, cr, sr = (np.cos(rpy[:, 2] / 2), np.sin(rpy[:, 2] / 2), np.cos(rpy[:, 1] / 2), np.sin(rpy[:, 1] / 2),
+                                  np.cos(rpy[:, 0] / 2), np.sin(rpy[:, 0] / 2))
+        body = np.zeros((n, 13), dtype=np.float32)
+        body[:, 0] = 0.3 * t
+        body[:, 2] = self.H
+        body[:, 3:7] = np.stack([sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy,
+                                 cr * cp * cy + sr * sp * sy], -1)
+        body[:, 7:10] = self.v0 + 0.2 * np.sin(2 * np.pi * 0.5 * t + ph[:, 15:18])
+        body[:, 10:13] = 0.3 * np.sin(2 * np.pi * 0.9 * t + ph[:, 18:21])
+        cmd = np.zeros((n, 16), dtype=np.float32)
+        cmd[:, 0:3] = self.cmd
+        cmd[:, 3:15] = self.w
+        return dof, body, cmd
