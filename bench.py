@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--robots", type=int, default=4096, help="robots per GPU")
     ap.add_argument("--horizon", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-control-loop", action="store_true", help="skip the secondary controller.run leg (profiling runs)")
     args = ap.parse_args()
 
     import torch
@@ -140,7 +141,8 @@ def main():
                      "kernel_ms": float(kernel_ms.mean()), "flops_per_launch": flops_per_launch,
                      "frac_fp64_peak": achieved_tflops / FP64_VECTOR_PEAK_TFLOPS},
     }
-    out["control_loop"] = control_loop_leg(n, h, dev)
+    if not args.no_control_loop:
+        out["control_loop"] = control_loop_leg(n, h, dev)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, batches, W, h, gpu_first_forces=first_forces)
         out["max_grf_err_vs_osqp"] = out["cpu_baseline"].pop("_gpu_err", None)
