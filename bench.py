@@ -114,6 +114,16 @@ def main():
             dist.destroy_process_group()
         return
 
+    # HBM traffic of the solve kernel is a rocprofv3 PMC measurement taken offline on this same command
+    # (tools/pmc_passes.sh -> profiles/rNN_pmc_summary.json); bench.py cannot run the profiler on itself.
+    traffic = None
+    try:
+        import glob
+        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+        if pm and n == 4096 and h == 10:
+            traffic = float(json.load(open(pm[-1]))["hbm_traffic_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        traffic = None
     value = world * n * K / elapsed
     out = {
         "metric": "MPC control steps/sec (whole node) @ horizon=10, 4096 robots; max |GRF| err vs OSQP",
@@ -135,7 +145,8 @@ def main():
         "mean_admm_iters": float(info[..., 0].mean()),
         "mean_factorisations": float(info[..., 4].mean()),
         "roofline": {"bound": "mfma", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": None,
+                     "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic,
+                     "traffic_note": "HBM-side bytes per launch from rocprofv3 PMC (profiles/*_pmc_summary.json, measured offline on this command)",
                      "note": "vector-FP bound, no MFMA/HBM roofline applies (SURVEY 8d): algorithmic flops (n_r formula) / "
                              "mean kernel time from HIP events; kernel arithmetic is fp64 (peak 78.6 TF)",
                      "kernel_ms": float(kernel_ms.mean()), "flops_per_launch": flops_per_launch,
