@@ -113,7 +113,7 @@ struct Shared {
   double c, cinv, rho, ctmp;
   double rho_vec[C::M], rho_inv[C::M];
   int ctype[C::M];
-  double x[C::N], xt[C::N];
+  double x[C::N], xt[C::N], Px[C::N];                    // Px = P_s x, carried through the ADMM iterations
   double zz[2][C::M], yy[2][C::M], rr[2][C::N];          // z, y, rhs: ping-pong buffered across ADMM iterations
   double part[C::PARTLEN];                              // per (row, column-tile) partial sums / maxima
   double prow[2][C::N];                                 // sweep pivot row (double buffered)
@@ -133,7 +133,7 @@ struct Shared {
       double dt_[C::N], et_[C::M], cn_[C::N];           // Ruiz pass temporaries
     };
     struct {
-      double Ax[C::M], Px[C::N], Aty[C::N], rp[C::M], rd[C::N];
+      double Ax[C::M], Aty[C::N], rp[C::M], rd[C::N];
       int act[C::M];
       double Nb[C::NF * 9], Gm[C::NF * 9];              // per foot: null basis rows (3 x 3, zero padded), Gamma
       int nnull[C::NF], isnull[C::N];
@@ -734,7 +734,7 @@ struct Solver {
         const int f = t.tid / 3, c0 = t.tid - 3 * f;
         const double *a = s.As + 15 * f;
         const double *zc = s.zz[pp], *yc = s.yy[pp], *rc = s.rr[pp];
-        double xt[3], tm[5], zk0 = 0, yk0 = 0, zk1 = 0, yk1 = 0;
+        double xt[3], tm[5], zk0 = 0, yk0 = 0, zk1 = 0, yk1 = 0, arz = 0;
         // scheduling fences keep the live set small: the tile already occupies 144 of the 256 VGPRs
 #pragma unroll
         for (int c = 0; c < 3; ++c) { xt[c] = inv_combine(s, 3 * f + c, rc); MPC_SCHED_FENCE(); }
@@ -747,6 +747,7 @@ struct Solver {
           const double znr = clampd(zr + s.rho_inv[i] * yv, s.ls[i], s.us[i]);
           const double ynr = yv + rv * (zr - znr);
           tm[r] = rv * znr - ynr;
+          arz += a[3 * r + c0] * (rv * zt);
           if (r < 3) { zk0 = (r == c0) ? znr : zk0; yk0 = (r == c0) ? ynr : yk0; }      // rows c0 ...
           else { zk1 = (r == c0 + 3) ? znr : zk1; yk1 = (r == c0 + 3) ? ynr : yk1; }     // ... and c0 + 3
           MPC_SCHED_FENCE();
@@ -756,6 +757,8 @@ struct Solver {
         xtc = (c0 == 2) ? xt[2] : xtc;
 #pragma unroll
         for (int r = 0; r < 5; ++r) acc += a[3 * r + c0] * tm[r];
+        // P_s x without a matrix product: K x~ = rhs gives P_s x~ = rhs - sigma x~ - A^T R z~, and x is affine in x~
+        s.Px[t.tid] = kAlphaRelax * (rc[t.tid] - kSigma * xtc - arz) + (1.0 - kAlphaRelax) * s.Px[t.tid];
         const double xn = kAlphaRelax * xtc + (1.0 - kAlphaRelax) * s.x[t.tid];
         s.x[t.tid] = xn;
         s.rr[pp ^ 1][t.tid] = kSigma * xn - s.qs[t.tid] + acc;
@@ -792,9 +795,7 @@ struct Solver {
   //              6 ||Dinv rd|| 7 ||Dinv q|| 8 ||Dinv Aty|| 9 ||Dinv Px|| 10 ||rd|| 11 ||q|| 12 ||Aty|| 13 ||Px||
   // 64 threads stride over the rows and keep running maxima in registers; 14 threads finish.
   static constexpr int kRedW = 64;
-  MPC_HD void residuals(const double *x, const double *z, const double *y) {
-    mul_P(x, s.Px);
-    lap(9);
+  MPC_HD void residuals(const double *x, const double *z, const double *y, const double *Px) {
     ex.par([&](Th &t) {
       if (t.tid < kRedW) {
         double mx[14];
@@ -807,7 +808,7 @@ struct Solver {
           mx[3] = dmax(mx[3], fabs(r)); mx[4] = dmax(mx[4], fabs(z[i])); mx[5] = dmax(mx[5], fabs(ax));
         }
         for (int j = t.tid; j < N; j += kRedW) {
-          const double aty = at_col_dot(s, j, y), px = s.Px[j], qv = s.qs[j], r = qv + px + aty, di = s.Dinv[j];
+          const double aty = at_col_dot(s, j, y), px = Px[j], qv = s.qs[j], r = qv + px + aty, di = s.Dinv[j];
           s.Aty[j] = aty; s.rd[j] = r;
           mx[6] = dmax(mx[6], fabs(di * r)); mx[7] = dmax(mx[7], fabs(di * qv)); mx[8] = dmax(mx[8], fabs(di * aty));
           mx[9] = dmax(mx[9], fabs(di * px)); mx[10] = dmax(mx[10], fabs(r)); mx[11] = dmax(mx[11], fabs(qv));
@@ -988,27 +989,35 @@ struct Solver {
     sweep_all(true);   // Mx <- -(H + delta I)^{-1} on the null coordinates
     ex.par([&](Th &t) { if (t.tid == 0) s.nfact++; });
     lap(12);
-    // iterative refinement in the null space (polish.c:102-160: 1 solve + 3 refinements)
+    // delta-regularised solve + 3 refinement steps (polish.c:102-160) in the null space: with Hd = H + delta I,
+    // w_{k+1} = w_k + Hd^{-1} rho_k and rho_k = b - H w_k obey rho_{k+1} = delta Hd^{-1} rho_k (H Hd^{-1} = I - delta Hd^{-1}),
+    // so the refinement needs no further products with P.
+    ex.par([&](Th &t) {   // rho_0 = N~^T g
+      if (t.tid < N) {
+        const int j = t.tid, f = j / 3, k = j - 3 * f;
+        const double *nv = s.Nb + 9 * f + 3 * k;
+        s.rw[j] = (k < s.nnull[f]) ? nv[0] * s.g[3 * f] + nv[1] * s.g[3 * f + 1] + nv[2] * s.g[3 * f + 2] : 0.0;
+      }
+    });
     for (int it = 0; it <= kPolishRefine; ++it) {
-      ex.par([&](Th &t) {   // rw = N~^T (g - P xN)
-        if (t.tid < N) {
-          const int j = t.tid, f = j / 3, k = j - 3 * f;
-          const double *nv = s.Nb + 9 * f + 3 * k;
-          s.rw[j] = (k < s.nnull[f]) ? nv[0] * (s.g[3 * f] - s.PxN[3 * f]) + nv[1] * (s.g[3 * f + 1] - s.PxN[3 * f + 1]) + nv[2] * (s.g[3 * f + 2] - s.PxN[3 * f + 2]) : 0.0;
-        }
-      });
       ex.par([&](Th &t) { if (t.mact) tile_matvec_neg(t, s.rw); });
-      ex.par([&](Th &t) { if (t.tid < N && s.isnull[t.tid]) s.wv[t.tid] += inv_combine(s, t.tid, s.rw); });
-      ex.par([&](Th &t) {   // xN = N~ w
-        if (t.tid < N) {
-          const int j = t.tid, f = j / 3, c = j - 3 * f;
-          double v = 0;
-          for (int k = 0; k < 3; ++k) if (k < s.nnull[f]) v += s.Nb[9 * f + 3 * k + c] * s.wv[3 * f + k];
-          s.xN[j] = v;
+      ex.par([&](Th &t) {
+        if (t.tid < N && s.isnull[t.tid]) {
+          const double dw = inv_combine(s, t.tid, s.rw);
+          s.wv[t.tid] += dw;
+          s.rw[t.tid] = kDelta * dw;
         }
       });
-      mul_P(s.xN, s.PxN);
     }
+    ex.par([&](Th &t) {   // xN = N~ w
+      if (t.tid < N) {
+        const int j = t.tid, f = j / 3, c = j - 3 * f;
+        double v = 0;
+        for (int k = 0; k < 3; ++k) if (k < s.nnull[f]) v += s.Nb[9 * f + 3 * k + c] * s.wv[3 * f + k];
+        s.xN[j] = v;
+      }
+    });
+    mul_P(s.xN, s.PxN);
     lap(13);
     // x = u + xN ; y = A Gamma (g - P xN) on active rows ; z = A x ; normal-cone projection (proj.c:17-31)
     ex.par([&](Th &t) {
@@ -1031,7 +1040,8 @@ struct Solver {
     });
     // residuals at the polished point, acceptance (polish.c:306-345)
     const double pri0 = s.pri_res, dua0 = s.dua_res;
-    residuals(s.xt, s.zpol, s.ypol);
+    ex.par([&](Th &t) { if (t.tid < N) s.Pu[t.tid] += s.PxN[t.tid]; });   // P_s x_pol
+    residuals(s.xt, s.zpol, s.ypol, s.Pu);
     ex.par([&](Th &t) {
       if (t.tid == 0) {
         const double pri = bitsd(s.red[0]), dua = s.cinv * bitsd(s.red[6]);
@@ -1056,6 +1066,9 @@ struct Solver {
     scale();
     set_rho_vec();
     factor(false);
+    if (!s.first) mul_P(s.x, s.Px);                       // warm start: P_s x_0 once, then carried by recursion
+    else ex.par([&](Th &t) { if (t.tid < N) s.Px[t.tid] = 0.0; });
+    lap(9);
     admm_prepare();
     lap(8);
     int iter = 0;
@@ -1064,7 +1077,7 @@ struct Solver {
       admm_iter();
       if (iter % kCheck == 0) {
         lap(8);
-        residuals(s.x, cz(), cy());
+        residuals(s.x, cz(), cy(), s.Px);
         check_and_adapt(iter);
         lap(10);
         if (!s.done && s.rho_new > 0) {          // osqp_update_rho: new rho_vec, refactor
