@@ -232,12 +232,16 @@ struct Solver {
 #pragma unroll
     for (int a = 0; a < TR; ++a) s.part[(TR * t.ti + a) * GC + t.tj] = -acc[a];
   }
-  static MPC_HD double sum_parts(const Sh &s, int row) {
+  static MPC_HD double sum_parts(const Sh &s, int row) {   // fixed pairwise order (short dependency chains)
     const double *p = s.part + row * GC;
-    double acc = p[0];
+    double v[GC];
 #pragma unroll
-    for (int k = 1; k < GC; ++k) acc += p[k];
-    return acc;
+    for (int k = 0; k < GC; ++k) v[k] = p[k];
+#pragma unroll
+    for (int w = 1; w < GC; w *= 2)
+#pragma unroll
+      for (int k = 0; k + w < GC; k += 2 * w) v[k] += v[k + w];
+    return v[0];
   }
   // combine the partial products of (-Minv) v for a swept row: see sweep_all()
   static MPC_HD double inv_combine(const Sh &s, int row, const double *v) { return sum_parts(s, row) + 2.0 * v[row]; }
@@ -446,6 +450,15 @@ struct Solver {
   }
 
   // ================================ 2. scaling (scaling.c:44-156) ===============================
+  MPC_HD void apply_cost_scale(Th &t) {   // in-phase: P <- c_temp P, q <- c_temp q, c <- c_temp c
+    const double ct = s.ctmp;
+    if (t.mact) {
+#pragma unroll
+      for (int e = 0; e < TE; ++e) t.Mx[e] *= ct;
+    }
+    if (t.tid < N) s.qs[t.tid] *= ct;
+    if (t.tid == 0) s.c *= ct;
+  }
   MPC_HD void scale() {
     lap(2);
     ex.par([&](Th &t) {
@@ -460,7 +473,8 @@ struct Solver {
     });
     lap(3);
     for (int it = 0; it < kScalingIters; ++it) {
-      ex.par([&](Th &t) {   // row (= column) inf-norms of P, row norms of A
+      ex.par([&](Th &t) {   // (cost scale of the previous pass, deferred) ; row (= column) inf-norms of P, row norms of A
+        if (it > 0) apply_cost_scale(t);
         if (t.mact) tile_rowmax(t);
         if (t.tid < M) {
           const double *a = s.As + 3 * t.tid;
@@ -498,35 +512,24 @@ struct Solver {
         }
         if (t.tid < N) { s.qs[t.tid] *= s.dt_[t.tid]; s.D[t.tid] *= s.dt_[t.tid]; }
       });
-      ex.par([&](Th &t) {
-        if (t.tid < N) s.cn_[t.tid] = max_parts(s, t.tid);
-      });
-      ex.par([&](Th &t) {   // cost scaling (scaling.c:108-139), two-level: 12 x 3 foot-sized chunks...
+      ex.par([&](Th &t) {   // cost scaling (scaling.c:108-139), two-level: per-foot partial sums of the column norms ...
         if (t.tid < NF) {
           const int f = t.tid;
-          s.et_[f] = (s.cn_[3 * f] + s.cn_[3 * f + 1]) + s.cn_[3 * f + 2];                  // partial sum of column norms
-          s.et_[NF + f] = dmax(dmax(fabs(s.qs[3 * f]), fabs(s.qs[3 * f + 1])), fabs(s.qs[3 * f + 2]));   // partial ||q||_inf
+          s.cn_[f] = (max_parts(s, 3 * f) + max_parts(s, 3 * f + 1)) + max_parts(s, 3 * f + 2);
+          s.cn_[NF + f] = dmax(dmax(fabs(s.qs[3 * f]), fabs(s.qs[3 * f + 1])), fabs(s.qs[3 * f + 2]));
         }
       });
-      ex.par([&](Th &t) {   // ...then one thread combines the NF partials
+      ex.par([&](Th &t) {   // ... combined by one thread; applied at the start of the next phase that touches the tile
         if (t.tid == 0) {
           double mean = 0, nq = 0;
-          for (int f = 0; f < NF; ++f) { mean += s.et_[f]; nq = dmax(nq, s.et_[NF + f]); }
+          for (int f = 0; f < NF; ++f) { mean += s.cn_[f]; nq = dmax(nq, s.cn_[NF + f]); }
           mean /= N;
           nq = limit_scaling(nq);
           s.ctmp = 1.0 / limit_scaling(dmax(mean, nq));
         }
       });
-      ex.par([&](Th &t) {
-        const double ct = s.ctmp;
-        if (t.mact) {
-#pragma unroll
-          for (int e = 0; e < TE; ++e) t.Mx[e] *= ct;
-        }
-        if (t.tid < N) s.qs[t.tid] *= ct;
-        if (t.tid == 0) s.c *= ct;
-      });
     }
+    ex.par([&](Th &t) { apply_cost_scale(t); });
     lap(4);
     ex.par([&](Th &t) {
       if (t.tid == 0) s.cinv = 1.0 / s.c;
@@ -725,6 +728,9 @@ struct Solver {
     ex.par([&](Th &t) {
       if (t.mact) tile_matvec_neg(t, crhs());
     });
+#ifdef MPC_PROFILE_ADMM
+    lap(9);
+#endif
     ex.par([&](Th &t) {
       // Three threads per foot (tid = 3 f + c), each redoing the foot's 3 x~ and 5 row updates -- the
       // five rows are independent chains, which hides the fp64 latency a single thread would expose.
@@ -737,7 +743,7 @@ struct Solver {
         double xt[3], tm[5], zk0 = 0, yk0 = 0, zk1 = 0, yk1 = 0, arz = 0;
         // scheduling fences keep the live set small: the tile already occupies 144 of the 256 VGPRs
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { xt[c] = inv_combine(s, 3 * f + c, rc); MPC_SCHED_FENCE(); }
+        for (int c = 0; c < 3; ++c) xt[c] = inv_combine(s, 3 * f + c, rc);
 #pragma unroll
         for (int r = 0; r < 5; ++r) {
           const int i = 5 * f + r;
@@ -750,7 +756,6 @@ struct Solver {
           arz += a[3 * r + c0] * (rv * zt);
           if (r < 3) { zk0 = (r == c0) ? znr : zk0; yk0 = (r == c0) ? ynr : yk0; }      // rows c0 ...
           else { zk1 = (r == c0 + 3) ? znr : zk1; yk1 = (r == c0 + 3) ? ynr : yk1; }     // ... and c0 + 3
-          MPC_SCHED_FENCE();
         }
         double xtc = xt[0], acc = 0;
         xtc = (c0 == 1) ? xt[1] : xtc;
@@ -767,6 +772,9 @@ struct Solver {
       }
     });
     pp ^= 1;
+#ifdef MPC_PROFILE_ADMM
+    lap(8);
+#endif
   }
 
   // P_s v -> out (P_s tiles read from HBM scratch).  Two phases.
