@@ -114,7 +114,8 @@ struct Shared {
   double rho_vec[C::M], rho_inv[C::M];
   int ctype[C::M];
   double x[C::N], xt[C::N], Px[C::N];                    // Px = P_s x, carried through the ADMM iterations
-  double zz[2][C::M], yy[2][C::M], rr[2][C::N];          // z, y, rhs: ping-pong buffered across ADMM iterations
+  double zz[1][C::M], yy[1][C::M], rr[1][C::N];          // z, y, rhs
+  double tm[C::M], rzt[C::M];                            // R z - y and R z~ of the current iteration
   double part[C::PARTLEN];                              // per (row, column-tile) partial sums / maxima
   double prow[2][C::N];                                 // sweep pivot row (double buffered)
   double diag[C::N];                                    // diagonal of the matrix being swept
@@ -724,6 +725,12 @@ struct Solver {
       }
     });
   }
+  // One ADMM iteration = four short phases (each a single LDS round trip; the tile leaves few free
+  // registers, so long per-thread programs serialise into many round trips):
+  //   M: part <- (-Mx) rhs                       (tile threads; Mx = -K^{-1} + 2 I on the diagonal slots)
+  //   C: x~_j = sum of the partials + 2 rhs_j    (one thread per variable)
+  //   R: z~_i = (A x~)_i ; z, y update ; tm_i = rho_i z_i - y_i      (one thread per constraint row)
+  //   X: x update, P_s x recursion, next rhs_j = sigma x_j - q_j + (A^T tm)_j   (one thread per variable)
   MPC_HD void admm_iter() {
     ex.par([&](Th &t) {
       if (t.mact) tile_matvec_neg(t, crhs());
@@ -732,46 +739,38 @@ struct Solver {
     lap(9);
 #endif
     ex.par([&](Th &t) {
-      // Three threads per foot (tid = 3 f + c), each redoing the foot's 3 x~ and 5 row updates -- the
-      // five rows are independent chains, which hides the fp64 latency a single thread would expose.
-      // Thread c stores x[3f+c], rhs[3f+c] and rows c, c+3.  z, y and rhs are ping-pong buffered
-      // (siblings read the old values while others already store the new ones).
-      if (t.tid < N) {
-        const int f = t.tid / 3, c0 = t.tid - 3 * f;
-        const double *a = s.As + 15 * f;
-        const double *zc = s.zz[pp], *yc = s.yy[pp], *rc = s.rr[pp];
-        double xt[3], tm[5], zk0 = 0, yk0 = 0, zk1 = 0, yk1 = 0, arz = 0;
-        // scheduling fences keep the live set small: the tile already occupies 144 of the 256 VGPRs
-#pragma unroll
-        for (int c = 0; c < 3; ++c) xt[c] = inv_combine(s, 3 * f + c, rc);
-#pragma unroll
-        for (int r = 0; r < 5; ++r) {
-          const int i = 5 * f + r;
-          const double zt = a[3 * r] * xt[0] + a[3 * r + 1] * xt[1] + a[3 * r + 2] * xt[2];
-          const double zp = zc[i], yv = yc[i], rv = s.rho_vec[i];
-          const double zr = kAlphaRelax * zt + (1.0 - kAlphaRelax) * zp;
-          const double znr = clampd(zr + s.rho_inv[i] * yv, s.ls[i], s.us[i]);
-          const double ynr = yv + rv * (zr - znr);
-          tm[r] = rv * znr - ynr;
-          arz += a[3 * r + c0] * (rv * zt);
-          if (r < 3) { zk0 = (r == c0) ? znr : zk0; yk0 = (r == c0) ? ynr : yk0; }      // rows c0 ...
-          else { zk1 = (r == c0 + 3) ? znr : zk1; yk1 = (r == c0 + 3) ? ynr : yk1; }     // ... and c0 + 3
-        }
-        double xtc = xt[0], acc = 0;
-        xtc = (c0 == 1) ? xt[1] : xtc;
-        xtc = (c0 == 2) ? xt[2] : xtc;
-#pragma unroll
-        for (int r = 0; r < 5; ++r) acc += a[3 * r + c0] * tm[r];
-        // P_s x without a matrix product: K x~ = rhs gives P_s x~ = rhs - sigma x~ - A^T R z~, and x is affine in x~
-        s.Px[t.tid] = kAlphaRelax * (rc[t.tid] - kSigma * xtc - arz) + (1.0 - kAlphaRelax) * s.Px[t.tid];
-        const double xn = kAlphaRelax * xtc + (1.0 - kAlphaRelax) * s.x[t.tid];
-        s.x[t.tid] = xn;
-        s.rr[pp ^ 1][t.tid] = kSigma * xn - s.qs[t.tid] + acc;
-        s.zz[pp ^ 1][5 * f + c0] = zk0; s.yy[pp ^ 1][5 * f + c0] = yk0;
-        if (c0 < 2) { s.zz[pp ^ 1][5 * f + c0 + 3] = zk1; s.yy[pp ^ 1][5 * f + c0 + 3] = yk1; }
+      if (t.tid < N) s.xt[t.tid] = inv_combine(s, t.tid, crhs());
+    });
+    ex.par([&](Th &t) {
+      if (t.tid < M) {
+        const int i = t.tid, f = i / 5, r = i - 5 * f;
+        const double *a = s.As + 15 * f + 3 * r, *xt = s.xt + 3 * f;
+        const double zt = a[0] * xt[0] + a[1] * xt[1] + a[2] * xt[2];
+        const double zp = cz()[i], yv = cy()[i], rv = s.rho_vec[i];
+        const double zr = kAlphaRelax * zt + (1.0 - kAlphaRelax) * zp;
+        const double zn = clampd(zr + s.rho_inv[i] * yv, s.ls[i], s.us[i]);
+        const double yn = yv + rv * (zr - zn);
+        cz()[i] = zn;
+        cy()[i] = yn;
+        s.tm[i] = rv * zn - yn;
+        s.rzt[i] = rv * zt;
       }
     });
-    pp ^= 1;
+    ex.par([&](Th &t) {
+      if (t.tid < N) {
+        const int j = t.tid, f = j / 3, c = j - 3 * f;
+        const double *a = s.As + 15 * f + c, *tm = s.tm + 5 * f, *rz = s.rzt + 5 * f;
+        double acc = 0, arz = 0;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) { acc += a[3 * r] * tm[r]; arz += a[3 * r] * rz[r]; }
+        const double xt = s.xt[j], xp = s.x[j];
+        // P_s x without a matrix product: K x~ = rhs gives P_s x~ = rhs - sigma x~ - A^T R z~, and x is affine in x~
+        s.Px[j] = kAlphaRelax * (crhs()[j] - kSigma * xt - arz) + (1.0 - kAlphaRelax) * s.Px[j];
+        const double xn = kAlphaRelax * xt + (1.0 - kAlphaRelax) * xp;
+        s.x[j] = xn;
+        crhs()[j] = kSigma * xn - s.qs[j] + acc;
+      }
+    });
 #ifdef MPC_PROFILE_ADMM
     lap(8);
 #endif
