@@ -150,6 +150,7 @@ struct Thread {
   bool mact;                // holds a matrix tile (tid < MT)
   double Mx[C::TE];         // tile of the current n x n matrix (P_s, K, -Kinv, H, -Hinv), row-major 6 x 12
   double xprev, zprev;      // carried scalars
+  double dg[C::TR];         // sweep: true diagonal of my 6 rows (held by the tj == 0 thread of each tile row)
   MPC_HD void init(int id) {
     tid = id; ti = id / C::GC; tj = id - ti * C::GC; mact = id < C::MT; xprev = 0; zprev = 0;
   }
@@ -200,6 +201,11 @@ struct Solver {
   MPC_HD double *crhs() { return s.rr[pp]; }
   long long tc[kProfLen] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = 0;
+#ifdef MPC_PROFILE_SCALE   // sub-profile of one scaling pass (reuses slots 9..13; diagnostic builds only)
+#define MPC_SCALE_LAP(k) lap(k)
+#else
+#define MPC_SCALE_LAP(k) ((void)0)
+#endif
   MPC_HD void lap(int k) { const long long now = MPC_CLOCK(); tc[k] += now - tlast; tlast = now; }
 
   // ---- helpers valid inside a phase ------------------------------------------------------------
@@ -482,6 +488,7 @@ struct Solver {
           s.et_[t.tid] = 1.0 / sqrt(limit_scaling(dmax(dmax(fabs(a[0]), fabs(a[1])), fabs(a[2]))));
         }
       });
+      MPC_SCALE_LAP(9);
       ex.par([&](Th &t) {
         if (t.tid < N) {
           const int j = t.tid, f = j / 3, c = j - 3 * f;
@@ -490,6 +497,7 @@ struct Solver {
           s.dt_[j] = 1.0 / sqrt(limit_scaling(mx));
         }
       });
+      MPC_SCALE_LAP(10);
       ex.par([&](Th &t) {   // P <- D P D, A <- E A D, q <- D q; then the new column norms of P
         if (t.mact) {
           const double *dr = s.dt_ + TR * t.ti, *dc = s.dt_ + TC * t.tj;
@@ -513,6 +521,7 @@ struct Solver {
         }
         if (t.tid < N) { s.qs[t.tid] *= s.dt_[t.tid]; s.D[t.tid] *= s.dt_[t.tid]; }
       });
+      MPC_SCALE_LAP(11);
       ex.par([&](Th &t) {   // cost scaling (scaling.c:108-139), two-level: per-foot partial sums of the column norms ...
         if (t.tid < NF) {
           const int f = t.tid;
@@ -520,6 +529,7 @@ struct Solver {
           s.cn_[NF + f] = dmax(dmax(fabs(s.qs[3 * f]), fabs(s.qs[3 * f + 1])), fabs(s.qs[3 * f + 2]));
         }
       });
+      MPC_SCALE_LAP(12);
       ex.par([&](Th &t) {   // ... combined by one thread; applied at the start of the next phase that touches the tile
         if (t.tid == 0) {
           double mean = 0, nq = 0;
@@ -529,6 +539,7 @@ struct Solver {
           s.ctmp = 1.0 / limit_scaling(dmax(mean, nq));
         }
       });
+      MPC_SCALE_LAP(13);
     }
     ex.par([&](Th &t) { apply_cost_scale(t); });
     lap(4);
@@ -608,7 +619,11 @@ struct Solver {
   // The pivot loop is unrolled by TC = 12 so that the pivot row's position inside its tile is static.
   MPC_HD void sweep_all(bool masked) {
     int buf = 0;
-    ex.par([&](Th &t) {   // publish pivot row 0
+    ex.par([&](Th &t) {   // the tj == 0 threads take the diagonal of their rows into registers; publish pivot row 0
+      if (t.mact && t.tj == 0) {
+#pragma unroll
+        for (int a = 0; a < TR; ++a) t.dg[a] = s.diag[TR * t.ti + a];
+      }
       if (t.mact && t.ti == 0) publish_row<0, 0>(t, 0, 0, 0, s.diag[0]);
     });
     for (int kb = 0; kb < GC; ++kb) sweep_steps<0>(masked, kb, buf);
@@ -650,19 +665,13 @@ struct Solver {
           for (int b = 0; b < TC; ++b) pc[b] = pr[TC * t.tj + b];
 #pragma unroll
           for (int b = 0; b < TC; ++b) t.Mx[AN * TC + b] -= g[AN] * pc[b];
-          if (t.tj == 0) {
+          if (t.tj == 0) {   // the true diagonal lives in registers of this thread (no LDS round trip on the critical path)
 #pragma unroll
-            for (int a = 0; a < TR; ++a) {
-              const int row = TR * t.ti + a;
-              const double dn = (a == A && t.ti == tik) ? -pinv : s.diag[row] - f[a] * g[a];
-              s.diag[row] = dn;
-              if (a == AN) dnext = dn;
-            }
+            for (int a = 0; a < TR; ++a) t.dg[a] = (a == A && t.ti == tik) ? -pinv : t.dg[a] - f[a] * g[a];
             if (t.ti == tik && !(p > 0)) s.bad = 1;   // not positive definite
           }
-        } else if (t.tj == 0 && t.ti == tikn) {
-          dnext = s.diag[kn];
         }
+        if (t.tj == 0) dnext = t.dg[AN];
         if (pub && t.ti == tikn) publish_row<AN, BN>(t, buf ^ 1, kn, tjkn, dnext);
         MPC_SCHED_FENCE();
         if (active) {
