@@ -103,45 +103,50 @@ struct RobotModel {       // constructor arguments of ConvexMpc (mpc_osqp.cc:508
   double mass, inv_mass, inv_inertia[9], dt, alpha;
 };
 
+// Every vector in LDS starts on a 16-byte boundary so that runs of doubles can move as ds_read_b128 /
+// ds_write_b128 with an immediate address (no per-access address register).
+#define MPC_V alignas(16) double
 template <int H>
 struct Shared {
   using C = Cfg<H>;
   // ---- alive for the whole solve -------------------------------------------------------------
-  double q[C::N];                                       // unscaled q (becomes q_old of the next call)
-  double qs[C::N], ls[C::M], us[C::M], As[C::NF * 15];   // scaled problem
-  double D[C::N], Dinv[C::N], E[C::M], Einv[C::M];
+  MPC_V q[C::N];                                        // unscaled q (becomes q_old of the next call)
+  MPC_V qs[C::N]; MPC_V ls[C::M]; MPC_V us[C::M]; MPC_V As[C::NF * 15];   // scaled problem
+  MPC_V D[C::N]; MPC_V Dinv[C::N]; MPC_V E[C::M]; MPC_V Einv[C::M];
   double c, cinv, rho, ctmp;
-  double rho_vec[C::M], rho_inv[C::M];
+  MPC_V rho_vec[C::M]; MPC_V rho_inv[C::M];
   int ctype[C::M];
-  double x[C::N], xt[C::N], Px[C::N];                    // Px = P_s x, carried through the ADMM iterations
-  double zz[1][C::M], yy[1][C::M], rr[1][C::N];          // z, y, rhs
-  double tm[C::M], rzt[C::M];                            // R z - y and R z~ of the current iteration
-  double part[C::PARTLEN];                              // per (row, column-tile) partial sums / maxima
-  double prow[2][C::N];                                 // sweep pivot row (double buffered)
-  double diag[C::N];                                    // diagonal of the matrix being swept
-  double piv[2][2];                                     // current pivot and its reciprocal (double buffered)
+  MPC_V x[C::N]; MPC_V xt[C::N]; MPC_V Px[C::N];        // Px = P_s x, carried through the ADMM iterations
+  MPC_V zz[1][C::M]; MPC_V yy[1][C::M]; MPC_V rr[1][C::N];   // z, y, rhs
+  MPC_V tm[C::M]; MPC_V rzt[C::M];                      // R z - y and R z~ of the current iteration
+  MPC_V part[C::PARTLEN];                               // per (row, column-tile) partial sums / maxima
+  MPC_V prow[2][C::N];                                  // sweep pivot row (double buffered)
+  MPC_V diag[C::N];                                     // diagonal of the matrix being swept
+  MPC_V piv[2][2];                                      // current pivot and its reciprocal (double buffered)
   unsigned long long red[16];                           // max-reductions (bit pattern of doubles >= 0)
   int first, iter, status, status_polish, rho_updates, nfact, done, bad;   // control (uniform)
   double pri_res, dua_res, rho_new;
   // ---- phase-local storage: assembly + scaling, then residuals + polish share the same LDS ------
   union {
     struct {
-      double in[C::IN_LEN];
-      double x0[13], xref[13 * H], sdiff[13 * H], xk[13 * H];
-      double a_dt[169], b_dt[156], a_exp[169], b_exp[156], anb[H * 156];
-      double cone[15];
-      double l[C::M], u[C::M];                          // unscaled bounds
-      double dt_[C::N], et_[C::M], cn_[C::N];           // Ruiz pass temporaries
+      MPC_V in[C::IN_LEN];
+      MPC_V x0[13]; MPC_V xref[13 * H]; MPC_V sdiff[13 * H]; MPC_V xk[13 * H];
+      MPC_V a_dt[169]; MPC_V b_dt[156]; MPC_V a_exp[169]; MPC_V b_exp[156]; MPC_V anb[H * 156];
+      MPC_V cone[15];
+      MPC_V l[C::M]; MPC_V u[C::M];                     // unscaled bounds
+      MPC_V dt_[C::N]; MPC_V et_[C::M]; MPC_V cn_[C::N];   // Ruiz pass temporaries
     };
     struct {
-      double Ax[C::M], Aty[C::N], rp[C::M], rd[C::N];
+      MPC_V Ax[C::M]; MPC_V Aty[C::N]; MPC_V rp[C::M]; MPC_V rd[C::N];
       int act[C::M];
-      double Nb[C::NF * 9], Gm[C::NF * 9];              // per foot: null basis rows (3 x 3, zero padded), Gamma
+      MPC_V Nb[C::NF * 9]; MPC_V Gm[C::NF * 9];         // per foot: null basis rows (3 x 3, zero padded), Gamma
       int nnull[C::NF], isnull[C::N];
-      double u0[C::N], Pu[C::N], g[C::N], xN[C::N], PxN[C::N], wv[C::N], rw[C::N], ypol[C::M], zpol[C::M];
+      MPC_V u0[C::N]; MPC_V Pu[C::N]; MPC_V g[C::N]; MPC_V xN[C::N]; MPC_V PxN[C::N]; MPC_V wv[C::N]; MPC_V rw[C::N];
+      MPC_V ypol[C::M]; MPC_V zpol[C::M];
     };
   };
 };
+#undef MPC_V
 
 template <int H>
 struct Thread {
@@ -162,7 +167,8 @@ MPC_HD double limit_scaling(double v) {  // scaling.c:7-14
 }
 MPC_HD double dmax(double a, double b) { return a > b ? a : b; }
 MPC_HD double dmin(double a, double b) { return a < b ? a : b; }
-MPC_HD double clampd(double v, double lo, double hi) { return dmin(dmax(v, lo), hi); }
+// (fmax / fmin are single instructions; they equal the c_max / c_min selects whenever lo and hi are not NaN)
+MPC_HD double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 
 MPC_HD unsigned long long dbits(double v) {
   union { double d; unsigned long long u; } c;
@@ -252,19 +258,23 @@ struct Solver {
   }
   // combine the partial products of (-Minv) v for a swept row: see sweep_all()
   static MPC_HD double inv_combine(const Sh &s, int row, const double *v) { return sum_parts(s, row) + 2.0 * v[row]; }
-  static MPC_HD double max_parts(const Sh &s, int row) {
+  static MPC_HD double max_parts(const Sh &s, int row) {   // entries are norms (>= 0, never NaN: fmax drops NaNs)
     const double *p = s.part + row * GC;
-    double acc = p[0];
+    double v[GC];
 #pragma unroll
-    for (int k = 1; k < GC; ++k) acc = dmax(acc, p[k]);
-    return acc;
+    for (int k = 0; k < GC; ++k) v[k] = p[k];
+#pragma unroll
+    for (int w = 1; w < GC; w *= 2)
+#pragma unroll
+      for (int k = 0; k + w < GC; k += 2 * w) v[k] = fmax(v[k], v[k + w]);
+    return v[0];
   }
   MPC_HD void tile_rowmax(const Th &t) {   // part[row * GC + tj] <- max_b |tile row|
 #pragma unroll
     for (int a = 0; a < TR; ++a) {
       double mx = 0;
 #pragma unroll
-      for (int b = 0; b < TC; ++b) mx = dmax(mx, fabs(t.Mx[a * TC + b]));
+      for (int b = 0; b < TC; ++b) mx = fmax(mx, fabs(t.Mx[a * TC + b]));   // (finite data: same as c_max)
       s.part[(TR * t.ti + a) * GC + t.tj] = mx;
     }
   }
@@ -457,97 +467,134 @@ struct Solver {
   }
 
   // ================================ 2. scaling (scaling.c:44-156) ===============================
-  MPC_HD void apply_cost_scale(Th &t) {   // in-phase: P <- c_temp P, q <- c_temp q, c <- c_temp c
-    const double ct = s.ctmp;
-    if (t.mact) {
+  // One Ruiz pass is three phases.  P itself stays UNSCALED in the tile registers for all passes: a pass only
+  // needs the row norms of c D P D, which are c D_i max_j(|P_ij| D_j) with the cumulative D and c (one multiply
+  // and one max per entry instead of three multiplies); D, c, q, A, E are updated incrementally as in
+  // scaling.c, and c D P D is formed once after the last pass.  The cost scale c_temp of pass k is folded in
+  // lazily at pass k + 1.
+  template <bool MAX>
+  MPC_HD double fold_half(const double *p) const {   // tree-reduce NF / 2 values whose loads are issued as one batch
+    constexpr int L = NF / 2;
+    double v[L];
 #pragma unroll
-      for (int e = 0; e < TE; ++e) t.Mx[e] *= ct;
+    for (int f = 0; f < L; ++f) v[f] = p[f];
+    MPC_SCHED_FENCE();
+#pragma unroll
+    for (int w = 1; w < L; w *= 2)
+#pragma unroll
+      for (int k = 0; k + w < L; k += 2 * w) v[k] = MAX ? fmax(v[k], v[k + w]) : v[k] + v[k + w];
+    MPC_SCHED_FENCE();
+    return v[0];
+  }
+  MPC_HD double pending_cost_scale() const {   // scaling.c:108-139, from the per-foot partials in cn_
+    const double mean = (fold_half<false>(s.cn_) + fold_half<false>(s.cn_ + NF / 2)) / N;
+    const double nq = limit_scaling(fmax(fold_half<true>(s.cn_ + NF), fold_half<true>(s.cn_ + NF + NF / 2)));
+    return 1.0 / limit_scaling(fmax(mean, nq));
+  }
+  static MPC_HD double row_scale3(double a0, double a1, double a2) {   // 1 / sqrt(|row|_inf) of a 3-entry row of A
+    return 1.0 / sqrt(limit_scaling(fmax(fmax(fabs(a0), fabs(a1)), fabs(a2))));
+  }
+  MPC_HD void tile_scaled_rownorms(const Th &t) {   // part[row][tj] <- D_row max_b(|P_row,b| D_b)
+    const double *dr = s.D + TR * t.ti, *dc = s.D + TC * t.tj;
+    double dcv[TC], drv[TR];
+#pragma unroll
+    for (int b = 0; b < TC; ++b) dcv[b] = dc[b];
+#pragma unroll
+    for (int a = 0; a < TR; ++a) drv[a] = dr[a];
+#pragma unroll
+    for (int a = 0; a < TR; ++a) {
+      double mx = 0;
+#pragma unroll
+      for (int b = 0; b < TC; ++b) mx = fmax(mx, fabs(t.Mx[a * TC + b]) * dcv[b]);
+      s.part[(TR * t.ti + a) * GC + t.tj] = mx * drv[a];
     }
-    if (t.tid < N) s.qs[t.tid] *= ct;
-    if (t.tid == 0) s.c *= ct;
   }
   MPC_HD void scale() {
     lap(2);
     ex.par([&](Th &t) {
-      if (t.mact) load_tile(t, Pg);
+      if (t.mact) { load_tile(t, Pg); tile_rowmax(t); }
       if (t.tid < N) {
         s.qs[t.tid] = s.first ? s.q[t.tid] : s.xt[t.tid];   // osqp_update_P_A equilibrates with the PREVIOUS q
         s.D[t.tid] = 1.0;
       }
-      if (t.tid < M) s.E[t.tid] = 1.0;
+      if (t.tid < M) {
+        const double *a = s.cone + 3 * (t.tid % 5);
+        s.E[t.tid] = 1.0;
+        s.et_[t.tid] = row_scale3(a[0], a[1], a[2]);
+      }
       for (int k = t.tid; k < NF * 15; k += T) s.As[k] = s.cone[k % 15];
       if (t.tid == 0) s.c = 1.0;
     });
     lap(3);
     for (int it = 0; it < kScalingIters; ++it) {
-      ex.par([&](Th &t) {   // (cost scale of the previous pass, deferred) ; row (= column) inf-norms of P, row norms of A
-        if (it > 0) apply_cost_scale(t);
-        if (t.mact) tile_rowmax(t);
-        if (t.tid < M) {
-          const double *a = s.As + 3 * t.tid;
-          s.et_[t.tid] = 1.0 / sqrt(limit_scaling(dmax(dmax(fabs(a[0]), fabs(a[1])), fabs(a[2]))));
+      ex.par([&](Th &t) {   // column scales from |column|_inf of [c P ; A]; D <- D_temp D
+        if (t.tid < N) {
+          const int j = t.tid, f = j / 3, c = j - 3 * f;
+          const double ct = it > 0 ? pending_cost_scale() : 1.0;
+          double av[5];
+#pragma unroll
+          for (int r = 0; r < 5; ++r) av[r] = s.As[15 * f + 3 * r + c];
+          double mx = (s.c * ct) * max_parts(s, j);
+#pragma unroll
+          for (int r = 0; r < 5; ++r) mx = fmax(mx, fabs(av[r]));
+          const double d = 1.0 / sqrt(limit_scaling(mx));
+          s.dt_[j] = d;
+          s.D[j] *= d;
+          if (j == 0) s.ctmp = ct;
         }
       });
       MPC_SCALE_LAP(9);
-      ex.par([&](Th &t) {
-        if (t.tid < N) {
-          const int j = t.tid, f = j / 3, c = j - 3 * f;
-          double mx = max_parts(s, j);
-          for (int r = 0; r < 5; ++r) mx = dmax(mx, fabs(s.As[15 * f + 3 * r + c]));
-          s.dt_[j] = 1.0 / sqrt(limit_scaling(mx));
-        }
-      });
-      MPC_SCALE_LAP(10);
-      ex.par([&](Th &t) {   // P <- D P D, A <- E A D, q <- D q; then the new column norms of P
-        if (t.mact) {
-          const double *dr = s.dt_ + TR * t.ti, *dc = s.dt_ + TC * t.tj;
-          double dcv[TC];
-#pragma unroll
-          for (int b = 0; b < TC; ++b) dcv[b] = dc[b];
-#pragma unroll
-          for (int a = 0; a < TR; ++a) {
-            const double da = dr[a];
-#pragma unroll
-            for (int b = 0; b < TC; ++b) t.Mx[a * TC + b] = (t.Mx[a * TC + b] * da) * dcv[b];
-          }
-          tile_rowmax(t);
-        }
+      ex.par([&](Th &t) {   // A <- E A D, q <- D (c_temp q), c <- c_temp c; new row norms of D P D and A
+        const double ct = s.ctmp;
+        if (t.mact) tile_scaled_rownorms(t);
         if (t.tid < M) {
           const int f = t.tid / 5;
           double *a = s.As + 3 * t.tid;
-          const double e = s.et_[t.tid];
-          a[0] = (a[0] * e) * s.dt_[3 * f]; a[1] = (a[1] * e) * s.dt_[3 * f + 1]; a[2] = (a[2] * e) * s.dt_[3 * f + 2];
-          s.E[t.tid] *= e;
+          const double e = s.et_[t.tid], a0 = a[0], a1 = a[1], a2 = a[2];
+          const double d0 = s.dt_[3 * f], d1 = s.dt_[3 * f + 1], d2 = s.dt_[3 * f + 2], eo = s.E[t.tid];
+          const double n0 = (a0 * e) * d0, n1 = (a1 * e) * d1, n2 = (a2 * e) * d2;
+          a[0] = n0; a[1] = n1; a[2] = n2;
+          s.E[t.tid] = eo * e;
+          s.et_[t.tid] = row_scale3(n0, n1, n2);   // row scale of the next pass
         }
-        if (t.tid < N) { s.qs[t.tid] *= s.dt_[t.tid]; s.D[t.tid] *= s.dt_[t.tid]; }
+        if (t.tid < N) s.qs[t.tid] = (s.qs[t.tid] * ct) * s.dt_[t.tid];
+        if (t.tid == T - 1) s.c *= ct;
       });
-      MPC_SCALE_LAP(11);
-      ex.par([&](Th &t) {   // cost scaling (scaling.c:108-139), two-level: per-foot partial sums of the column norms ...
+      MPC_SCALE_LAP(10);
+      ex.par([&](Th &t) {   // cost scaling (scaling.c:108-139): per-foot partial sums of the column norms, |q|_inf
         if (t.tid < NF) {
           const int f = t.tid;
-          s.cn_[f] = (max_parts(s, 3 * f) + max_parts(s, 3 * f + 1)) + max_parts(s, 3 * f + 2);
-          s.cn_[NF + f] = dmax(dmax(fabs(s.qs[3 * f]), fabs(s.qs[3 * f + 1])), fabs(s.qs[3 * f + 2]));
+          const double q0 = s.qs[3 * f], q1 = s.qs[3 * f + 1], q2 = s.qs[3 * f + 2];
+          s.cn_[f] = s.c * ((max_parts(s, 3 * f) + max_parts(s, 3 * f + 1)) + max_parts(s, 3 * f + 2));
+          s.cn_[NF + f] = dmax(dmax(fabs(q0), fabs(q1)), fabs(q2));
         }
       });
-      MPC_SCALE_LAP(12);
-      ex.par([&](Th &t) {   // ... combined by one thread; applied at the start of the next phase that touches the tile
-        if (t.tid == 0) {
-          double mean = 0, nq = 0;
-          for (int f = 0; f < NF; ++f) { mean += s.cn_[f]; nq = dmax(nq, s.cn_[NF + f]); }
-          mean /= N;
-          nq = limit_scaling(nq);
-          s.ctmp = 1.0 / limit_scaling(dmax(mean, nq));
-        }
-      });
-      MPC_SCALE_LAP(13);
+      MPC_SCALE_LAP(11);
     }
-    ex.par([&](Th &t) { apply_cost_scale(t); });
+    ex.par([&](Th &t) {   // the last pass's cost scale; P_s = c D P D
+      const double ct = pending_cost_scale(), cf = s.c * ct;
+      if (t.mact) {
+        const double *dr = s.D + TR * t.ti, *dc = s.D + TC * t.tj;
+        double dcv[TC];
+#pragma unroll
+        for (int b = 0; b < TC; ++b) dcv[b] = dc[b];
+#pragma unroll
+        for (int a = 0; a < TR; ++a) {
+          const double ra = dr[a] * cf;
+#pragma unroll
+          for (int b = 0; b < TC; ++b) t.Mx[a * TC + b] = (t.Mx[a * TC + b] * dcv[b]) * ra;
+        }
+      }
+      if (t.tid < N) s.qs[t.tid] *= ct;
+      if (t.tid == T - 1) s.ctmp = cf;   // (s.c is still being read in this phase)
+    });
     lap(4);
     ex.par([&](Th &t) {
-      if (t.tid == 0) s.cinv = 1.0 / s.c;
+      const double cf = s.ctmp;
+      if (t.tid == 0) { s.c = cf; s.cinv = 1.0 / cf; }
       if (t.tid < N) {
         s.Dinv[t.tid] = 1.0 / s.D[t.tid];
-        if (!s.first) s.qs[t.tid] = (s.D[t.tid] * s.q[t.tid]) * s.c;     // osqp_update_lin_cost (osqp.c:765-770)
+        if (!s.first) s.qs[t.tid] = (s.D[t.tid] * s.q[t.tid]) * cf;      // osqp_update_lin_cost (osqp.c:765-770)
       }
       if (t.tid < M) {
         const int i = t.tid;
