@@ -65,7 +65,7 @@ __global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= 256 ? MPC_MIN_WAVES : 1)) 
                               mdl,
                               in + (size_t)robot * C::IN_LEN,
                               state + (size_t)robot * state_len<H>(),
-                              scratch + (size_t)robot * C::N * C::N,
+                              scratch + (size_t)robot * C::PG_LEN,
                               forces + (size_t)robot * C::N,
                               info + (size_t)robot * kInfoLen,
                               prof ? prof + (size_t)robot * kProfLen : nullptr};
@@ -119,7 +119,7 @@ int mpc_batch_create(mpc_batch **out, int n, int horizon, double timestep, doubl
   mpc_batch *b = new mpc_batch();
   b->n = n;
   b->h = horizon;
-  const size_t N = 12 * (size_t)horizon;
+  const size_t pg_len = horizon == 10 ? Cfg<10>::PG_LEN : Cfg<16>::PG_LEN;   // P_s scratch, lower-triangle tiles
   b->state_len = (int)(64 * horizon + 2);
   std::vector<RobotModel> models(n);
   for (int i = 0; i < n; ++i) models[i] = make_model(mass[i], inertia9 + 9 * (size_t)i, timestep, alpha);
@@ -127,7 +127,7 @@ int mpc_batch_create(mpc_batch **out, int n, int horizon, double timestep, doubl
   hipError_t e;
   if ((e = hipMalloc(&b->d_models, sizeof(RobotModel) * n)) != hipSuccess ||
       (e = hipMalloc(&b->d_state, sizeof(double) * (size_t)n * b->state_len)) != hipSuccess ||
-      (e = hipMalloc(&b->d_scratch, sizeof(double) * (size_t)n * N * N)) != hipSuccess ||
+      (e = hipMalloc(&b->d_scratch, sizeof(double) * (size_t)n * pg_len)) != hipSuccess ||
       (e = hipMalloc(&b->d_info, sizeof(int) * (size_t)n * kInfoLen)) != hipSuccess ||
       (e = hipMalloc(&b->d_prof, sizeof(long long) * (size_t)n * kProfLen)) != hipSuccess ||
       (e = hipMemcpy(b->d_models, models.data(), sizeof(RobotModel) * n, hipMemcpyHostToDevice)) != hipSuccess ||
@@ -135,7 +135,7 @@ int mpc_batch_create(mpc_batch **out, int n, int horizon, double timestep, doubl
     cleanup();
     return fail(MPC_E_HIP, std::string("mpc_batch_create: ") + hipGetErrorString(e));
   }
-  b->bytes = (long long)(sizeof(RobotModel) * n + sizeof(double) * (size_t)n * (b->state_len + N * N) + sizeof(int) * (size_t)n * kInfoLen);
+  b->bytes = (long long)(sizeof(RobotModel) * n + sizeof(double) * (size_t)n * (b->state_len + pg_len) + sizeof(int) * (size_t)n * kInfoLen);
   *out = b;
   return MPC_OK;
 }

@@ -14,14 +14,18 @@
 //      (scaling.c:44-156), ADMM (auxil.c:164-228), residuals/termination (auxil.c:243-362,684-793),
 //      rho adaptation (auxil.c:13-77), polish (polish.c) -- restated for dense algebra:
 //        KKT solve      -> x~ = Kinv (sigma x - q + A^T(R z - y)),  K = P + sigma I + A^T R A,  z~ = A x~
-//        Kinv           -> explicit inverse by symmetric sweeps, one row slice per thread, in registers
+//        Kinv           -> explicit inverse by symmetric sweeps on register tiles
 //        polish         -> delta-regularised refinement in the null space of the active rows
 //   All arithmetic is fp64: an fp32 ADMM does not reproduce OSQP's iterates (oracle/README).
 //
-// Thread layout: every n x n matrix (n = 12 H) is held as 6 x 12 register tiles (2 feet x 4 feet), one
-// per thread: thread tid < 2H*H owns rows [6 ti, 6 ti + 6), columns [12 tj, 12 tj + 12) with
-// ti = tid / H, tj = tid % H.  A rank-1 update then costs 18 LDS reads per 72 FMAs (a row-slice
-// layout needs one LDS read per FMA and is LDS-bandwidth bound).  Vector phases use tid < n / tid < m.
+// Thread layout: every n x n matrix on the path (P_s, K, -K^{-1}, H, -H^{-1}; n = 12 H) is SYMMETRIC and is
+// held as the lower triangle of a G x G grid (G = 2 H) of 6 x 6 register tiles (2 feet x 2 feet), one tile
+// per thread: thread tid < G (G + 1) / 2 owns tile (ti, tj), tj <= ti, tid = ti (ti + 1) / 2 + tj; a diagonal
+// tile is stored in full.  An off-diagonal tile stands for itself and for its transpose, so
+//   * a symmetric sweep step costs 36 FMAs per thread (half of a full-matrix update) for 12 LDS reads,
+//   * a matrix-vector product uses every tile twice (T v_cols -> rows, T^T v_rows -> cols),
+//   * P_s in HBM is one contiguous 288-byte run per thread (tile-major), half the bytes of the full matrix.
+// Vector phases use tid < n / tid < m.
 #pragma once
 
 #include <math.h>
@@ -69,15 +73,16 @@ constexpr int kStSolved = 1, kStSolvedInaccurate = 2, kStMaxIter = -2, kStNonCvx
 template <int H>
 struct Cfg {
   static constexpr int N = 12 * H, M = 20 * H, NF = 4 * H;
-  static constexpr int TR = 6, TC = 12;                  // register tile (rows x cols), multiples of 3
-  static constexpr int GR = N / TR, GC = N / TC;         // tile grid: 2H x H
-  static constexpr int MT = GR * GC;                     // threads that hold a tile
-  static constexpr int TE = TR * TC;                     // tile elements per thread
+  static constexpr int TS = 6;                           // register tile side (2 feet)
+  static constexpr int G = N / TS;                       // tile grid G x G, lower triangle stored
+  static constexpr int MT = G * (G + 1) / 2;             // threads that hold a tile
+  static constexpr int TE = TS * TS;                     // tile elements per thread
+  static constexpr int PG_LEN = MT * TE;                 // doubles of P_s scratch per robot (tile-major)
   static constexpr int T = (((MT > M ? MT : M) + 63) / 64) * 64;   // workgroup size
   static constexpr int IN_LEN = 56 + 4 * H;
   static constexpr int NTASK = 78 + (H - 1) * 144;       // P assembly tasks (d, a, b)
   static_assert(T <= 1024, "workgroup too large");
-  static constexpr int PARTLEN = (N * GC > 14 * 64) ? N * GC : 14 * 64;   // part[] doubles as the reduction scratch
+  static constexpr int PARTLEN = (N * G > 14 * 64) ? N * G : 14 * 64;   // part[] doubles as the reduction scratch
 };
 
 // Flat input record offsets (include/mpc_batch.h, layout.py)
@@ -118,10 +123,11 @@ struct Shared {
   int ctype[C::M];
   MPC_V x[C::N]; MPC_V xt[C::N]; MPC_V Px[C::N];        // Px = P_s x, carried through the ADMM iterations
   MPC_V zz[1][C::M]; MPC_V yy[1][C::M]; MPC_V rr[1][C::N];   // z, y, rhs
-  MPC_V tm[C::M]; MPC_V rzt[C::M];                      // R z - y and R z~ of the current iteration
-  MPC_V part[C::PARTLEN];                               // per (row, column-tile) partial sums / maxima
+  union {
+    MPC_V part[C::PARTLEN];                             // [slot][row] partial sums / maxima of the tile products
+    struct { MPC_V tm[C::M]; MPC_V rzt[C::M]; };        // R z - y and R z~ of the current ADMM iteration (part is dead then)
+  };
   MPC_V prow[2][C::N];                                  // sweep pivot row (double buffered)
-  MPC_V diag[C::N];                                     // diagonal of the matrix being swept
   MPC_V piv[2][2];                                      // current pivot and its reciprocal (double buffered)
   unsigned long long red[16];                           // max-reductions (bit pattern of doubles >= 0)
   int first, iter, status, status_polish, rho_updates, nfact, done, bad;   // control (uniform)
@@ -151,13 +157,14 @@ struct Shared {
 template <int H>
 struct Thread {
   using C = Cfg<H>;
-  int tid, ti, tj;          // thread id; tile row / tile column
-  bool mact;                // holds a matrix tile (tid < MT)
-  double Mx[C::TE];         // tile of the current n x n matrix (P_s, K, -Kinv, H, -Hinv), row-major 6 x 12
-  double xprev, zprev;      // carried scalars
-  double dg[C::TR];         // sweep: true diagonal of my 6 rows (held by the tj == 0 thread of each tile row)
+  int tid, ti, tj;          // thread id; tile row / tile column (tj <= ti)
+  bool mact, dia;           // holds a matrix tile (tid < MT); the tile sits on the diagonal
+  double Mx[C::TE];         // tile of the current symmetric n x n matrix (P_s, K, -Kinv, H, -Hinv), row-major 6 x 6
   MPC_HD void init(int id) {
-    tid = id; ti = id / C::GC; tj = id - ti * C::GC; mact = id < C::MT; xprev = 0; zprev = 0;
+    tid = id; mact = id < C::MT;
+    int r = 0;
+    while ((r + 1) * (r + 2) / 2 <= id) ++r;
+    ti = r; tj = id - r * (r + 1) / 2; dia = ti == tj;
   }
 };
 
@@ -190,7 +197,7 @@ struct Solver {
   using C = Cfg<H>;
   using Th = Thread<H>;
   using Sh = Shared<H>;
-  static constexpr int N = C::N, M = C::M, NF = C::NF, T = C::T, TR = C::TR, TC = C::TC, GC = C::GC, TE = C::TE;
+  static constexpr int N = C::N, M = C::M, NF = C::NF, T = C::T, TS = C::TS, G = C::G, TE = C::TE;
 
   Exec &ex;
   Sh &s;
@@ -227,72 +234,81 @@ struct Solver {
     for (int r = 0; r < 5; ++r) t += a[3 * r] * v[5 * f + r];
     return t;
   }
-  // part[row * GC + tj] <- -(tile row) . v[my columns]   (partial products of (-Mx) v)
+  // Partial results of the tile products live in part[slot * N + row]: row i of tile row I gets slot J from the
+  // tile (I, J) itself (J <= I) and slot J > I from the transpose of tile (J, I) -- G slots per row, each written
+  // by exactly one thread, six consecutive doubles per thread and slot.
+  // part <- partial products of (-Mx) v, both orientations of the tile
   MPC_HD void tile_matvec_neg(const Th &t, const double *v) {
-    const double *vv = v + TC * t.tj;
-    double vr[TC];
+    double vc[TS], vr[TS], ar[TS], ac[TS];
 #pragma unroll
-    for (int b = 0; b < TC; ++b) vr[b] = vv[b];
-    double acc[TR];
+    for (int b = 0; b < TS; ++b) { vc[b] = v[TS * t.tj + b]; vr[b] = v[TS * t.ti + b]; ar[b] = 0; ac[b] = 0; }
 #pragma unroll
-    for (int a = 0; a < TR; ++a) acc[a] = 0;
+    for (int a = 0; a < TS; ++a)
 #pragma unroll
-    for (int b = 0; b < TC; ++b) {   // six independent accumulation chains (fp64 FMA latency)
+      for (int b = 0; b < TS; ++b) {   // twelve independent accumulation chains
+        const double m = t.Mx[a * TS + b];
+        ar[a] += m * vc[b];
+        ac[b] += m * vr[a];
+      }
+    double *pd = s.part + t.tj * N + TS * t.ti, *pt = s.part + t.ti * N + TS * t.tj;
 #pragma unroll
-      for (int a = 0; a < TR; ++a) acc[a] += t.Mx[a * TC + b] * vr[b];
-      if (b % 4 == 3) MPC_SCHED_FENCE();
+    for (int a = 0; a < TS; ++a) pd[a] = -ar[a];
+    if (!t.dia) {
+#pragma unroll
+      for (int b = 0; b < TS; ++b) pt[b] = -ac[b];
     }
-#pragma unroll
-    for (int a = 0; a < TR; ++a) s.part[(TR * t.ti + a) * GC + t.tj] = -acc[a];
   }
-  static MPC_HD double sum_parts(const Sh &s, int row) {   // fixed pairwise order (short dependency chains)
-    const double *p = s.part + row * GC;
-    double v[GC];
+  template <bool MAX>
+  static MPC_HD double fold_parts(const Sh &s, int row) {   // fixed pairwise order (short dependency chains)
+    double v[G];
 #pragma unroll
-    for (int k = 0; k < GC; ++k) v[k] = p[k];
+    for (int k = 0; k < G; ++k) v[k] = s.part[k * N + row];
 #pragma unroll
-    for (int w = 1; w < GC; w *= 2)
+    for (int w = 1; w < G; w *= 2)
 #pragma unroll
-      for (int k = 0; k + w < GC; k += 2 * w) v[k] += v[k + w];
+      for (int k = 0; k + w < G; k += 2 * w) v[k] = MAX ? fmax(v[k], v[k + w]) : v[k] + v[k + w];
     return v[0];
   }
+  static MPC_HD double sum_parts(const Sh &s, int row) { return fold_parts<false>(s, row); }
   // combine the partial products of (-Minv) v for a swept row: see sweep_all()
   static MPC_HD double inv_combine(const Sh &s, int row, const double *v) { return sum_parts(s, row) + 2.0 * v[row]; }
-  static MPC_HD double max_parts(const Sh &s, int row) {   // entries are norms (>= 0, never NaN: fmax drops NaNs)
-    const double *p = s.part + row * GC;
-    double v[GC];
+  // (entries are norms: >= 0, never NaN since fmax drops NaNs)
+  static MPC_HD double max_parts(const Sh &s, int row) { return fold_parts<true>(s, row); }
+  // part <- D_i max_j (|m_ij| D_j) over the tile, for its rows and (transposed) for its columns; D = 1 if null
+  MPC_HD void tile_rownorms(const Th &t, const double *D) {
+    double dc[TS], dr[TS], mr[TS], mc[TS];
 #pragma unroll
-    for (int k = 0; k < GC; ++k) v[k] = p[k];
+    for (int b = 0; b < TS; ++b) { dc[b] = D ? D[TS * t.tj + b] : 1.0; dr[b] = D ? D[TS * t.ti + b] : 1.0; mr[b] = 0; mc[b] = 0; }
 #pragma unroll
-    for (int w = 1; w < GC; w *= 2)
+    for (int a = 0; a < TS; ++a)
 #pragma unroll
-      for (int k = 0; k + w < GC; k += 2 * w) v[k] = fmax(v[k], v[k + w]);
-    return v[0];
-  }
-  MPC_HD void tile_rowmax(const Th &t) {   // part[row * GC + tj] <- max_b |tile row|
+      for (int b = 0; b < TS; ++b) {
+        const double m = fabs(t.Mx[a * TS + b]);
+        mr[a] = fmax(mr[a], m * dc[b]);
+        mc[b] = fmax(mc[b], m * dr[a]);
+      }
+    double *pd = s.part + t.tj * N + TS * t.ti, *pt = s.part + t.ti * N + TS * t.tj;
 #pragma unroll
-    for (int a = 0; a < TR; ++a) {
-      double mx = 0;
+    for (int a = 0; a < TS; ++a) pd[a] = mr[a] * dr[a];
+    if (!t.dia) {
 #pragma unroll
-      for (int b = 0; b < TC; ++b) mx = fmax(mx, fabs(t.Mx[a * TC + b]));   // (finite data: same as c_max)
-      s.part[(TR * t.ti + a) * GC + t.tj] = mx;
+      for (int b = 0; b < TS; ++b) pt[b] = mc[b] * dc[b];
     }
   }
-  MPC_HD void load_tile(Th &t, const double *G) {   // Mx <- G[my rows][my columns]
+  // P_s in HBM is tile-major: thread tid's tile is the 36 doubles at G[36 tid]
+  MPC_HD void load_tile(Th &t, const double *Gm) {
+    const double *g = Gm + (size_t)t.tid * TE;
 #pragma unroll
-    for (int a = 0; a < TR; ++a) {
-      const double *g = G + (size_t)(TR * t.ti + a) * N + TC * t.tj;
-#pragma unroll
-      for (int b = 0; b < TC; ++b) t.Mx[a * TC + b] = g[b];
-    }
+    for (int e = 0; e < TE; ++e) t.Mx[e] = g[e];
   }
-  MPC_HD void store_tile(const Th &t, double *G) {
+  MPC_HD void store_tile(const Th &t, double *Gm) {
+    double *g = Gm + (size_t)t.tid * TE;
 #pragma unroll
-    for (int a = 0; a < TR; ++a) {
-      double *g = G + (size_t)(TR * t.ti + a) * N + TC * t.tj;
-#pragma unroll
-      for (int b = 0; b < TC; ++b) g[b] = t.Mx[a * TC + b];
-    }
+    for (int e = 0; e < TE; ++e) g[e] = t.Mx[e];
+  }
+  static MPC_HD size_t pg_index(int r, int c) {   // offset of entry (r, c) in the tile-major store; needs r / 6 >= c / 6
+    const int I = r / TS, J = c / TS;
+    return (size_t)(I * (I + 1) / 2 + J) * TE + (r - TS * I) * TS + (c - TS * J);
   }
 
   // ================================ 1. assembly =================================================
@@ -420,7 +436,7 @@ struct Solver {
       for (int k = t.tid; k < 13 * H; k += T) s.sdiff[k] = (k < 13 * (H - 1) ? s.xk[k] : 0.0) - s.xref[k];
     });
     lap(1);
-    // q (:683) and P (:387-434) -> Pg (unscaled, full symmetric)
+    // q (:683) and P (:387-434) -> Pg (unscaled, lower-triangle tiles)
     ex.par([&](Th &t) {
       if (t.tid < N) {
         const int j = t.tid / 12, c = t.tid - 12 * j;
@@ -454,8 +470,8 @@ struct Solver {
           const int ri = 12 * I + a, cj = 12 * J + b;
           double v = 2.0 * acc;
           if (ri == cj) v += mdl.alpha;
-          Pg[(size_t)ri * N + cj] = v;
-          if (ri != cj) Pg[(size_t)cj * N + ri] = v;
+          Pg[pg_index(cj, ri)] = v;                                   // ri <= cj: (cj, ri) is in the lower triangle
+          if (ri != cj && ri / TS == cj / TS) Pg[pg_index(ri, cj)] = v;   // diagonal tiles are stored in full
         }
       }
     });
@@ -468,8 +484,7 @@ struct Solver {
 
   // ================================ 2. scaling (scaling.c:44-156) ===============================
   // One Ruiz pass is three phases.  P itself stays UNSCALED in the tile registers for all passes: a pass only
-  // needs the row norms of c D P D, which are c D_i max_j(|P_ij| D_j) with the cumulative D and c (one multiply
-  // and one max per entry instead of three multiplies); D, c, q, A, E are updated incrementally as in
+  // needs the row norms of c D P D, which are c D_i max_j(|P_ij| D_j) with the cumulative D and c (tile_rownorms); D, c, q, A, E are updated incrementally as in
   // scaling.c, and c D P D is formed once after the last pass.  The cost scale c_temp of pass k is folded in
   // lazily at pass k + 1.
   template <bool MAX>
@@ -494,25 +509,10 @@ struct Solver {
   static MPC_HD double row_scale3(double a0, double a1, double a2) {   // 1 / sqrt(|row|_inf) of a 3-entry row of A
     return 1.0 / sqrt(limit_scaling(fmax(fmax(fabs(a0), fabs(a1)), fabs(a2))));
   }
-  MPC_HD void tile_scaled_rownorms(const Th &t) {   // part[row][tj] <- D_row max_b(|P_row,b| D_b)
-    const double *dr = s.D + TR * t.ti, *dc = s.D + TC * t.tj;
-    double dcv[TC], drv[TR];
-#pragma unroll
-    for (int b = 0; b < TC; ++b) dcv[b] = dc[b];
-#pragma unroll
-    for (int a = 0; a < TR; ++a) drv[a] = dr[a];
-#pragma unroll
-    for (int a = 0; a < TR; ++a) {
-      double mx = 0;
-#pragma unroll
-      for (int b = 0; b < TC; ++b) mx = fmax(mx, fabs(t.Mx[a * TC + b]) * dcv[b]);
-      s.part[(TR * t.ti + a) * GC + t.tj] = mx * drv[a];
-    }
-  }
   MPC_HD void scale() {
     lap(2);
     ex.par([&](Th &t) {
-      if (t.mact) { load_tile(t, Pg); tile_rowmax(t); }
+      if (t.mact) { load_tile(t, Pg); tile_rownorms(t, nullptr); }
       if (t.tid < N) {
         s.qs[t.tid] = s.first ? s.q[t.tid] : s.xt[t.tid];   // osqp_update_P_A equilibrates with the PREVIOUS q
         s.D[t.tid] = 1.0;
@@ -546,7 +546,7 @@ struct Solver {
       MPC_SCALE_LAP(9);
       ex.par([&](Th &t) {   // A <- E A D, q <- D (c_temp q), c <- c_temp c; new row norms of D P D and A
         const double ct = s.ctmp;
-        if (t.mact) tile_scaled_rownorms(t);
+        if (t.mact) tile_rownorms(t, s.D);
         if (t.tid < M) {
           const int f = t.tid / 5;
           double *a = s.As + 3 * t.tid;
@@ -574,16 +574,13 @@ struct Solver {
     ex.par([&](Th &t) {   // the last pass's cost scale; P_s = c D P D
       const double ct = pending_cost_scale(), cf = s.c * ct;
       if (t.mact) {
-        const double *dr = s.D + TR * t.ti, *dc = s.D + TC * t.tj;
-        double dcv[TC];
+        double dc[TS], ra[TS];
 #pragma unroll
-        for (int b = 0; b < TC; ++b) dcv[b] = dc[b];
+        for (int b = 0; b < TS; ++b) { dc[b] = s.D[TS * t.tj + b]; ra[b] = s.D[TS * t.ti + b] * cf; }
 #pragma unroll
-        for (int a = 0; a < TR; ++a) {
-          const double ra = dr[a] * cf;
+        for (int a = 0; a < TS; ++a)
 #pragma unroll
-          for (int b = 0; b < TC; ++b) t.Mx[a * TC + b] = (t.Mx[a * TC + b] * dcv[b]) * ra;
-        }
+          for (int b = 0; b < TS; ++b) t.Mx[a * TS + b] = (t.Mx[a * TS + b] * dc[b]) * ra[a];
       }
       if (t.tid < N) s.qs[t.tid] *= ct;
       if (t.tid == T - 1) s.ctmp = cf;   // (s.c is still being read in this phase)
@@ -622,31 +619,27 @@ struct Solver {
   }
 
   // ================================ 3. K = P_s + sigma I + A^T R A ; Mx <- -K^{-1} ==============
-  // A^T R A is block diagonal (3 x 3 per foot); a tile holds 2 row feet x 4 column feet.
+  // A^T R A is block diagonal (3 x 3 per foot): only the diagonal tiles (feet 2 ti, 2 ti + 1) change.
   MPC_HD void factor(bool reload) {
     ex.par([&](Th &t) {
       if (t.mact) {
         if (reload) load_tile(t, Pg);
+        if (t.dia) {
 #pragma unroll
-        for (int fr = 0; fr < 2; ++fr)
-#pragma unroll
-          for (int fc = 0; fc < 4; ++fc) {
+          for (int fr = 0; fr < 2; ++fr) {
             const int f = 2 * t.ti + fr;
-            if (f == 4 * t.tj + fc) {      // this 3x3 sub-block sits on the block diagonal
-              const double *a = s.As + 15 * f, *rv = s.rho_vec + 5 * f;
+            const double *a = s.As + 15 * f, *rv = s.rho_vec + 5 * f;
 #pragma unroll
-              for (int c1 = 0; c1 < 3; ++c1)
+            for (int c1 = 0; c1 < 3; ++c1)
 #pragma unroll
-                for (int c2 = 0; c2 < 3; ++c2) {
-                  double g = 0;
-                  for (int r = 0; r < 5; ++r) g += a[3 * r + c1] * rv[r] * a[3 * r + c2];
-                  if (c1 == c2) g += kSigma;
-                  t.Mx[(3 * fr + c1) * TC + 3 * fc + c2] += g;
-                }
-#pragma unroll
-              for (int c1 = 0; c1 < 3; ++c1) s.diag[3 * f + c1] = t.Mx[(3 * fr + c1) * TC + 3 * fc + c1];
-            }
+              for (int c2 = 0; c2 < 3; ++c2) {
+                double g = 0;
+                for (int r = 0; r < 5; ++r) g += a[3 * r + c1] * rv[r] * a[3 * r + c2];
+                if (c1 == c2) g += kSigma;
+                t.Mx[(3 * fr + c1) * TS + 3 * fr + c2] += g;
+              }
           }
+        }
       }
     });
     lap(6);
@@ -657,93 +650,87 @@ struct Solver {
 
   // Symmetric sweep of every pivot (masked: the update is skipped for pivots with !isnull[k]).  After
   // all pivots the matrix equals -inverse.  Per step k:  p = a_kk;  a_ij -= a_ik a_kj / p (i,j != k);
-  // a_ik -> a_ik / p;  a_kk -> -1/p.  The matrix stays symmetric, so a_ik is read from the published
-  // pivot row.  That row carries (p - 1) in slot k, which makes the generic update
+  // a_ik -> a_ik / p;  a_kk -> -1/p.  The matrix stays symmetric, so both a_ik and a_kj are read from the
+  // published pivot row, and only the lower-triangle tiles are updated.  That row carries (p - 1) in
+  // slot k, which makes the generic update
   //   a_ij -= (row_k[i] / p) * row_k[j]
-  // produce a_ik / p on column k and a_kj / p on row k with no per-element select.  The true diagonal
-  // lives in LDS (s.diag); the register copy of a diagonal element takes the generic update and ends
-  // up as (true value + 2) on every swept row -- the matrix-vector products add 2 v[row] back.
-  // The pivot loop is unrolled by TC = 12 so that the pivot row's position inside its tile is static.
+  // produce a_ik / p on column k and a_kj / p on row k with no per-element select; the diagonal element
+  // of a swept row takes the generic update too and ends up as (true value + 2) -- the matrix-vector
+  // products add 2 v[row] back (inv_combine).  Un-swept diagonal elements are exact, so the pivot is
+  // read straight from the diagonal tile.
+  // The pivot loop is unrolled by TS = 6 so that the pivot's position inside its tile is static.
   MPC_HD void sweep_all(bool masked) {
     int buf = 0;
-    ex.par([&](Th &t) {   // the tj == 0 threads take the diagonal of their rows into registers; publish pivot row 0
-      if (t.mact && t.tj == 0) {
-#pragma unroll
-        for (int a = 0; a < TR; ++a) t.dg[a] = s.diag[TR * t.ti + a];
-      }
-      if (t.mact && t.ti == 0) publish_row<0, 0>(t, 0, 0, 0, s.diag[0]);
-    });
-    for (int kb = 0; kb < GC; ++kb) sweep_steps<0>(masked, kb, buf);
+    ex.par([&](Th &t) { if (t.mact) publish<0>(t, 0, 0); });
+    for (int kt = 0; kt < G; ++kt) sweep_steps<0>(masked, kt, buf);
   }
-  template <int KK>
-  MPC_HD void sweep_steps(bool masked, int kb, int &buf) {
-    if constexpr (KK < TC) {
-      sweep_step<KK>(masked, kb, buf);
+  template <int A>
+  MPC_HD void sweep_steps(bool masked, int kt, int &buf) {
+    if constexpr (A < TS) {
+      sweep_step<A>(masked, kt, buf);
       buf ^= 1;
-      sweep_steps<KK + 1>(masked, kb, buf);
+      sweep_steps<A + 1>(masked, kt, buf);
     }
   }
-  // Pivot step k = 12 kb + KK.  Order inside the phase: the tile row that holds pivot row k+1 is
-  // updated first, then the LDS diagonal, then row k+1 is published -- so that the LDS stores and the
-  // reciprocal are in flight while the other five tile rows take their update.
-  template <int KK>
-  MPC_HD void sweep_step(bool masked, int kb, int buf) {
-    constexpr int A = KK % TR;                       // pivot row's position inside its tile
-    constexpr int KN = KK + 1;                       // next pivot, relative to 12 kb
-    constexpr int AN = KN % TR, BN = KN % TC;
-    const int k = TC * kb + KK;
-    const int tik = 2 * kb + KK / TR;
-    const int kn = k + 1;
-    const int tikn = (KN < TC) ? 2 * kb + KN / TR : 2 * (kb + 1);
-    const int tjkn = (KN < TC) ? kb : kb + 1;
+  // Pivot step k = 6 kt + A.  Order inside the phase: first the cross through the next pivot (row AN and
+  // column AN of every tile, 11 FMAs), then the tiles of tile row / tile column of the next pivot publish
+  // row k + 1 -- so that the LDS stores and the reciprocal are in flight while the other 25 entries take
+  // their update.
+  template <int A>
+  MPC_HD void sweep_step(bool masked, int kt, int buf) {
+    constexpr int AN = (A + 1) % TS;                 // next pivot's position inside its tile
+    const int k = TS * kt + A, kn = k + 1;
+    const int ktn = (A + 1 < TS) ? kt : kt + 1;      // tile row (= column) of the next pivot
     const bool active = !masked || s.isnull[k];      // uniform
     const bool pub = kn < N && (!masked || s.isnull[kn]);   // the next pivot row is only needed if that pivot is used
     if (!active && !pub) return;
     ex.par([&](Th &t) {
       if (t.mact) {
-        double g[TR], pc[TC], dnext = 0;
+        double g[TS], pc[TS];
         if (active) {
           const double p = s.piv[buf][0], pinv = s.piv[buf][1];
           const double *pr = s.prow[buf];
-          double f[TR];
 #pragma unroll
-          for (int a = 0; a < TR; ++a) { f[a] = pr[TR * t.ti + a]; g[a] = f[a] * pinv; }
+          for (int a = 0; a < TS; ++a) { g[a] = pr[TS * t.ti + a] * pinv; pc[a] = pr[TS * t.tj + a]; }
 #pragma unroll
-          for (int b = 0; b < TC; ++b) pc[b] = pr[TC * t.tj + b];
+          for (int b = 0; b < TS; ++b) t.Mx[AN * TS + b] -= g[AN] * pc[b];
 #pragma unroll
-          for (int b = 0; b < TC; ++b) t.Mx[AN * TC + b] -= g[AN] * pc[b];
-          if (t.tj == 0) {   // the true diagonal lives in registers of this thread (no LDS round trip on the critical path)
-#pragma unroll
-            for (int a = 0; a < TR; ++a) t.dg[a] = (a == A && t.ti == tik) ? -pinv : t.dg[a] - f[a] * g[a];
-            if (t.ti == tik && !(p > 0)) s.bad = 1;   // not positive definite
-          }
+          for (int a = 0; a < TS; ++a)
+            if (a != AN) t.Mx[a * TS + AN] -= g[a] * pc[AN];
+          if (t.tid == 0 && !(p > 0)) s.bad = 1;     // not positive definite
         }
-        if (t.tj == 0) dnext = t.dg[AN];
-        if (pub && t.ti == tikn) publish_row<AN, BN>(t, buf ^ 1, kn, tjkn, dnext);
+        if (pub) publish<AN>(t, buf ^ 1, ktn);
         MPC_SCHED_FENCE();
         if (active) {
 #pragma unroll
-          for (int a = 0; a < TR; ++a) {
-            if (a == AN) continue;
+          for (int a = 0; a < TS; ++a)
 #pragma unroll
-            for (int b = 0; b < TC; ++b) t.Mx[a * TC + b] -= g[a] * pc[b];
-          }
+            for (int b = 0; b < TS; ++b)
+              if (a != AN && b != AN) t.Mx[a * TS + b] -= g[a] * pc[b];
         }
       }
     });
   }
-  // The threads of tile row (k / 6) copy row k of their tiles to prow[b]; slot k itself gets
-  // (pivot - 1) and piv[b] = {pivot, 1/pivot}, written by the tj == 0 thread (owner of the LDS diagonal).
-  template <int A, int B>
-  MPC_HD void publish_row(Th &t, int b, int k, int tjk, double pivot) {
-    double *pn = s.prow[b] + TC * t.tj;
+  // Row k = 6 kt + A of the matrix -> prow[b]: the tiles of tile row kt hold its part left of (and on) the
+  // diagonal as their row A, the tiles of tile column kt hold the rest as their column A.  Slot k itself
+  // gets (pivot - 1), and piv[b] = {pivot, 1 / pivot}.
+  template <int A>
+  MPC_HD void publish(const Th &t, int b, int kt) {
+    if (t.ti == kt) {
+      double *pn = s.prow[b] + TS * t.tj;
 #pragma unroll
-    for (int bb = 0; bb < TC; ++bb)
-      if (!(bb == B && t.tj == tjk)) pn[bb] = t.Mx[A * TC + bb];
-    if (t.tj == 0) {
-      s.prow[b][k] = pivot - 1.0;
-      s.piv[b][0] = pivot;
-      s.piv[b][1] = fast_recip(pivot);
+      for (int bb = 0; bb < TS; ++bb)
+        if (bb != A) pn[bb] = t.Mx[A * TS + bb];
+      const double pivot = t.Mx[A * TS + A];
+      pn[A] = t.dia ? pivot - 1.0 : pivot;
+      if (t.dia) {
+        s.piv[b][0] = pivot;
+        s.piv[b][1] = fast_recip(pivot);
+      }
+    } else if (t.tj == kt) {
+      double *pn = s.prow[b] + TS * t.ti;
+#pragma unroll
+      for (int a = 0; a < TS; ++a) pn[a] = t.Mx[a * TS + A];
     }
   }
   static MPC_HD double fast_recip(double d) {
@@ -832,21 +819,28 @@ struct Solver {
 #endif
   }
 
-  // P_s v -> out (P_s tiles read from HBM scratch).  Two phases.
+  // P_s v -> out (P_s tiles read from HBM scratch, each used in both orientations).  Two phases.
   MPC_HD void mul_P(const double *v, double *out) {
     ex.par([&](Th &t) {
       if (t.mact) {
-        const double *vv = v + TC * t.tj;
-        double vr[TC];
+        const double *g = Pg + (size_t)t.tid * TE;
+        double vc[TS], vr[TS], ar[TS], ac[TS];
 #pragma unroll
-        for (int b = 0; b < TC; ++b) vr[b] = vv[b];
+        for (int b = 0; b < TS; ++b) { vc[b] = v[TS * t.tj + b]; vr[b] = v[TS * t.ti + b]; ar[b] = 0; ac[b] = 0; }
 #pragma unroll
-        for (int a = 0; a < TR; ++a) {
-          const double *g = Pg + (size_t)(TR * t.ti + a) * N + TC * t.tj;
-          double acc = 0;
+        for (int a = 0; a < TS; ++a)
 #pragma unroll
-          for (int b = 0; b < TC; ++b) acc += g[b] * vr[b];
-          s.part[(TR * t.ti + a) * GC + t.tj] = acc;
+          for (int b = 0; b < TS; ++b) {
+            const double m = g[a * TS + b];
+            ar[a] += m * vc[b];
+            ac[b] += m * vr[a];
+          }
+        double *pd = s.part + t.tj * N + TS * t.ti, *pt = s.part + t.ti * N + TS * t.tj;
+#pragma unroll
+        for (int a = 0; a < TS; ++a) pd[a] = ar[a];
+        if (!t.dia) {
+#pragma unroll
+          for (int b = 0; b < TS; ++b) pt[b] = ac[b];
         }
       }
     });
@@ -1016,7 +1010,7 @@ struct Solver {
     mul_P(s.u0, s.Pu);
     lap(11);
     // H = N~^T P N~ + delta I on the null coordinates, identity elsewhere; N~ = blockdiag([N_f | 0]).
-    // Tile-local: 2 row feet x 4 column feet of 3 x 3 blocks, all register indices static.
+    // Tile-local: 2 row feet x 2 column feet of 3 x 3 blocks, all register indices static.
     ex.par([&](Th &t) {
       if (t.tid < N) s.g[t.tid] = -s.qs[t.tid] - s.Pu[t.tid];
       if (t.mact) {
@@ -1024,8 +1018,8 @@ struct Solver {
 #pragma unroll
         for (int fr = 0; fr < 2; ++fr)
 #pragma unroll
-          for (int fc = 0; fc < 4; ++fc) {
-            const int rf = 2 * t.ti + fr, cf = 4 * t.tj + fc;
+          for (int fc = 0; fc < 2; ++fc) {
+            const int rf = 2 * t.ti + fr, cf = 2 * t.tj + fc;
             const double *nr = s.Nb + 9 * rf, *nc = s.Nb + 9 * cf;   // row k = null vector k (zero rows beyond nnull)
             const int nnr = s.nnull[rf], nnc = s.nnull[cf];
             double T1[9];
@@ -1033,18 +1027,15 @@ struct Solver {
             for (int r = 0; r < 3; ++r)
 #pragma unroll
               for (int k2 = 0; k2 < 3; ++k2)
-                T1[3 * r + k2] = t.Mx[(3 * fr + r) * TC + 3 * fc] * nc[3 * k2] + t.Mx[(3 * fr + r) * TC + 3 * fc + 1] * nc[3 * k2 + 1] +
-                                 t.Mx[(3 * fr + r) * TC + 3 * fc + 2] * nc[3 * k2 + 2];
+                T1[3 * r + k2] = t.Mx[(3 * fr + r) * TS + 3 * fc] * nc[3 * k2] + t.Mx[(3 * fr + r) * TS + 3 * fc + 1] * nc[3 * k2 + 1] +
+                                 t.Mx[(3 * fr + r) * TS + 3 * fc + 2] * nc[3 * k2 + 2];
 #pragma unroll
             for (int k1 = 0; k1 < 3; ++k1)
 #pragma unroll
               for (int k2 = 0; k2 < 3; ++k2) {
                 double v = (k1 < nnr && k2 < nnc) ? nr[3 * k1] * T1[k2] + nr[3 * k1 + 1] * T1[3 + k2] + nr[3 * k1 + 2] * T1[6 + k2] : 0.0;
-                if (k1 == k2 && rf == cf) {
-                  v = (k1 < nnr) ? v + kDelta : 1.0;
-                  s.diag[3 * rf + k1] = v;
-                }
-                t.Mx[(3 * fr + k1) * TC + 3 * fc + k2] = v;
+                if (k1 == k2 && rf == cf) v = (k1 < nnr) ? v + kDelta : 1.0;
+                t.Mx[(3 * fr + k1) * TS + 3 * fc + k2] = v;
               }
           }
       }
