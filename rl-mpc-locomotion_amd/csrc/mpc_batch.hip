@@ -19,6 +19,9 @@ using namespace mpc;
 #ifndef MPC_MIN_WAVES
 #define MPC_MIN_WAVES 2
 #endif
+#ifndef MPC_MIN_WAVES_MAX_T
+#define MPC_MIN_WAVES_MAX_T 256   // larger workgroups (h = 16) run one per CU
+#endif
 
 namespace {
 
@@ -42,7 +45,7 @@ struct DeviceExec {
 };
 
 template <int H>
-__global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= 256 ? MPC_MIN_WAVES : 1)) void mpc_solve_kernel(int n, const RobotModel *__restrict__ models,
+__global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= MPC_MIN_WAVES_MAX_T ? MPC_MIN_WAVES : 1)) void mpc_solve_kernel(int n, const RobotModel *__restrict__ models,
                                                                const float *__restrict__ in, double *__restrict__ state,
                                                                double *__restrict__ scratch, double *__restrict__ forces,
                                                                int *__restrict__ info, long long *__restrict__ prof,

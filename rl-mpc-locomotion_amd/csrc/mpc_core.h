@@ -78,7 +78,11 @@ struct Cfg {
   static constexpr int MT = G * (G + 1) / 2;             // threads that hold a tile
   static constexpr int TE = TS * TS;                     // tile elements per thread
   static constexpr int PG_LEN = MT * TE;                 // doubles of P_s scratch per robot (tile-major)
+#ifdef MPC_FORCE_T
+  static constexpr int T = MPC_FORCE_T;                  // (register-budget experiments)
+#else
   static constexpr int T = (((MT > M ? MT : M) + 63) / 64) * 64;   // workgroup size
+#endif
   static constexpr int IN_LEN = 56 + 4 * H;
   static constexpr int NTASK = 78 + (H - 1) * 144;       // P assembly tasks (d, a, b)
   static_assert(T <= 1024, "workgroup too large");
@@ -151,6 +155,9 @@ struct Shared {
       MPC_V ypol[C::M]; MPC_V zpol[C::M];
     };
   };
+#ifdef MPC_LDS_PAD
+  char pad[MPC_LDS_PAD];                                // occupancy experiments only
+#endif
 };
 #undef MPC_V
 
