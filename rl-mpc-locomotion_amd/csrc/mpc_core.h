@@ -86,7 +86,8 @@ struct Cfg {
   static constexpr int IN_LEN = 56 + 4 * H;
   static constexpr int NTASK = 78 + (H - 1) * 144;       // P assembly tasks (d, a, b)
   static_assert(T <= 1024, "workgroup too large");
-  static constexpr int PARTLEN = (N * G > 14 * 64) ? N * G : 14 * 64;   // part[] doubles as the reduction scratch
+  static constexpr int PARTLEN0 = (N * G > 14 * 64) ? N * G : 14 * 64;   // part[] doubles as the reduction scratch ...
+  static constexpr int PARTLEN = PARTLEN0 > H * 156 ? PARTLEN0 : H * 156;  // ... and as W A^k B during assembly
 };
 
 // Flat input record offsets (include/mpc_batch.h, layout.py)
@@ -130,6 +131,7 @@ struct Shared {
   union {
     MPC_V part[C::PARTLEN];                             // [slot][row] partial sums / maxima of the tile products
     struct { MPC_V tm[C::M]; MPC_V rzt[C::M]; };        // R z - y and R z~ of the current ADMM iteration (part is dead then)
+    MPC_V wanb[H * 156];                                // assembly: diag(w) A^k B (part is not in use yet)
   };
   MPC_V prow[2][C::N];                                  // sweep pivot row (double buffered)
   MPC_V piv[2][2];                                      // current pivot and its reciprocal (double buffered)
@@ -221,11 +223,12 @@ struct Solver {
   MPC_HD double *crhs() { return s.rr[pp]; }
   long long tc[kProfLen] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = 0;
-#ifdef MPC_PROFILE_SCALE   // sub-profile of one scaling pass (reuses slots 9..13; diagnostic builds only)
-#define MPC_SCALE_LAP(k) lap(k)
-#else
-#define MPC_SCALE_LAP(k) ((void)0)
+  // Diagnostic builds (-DMPC_PROFILE_SUB=<section>) split one section into slots 9..13 of the profile record:
+  // 1 = dynamics, 2 = one scaling pass, 3 = polish set-up, 4 = A dt / B dt set-up.
+#ifndef MPC_PROFILE_SUB
+#define MPC_PROFILE_SUB 0
 #endif
+#define MPC_SUBLAP(sec, k) do { if (MPC_PROFILE_SUB == (sec)) lap(k); } while (0)
   MPC_HD void lap(int k) { const long long now = MPC_CLOCK(); tc[k] += now - tlast; tlast = now; }
 
   // ---- helpers valid inside a phase ------------------------------------------------------------
@@ -334,43 +337,54 @@ struct Solver {
       }
     });
     lap(0);
-    // A dt, B dt (mpc_osqp.cc:299-336, 606-617, 661-673) -- a few hundred flops, one thread
+    // ---- A dt, B dt (mpc_osqp.cc:299-336, 606-617, 661-673): every 3 x 3 product is one entry per thread;
+    // the intermediates live in the (not yet used) xk area:
+    //   tr[0..6] = cr sr cp sp cy sy tan(pitch); m1 = Rx Ry; m2 = Rz Ry; rxyz; rzyx; fw[12]; t2 = rzyx I^-1; iw
+    double *const tr = s.xk, *const m1 = s.xk + 7, *const m2 = s.xk + 16, *const rxyz = s.xk + 25, *const rzyx = s.xk + 34,
+                 *const fw = s.xk + 43, *const t2 = s.xk + 55, *const iw = s.xk + 64;
+    static_assert(13 * H >= 73, "xk too small for the set-up scratch");
     ex.par([&](Th &t) {
-      if (t.tid == 0) {
-        if (s.first) s.rho = kRho0;
-        const double *rpy = s.in + IN_RPY;
-        const double cr = cos(rpy[0]), sr = sin(rpy[0]), cp = cos(rpy[1]), sp = sin(rpy[1]), cy = cos(rpy[2]), sy = sin(rpy[2]);
-        const double rx[9] = {1, 0, 0, 0, cr, -sr, 0, sr, cr}, ry[9] = {cp, 0, sp, 0, 1, 0, -sp, 0, cp}, rz[9] = {cy, -sy, 0, sy, cy, 0, 0, 0, 1};
-        double tmp[9], rxyz[9], rzyx[9], iw[9], fw[12];
-        mat3(rx, ry, tmp); mat3(tmp, rz, rxyz);                        // feet: Rx Ry Rz (:606-609)
-        mat3(rz, ry, tmp); mat3(tmp, rx, rzyx);                        // inertia: Rz Ry Rx (:283-291)
-        const double *fb = s.in + in_foot<H>();
-        for (int i = 0; i < 4; ++i)
-          for (int r = 0; r < 3; ++r) fw[3 * i + r] = rxyz[3 * r] * fb[3 * i] + rxyz[3 * r + 1] * fb[3 * i + 1] + rxyz[3 * r + 2] * fb[3 * i + 2];
-        double rt[9];
-        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) rt[3 * r + c] = rzyx[3 * c + r];
-        mat3(rzyx, mdl.inv_inertia, tmp); mat3(tmp, rt, iw);           // :670-671
-        const double tp = tan(rpy[1]), dt = mdl.dt;
-        const double tm3[9] = {cy / cp, sy / cp, 0, -sy, cy, 0, cy * tp, sy * tp, 1};   // :311-312
-        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) s.a_dt[r * 13 + 6 + c] = tm3[3 * r + c] * dt;
-        s.a_dt[3 * 13 + 9] = dt; s.a_dt[4 * 13 + 10] = dt; s.a_dt[5 * 13 + 11] = dt;
-        for (int r = 0; r < 3; ++r) s.a_dt[(9 + r) * 13 + 12] = s.in[IN_NRM + r] * dt;
-        for (int i = 0; i < 4; ++i) {
-          const double *v = fw + 3 * i;
-          const double skew[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
-          double blk[9];
-          mat3(iw, skew, blk);
-          for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) s.b_dt[(6 + r) * 12 + 3 * i + c] = blk[3 * r + c] * dt;
-          for (int r = 0; r < 3; ++r) s.b_dt[(9 + r) * 12 + 3 * i + r] = mdl.inv_mass * dt;
-        }
-        const double *fr = s.in + in_fric<H>();
-        const double cb[15] = {-1, 0, fr[0], 1, 0, fr[1], 0, -1, fr[2], 0, 1, fr[3], 0, 0, 1};   // :437-447
-        for (int k = 0; k < 15; ++k) s.cone[k] = cb[k];
+      if (t.tid < 7) {
+        const double ang = s.in[IN_RPY + (t.tid < 6 ? t.tid / 2 : 1)];
+        tr[t.tid] = t.tid == 6 ? tan(ang) : (t.tid & 1) ? sin(ang) : cos(ang);
+      }
+      if (t.tid == 7 && s.first) s.rho = kRho0;
+    });
+    MPC_SUBLAP(4, 9);
+    auto rot = [&](int which, double *r) {   // 0: Rx(roll) 1: Ry(pitch) 2: Rz(yaw)
+      const double c = tr[2 * which], sn = tr[2 * which + 1];
+      const double rx[9] = {1, 0, 0, 0, c, -sn, 0, sn, c}, ry[9] = {c, 0, sn, 0, 1, 0, -sn, 0, c}, rz[9] = {c, -sn, 0, sn, c, 0, 0, 0, 1};
+      for (int k = 0; k < 9; ++k) r[k] = which == 0 ? rx[k] : which == 1 ? ry[k] : rz[k];
+    };
+    ex.par([&](Th &t) {   // m1 = Rx Ry (feet, :606-609), m2 = Rz Ry (inertia, :283-291)
+      if (t.tid < 18) {
+        double a[9], bm[9];
+        rot(t.tid < 9 ? 0 : 2, a); rot(1, bm);
+        const int e = t.tid % 9;
+        (t.tid < 9 ? m1 : m2)[e] = mat3e(a, bm, e);
       }
       // x0 (:630-633)
-      if (t.tid < 13) {
-        const int i = t.tid;
+      if (t.tid >= 32 && t.tid < 45) {
+        const int i = t.tid - 32;
         s.x0[i] = i < 3 ? s.in[IN_RPY + i] : i < 6 ? s.in[IN_POS + i - 3] : i < 9 ? s.in[IN_ANG + i - 6] : i < 12 ? s.in[IN_VEL + i - 9] : -kGravity;
+      }
+      // bounds (:449-477, 685-688, 720-721)
+      if (t.tid < M) {
+        const int i = t.tid, f = i / 5, r = i - 5 * f;
+        const double cst = s.in[IN_CONTACT + f];
+        const double fzmax = mdl.mass * kGravity * kMaxScale, fzmin = mdl.mass * kGravity * kMinScale;
+        const double mu0 = s.in[in_fric<H>()];
+        s.l[i] = dmax(r < 4 ? 0.0 : fzmin * cst, -kInfty);
+        s.u[i] = dmin(r < 4 ? (mu0 + 1) * fzmax * cst : fzmax * cst, kInfty);
+      }
+    });
+    MPC_SUBLAP(4, 10);
+    ex.par([&](Th &t) {   // rxyz = (Rx Ry) Rz, rzyx = (Rz Ry) Rx
+      if (t.tid < 18) {
+        double bm[9];
+        rot(t.tid < 9 ? 2 : 0, bm);
+        const int e = t.tid % 9;
+        (t.tid < 9 ? rxyz : rzyx)[e] = mat3e(t.tid < 9 ? m1 : m2, bm, e);
       }
       // x_ref (:635-659)
       for (int k = t.tid; k < 13 * H; k += T) {
@@ -395,50 +409,106 @@ struct Solver {
         }
         s.xref[k] = v;
       }
-      // bounds (:449-477, 685-688, 720-721)
-      if (t.tid < M) {
-        const int i = t.tid, f = i / 5, r = i - 5 * f;
-        const double cst = s.in[IN_CONTACT + f];
-        const double fzmax = mdl.mass * kGravity * kMaxScale, fzmin = mdl.mass * kGravity * kMinScale;
-        const double mu0 = s.in[in_fric<H>()];
-        s.l[i] = dmax(r < 4 ? 0.0 : fzmin * cst, -kInfty);
-        s.u[i] = dmin(r < 4 ? (mu0 + 1) * fzmax * cst : fzmax * cst, kInfty);
+    });
+    MPC_SUBLAP(4, 11);
+    ex.par([&](Th &t) {   // feet in the world frame; t2 = rzyx I^-1 (:670)
+      if (t.tid < 12) {
+        const int i = t.tid / 3, r = t.tid - 3 * i;
+        const double *fb = s.in + in_foot<H>();
+        fw[t.tid] = rxyz[3 * r] * fb[3 * i] + rxyz[3 * r + 1] * fb[3 * i + 1] + rxyz[3 * r + 2] * fb[3 * i + 2];
+      } else if (t.tid < 21) {
+        t2[t.tid - 12] = mat3e(rzyx, mdl.inv_inertia, t.tid - 12);
       }
     });
-    // exact exponential (mpc_osqp.cc:338-351; M^3 = 0): A_exp = I + A dt + (A dt)^2/2, B_exp = B dt + (A dt)(B dt)/2
+    MPC_SUBLAP(4, 12);
+    ex.par([&](Th &t) {   // iw = t2 rzyx^T (:671)
+      if (t.tid < 9) {
+        double rt[9];
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) rt[3 * r + c] = rzyx[3 * c + r];
+        iw[t.tid] = mat3e(t2, rt, t.tid);
+      }
+    });
+    ex.par([&](Th &t) {
+      const double dt = mdl.dt;
+      if (t.tid < 36) {   // B rows 6-8: I_w^-1 [r_i]x (:324-336)
+        const int i = t.tid / 9, e = t.tid - 9 * i, r = e / 3, c = e - 3 * r;
+        const double *v = fw + 3 * i;
+        const double skew[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
+        s.b_dt[(6 + r) * 12 + 3 * i + c] = mat3e(iw, skew, e) * dt;
+      } else if (t.tid < 48) {   // B rows 9-11: I / m
+        const int k = t.tid - 36, i = k / 3, r = k - 3 * i;
+        s.b_dt[(9 + r) * 12 + 3 * i + r] = mdl.inv_mass * dt;
+      } else if (t.tid < 57) {   // A rows 0-2: omega -> rpy rates (:311-312)
+        const int e = t.tid - 48, r = e / 3, c = e - 3 * r;
+        const double cp = tr[2], cy = tr[4], sy = tr[5], tp = tr[6];
+        const double tm3[9] = {cy / cp, sy / cp, 0, -sy, cy, 0, cy * tp, sy * tp, 1};
+        s.a_dt[r * 13 + 6 + c] = tm3[e] * dt;
+      } else if (t.tid < 60) {
+        const int r = t.tid - 57;
+        s.a_dt[(3 + r) * 13 + 9 + r] = dt;
+        s.a_dt[(9 + r) * 13 + 12] = s.in[IN_NRM + r] * dt;
+      } else if (t.tid == 60) {
+        const double *fr = s.in + in_fric<H>();
+        const double cb[15] = {-1, 0, fr[0], 1, 0, fr[1], 0, -1, fr[2], 0, 1, fr[3], 0, 0, 1};   // :437-447
+        for (int k = 0; k < 15; ++k) s.cone[k] = cb[k];
+      }
+    });
+    MPC_SUBLAP(1, 9);
+    MPC_SUBLAP(4, 13);
+    // exact exponential (mpc_osqp.cc:338-351; M^3 = 0): A_exp = I + A dt + (A dt)^2/2, B_exp = B dt + (A dt)(B dt)/2.
+    // A dt is nonzero only at rows 0-2 x cols 6-8, (3+i, 9+i) and rows 9-11 x col 12; the dense products of the
+    // reference add exact zeros elsewhere, so only the nonzero terms are formed (same order, same values).
     ex.par([&](Th &t) {
       for (int k = t.tid; k < 169 + 156; k += T) {
         if (k < 169) {
           const int r = k / 13, c = k - 13 * r;
-          double acc = 0;
-          for (int j = 0; j < 13; ++j) acc += s.a_dt[r * 13 + j] * s.a_dt[j * 13 + c];
+          const double acc = (r >= 3 && r < 6 && c == 12) ? s.a_dt[r * 13 + r + 6] * s.a_dt[(r + 6) * 13 + 12] : 0.0;
           s.a_exp[k] = (r == c ? 1.0 : 0.0) + s.a_dt[k] + acc / 2;
         } else {
           const int kk = k - 169, r = kk / 12, c = kk - 12 * r;
           double acc = 0;
-          for (int j = 0; j < 13; ++j) acc += s.a_dt[r * 13 + j] * s.b_dt[j * 12 + c];
+          if (r < 3) { for (int j = 6; j < 9; ++j) acc += s.a_dt[r * 13 + j] * s.b_dt[j * 12 + c]; }
+          else if (r < 6) acc += s.a_dt[r * 13 + r + 6] * s.b_dt[(r + 6) * 12 + c];
           s.b_exp[kk] = s.b_dt[kk] + acc / 2;
-          s.anb[kk] = s.b_exp[kk];
         }
       }
     });
-    // A^k B (:368-373) and the free response A^{i+1} x0, i < H-1 (:360-364; the last A_qp block stays 0)
-    for (int k = 1; k < H; ++k) {
-      ex.par([&](Th &t) {
-        if (t.tid < 156) {
-          const int r = t.tid / 12, c = t.tid - 12 * r;
-          double acc = 0;
-          for (int j = 0; j < 13; ++j) acc += s.a_exp[r * 13 + j] * s.anb[(k - 1) * 156 + j * 12 + c];
-          s.anb[k * 156 + t.tid] = acc;
-        } else if (t.tid < 156 + 13) {
-          const int r = t.tid - 156;
-          const double *prev = (k == 1) ? s.x0 : s.xk + 13 * (k - 2);
-          double acc = 0;
-          for (int j = 0; j < 13; ++j) acc += s.a_exp[r * 13 + j] * prev[j];
-          s.xk[13 * (k - 1) + r] = acc;
-        }
-      });
-    }
+    MPC_SUBLAP(1, 10);
+    // A^k B (:368-373) and the free response A^{i+1} x0, i < H-1 (:360-364; the last A_qp block stays 0).
+    // A dt is nilpotent, so A_exp^k = exp(k A dt) = I + k A dt + k^2 (A dt)^2 / 2 exactly, and (A dt)^2 B_exp = 0
+    // (its only column, 12, meets the zero row 12 of B_exp):  A_exp^k B_exp = B_exp + k U,  U = (A dt) B_exp,
+    // which is nonzero in rows 0-5 only.  All k are formed at once (the reference multiplies k times; the two
+    // agree to rounding).  U overwrites b_dt, (A dt) x0 and (A dt)^2 x0 go to the first 26 slots of sdiff.
+    ex.par([&](Th &t) {
+      if (t.tid < 72) {
+        const int r = t.tid / 12, c = t.tid - 12 * r;
+        double acc = 0;
+        if (r < 3) { for (int j = 6; j < 9; ++j) acc += s.a_dt[r * 13 + j] * s.b_exp[j * 12 + c]; }
+        else acc = s.a_dt[r * 13 + r + 6] * s.b_exp[(r + 6) * 12 + c];
+        s.b_dt[t.tid] = acc;
+      } else if (t.tid < 72 + 13) {
+        const int r = t.tid - 72;
+        double a1 = 0, a2 = 0;
+        if (r < 3) { for (int j = 6; j < 9; ++j) a1 += s.a_dt[r * 13 + j] * s.x0[j]; }
+        else if (r < 6) { a1 = s.a_dt[r * 13 + r + 6] * s.x0[r + 6]; a2 = (s.a_dt[r * 13 + r + 6] * s.a_dt[(r + 6) * 13 + 12]) * s.x0[12]; }
+        else if (r >= 9 && r < 12) a1 = s.a_dt[r * 13 + 12] * s.x0[12];
+        s.sdiff[r] = a1; s.sdiff[13 + r] = a2;
+      }
+    });
+    ex.par([&](Th &t) {
+      for (int e = t.tid; e < H * 156; e += T) {
+        const int k = e / 156, rc = e - 156 * k, r = rc / 12;
+        const double v = r < 6 ? s.b_exp[rc] + (double)k * s.b_dt[rc] : s.b_exp[rc];
+        s.anb[e] = v;
+        s.wanb[e] = s.in[IN_W + r] * v;
+      }
+      for (int e = t.tid; e < 13 * (H - 1); e += T) {   // (this overwrites the set-up scratch, which is dead by now)
+        const int i = e / 13, r = e - 13 * i;
+        const double kk = i + 1;
+        s.xk[e] = s.x0[r] + kk * s.sdiff[r] + (kk * kk / 2) * s.sdiff[13 + r];
+      }
+    });
+    MPC_SUBLAP(1, 11);
     ex.par([&](Th &t) {   // state_diff (:681)
       for (int k = t.tid; k < 13 * H; k += T) s.sdiff[k] = (k < 13 * (H - 1) ? s.xk[k] : 0.0) - s.xref[k];
     });
@@ -449,8 +519,14 @@ struct Solver {
         const int j = t.tid / 12, c = t.tid - 12 * j;
         double acc = 0;
         for (int i = j; i < H; ++i) {
-          const double *bk = s.anb + (i - j) * 156;
-          for (int r = 0; r < 13; ++r) acc += bk[r * 12 + c] * (s.in[IN_W + r] * s.sdiff[13 * i + r]);
+          const double *bk = s.wanb + (i - j) * 156 + c, *sd = s.sdiff + 13 * i;
+          double e = 0, o = 0;   // two FMA chains per horizon step
+#pragma unroll
+          for (int r = 0; r < 13; ++r) {
+            if (r & 1) o += bk[r * 12] * sd[r];
+            else e += bk[r * 12] * sd[r];
+          }
+          acc += e + o;
         }
         s.q[t.tid] = 2 * acc;
       }
@@ -467,23 +543,42 @@ struct Solver {
           const int ab = k - (d - 1) * 144;
           a = ab / 12; b = ab - 12 * a;
         }
+        // entry (12 I + a, 12 J + b), I = J - d <= J, lives at row 12 J + b, column 12 I + a of the lower triangle:
+        // tile (2 J + b / 6, 2 I + a / 6), position (b % 6, a % 6); a diagonal tile also takes the mirrored entry
+        const int ah = a / TS, bh = b / TS, lo = (b - TS * bh) * TS + (a - TS * ah), lom = (a - TS * ah) * TS + (b - TS * bh);
+        const bool mirror = d == 0 && ah == bh && a != b;
+        const double *xa = s.wanb + d * 156 + a, *yb = s.anb + b;
         double acc = 0;
-        for (int sidx = 0; sidx + d < H; ++sidx) {
-          const double *xa = s.anb + (sidx + d) * 156, *yb = s.anb + sidx * 156;
-          double tsum = 0;
-          for (int r = 0; r < 13; ++r) tsum += xa[r * 12 + a] * s.in[IN_W + r] * yb[r * 12 + b];
-          acc += tsum;
-          const int J = H - 1 - sidx, I = J - d;
-          const int ri = 12 * I + a, cj = 12 * J + b;
-          double v = 2.0 * acc;
-          if (ri == cj) v += mdl.alpha;
-          Pg[pg_index(cj, ri)] = v;                                   // ri <= cj: (cj, ri) is in the lower triangle
-          if (ri != cj && ri / TS == cj / TS) Pg[pg_index(ri, cj)] = v;   // diagonal tiles are stored in full
+        const int ns = H - d;
+        for (int sidx = 0; sidx < ns; sidx += 2) {   // two horizon offsets per trip: four independent FMA chains
+          const int s1 = sidx + 1 < ns ? sidx + 1 : sidx;
+          const double *x0 = xa + sidx * 156, *y0 = yb + sidx * 156, *x1 = xa + s1 * 156, *y1 = yb + s1 * 156;
+          double e0 = 0, o0 = 0, e1 = 0, o1 = 0;
+#pragma unroll
+          for (int r = 0; r < 13; ++r) {
+            if (r & 1) { o0 += x0[r * 12] * y0[r * 12]; o1 += x1[r * 12] * y1[r * 12]; }
+            else { e0 += x0[r * 12] * y0[r * 12]; e1 += x1[r * 12] * y1[r * 12]; }
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            if (u == 1 && sidx + 1 >= ns) break;
+            acc += u == 0 ? e0 + o0 : e1 + o1;
+            const int J = H - 1 - (sidx + u), I = J - d;
+            const int tr = 2 * J + bh, tix = tr * (tr + 1) / 2 + 2 * I + ah;
+            double v = 2.0 * acc;
+            if (d == 0 && a == b) v += mdl.alpha;
+            Pg[(size_t)tix * TE + lo] = v;
+            if (mirror) Pg[(size_t)tix * TE + lom] = v;
+          }
         }
       }
     });
   }
   // (lap(2) is taken at the start of scale())
+  static MPC_HD double mat3e(const double *a, const double *b, int e) {   // entry e = 3 i + j of the 3 x 3 product a b
+    const int i = e / 3, j = e - 3 * i;
+    return a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+  }
   static MPC_HD void mat3(const double *a, const double *b, double *c) {
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) c[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
@@ -550,7 +645,7 @@ struct Solver {
           if (j == 0) s.ctmp = ct;
         }
       });
-      MPC_SCALE_LAP(9);
+      MPC_SUBLAP(2, 9);
       ex.par([&](Th &t) {   // A <- E A D, q <- D (c_temp q), c <- c_temp c; new row norms of D P D and A
         const double ct = s.ctmp;
         if (t.mact) tile_rownorms(t, s.D);
@@ -567,7 +662,7 @@ struct Solver {
         if (t.tid < N) s.qs[t.tid] = (s.qs[t.tid] * ct) * s.dt_[t.tid];
         if (t.tid == T - 1) s.c *= ct;
       });
-      MPC_SCALE_LAP(10);
+      MPC_SUBLAP(2, 10);
       ex.par([&](Th &t) {   // cost scaling (scaling.c:108-139): per-foot partial sums of the column norms, |q|_inf
         if (t.tid < NF) {
           const int f = t.tid;
@@ -576,7 +671,7 @@ struct Solver {
           s.cn_[NF + f] = dmax(dmax(fabs(q0), fabs(q1)), fabs(q2));
         }
       });
-      MPC_SCALE_LAP(11);
+      MPC_SUBLAP(2, 11);
     }
     ex.par([&](Th &t) {   // the last pass's cost scale; P_s = c D P D
       const double ct = pending_cost_scale(), cf = s.c * ct;
