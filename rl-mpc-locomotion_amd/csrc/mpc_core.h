@@ -1091,6 +1091,7 @@ struct Solver {
         }
       }
     });
+    MPC_SUBLAP(3, 9);
     // u = Gamma A_act^T b  (the point satisfying the active rows), g = -q - P u
     ex.par([&](Th &t) {
       if (t.tid < N) {
@@ -1109,7 +1110,9 @@ struct Solver {
         s.xN[j] = 0; s.PxN[j] = 0; s.wv[j] = 0;
       }
     });
+    MPC_SUBLAP(3, 10);
     mul_P(s.u0, s.Pu);
+    MPC_SUBLAP(3, 11);
     lap(11);
     // H = N~^T P N~ + delta I on the null coordinates, identity elsewhere; N~ = blockdiag([N_f | 0]).
     // Tile-local: 2 row feet x 2 column feet of 3 x 3 blocks, all register indices static.
@@ -1142,6 +1145,7 @@ struct Solver {
           }
       }
     });
+    MPC_SUBLAP(3, 12);
     sweep_all(true);   // Mx <- -(H + delta I)^{-1} on the null coordinates
     ex.par([&](Th &t) { if (t.tid == 0) s.nfact++; });
     lap(12);
