@@ -337,31 +337,37 @@ struct Solver {
       }
     });
     lap(0);
-    // ---- A dt, B dt (mpc_osqp.cc:299-336, 606-617, 661-673): every 3 x 3 product is one entry per thread;
-    // the intermediates live in the (not yet used) xk area:
-    //   tr[0..6] = cr sr cp sp cy sy tan(pitch); m1 = Rx Ry; m2 = Rz Ry; rxyz; rzyx; fw[12]; t2 = rzyx I^-1; iw
-    double *const tr = s.xk, *const m1 = s.xk + 7, *const m2 = s.xk + 16, *const rxyz = s.xk + 25, *const rzyx = s.xk + 34,
+    // ---- A dt, B dt (mpc_osqp.cc:299-336, 606-617, 661-673): every 3 x 3 product is one entry per thread, all
+    // operands in LDS (a thread-local array indexed by a runtime entry number would live in scratch memory).
+    // The intermediates use the not yet used xk / sdiff areas:
+    //   xk:    tan(pitch); m1 = Rx Ry; m2 = Rz Ry; rxyz; rzyx; fw[12]; t2 = rzyx I^-1; iw
+    //   sdiff: [26..53) Rx, Ry, Rz; [53..62) I^-1 (body)
+    double *const tp_ = s.xk, *const m1 = s.xk + 7, *const m2 = s.xk + 16, *const rxyz = s.xk + 25, *const rzyx = s.xk + 34,
                  *const fw = s.xk + 43, *const t2 = s.xk + 55, *const iw = s.xk + 64;
-    static_assert(13 * H >= 73, "xk too small for the set-up scratch");
+    double *const rxm = s.sdiff + 26, *const rym = s.sdiff + 35, *const rzm = s.sdiff + 44, *const iib = s.sdiff + 53;
+    static_assert(13 * H >= 73, "xk / sdiff too small for the set-up scratch");
     ex.par([&](Th &t) {
-      if (t.tid < 7) {
-        const double ang = s.in[IN_RPY + (t.tid < 6 ? t.tid / 2 : 1)];
-        tr[t.tid] = t.tid == 6 ? tan(ang) : (t.tid & 1) ? sin(ang) : cos(ang);
+      if (t.tid < 27) {   // entry k of rotation `which` about x / y / z: 0, 1, cos, sin or -sin of its angle
+        const int which = t.tid / 9, k = t.tid - 9 * which;
+        const int ax = which, u = (ax + 1) % 3, v = (ax + 2) % 3, r = k / 3, c = k - 3 * r;
+        const double ang = s.in[IN_RPY + which];
+        double val;
+        if (r == ax || c == ax) val = (r == c) ? 1.0 : 0.0;
+        else if (r == c) val = cos(ang);
+        else val = (r == v && c == u) ? sin(ang) : -sin(ang);     // R[u][v] = -sin, R[v][u] = +sin
+        rxm[t.tid] = val;
+      } else if (t.tid == 64) {
+        tp_[0] = tan(s.in[IN_RPY + 1]);
+      } else if (t.tid >= 96 && t.tid < 105) {
+        iib[t.tid - 96] = mdl.inv_inertia[t.tid - 96];
       }
-      if (t.tid == 7 && s.first) s.rho = kRho0;
+      if (t.tid == 128 % T && s.first) s.rho = kRho0;
     });
     MPC_SUBLAP(4, 9);
-    auto rot = [&](int which, double *r) {   // 0: Rx(roll) 1: Ry(pitch) 2: Rz(yaw)
-      const double c = tr[2 * which], sn = tr[2 * which + 1];
-      const double rx[9] = {1, 0, 0, 0, c, -sn, 0, sn, c}, ry[9] = {c, 0, sn, 0, 1, 0, -sn, 0, c}, rz[9] = {c, -sn, 0, sn, c, 0, 0, 0, 1};
-      for (int k = 0; k < 9; ++k) r[k] = which == 0 ? rx[k] : which == 1 ? ry[k] : rz[k];
-    };
     ex.par([&](Th &t) {   // m1 = Rx Ry (feet, :606-609), m2 = Rz Ry (inertia, :283-291)
       if (t.tid < 18) {
-        double a[9], bm[9];
-        rot(t.tid < 9 ? 0 : 2, a); rot(1, bm);
         const int e = t.tid % 9;
-        (t.tid < 9 ? m1 : m2)[e] = mat3e(a, bm, e);
+        (t.tid < 9 ? m1 : m2)[e] = mat3e(t.tid < 9 ? rxm : rzm, rym, e);
       }
       // x0 (:630-633)
       if (t.tid >= 32 && t.tid < 45) {
@@ -381,33 +387,19 @@ struct Solver {
     MPC_SUBLAP(4, 10);
     ex.par([&](Th &t) {   // rxyz = (Rx Ry) Rz, rzyx = (Rz Ry) Rx
       if (t.tid < 18) {
-        double bm[9];
-        rot(t.tid < 9 ? 2 : 0, bm);
         const int e = t.tid % 9;
-        (t.tid < 9 ? rxyz : rzyx)[e] = mat3e(t.tid < 9 ? m1 : m2, bm, e);
+        (t.tid < 9 ? rxyz : rzyx)[e] = mat3e(t.tid < 9 ? m1 : m2, t.tid < 9 ? rzm : rxm, e);
       }
-      // x_ref (:635-659)
+      // x_ref (:635-659): row r of step i is base_r + dt (i + 1) slope_r  (slope 0 for the constant rows)
       for (int k = t.tid; k < 13 * H; k += T) {
         const int i = k / 13, r = k - 13 * i;
         const double tt = mdl.dt * (i + 1);
-        const double *drpy = s.in + in_drpy<H>(), *dvel = s.in + in_dvel<H>(), *dang = s.in + in_dang<H>();
-        double v;
-        switch (r) {
-          case 0: v = drpy[0]; break;
-          case 1: v = drpy[1]; break;
-          case 2: v = s.in[IN_RPY + 2] + tt * dang[2]; break;
-          case 3: v = tt * dvel[0] + s.in[IN_POS]; break;
-          case 4: v = tt * dvel[1] + s.in[IN_POS + 1]; break;
-          case 5: v = s.in[in_dpos<H>() + 2]; break;
-          case 6: v = dang[0]; break;
-          case 7: v = dang[1]; break;
-          case 8: v = dang[2]; break;
-          case 9: v = dvel[0]; break;
-          case 10: v = dvel[1]; break;
-          case 11: v = 0; break;
-          default: v = -kGravity;
-        }
-        s.xref[k] = v;
+        const int drpy = in_drpy<H>(), dvel = in_dvel<H>(), dang = in_dang<H>(), dpos = in_dpos<H>();
+        const int bi = r < 2 ? drpy + r : r == 2 ? IN_RPY + 2 : r < 5 ? IN_POS + r - 3 : r == 5 ? dpos + 2 : r < 9 ? dang + r - 6 : dvel + (r < 11 ? r - 9 : 0);
+        const int si = r == 2 ? dang + 2 : dvel + (r == 4 ? 1 : 0);
+        const double base = s.in[bi], slope = s.in[si];
+        const double v = (r == 2 || r == 3 || r == 4) ? tt * slope + base : base;
+        s.xref[k] = r == 11 ? 0.0 : r == 12 ? -kGravity : v;
       }
     });
     MPC_SUBLAP(4, 11);
@@ -417,32 +409,41 @@ struct Solver {
         const double *fb = s.in + in_foot<H>();
         fw[t.tid] = rxyz[3 * r] * fb[3 * i] + rxyz[3 * r + 1] * fb[3 * i + 1] + rxyz[3 * r + 2] * fb[3 * i + 2];
       } else if (t.tid < 21) {
-        t2[t.tid - 12] = mat3e(rzyx, mdl.inv_inertia, t.tid - 12);
+        t2[t.tid - 12] = mat3e(rzyx, iib, t.tid - 12);
       }
     });
     MPC_SUBLAP(4, 12);
     ex.par([&](Th &t) {   // iw = t2 rzyx^T (:671)
       if (t.tid < 9) {
-        double rt[9];
-        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) rt[3 * r + c] = rzyx[3 * c + r];
-        iw[t.tid] = mat3e(t2, rt, t.tid);
+        const int i = t.tid / 3, j = t.tid - 3 * i;
+        iw[t.tid] = t2[3 * i] * rzyx[3 * j] + t2[3 * i + 1] * rzyx[3 * j + 1] + t2[3 * i + 2] * rzyx[3 * j + 2];
       }
     });
     ex.par([&](Th &t) {
       const double dt = mdl.dt;
-      if (t.tid < 36) {   // B rows 6-8: I_w^-1 [r_i]x (:324-336)
+      if (t.tid < 36) {   // B rows 6-8: I_w^-1 [r_i]x (:324-336); [v]x = {0, -v2, v1; v2, 0, -v0; -v1, v0, 0}
         const int i = t.tid / 9, e = t.tid - 9 * i, r = e / 3, c = e - 3 * r;
         const double *v = fw + 3 * i;
-        const double skew[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
-        s.b_dt[(6 + r) * 12 + 3 * i + c] = mat3e(iw, skew, e) * dt;
+        double acc = 0;
+        for (int k = 0; k < 3; ++k) {   // same left-to-right sum as the 3 x 3 product, with skew[k][c] formed on the fly
+          const double sk = (k == c) ? 0.0 : (((c - k + 3) % 3 == 1) ? -v[3 - k - c] : v[3 - k - c]);
+          const double term = iw[3 * r + k] * sk;
+          acc = k == 0 ? term : acc + term;
+        }
+        s.b_dt[(6 + r) * 12 + 3 * i + c] = acc * dt;
       } else if (t.tid < 48) {   // B rows 9-11: I / m
         const int k = t.tid - 36, i = k / 3, r = k - 3 * i;
         s.b_dt[(9 + r) * 12 + 3 * i + r] = mdl.inv_mass * dt;
-      } else if (t.tid < 57) {   // A rows 0-2: omega -> rpy rates (:311-312)
+      } else if (t.tid < 57) {   // A rows 0-2: omega -> rpy rates (:311-312): {cy/cp, sy/cp, 0; -sy, cy, 0; cy tp, sy tp, 1}
         const int e = t.tid - 48, r = e / 3, c = e - 3 * r;
-        const double cp = tr[2], cy = tr[4], sy = tr[5], tp = tr[6];
-        const double tm3[9] = {cy / cp, sy / cp, 0, -sy, cy, 0, cy * tp, sy * tp, 1};
-        s.a_dt[r * 13 + 6 + c] = tm3[e] * dt;
+        const double cp = rym[0], cy = rzm[0], sy = rzm[3], tp = tp_[0];
+        const double num = c == 0 ? cy : sy;
+        double val;
+        if (c == 2) val = r == 2 ? 1.0 : 0.0;
+        else if (r == 0) val = num / cp;
+        else if (r == 1) val = c == 0 ? -sy : cy;
+        else val = num * tp;
+        s.a_dt[r * 13 + 6 + c] = val * dt;
       } else if (t.tid < 60) {
         const int r = t.tid - 57;
         s.a_dt[(3 + r) * 13 + 9 + r] = dt;
@@ -1024,29 +1025,38 @@ struct Solver {
       if (t.tid < NF) {
         const int f = t.tid;
         const double *a = s.As + 15 * f;
+        // (all register arrays are indexed statically: a runtime row index would push them to scratch memory.
+        //  Rows of Q beyond the current rank are zero, so projecting on all three rows equals projecting on the
+        //  first r of them.)
         double Q[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Nn[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         int r = 0;
+#pragma unroll
         for (int row = 0; row < 5; ++row) {
-          if (r >= 3 || !s.act[5 * f + row]) continue;
+          const bool cand = r < 3 && s.act[5 * f + row];
           double v[3] = {a[3 * row], a[3 * row + 1], a[3 * row + 2]};
           const double n0 = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+#pragma unroll
           for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
             for (int k = 0; k < 3; ++k) {
-              if (k >= r) break;
               const double d = v[0] * Q[3 * k] + v[1] * Q[3 * k + 1] + v[2] * Q[3 * k + 2];
               v[0] -= d * Q[3 * k]; v[1] -= d * Q[3 * k + 1]; v[2] -= d * Q[3 * k + 2];
             }
           const double nr = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-          if (!(nr > 1e-6 * n0)) continue;
-          Q[3 * r] = v[0] / nr; Q[3 * r + 1] = v[1] / nr; Q[3 * r + 2] = v[2] / nr;
-          ++r;
+          const bool take = cand && nr > 1e-6 * n0;
+          const double q0 = v[0] / nr, q1 = v[1] / nr, q2 = v[2] / nr;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const bool here = take && r == k;
+            Q[3 * k] = here ? q0 : Q[3 * k]; Q[3 * k + 1] = here ? q1 : Q[3 * k + 1]; Q[3 * k + 2] = here ? q2 : Q[3 * k + 2];
+          }
+          r += take ? 1 : 0;
         }
         if (r == 0) { Nn[0] = 1; Nn[4] = 1; Nn[8] = 1; }
         else if (r == 1) {
           const int imin = fabs(Q[0]) <= fabs(Q[1]) ? (fabs(Q[0]) <= fabs(Q[2]) ? 0 : 2) : (fabs(Q[1]) <= fabs(Q[2]) ? 1 : 2);
-          double e[3] = {0, 0, 0};
-          e[imin] = 1;
-          const double d = Q[imin];
+          const double e[3] = {imin == 0 ? 1.0 : 0.0, imin == 1 ? 1.0 : 0.0, imin == 2 ? 1.0 : 0.0};
+          const double d = imin == 0 ? Q[0] : imin == 1 ? Q[1] : Q[2];
           double v[3] = {e[0] - d * Q[0], e[1] - d * Q[1], e[2] - d * Q[2]};
           const double nr = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
           Nn[0] = v[0] / nr; Nn[1] = v[1] / nr; Nn[2] = v[2] / nr;
