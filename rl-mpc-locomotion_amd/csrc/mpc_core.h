@@ -605,12 +605,12 @@ struct Solver {
     return v[0];
   }
   MPC_HD double pending_cost_scale() const {   // scaling.c:108-139, from the per-foot partials in cn_
-    const double mean = (fold_half<false>(s.cn_) + fold_half<false>(s.cn_ + NF / 2)) / N;
+    const double mean = (fold_half<false>(s.cn_) + fold_half<false>(s.cn_ + NF / 2)) * (1.0 / N);
     const double nq = limit_scaling(fmax(fold_half<true>(s.cn_ + NF), fold_half<true>(s.cn_ + NF + NF / 2)));
-    return 1.0 / limit_scaling(fmax(mean, nq));
+    return fast_recip(limit_scaling(fmax(mean, nq)));
   }
   static MPC_HD double row_scale3(double a0, double a1, double a2) {   // 1 / sqrt(|row|_inf) of a 3-entry row of A
-    return 1.0 / sqrt(limit_scaling(fmax(fmax(fabs(a0), fabs(a1)), fabs(a2))));
+    return fast_rsqrt(limit_scaling(fmax(fmax(fabs(a0), fabs(a1)), fabs(a2))));
   }
   MPC_HD void scale() {
     lap(2);
@@ -640,7 +640,7 @@ struct Solver {
           double mx = (s.c * ct) * max_parts(s, j);
 #pragma unroll
           for (int r = 0; r < 5; ++r) mx = fmax(mx, fabs(av[r]));
-          const double d = 1.0 / sqrt(limit_scaling(mx));
+          const double d = fast_rsqrt(limit_scaling(mx));
           s.dt_[j] = d;
           s.D[j] *= d;
           if (j == 0) s.ctmp = ct;
@@ -835,6 +835,17 @@ struct Solver {
 #pragma unroll
       for (int a = 0; a < TS; ++a) pn[a] = t.Mx[a * TS + A];
     }
+  }
+  static MPC_HD double fast_rsqrt(double d) {   // 1 / sqrt(d), d > 0 finite: v_rsq_f64 + two Newton steps (to the last ulp or two)
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    r = r * (1.5 - h * r * r);
+    r = r * (1.5 - h * r * r);
+    return r;
+#else
+    return 1.0 / sqrt(d);
+#endif
   }
   static MPC_HD double fast_recip(double d) {
 #if defined(__HIP_DEVICE_COMPILE__)
