@@ -48,6 +48,12 @@
 #define MPC_SCHED_FENCE() ((void)0)
 #endif
 #define MPC_CHUNK 10   // columns between scheduling fences
+// A value that is the same in every lane, moved to a scalar register (so that branches on it are scalar branches)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MPC_UNIFORM_INT(x) __builtin_amdgcn_readfirstlane(x)
+#else
+#define MPC_UNIFORM_INT(x) (x)
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MPC_CLOCK() ((long long)__builtin_readcyclecounter())
 #else
@@ -152,7 +158,7 @@ struct Shared {
       MPC_V Ax[C::M]; MPC_V Aty[C::N]; MPC_V rp[C::M]; MPC_V rd[C::N];
       int act[C::M];
       MPC_V Nb[C::NF * 9]; MPC_V Gm[C::NF * 9];         // per foot: null basis rows (3 x 3, zero padded), Gamma
-      int nnull[C::NF], isnull[C::N];
+      int nnull[C::NF], isnull[C::N], rowmask[C::G];      // rowmask: isnull of a tile row's 6 coordinates, one bit each
       MPC_V u0[C::N]; MPC_V Pu[C::N]; MPC_V g[C::N]; MPC_V xN[C::N]; MPC_V PxN[C::N]; MPC_V wv[C::N]; MPC_V rw[C::N];
       MPC_V ypol[C::M]; MPC_V zpol[C::M];
     };
@@ -765,14 +771,19 @@ struct Solver {
   MPC_HD void sweep_all(bool masked) {
     int buf = 0;
     ex.par([&](Th &t) { if (t.mact) publish<0>(t, 0, 0); });
-    for (int kt = 0; kt < G; ++kt) sweep_steps<0>(masked, kt, buf);
+    for (int kt = 0; kt < G; ++kt) {
+      // bit A: pivot 6 kt + A is swept; bit 6: so is the first pivot of the next tile row (one LDS read per six steps)
+      int bits = kt + 1 < G ? 0x7f : 0x3f;
+      if (masked) bits = MPC_UNIFORM_INT(s.rowmask[kt] | (kt + 1 < G ? (s.rowmask[kt + 1] & 1) << TS : 0));
+      sweep_steps<0>(bits, kt, buf);
+    }
   }
   template <int A>
-  MPC_HD void sweep_steps(bool masked, int kt, int &buf) {
+  MPC_HD void sweep_steps(int bits, int kt, int &buf) {
     if constexpr (A < TS) {
-      sweep_step<A>(masked, kt, buf);
+      sweep_step<A>(bits, kt, buf);
       buf ^= 1;
-      sweep_steps<A + 1>(masked, kt, buf);
+      sweep_steps<A + 1>(bits, kt, buf);
     }
   }
   // Pivot step k = 6 kt + A.  Order inside the phase: first the cross through the next pivot (row AN and
@@ -780,12 +791,11 @@ struct Solver {
   // row k + 1 -- so that the LDS stores and the reciprocal are in flight while the other 25 entries take
   // their update.
   template <int A>
-  MPC_HD void sweep_step(bool masked, int kt, int buf) {
+  MPC_HD void sweep_step(int bits, int kt, int buf) {
     constexpr int AN = (A + 1) % TS;                 // next pivot's position inside its tile
-    const int k = TS * kt + A, kn = k + 1;
     const int ktn = (A + 1 < TS) ? kt : kt + 1;      // tile row (= column) of the next pivot
-    const bool active = !masked || s.isnull[k];      // uniform
-    const bool pub = kn < N && (!masked || s.isnull[kn]);   // the next pivot row is only needed if that pivot is used
+    const bool active = (bits >> A) & 1;             // uniform
+    const bool pub = (bits >> (A + 1)) & 1;          // the next pivot row is only needed if that pivot is used
     if (!active && !pub) return;
     ex.par([&](Th &t) {
       if (t.mact) {
@@ -1129,6 +1139,11 @@ struct Solver {
         const double *G = s.Gm + 9 * f + 3 * (j - 3 * f);
         s.u0[j] = G[0] * v[0] + G[1] * v[1] + G[2] * v[2];
         s.xN[j] = 0; s.PxN[j] = 0; s.wv[j] = 0;
+        if (j % TS == 0) {
+          int m = 0;
+          for (int b = 0; b < TS; ++b) m |= (s.isnull[j + b] ? 1 : 0) << b;
+          s.rowmask[j / TS] = m;
+        }
       }
     });
     MPC_SUBLAP(3, 10);
