@@ -154,6 +154,7 @@ def main():
     }
     if not args.no_control_loop:
         out["control_loop"] = control_loop_leg(n, h, dev)
+        out["policy"] = policy_leg(n, dev)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, batches, W, h, gpu_first_forces=first_forces)
         out["max_grf_err_vs_osqp"] = out["cpu_baseline"].pop("_gpu_err", None)
@@ -184,6 +185,32 @@ def control_loop_leg(n, h, dev, ticks=40, warm=10):
     return {"robot_ticks_per_s": n * ticks / dt, "ms_per_tick": dt / ticks * 1e3, "ticks": ticks, "mpc_every_n_ticks": 2,
             "solved_fraction_last_mpc": solved,
             "note": "controller.run for every robot per tick; the MPC solve runs on every 2nd tick, so this is ~2x the control-step rate by construction"}
+
+
+def policy_leg(n, dev, steps=50, warm=5):
+    """Secondary figure: the weight policy in front of the controller (observations -> 48-512-256-128-12 ELU actor ->
+    MPC weights -> command record) for all robots, random-init parameters of the reference architecture."""
+    import torch
+    from rl_mpc_locomotion_amd.weight_policy import WeightPolicy
+    rng = np.random.default_rng(99)
+    dims = [48, 512, 256, 128, 12]
+    layers = [((rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32), np.zeros(dims[i + 1], np.float32)) for i in range(4)]
+    pol = WeightPolicy(layers, device=dev)
+    t = lambda *shape: torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).to(dev)
+    dof, est, nrm, cmd, act = t(n, 12, 2), t(n, 18), t(n, 3), t(n, 3), t(n, 12)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for k in range(warm + steps):
+        if k == warm:
+            ev0.record()
+        obs = pol.compute_observations(dof, est, nrm, cmd, act)
+        w = pol.step(obs)
+        pol.pack_commands(cmd, w)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    ms = ev0.elapsed_time(ev1) / steps
+    flops = 2.0 * n * sum(dims[i] * dims[i + 1] for i in range(4))
+    return {"ms_per_step": ms, "robots": n, "tflops_fp32": flops / (ms * 1e-3) / 1e12,
+            "note": "three launches per step (observations, fused MLP on the fp32 MFMA pipe, command packing); not part of `value`"}
 
 
 def usable_cores():

@@ -125,6 +125,39 @@ int mpc_ctrl_reset(mpc_ctrl *c, const int *ids, int k, void *stream);      /* HO
 int mpc_ctrl_set_gait(mpc_ctrl *c, const int *gait_id, void *stream);       /* HOST [n] */
 int mpc_ctrl_solver_info(mpc_ctrl *c, int *h_info);                          /* [n, 8] of the last solves */
 
+/* ---- weight policy: observations -> MPC weights (the deployment path of the learned policy) ----------
+ *
+ *   mpc_policy_create        <- WeightPolicy.__init__ (RL_Environment/WeightPolicy.py:33-92): the actor of rsl_rl's
+ *                               ActorCritic (act_inference = actor(obs), a Linear/ELU stack, hidden sizes
+ *                               LeggedCfgPPO.policy.actor_hidden_dims = [512, 256, 128],
+ *                               RL_Environment/tasks/legged_config_ppo.py:5-9) with the parameters of a loaded
+ *                               state_dict; weights[l] is layer l's torch Linear.weight, [dims[l+1]][dims[l]] row-major.
+ *                               act_scale / act_const = Parameters.MPC_param_scale / MPC_param_const
+ *                               (MPC_Controller/Parameters.py:25-33).
+ *   mpc_policy_step          <- WeightPolicy.step (:94-118): actions = actor(obs); weights = clamp(actions, -1, 1) *
+ *                               scale + const.  d_obs [n, dims[0]], d_actions [n, dims[L]] (raw actor output, may be
+ *                               NULL), d_weights [n, dims[L]]; float32, fp32 arithmetic (MFMA f32).
+ *   mpc_policy_observations  <- WeightPolicy.compute_observations (:120-139): 48 floats per robot =
+ *                               vBody * lin, omegaBody * ang, -ground_normal_yaw, commands * (lin, lin, ang),
+ *                               dof_pos * dof_pos_scale, dof_vel * dof_vel_scale, previous actions.
+ *                               d_est [n, 18] = vBody3, omegaBody3, rpyBody3, ground_R_body_frame9 (the record
+ *                               mpc_ctrl_step takes); scales4 = {lin, ang, dof_pos, dof_vel} (HOST).
+ *   mpc_ctrl_estimate        <- the StateEstimate the reference hands to compute_observations: copies the result of
+ *                               the last mpc_ctrl_run's StateEstimator.update ([n, 18]) and the controller's
+ *                               ground_normal_yaw ([n, 3], StateEstimator.py:99-143) to caller buffers (either may be NULL).
+ *   mpc_pack_commands        <- np.concatenate((commands, actions_rescale, [0.0])) (RL_Environment/tasks/aliengo.py:251):
+ *                               [n, 3] + [n, 12] -> the [n, 16] command record of mpc_ctrl_step / mpc_ctrl_run.
+ */
+typedef struct mpc_policy mpc_policy;
+int mpc_policy_create(mpc_policy **out, int n_layers, const int *dims, const float *const *weights, const float *const *biases,
+                      const float *act_scale, const float *act_const);
+void mpc_policy_destroy(mpc_policy *p);
+int mpc_policy_step(mpc_policy *p, int n, const float *d_obs, float *d_actions, float *d_weights, void *stream);
+int mpc_policy_observations(int n, const float *d_dof, const float *d_est, const float *d_ground_normal, const float *d_cmd3,
+                            const float *d_prev_actions, const float *scales4, float *d_obs, void *stream);
+int mpc_ctrl_estimate(mpc_ctrl *c, float *d_est, float *d_ground_normal, void *stream);
+int mpc_pack_commands(int n, const float *d_cmd3, const float *d_weights12, float *d_cmd16, void *stream);
+
 const char *mpc_last_error(void);
 
 #ifdef __cplusplus

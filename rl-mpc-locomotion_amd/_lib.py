@@ -14,6 +14,7 @@ SYMBOLS = [
     "mpc_batch_reset", "mpc_batch_solve_host", "mpc_batch_size", "mpc_batch_horizon", "mpc_batch_device_bytes",
     "mpc_batch_state_len", "mpc_batch_get_state", "mpc_batch_set_state", "mpc_batch_get_profile", "mpc_last_error",
     "mpc_ctrl_create", "mpc_ctrl_destroy", "mpc_ctrl_step", "mpc_ctrl_run", "mpc_ctrl_reset", "mpc_ctrl_set_gait", "mpc_ctrl_solver_info",
+    "mpc_policy_create", "mpc_policy_destroy", "mpc_policy_step", "mpc_policy_observations", "mpc_ctrl_estimate", "mpc_pack_commands",
 ]
 
 
@@ -51,6 +52,12 @@ def lib():
         L.mpc_ctrl_reset.argtypes = [vp, vp, ci, vp]; L.mpc_ctrl_reset.restype = ci
         L.mpc_ctrl_set_gait.argtypes = [vp, vp, vp]; L.mpc_ctrl_set_gait.restype = ci
         L.mpc_ctrl_solver_info.argtypes = [vp, vp]; L.mpc_ctrl_solver_info.restype = ci
+        L.mpc_policy_create.argtypes = [C.POINTER(vp), ci, vp, vp, vp, vp, vp]; L.mpc_policy_create.restype = ci
+        L.mpc_policy_destroy.argtypes = [vp]; L.mpc_policy_destroy.restype = None
+        L.mpc_policy_step.argtypes = [vp, ci, vp, vp, vp, vp]; L.mpc_policy_step.restype = ci
+        L.mpc_policy_observations.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, vp]; L.mpc_policy_observations.restype = ci
+        L.mpc_ctrl_estimate.argtypes = [vp, vp, vp, vp]; L.mpc_ctrl_estimate.restype = ci
+        L.mpc_pack_commands.argtypes = [ci, vp, vp, vp, vp]; L.mpc_pack_commands.restype = ci
         L.mpc_last_error.argtypes = []; L.mpc_last_error.restype = C.c_char_p
         _LIB = L
     return _LIB

@@ -11,6 +11,7 @@
 #include "controller.h"
 #include "mpc_core.h"
 #include "mpc_model.h"
+#include "policy_mlp.h"
 
 using namespace mpc;
 
@@ -405,6 +406,98 @@ int mpc_ctrl_solver_info(mpc_ctrl *c, int *h_info) {
   if (!c || !h_info) return fail(MPC_E_ARG, "mpc_ctrl_solver_info: bad argument");
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(h_info, c->d_info, sizeof(int) * (size_t)c->n * kInfoLen, hipMemcpyDeviceToHost));
+  return MPC_OK;
+}
+
+// ---- weight policy (RL_Environment/WeightPolicy.py) ------------------------------------------------------
+struct mpc_policy {
+  policy::Net net{};
+  float *d_params = nullptr;   // all weights and biases, one allocation
+  size_t lds = 0;
+};
+
+namespace {
+__global__ void ctrl_estimate_kernel(int n, const CtrlState *st, const float *est_in, float *est_out, float *normal_out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  if (est_out) for (int k = 0; k < 18; ++k) est_out[18 * r + k] = est_in[18 * r + k];
+  if (normal_out) for (int k = 0; k < 3; ++k) normal_out[3 * r + k] = st[r].normal[k];
+}
+}  // namespace
+
+void mpc_policy_destroy(mpc_policy *p) {
+  if (!p) return;
+  if (p->d_params) (void)hipFree(p->d_params);
+  delete p;
+}
+
+int mpc_policy_create(mpc_policy **out, int n_layers, const int *dims, const float *const *weights, const float *const *biases,
+                      const float *act_scale, const float *act_const) {
+  if (!out || n_layers <= 0 || n_layers > policy::kMaxLayers || !dims || !weights || !biases || !act_scale || !act_const)
+    return fail(MPC_E_ARG, "mpc_policy_create: bad argument");
+  size_t total = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    if (dims[l] <= 0 || dims[l + 1] <= 0 || dims[l] % 8 != 0 || !weights[l] || !biases[l])
+      return fail(MPC_E_ARG, "mpc_policy_create: layer input widths must be positive multiples of 8");
+    total += (size_t)dims[l] * dims[l + 1] + (((size_t)dims[l + 1] + 7) / 8) * 8;   // keeps every array 32-byte aligned
+  }
+  if (dims[n_layers] > 16) return fail(MPC_E_ARG, "mpc_policy_create: at most 16 outputs");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MPC_E_NODEVICE, "mpc_policy_create: no HIP device");
+  mpc_policy *p = new mpc_policy();
+  p->net.n_layers = n_layers;
+  for (int l = 0; l <= n_layers; ++l) p->net.dims[l] = dims[l];
+  std::vector<float> host(total, 0.f);
+  if (hipMalloc(&p->d_params, sizeof(float) * total) != hipSuccess) { delete p; return fail(MPC_E_HIP, "mpc_policy_create: hipMalloc"); }
+  size_t off = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    const size_t nw = (size_t)dims[l] * dims[l + 1], nb = (((size_t)dims[l + 1] + 7) / 8) * 8;
+    std::memcpy(host.data() + off, weights[l], sizeof(float) * nw);
+    p->net.w[l] = p->d_params + off; off += nw;
+    std::memcpy(host.data() + off, biases[l], sizeof(float) * dims[l + 1]);
+    p->net.b[l] = p->d_params + off; off += nb;
+  }
+  for (int k = 0; k < dims[n_layers]; ++k) { p->net.scale[k] = act_scale[k]; p->net.shift[k] = act_const[k]; }
+  p->lds = policy::lds_bytes(p->net);
+  if (p->lds > 160 * 1024) { mpc_policy_destroy(p); return fail(MPC_E_ARG, "mpc_policy_create: layers too wide for one CU's LDS"); }
+  if (hipMemcpy(p->d_params, host.data(), sizeof(float) * total, hipMemcpyHostToDevice) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void *>(policy::mlp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds) != hipSuccess) {
+    mpc_policy_destroy(p);
+    return fail(MPC_E_HIP, "mpc_policy_create: device set-up failed");
+  }
+  *out = p;
+  return MPC_OK;
+}
+
+int mpc_policy_step(mpc_policy *p, int n, const float *d_obs, float *d_actions, float *d_weights, void *stream) {
+  if (!p || n <= 0 || !d_obs || !d_weights) return fail(MPC_E_ARG, "mpc_policy_step: bad argument");
+  const int blocks = (n + policy::kRows - 1) / policy::kRows;
+  hipLaunchKernelGGL(policy::mlp_kernel, dim3(blocks), dim3(policy::kThreads), p->lds, (hipStream_t)stream, p->net, n, d_obs, d_actions, d_weights);
+  HIP_TRY(hipGetLastError());
+  return MPC_OK;
+}
+
+int mpc_policy_observations(int n, const float *d_dof, const float *d_est, const float *d_normal, const float *d_cmd3,
+                            const float *d_prev_actions, const float *scales4, float *d_obs, void *stream) {
+  if (n <= 0 || !d_dof || !d_est || !d_normal || !d_cmd3 || !d_prev_actions || !scales4 || !d_obs)
+    return fail(MPC_E_ARG, "mpc_policy_observations: bad argument");
+  hipLaunchKernelGGL(policy::observations_kernel, dim3((n * 48 + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, d_dof, d_est, d_normal,
+                     d_cmd3, d_prev_actions, scales4[0], scales4[1], scales4[2], scales4[3], d_obs);
+  HIP_TRY(hipGetLastError());
+  return MPC_OK;
+}
+
+int mpc_pack_commands(int n, const float *d_cmd3, const float *d_weights12, float *d_cmd16, void *stream) {
+  if (n <= 0 || !d_cmd3 || !d_weights12 || !d_cmd16) return fail(MPC_E_ARG, "mpc_pack_commands: bad argument");
+  hipLaunchKernelGGL(policy::pack_commands_kernel, dim3((n * 16 + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, d_cmd3, d_weights12, d_cmd16);
+  HIP_TRY(hipGetLastError());
+  return MPC_OK;
+}
+
+int mpc_ctrl_estimate(mpc_ctrl *c, float *d_est, float *d_ground_normal, void *stream) {
+  if (!c || (!d_est && !d_ground_normal)) return fail(MPC_E_ARG, "mpc_ctrl_estimate: bad argument");
+  hipLaunchKernelGGL(ctrl_estimate_kernel, dim3((c->n + 127) / 128), dim3(128), 0, (hipStream_t)stream, c->n, c->d_state, c->d_est, d_est, d_ground_normal);
+  HIP_TRY(hipGetLastError());
   return MPC_OK;
 }
 

@@ -86,6 +86,16 @@ class BatchedLocomotion:
         _lib.check(_lib.lib().mpc_ctrl_set_gait(self._handle, gi.ctypes.data, stream), "mpc_ctrl_set_gait")
         torch.cuda.current_stream(self.device).synchronize()
 
+    def estimate(self):
+        """(est [n,18], ground_normal_yaw [n,3]) of the last ``run``: the StateEstimate the reference passes to
+        ``WeightPolicy.compute_observations`` (vBody, omegaBody, rpyBody, ground_R_body_frame; StateEstimator.py:99-143)."""
+        import torch
+        est = torch.empty((self.n, 18), dtype=torch.float32, device=self.device)
+        nrm = torch.empty((self.n, 3), dtype=torch.float32, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.lib().mpc_ctrl_estimate(self._handle, est.data_ptr(), nrm.data_ptr(), stream), "mpc_ctrl_estimate")
+        return est, nrm
+
     def solver_info(self):
         out = np.zeros((self.n, 8), dtype=np.int32)
         _lib.check(_lib.lib().mpc_ctrl_solver_info(self._handle, out.ctypes.data), "mpc_ctrl_solver_info")

@@ -1,0 +1,144 @@
+"""Weight policy: oracle vs the torch-minted golden vectors on the CPU; the HIP MLP /
+observation / command-packing kernels vs the oracle on the GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import policy_ref
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "policy_mlp.npz")
+# fp32 network, 512-term dot products: the MFMA chain and a CPU sgemm differ by summation order only
+ACT_ATOL, ACT_RTOL = 2e-5, 2e-5
+
+
+def _gold():
+    g = np.load(GOLD)
+    sd = {k.replace("__", "."): g[k] for k in g.files if k.startswith("actor")}
+    return g, sd
+
+
+def test_oracle_matches_torch_golden():
+    g, sd = _gold()
+    params = policy_ref.actor_params_from_state_dict(sd)
+    assert [w.shape for w, _ in params] == [(512, 48), (256, 512), (128, 256), (12, 128)]
+    act, wts = policy_ref.step(params, g["obs"])
+    np.testing.assert_allclose(act, g["actions"], rtol=ACT_RTOL, atol=ACT_ATOL)
+    np.testing.assert_allclose(wts, g["weights"], rtol=ACT_RTOL, atol=20 * ACT_ATOL)
+    assert (np.abs(g["actions"]) > 1).any() and (np.abs(g["actions"]) < 1).any()     # the clamp is exercised both ways
+
+
+def test_oracle_observation_layout():
+    """WeightPolicy.compute_observations (WeightPolicy.py:120-139): order and scaling of the 48 entries."""
+    rng = np.random.default_rng(0)
+    n = 3
+    dof = rng.normal(size=(n, 12, 2)).astype(np.float32)
+    vb, om, nrm = (rng.normal(size=(n, 3)).astype(np.float32) for _ in range(3))
+    cmd = rng.normal(size=(n, 3)).astype(np.float32); act = rng.normal(size=(n, 12)).astype(np.float32)
+    o = policy_ref.observations(dof, vb, om, nrm, cmd, act, lin=2.0, ang=0.25, dof_pos=1.0, dof_vel=0.05)
+    assert o.shape == (n, 48)
+    np.testing.assert_array_equal(o[:, 0:3], vb * np.float32(2.0))
+    np.testing.assert_array_equal(o[:, 3:6], om * np.float32(0.25))
+    np.testing.assert_array_equal(o[:, 6:9], -nrm)
+    np.testing.assert_array_equal(o[:, 9:12], cmd * np.array([2.0, 2.0, 0.25], np.float32))
+    np.testing.assert_array_equal(o[:, 12:24], dof[:, :, 0])
+    np.testing.assert_array_equal(o[:, 24:36], dof[:, :, 1] * np.float32(0.05))
+    np.testing.assert_array_equal(o[:, 36:48], act)
+
+
+def test_reference_constants():
+    """scale / const tables and the actor sizes against the reference sources (skipped where /root/reference is absent)."""
+    ref = "/root/reference"
+    if not os.path.isdir(ref):
+        pytest.skip("reference tree not present")
+    import re
+    src = open(os.path.join(ref, "MPC_Controller", "Parameters.py")).read()
+    def table(name):
+        body = re.search(name + r"\s*=\s*\[(.*?)\]", src, re.S).group(1)
+        return [float(x) for x in re.findall(r"[-+]?\d+\.?\d*", re.sub(r"#.*", "", body))]
+    assert table("MPC_param_scale") == list(policy_ref.MPC_PARAM_SCALE)
+    assert table("MPC_param_const") == list(policy_ref.MPC_PARAM_CONST)
+    cfg = open(os.path.join(ref, "RL_Environment", "tasks", "legged_config_ppo.py")).read()
+    assert "actor_hidden_dims = [512, 256, 128]" in cfg and "activation = 'elu'" in cfg
+    import rl_mpc_locomotion_amd  # noqa: F401
+    from rl_mpc_locomotion_amd import weight_policy
+    assert list(weight_policy.MPC_PARAM_SCALE) == list(policy_ref.MPC_PARAM_SCALE)
+    assert list(weight_policy.MPC_PARAM_CONST) == list(policy_ref.MPC_PARAM_CONST)
+
+
+# ------------------------------------------------------------------------------------------------- GPU
+def _policy(sd, **kw):
+    import rl_mpc_locomotion_amd  # noqa: F401
+    from rl_mpc_locomotion_amd.weight_policy import WeightPolicy
+    return WeightPolicy.from_state_dict(sd, **kw)
+
+
+@pytest.mark.gpu
+def test_gpu_mlp_matches_golden_and_oracle():
+    import torch
+    g, sd = _gold()
+    pol = _policy(sd)
+    w, a = pol.step(torch.from_numpy(g["obs"]).cuda(), return_actions=True)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(a.cpu().numpy(), g["actions"], rtol=ACT_RTOL, atol=ACT_ATOL)
+    np.testing.assert_allclose(w.cpu().numpy(), g["weights"], rtol=ACT_RTOL, atol=20 * ACT_ATOL)
+    # sizes around the 32-robot tile, against the oracle on fresh inputs
+    params = policy_ref.actor_params_from_state_dict(sd)
+    rng = np.random.default_rng(1)
+    for n in (1, 31, 32, 33, 4096):
+        obs = rng.normal(0, 1.5, (n, 48)).astype(np.float32)
+        w = pol.step(torch.from_numpy(obs).cuda()).cpu().numpy()
+        _, wr = policy_ref.step(params, obs)
+        np.testing.assert_allclose(w, wr, rtol=ACT_RTOL, atol=20 * ACT_ATOL)
+
+
+@pytest.mark.gpu
+def test_gpu_observations_and_pack_commands():
+    import torch
+    g, sd = _gold()
+    scales = (2.0, 0.25, 1.0, 0.05)
+    pol = _policy(sd, obs_scales=scales)
+    rng = np.random.default_rng(2)
+    n = 100
+    dof = rng.normal(size=(n, 12, 2)).astype(np.float32); est = rng.normal(size=(n, 18)).astype(np.float32)
+    nrm = rng.normal(size=(n, 3)).astype(np.float32); cmd = rng.normal(size=(n, 3)).astype(np.float32)
+    act = rng.normal(size=(n, 12)).astype(np.float32)
+    t = lambda x: torch.from_numpy(x).cuda()
+    obs = pol.compute_observations(t(dof), t(est), t(nrm), t(cmd), t(act)).cpu().numpy()
+    ref = policy_ref.observations(dof, est[:, 0:3], est[:, 3:6], nrm, cmd, act, *scales)
+    np.testing.assert_array_equal(obs, ref)                       # one float32 multiply per entry: bit-exact
+    wts = rng.normal(size=(n, 12)).astype(np.float32)
+    c16 = pol.pack_commands(t(cmd), t(wts)).cpu().numpy()
+    np.testing.assert_array_equal(c16, np.concatenate((cmd, wts, np.zeros((n, 1), np.float32)), axis=1))
+
+
+@pytest.mark.gpu
+def test_gpu_policy_drives_the_controller():
+    """obs from the controller's own estimate -> policy -> command record -> controller.run: the deployment loop of
+    RL_MPC_Locomotion.py with tensors; the weights entering the solver are the policy's."""
+    import torch
+    import rl_mpc_locomotion_amd  # noqa: F401
+    from rl_mpc_locomotion_amd.locomotion import BatchedLocomotion
+    from rl_mpc_locomotion_amd.synthetic import TickStream
+    g, sd = _gold()
+    pol = _policy(sd)
+    n = 64
+    loco = BatchedLocomotion(np.zeros(n, np.int32), np.zeros(n, np.int32), horizon=10)
+    ts = TickStream(n, seed=3)
+    params = policy_ref.actor_params_from_state_dict(sd)
+    actions = torch.zeros((n, 12), dtype=torch.float32, device="cuda")
+    for tick in range(4):
+        dof, body, cmd16 = ts.tick(tick)
+        dof_t, body_t = torch.from_numpy(dof).cuda(), torch.from_numpy(body).cuda()
+        cmd3 = torch.from_numpy(np.ascontiguousarray(cmd16[:, :3])).cuda()
+        if tick == 0:
+            loco.run(dof_t, body_t, torch.from_numpy(cmd16).cuda())       # produces the first estimate
+        est, nrm = loco.estimate()
+        obs = pol.compute_observations(dof_t, est, nrm, cmd3, actions)
+        weights, actions = pol.step(obs, return_actions=True)
+        _, wr = policy_ref.step(params, obs.cpu().numpy())
+        np.testing.assert_allclose(weights.cpu().numpy(), wr, rtol=ACT_RTOL, atol=20 * ACT_ATOL)
+        tau = loco.run(dof_t, body_t, pol.pack_commands(cmd3, weights))
+        torch.cuda.synchronize()
+        assert torch.isfinite(tau).all()
+    assert (loco.solver_info()[:, 1] == 1).all()
