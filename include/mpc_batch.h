@@ -125,6 +125,29 @@ int mpc_ctrl_reset(mpc_ctrl *c, const int *ids, int k, void *stream);      /* HO
 int mpc_ctrl_set_gait(mpc_ctrl *c, const int *gait_id, void *stream);       /* HOST [n] */
 int mpc_ctrl_solver_info(mpc_ctrl *c, int *h_info);                          /* [n, 8] of the last solves */
 
+/* ---- control FSM around the controller (RobotRunnerFSM) -------------------------------------------
+ *
+ *   mpc_ctrl_fsm_init   <- RobotRunnerFSM.init (robot_runner/RobotRunnerFSM.py:13-39) -> ControlFSM.__init__ / initialize
+ *                          (FSM_states/ControlFSM.py:28-78): fresh controller objects, then onEnter of the state named by
+ *                          control_mode[r] (HOST [n]; 0 PASSIVE, 4 LOCOMOTION, 6 RECOVERY_STAND = FSM_StateName,
+ *                          MPC_Controller/utils.py:26-30).  The reference's process-global Parameters.control_mode /
+ *                          operatingMode / FSM_check_safety (Parameters.py:35-42) become per-robot / per-handle here;
+ *                          operating_mode: 0 TEST, 1 NORMAL (utils.py:32-35).
+ *   mpc_ctrl_run_fsm    <- RobotRunnerFSM.run(dof_states, body_states, commands) (:44-71): updateData, zeroCommand,
+ *                          StateEstimator.update, ControlFSM.runFSM (:80-124 -- Passive / RecoveryStand joint-PD states,
+ *                          Locomotion = the mpc_ctrl_run path incl. locomotionSafe, FSM_State_Locomotion.py:104-136),
+ *                          LegController.updateCommand.  d_request [n] int32 = the control mode requested for each robot
+ *                          this tick (what Parameters.control_mode holds when the reference's run() is called).
+ *   mpc_ctrl_fsm_reset  <- RobotRunnerFSM.reset (:41-42) = ControlFSM.initialize for the robots in ids (HOST, NULL = all),
+ *                          control_mode HOST [n] or NULL (keep the modes of the last initialisation).
+ *   mpc_ctrl_fsm_state  <- [n, 4] int32 HOST: current FSM_StateName, operating mode, RecoveryStand flag (0 StandUp, 1 FoldLegs,
+ *                          2 RollOver), and the per-robot "locomotion was unsafe" flag (Parameters.locomotionUnsafe).
+ */
+int mpc_ctrl_fsm_init(mpc_ctrl *c, const int *control_mode, int operating_mode, int check_safety, void *stream);
+int mpc_ctrl_run_fsm(mpc_ctrl *c, const float *d_dof, const float *d_body, const float *d_cmd, const int *d_request, float *d_torques, void *stream);
+int mpc_ctrl_fsm_reset(mpc_ctrl *c, const int *ids, int k, const int *control_mode, void *stream);
+int mpc_ctrl_fsm_state(mpc_ctrl *c, int *h_out);
+
 /* ---- weight policy: observations -> MPC weights (the deployment path of the learned policy) ----------
  *
  *   mpc_policy_create        <- WeightPolicy.__init__ (RL_Environment/WeightPolicy.py:33-92): the actor of rsl_rl's

@@ -14,6 +14,7 @@ SYMBOLS = [
     "mpc_batch_reset", "mpc_batch_solve_host", "mpc_batch_size", "mpc_batch_horizon", "mpc_batch_device_bytes",
     "mpc_batch_state_len", "mpc_batch_get_state", "mpc_batch_set_state", "mpc_batch_get_profile", "mpc_last_error",
     "mpc_ctrl_create", "mpc_ctrl_destroy", "mpc_ctrl_step", "mpc_ctrl_run", "mpc_ctrl_reset", "mpc_ctrl_set_gait", "mpc_ctrl_solver_info",
+    "mpc_ctrl_fsm_init", "mpc_ctrl_run_fsm", "mpc_ctrl_fsm_reset", "mpc_ctrl_fsm_state",
     "mpc_policy_create", "mpc_policy_destroy", "mpc_policy_step", "mpc_policy_observations", "mpc_ctrl_estimate", "mpc_pack_commands",
 ]
 
@@ -52,6 +53,10 @@ def lib():
         L.mpc_ctrl_reset.argtypes = [vp, vp, ci, vp]; L.mpc_ctrl_reset.restype = ci
         L.mpc_ctrl_set_gait.argtypes = [vp, vp, vp]; L.mpc_ctrl_set_gait.restype = ci
         L.mpc_ctrl_solver_info.argtypes = [vp, vp]; L.mpc_ctrl_solver_info.restype = ci
+        L.mpc_ctrl_fsm_init.argtypes = [vp, vp, ci, ci, vp]; L.mpc_ctrl_fsm_init.restype = ci
+        L.mpc_ctrl_run_fsm.argtypes = [vp, vp, vp, vp, vp, vp, vp]; L.mpc_ctrl_run_fsm.restype = ci
+        L.mpc_ctrl_fsm_reset.argtypes = [vp, vp, ci, vp, vp]; L.mpc_ctrl_fsm_reset.restype = ci
+        L.mpc_ctrl_fsm_state.argtypes = [vp, vp]; L.mpc_ctrl_fsm_state.restype = ci
         L.mpc_policy_create.argtypes = [C.POINTER(vp), ci, vp, vp, vp, vp, vp]; L.mpc_policy_create.restype = ci
         L.mpc_policy_destroy.argtypes = [vp]; L.mpc_policy_destroy.restype = None
         L.mpc_policy_step.argtypes = [vp, ci, vp, vp, vp, vp]; L.mpc_policy_step.restype = ci

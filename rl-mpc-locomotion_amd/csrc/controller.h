@@ -246,6 +246,21 @@ MPC_HD void estimator_update(const float *body, const float *normal, float *est)
   est[6] = roll; est[7] = pitch; est[8] = yawb;
 }
 
+// LegController.updateData (LegController.py:89-106): joint state, leg FK / Jacobian, foot velocity
+MPC_HD void leg_update_data(CtrlState &s, const RobotConst &rc, const float *dof) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  for (int leg = 0; leg < 4; ++leg) {
+    for (int j = 0; j < 3; ++j) { s.q[3 * leg + j] = dof[2 * (3 * leg + j)]; s.qd[3 * leg + j] = dof[2 * (3 * leg + j) + 1]; }
+    leg_kinematics(rc, leg, s.q + 3 * leg, s.p + 3 * leg, s.J + 9 * leg);
+    for (int r = 0; r < 3; ++r) {
+      const float *Jr = s.J + 9 * leg + 3 * r, *qd = s.qd + 3 * leg;
+      s.v[3 * leg + r] = Jr[0] * qd[0] + Jr[1] * qd[1] + Jr[2] * qd[2];
+    }
+  }
+}
+
 // ---- first half of the tick -----------------------------------------------------------------
 // dof: [12][2] (pos, vel) leg-major; est: kEstLen floats; cmd: 16 floats (vx vy yaw_rate w[13]).
 // rec: solver input record [56 + 4h] (written only when s.do_solve).
@@ -255,15 +270,7 @@ MPC_HD void ctrl_pre(CtrlState &s, const RobotConst &rc, const GaitTable &gt, co
 #pragma clang fp contract(off)
 #endif
   const int nseg = gt.n_seg;
-  // LegController.updateData (LegController.py:89-106)
-  for (int leg = 0; leg < 4; ++leg) {
-    for (int j = 0; j < 3; ++j) { s.q[3 * leg + j] = dof[2 * (3 * leg + j)]; s.qd[3 * leg + j] = dof[2 * (3 * leg + j) + 1]; }
-    leg_kinematics(rc, leg, s.q + 3 * leg, s.p + 3 * leg, s.J + 9 * leg);
-    for (int r = 0; r < 3; ++r) {
-      const float *Jr = s.J + 9 * leg + 3 * r, *qd = s.qd + 3 * leg;
-      s.v[3 * leg + r] = Jr[0] * qd[0] + Jr[1] * qd[1] + Jr[2] * qd[2];
-    }
-  }
+  leg_update_data(s, rc, dof);
   const float *vBody = est, *omegaBody = est + 3, *rpyBody = est + 6, *gRb = est + 9;
   const float x_vel_des = cmd[0], y_vel_des = cmd[1], yaw_rate = cmd[2];   // ConvexMPCLocomotion.py:119-126
   const float *off = gt.offsets[s.gait_id], *dur = gt.durations[s.gait_id];
@@ -465,6 +472,222 @@ MPC_HD void ctrl_post(CtrlState &s, const RobotConst &rc, const double *forces, 
       tau += kdj * (0.f - s.qd[3 * foot + j]);                                             // kdJoint (qdDes = 0)
       torques[3 * foot + j] = tau;
     }
+  }
+}
+
+
+// ============================================================================================================
+// Control FSM (MPC_Controller/FSM_states/ControlFSM.py:71-124 runFSM; FSM_State_Passive.py, FSM_State_RecoveryStand.py,
+// FSM_State_Locomotion.py; driven by robot_runner/RobotRunnerFSM.py:44-71), one robot per thread.  The reference's
+// process-global Parameters.control_mode becomes a per-robot request, Parameters.locomotionUnsafe a per-robot flag.
+// ============================================================================================================
+enum { kFsmPassive = 0, kFsmLocomotion = 4, kFsmRecoveryStand = 6 };          // FSM_StateName (utils.py:26-30)
+enum { kOpTest = 0, kOpNormal = 1, kOpTransitioning = 2 };                    // FSM_OperatingMode (utils.py:32-35)
+enum { kRsStandUp = 0, kRsFoldLegs = 1, kRsRollOver = 2 };                    // FSM_State_RecoveryStand.py:8-10
+
+struct FsmParams {
+  int check_safety;                                      // Parameters.FSM_check_safety
+  int fold_ramp, fold_settle, standup_ramp, standup_settle, roll_ramp, roll_settle;   // int(k / (controller_dt * 100)), RecoveryStand :35-57
+};
+struct FsmState {
+  int cur, next_state, op_mode;
+  int passive_iter, loco_iter, rs_iter, rs_state_iter, rs_motion_start, rs_flag;
+  float rs_initial[12];
+  int unsafe;                     // set when locomotionSafe() failed (Parameters.locomotionUnsafe)
+  float last_rb22;                // rBody[2,2] of the estimator's current result (0 after StateEstimator.reset)
+  // this tick's outcome
+  int run_loco, entered_loco;     // ConvexMPCLocomotion.run is due / LOCOMOTION was entered (new ConvexMpc object: cold solver)
+  float qdes[12], kpj, kdj;       // joint PD command (kp = kd = 0 after zeroCommand when no state ran)
+};
+
+MPC_HD FsmParams fsm_params(double controller_dt, int check_safety) {
+  FsmParams P;
+  const double d = controller_dt * 100.0;
+  P.check_safety = check_safety;
+  P.fold_ramp = (int)(45 / d); P.fold_settle = (int)(75 / d); P.standup_ramp = (int)(30 / d); P.standup_settle = (int)(30 / d);
+  P.roll_ramp = (int)(13 / d); P.roll_settle = (int)(15 / d);
+  return P;
+}
+// rBody[2,2] of quat_to_rot (orientation_tools.py:135-149; float32 arithmetic, float16 storage) -- _UpsideDown reads its sign
+MPC_HD float rbody22(const float *body) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  const float e1 = body[3], e2 = body[4];
+  return round_to_half(1.f - 2.f * (e1 * e1 + e2 * e2));
+}
+// roll and pitch of quat_to_rpy (orientation_tools.py:120-133) as the estimator stores them (float16)
+MPC_HD void world_roll_pitch(const float *body, float *roll, float *pitch) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  const float x = body[3], y = body[4], z = body[5], w = body[6];
+  *roll = round_to_half(atan2f(2.f * (y * z + w * x), w * w - x * x - y * y + z * z));
+  *pitch = round_to_half_d(asin(fmin((double)(-2.f * (x * z - w * y)), 0.99999)));
+}
+
+MPC_HD void fsm_on_enter(FsmState &f, int state, CtrlState &s, const RobotConst &rc, float rb22) {
+  f.next_state = state;
+  if (state == kFsmLocomotion) {            // FSM_State_Locomotion.onEnter (:32-42): cMPC.initialize, command reset, estimator reset
+    ctrl_reset(s, rc);
+    f.entered_loco = 1;
+    f.last_rb22 = 0.f;                      // stateEstimator.reset(): fresh StateEstimate (rBody = 0)
+  } else if (state == kFsmRecoveryStand) {  // FSM_State_RecoveyrStand.onEnter (:65-92)
+    f.rs_iter = 0; f.rs_state_iter = 0;
+    for (int k = 0; k < 12; ++k) f.rs_initial[k] = s.q[k];
+    const float h = s.pos_z;                // stateEstimator.getResult().position[2]
+    f.rs_flag = kRsFoldLegs;
+    if (!(rb22 < 0.f) && 0.2f < h && h < 0.45f) f.rs_flag = kRsStandUp;
+    f.rs_motion_start = 0;
+  }
+}
+
+// ControlFSM.__init__ / initialize (:28-78): fresh states, enter the state Parameters.control_mode names
+MPC_HD void fsm_init(FsmState &f, int control_mode, int op_mode, CtrlState &s, const RobotConst &rc, float rb22) {
+  f.passive_iter = 0; f.loco_iter = 0; f.rs_iter = 0; f.rs_state_iter = 0; f.rs_motion_start = 0; f.rs_flag = kRsFoldLegs;
+  for (int k = 0; k < 12; ++k) { f.rs_initial[k] = 0.f; f.qdes[k] = 0.f; }
+  f.unsafe = 0; f.run_loco = 0; f.entered_loco = 0; f.kpj = 0.f; f.kdj = 0.f; f.last_rb22 = rb22;
+  f.cur = control_mode;
+  fsm_on_enter(f, control_mode, s, rc, rb22);
+  f.op_mode = op_mode;
+}
+// ControlFSM.initialize again (RobotRunnerFSM.reset, :41-42): the state objects and their counters persist
+MPC_HD void fsm_reinit(FsmState &f, int control_mode, int op_mode, CtrlState &s, const RobotConst &rc, float rb22) {
+  f.cur = control_mode;
+  fsm_on_enter(f, control_mode, s, rc, rb22);
+  f.op_mode = op_mode;
+}
+
+MPC_HD void fsm_joint_pd(FsmState &f, int leg, const float *qdes) {   // FSM_State.jointPDControl (:44-66): kp = 80 I, kd = I
+  for (int j = 0; j < 3; ++j) f.qdes[3 * leg + j] = qdes[j];
+  f.kpj = 80.f; f.kdj = 1.f;
+}
+MPC_HD void fsm_interp(FsmState &f, int curr, int max_iter, const float *fin12) {   // _SetJPosInterPts (:167-181), all legs
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  double a = 0.0, b = 1.0;
+  if (curr <= max_iter) { b = (double)curr / (double)max_iter; a = 1.0 - b; }
+  const float af = (float)a, bf = (float)b;                 // Python floats enter the float32 array arithmetic as float32
+  for (int leg = 0; leg < 4; ++leg) {
+    float q[3];
+    for (int j = 0; j < 3; ++j) q[j] = af * f.rs_initial[3 * leg + j] + bf * fin12[3 * leg + j];
+    fsm_joint_pd(f, leg, q);
+  }
+}
+
+MPC_HD void fsm_run_state(FsmState &f, CtrlState &s, const RobotConst &rc, const FsmParams &P, float rb22) {
+  const float fold[12] = {0.0f, 1.4f, -2.7f, -0.0f, 1.4f, -2.7f, 0.0f, 1.4f, -2.7f, -0.0f, 1.4f, -2.7f};        // :37-41
+  const float stand[12] = {0.f, 0.8f, -1.6f, 0.f, 0.8f, -1.6f, 0.f, 0.8f, -1.6f, 0.f, 0.8f, -1.6f};            // :47-51
+  const float rolling[12] = {1.3f, 3.1f, -2.77f, 0.0f, 1.6f, -2.77f, 1.3f, 3.1f, -2.77f, 0.0f, 1.6f, -2.77f};  // :57-61
+  if (f.cur == kFsmPassive) {                 // FSM_State_Passive.run (:31-42)
+    if (f.passive_iter < 10) {
+      const float q[3] = {0.0f, 0.01f, 0.01f};
+      for (int leg = 0; leg < 4; ++leg) fsm_joint_pd(f, leg, q);
+    }
+  } else if (f.cur == kFsmLocomotion) {       // LocomotionControlStep (:138-139)
+    f.run_loco = 1;
+  } else {                                    // FSM_State_RecoveyrStand.run (:94-106)
+    const int curr = f.rs_state_iter - f.rs_motion_start;
+    const bool upside = rb22 < 0.f;
+    if (f.rs_flag == kRsStandUp) {            // _StandUp (:184-205)
+      const bool wrong = upside || rc.body_height < 0.1;
+      if (curr > (int)floor(P.standup_ramp * 0.7) && wrong) {
+        for (int k = 0; k < 12; ++k) f.rs_initial[k] = s.q[k];
+        f.rs_flag = kRsFoldLegs;
+        f.rs_motion_start = f.rs_state_iter + 1;
+      } else {
+        fsm_interp(f, curr, P.standup_ramp, stand);
+      }
+    } else if (f.rs_flag == kRsFoldLegs) {    // _FoldLegs (:209-224) -- ramps over rollover_ramp_iter, as written there
+      fsm_interp(f, curr, P.roll_ramp, fold);
+      if (curr >= P.fold_ramp + P.fold_settle) {
+        f.rs_flag = upside ? kRsRollOver : kRsStandUp;
+        for (int k = 0; k < 12; ++k) f.rs_initial[k] = fold[k];
+        f.rs_motion_start = f.rs_state_iter + 1;
+      }
+    } else {                                  // _RollOver (:226-235)
+      fsm_interp(f, curr, P.roll_ramp, rolling);
+      if (curr > P.roll_ramp + P.roll_settle) {
+        f.rs_flag = kRsFoldLegs;
+        for (int k = 0; k < 12; ++k) f.rs_initial[k] = rolling[k];
+        f.rs_motion_start = f.rs_state_iter + 1;
+      }
+    }
+    f.rs_state_iter += 1;
+  }
+}
+
+// FSM_State_Locomotion.locomotionSafe (:104-136), comparisons in the types numpy uses there: float16 angles against the
+// float16-rounded limit, float32 leg positions against float32 constants; the roll test has no abs (as written)
+MPC_HD bool fsm_locomotion_safe(const CtrlState &s, const FsmParams &P, const float *body) {
+  if (!P.check_safety) return true;
+  float roll, pitch;
+  world_roll_pitch(body, &roll, &pitch);
+  const float lim = round_to_half_d(40.0 * 3.14159265358979323846 / 180.0);
+  if (roll > lim) return false;
+  if (fabsf(pitch) > lim) return false;
+  for (int leg = 0; leg < 4; ++leg) {
+    if (s.p[3 * leg + 2] > 0.f) return false;
+    if (s.p[3 * leg + 1] > 0.18f) return false;
+  }
+  return true;
+}
+
+MPC_HD int fsm_check_transition(FsmState &f, const CtrlState &s, const FsmParams &P, int request, const float *body) {
+  if (f.cur == kFsmPassive) {                 // FSM_State_Passive.checkTransition (:52-74)
+    f.next_state = f.cur;
+    f.passive_iter += 1;
+    if (request == kFsmRecoveryStand) f.next_state = kFsmRecoveryStand;     // anything else but PASSIVE: refused
+  } else if (f.cur == kFsmRecoveryStand) {    // FSM_State_RecoveyrStand.checkTransition (:115-140)
+    f.next_state = f.cur;
+    f.rs_iter += 1;
+    if (request == kFsmLocomotion || request == kFsmPassive) f.next_state = request;
+  } else {                                    // FSM_State_Locomotion.checkTransition (:54-84)
+    f.loco_iter += 1;
+    if (fsm_locomotion_safe(s, P, body)) {
+      if (request == kFsmPassive || request == kFsmRecoveryStand) f.next_state = request;
+    } else {
+      f.next_state = kFsmRecoveryStand;
+      f.unsafe = 1;
+    }
+  }
+  return f.next_state;
+}
+
+// One tick of ControlFSM.runFSM after updateData / zeroCommand / StateEstimator.update.  On return f.run_loco tells whether
+// ConvexMPCLocomotion.run is due (the caller then runs ctrl_pre / solve / ctrl_post), otherwise f.qdes / kpj / kdj hold the
+// joint PD command of the tick.
+MPC_HD void fsm_tick(FsmState &f, CtrlState &s, const RobotConst &rc, const FsmParams &P, const float *dof, const float *body, int request) {
+  leg_update_data(s, rc, dof);
+  for (int k = 0; k < 12; ++k) f.qdes[k] = 0.f;
+  f.kpj = 0.f; f.kdj = 0.f; f.run_loco = 0; f.entered_loco = 0;
+  const float rb22 = rbody22(body);
+  f.last_rb22 = rb22;
+  if (f.op_mode == kOpTest) {
+    fsm_run_state(f, s, rc, P, rb22);
+  } else if (f.op_mode == kOpNormal) {
+    const int nxt = fsm_check_transition(f, s, P, request, body);
+    if (nxt != f.cur) { f.op_mode = kOpTransitioning; f.next_state = nxt; }
+    else fsm_run_state(f, s, rc, P, rb22);
+  } else {   // TRANSITIONING: every transition() of the three states completes at once (:86-105 / :142-164 / :76-85)
+    if (f.cur == kFsmLocomotion) f.loco_iter = 0;       // FSM_State_Locomotion.onExit (:50-51)
+    f.cur = f.next_state;
+    fsm_on_enter(f, f.cur, s, rc, rb22);
+    f.op_mode = kOpNormal;
+  }
+}
+
+// LegController.updateCommand (LegController.py:108-132) when only the joint PD part of the command is set
+MPC_HD void fsm_joint_torques(const FsmState &f, const CtrlState &s, float *torques) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  for (int k = 0; k < 12; ++k) {
+    float tau = 0.f;
+    tau += f.kpj * (f.qdes[k] - s.q[k]);
+    tau += f.kdj * (0.f - s.qd[k]);
+    torques[k] = tau;
   }
 }
 

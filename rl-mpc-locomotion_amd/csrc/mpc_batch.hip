@@ -263,6 +263,48 @@ __global__ void estimator_kernel(int n, const CtrlState *st, const float *body, 
   estimator_update(body + (size_t)r * 13, nrm, e);
   for (int k = 0; k < kEstLen; ++k) est[(size_t)r * kEstLen + k] = e[k];
 }
+__global__ void fsm_init_kernel(int n, CtrlState *st, FsmState *fs, const RobotConst *rc, const int *mode, int op_mode, const int *ids, int k, int fresh) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k) return;
+  const int r = ids ? ids[i] : i;
+  if (r < 0 || r >= n) return;
+  CtrlState s = st[r];
+  FsmState f = fs[r];
+  if (fresh) fsm_init(f, mode[r], op_mode, s, rc[s.robot_type], 0.f);
+  else fsm_reinit(f, mode[r], op_mode, s, rc[s.robot_type], f.last_rb22);
+  st[r] = s; fs[r] = f;
+}
+// RobotRunnerFSM.run up to the solver launch: fsm_tick, then ctrl_pre for the robots whose state runs the locomotion controller
+__global__ void fsm_pre_kernel(int n, CtrlState *st, FsmState *fs, const RobotConst *rc, GaitTable gt, CtrlParams cp, FsmParams fp,
+                               const float *dof, const float *body, const float *est, const float *cmd, const int *request, float *rec,
+                               int *active, double *solver_state, int state_len) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  CtrlState s = st[r];
+  FsmState f = fs[r];
+  fsm_tick(f, s, rc[s.robot_type], fp, dof + (size_t)r * 24, body + (size_t)r * 13, request[r]);
+  if (f.entered_loco)    // cMPC.initialize built a new ConvexMpc (ConvexMPCLocomotion.py:102-108): the next solve is a cold one
+    for (int k = 0; k < state_len; ++k) solver_state[(size_t)r * state_len + k] = 0.0;
+  int act = 0;
+  if (f.run_loco) {
+    ctrl_pre(s, rc[s.robot_type], gt, cp, dof + (size_t)r * 24, est + (size_t)r * kEstLen, cmd + (size_t)r * 16, rec + (size_t)r * (56 + 4 * cp.horizon));
+    act = s.do_solve;
+  }
+  active[r] = act;
+  st[r] = s; fs[r] = f;
+}
+__global__ void fsm_post_kernel(int n, CtrlState *st, const FsmState *fs, const RobotConst *rc, int horizon, const double *forces, const int *info,
+                                float *torques) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  if (fs[r].run_loco) {
+    CtrlState s = st[r];
+    ctrl_post(s, rc[s.robot_type], forces + (size_t)r * 12 * horizon, info[(size_t)r * kInfoLen + 1] == kStSolved, torques + (size_t)r * 12);
+    st[r] = s;
+  } else {
+    fsm_joint_torques(fs[r], st[r], torques + (size_t)r * 12);
+  }
+}
 __global__ void ctrl_post_kernel(int n, CtrlState *st, const RobotConst *rc, int horizon, const double *forces, const int *info,
                                  float *torques) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -284,6 +326,10 @@ struct mpc_ctrl {
   double *d_forces = nullptr;
   GaitTable gt;
   CtrlParams cp;
+  FsmState *d_fsm = nullptr;      // control FSM (allocated by mpc_ctrl_fsm_init)
+  int *d_fsm_mode = nullptr;      // per-robot control mode of the last (re)initialisation
+  FsmParams fp{};
+  int fsm_op_mode = kOpNormal;
 };
 
 extern "C" {
@@ -291,7 +337,7 @@ extern "C" {
 void mpc_ctrl_destroy(mpc_ctrl *c) {
   if (!c) return;
   mpc_batch_destroy(c->solver);
-  void *ptrs[] = {c->d_state, c->d_rc, c->d_robot_type, c->d_gait, c->d_active, c->d_info, c->d_rec, c->d_est, c->d_forces};
+  void *ptrs[] = {c->d_state, c->d_rc, c->d_robot_type, c->d_gait, c->d_active, c->d_info, c->d_rec, c->d_est, c->d_forces, c->d_fsm, c->d_fsm_mode};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   delete c;
 }
@@ -399,6 +445,77 @@ int mpc_ctrl_set_gait(mpc_ctrl *c, const int *gait_id, void *stream) {
   HIP_TRY(hipMemcpyAsync(c->d_gait, gait_id, sizeof(int) * c->n, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(ctrl_set_gait_kernel, dim3((c->n + 127) / 128), dim3(128), 0, st, c->n, c->d_state, c->d_gait);
   HIP_TRY(hipGetLastError());
+  return MPC_OK;
+}
+
+int mpc_ctrl_fsm_init(mpc_ctrl *c, const int *control_mode, int operating_mode, int check_safety, void *stream) {
+  if (!c || !control_mode || (operating_mode != kOpTest && operating_mode != kOpNormal)) return fail(MPC_E_ARG, "mpc_ctrl_fsm_init: bad argument");
+  for (int r = 0; r < c->n; ++r)
+    if (control_mode[r] != kFsmPassive && control_mode[r] != kFsmLocomotion && control_mode[r] != kFsmRecoveryStand)
+      return fail(MPC_E_ARG, "mpc_ctrl_fsm_init: control mode must be 0 (PASSIVE), 4 (LOCOMOTION) or 6 (RECOVERY_STAND)");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!c->d_fsm) {
+    HIP_TRY(hipMalloc(&c->d_fsm, sizeof(FsmState) * c->n));
+    HIP_TRY(hipMalloc(&c->d_fsm_mode, sizeof(int) * c->n));
+  }
+  c->fp = fsm_params(c->cp.dt, check_safety);
+  c->fsm_op_mode = operating_mode;
+  HIP_TRY(hipMemcpyAsync(c->d_fsm_mode, control_mode, sizeof(int) * c->n, hipMemcpyHostToDevice, st));
+  int rc = mpc_batch_reset(c->solver, nullptr, 0, stream);   // RobotRunnerFSM.init builds fresh objects
+  if (rc != MPC_OK) return rc;
+  hipLaunchKernelGGL(ctrl_init_kernel, dim3((c->n + 127) / 128), dim3(128), 0, st, c->n, c->d_state, c->d_rc, c->d_robot_type, c->d_gait);
+  hipLaunchKernelGGL(fsm_init_kernel, dim3((c->n + 127) / 128), dim3(128), 0, st, c->n, c->d_state, c->d_fsm, c->d_rc, c->d_fsm_mode, operating_mode,
+                     (const int *)nullptr, c->n, 1);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(st));                          // control_mode is a host buffer
+  return MPC_OK;
+}
+
+int mpc_ctrl_fsm_reset(mpc_ctrl *c, const int *ids, int k, const int *control_mode, void *stream) {
+  if (!c || !c->d_fsm || (ids && k < 0)) return fail(MPC_E_ARG, "mpc_ctrl_fsm_reset: bad argument (mpc_ctrl_fsm_init first)");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (control_mode) HIP_TRY(hipMemcpyAsync(c->d_fsm_mode, control_mode, sizeof(int) * c->n, hipMemcpyHostToDevice, st));
+  const int cnt = ids ? k : c->n;
+  if (cnt == 0) return MPC_OK;
+  int *d_ids = nullptr;
+  if (ids) {
+    HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&d_ids), sizeof(int) * k, st));
+    HIP_TRY(hipMemcpyAsync(d_ids, ids, sizeof(int) * k, hipMemcpyHostToDevice, st));
+  }
+  hipLaunchKernelGGL(fsm_init_kernel, dim3((cnt + 127) / 128), dim3(128), 0, st, c->n, c->d_state, c->d_fsm, c->d_rc, c->d_fsm_mode, c->fsm_op_mode, d_ids, cnt, 0);
+  HIP_TRY(hipGetLastError());
+  if (d_ids) HIP_TRY(hipFreeAsync(d_ids, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return MPC_OK;
+}
+
+int mpc_ctrl_run_fsm(mpc_ctrl *c, const float *d_dof, const float *d_body, const float *d_cmd, const int *d_request, float *d_torques, void *stream) {
+  if (!c || !d_dof || !d_body || !d_cmd || !d_request || !d_torques) return fail(MPC_E_ARG, "mpc_ctrl_run_fsm: bad argument");
+  if (!c->d_fsm) return fail(MPC_E_ARG, "mpc_ctrl_run_fsm: call mpc_ctrl_fsm_init first");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int n = c->n, blocks = (n + 127) / 128;
+  mpc_batch *b = c->solver;
+  hipLaunchKernelGGL(estimator_kernel, dim3(blocks), dim3(128), 0, st, n, c->d_state, d_body, c->d_est);
+  hipLaunchKernelGGL(fsm_pre_kernel, dim3(blocks), dim3(128), 0, st, n, c->d_state, c->d_fsm, c->d_rc, c->gt, c->cp, c->fp, d_dof, d_body, c->d_est, d_cmd,
+                     d_request, c->d_rec, c->d_active, b->d_state, b->state_len);
+  HIP_TRY(hipGetLastError());
+  int rc = MPC_E_HORIZON;
+  switch (b->h) {
+    case 10: rc = launch<10>(b->n, b->d_models, c->d_rec, b->d_state, b->d_scratch, c->d_forces, c->d_info, b->d_prof, c->d_active, st); break;
+    case 16: rc = launch<16>(b->n, b->d_models, c->d_rec, b->d_state, b->d_scratch, c->d_forces, c->d_info, b->d_prof, c->d_active, st); break;
+  }
+  if (rc != MPC_OK) return rc;
+  hipLaunchKernelGGL(fsm_post_kernel, dim3(blocks), dim3(128), 0, st, n, c->d_state, c->d_fsm, c->d_rc, c->cp.horizon, c->d_forces, c->d_info, d_torques);
+  HIP_TRY(hipGetLastError());
+  return MPC_OK;
+}
+
+int mpc_ctrl_fsm_state(mpc_ctrl *c, int *h_out) {
+  if (!c || !c->d_fsm || !h_out) return fail(MPC_E_ARG, "mpc_ctrl_fsm_state: bad argument");
+  std::vector<FsmState> h(c->n);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(h.data(), c->d_fsm, sizeof(FsmState) * c->n, hipMemcpyDeviceToHost));
+  for (int r = 0; r < c->n; ++r) { h_out[4 * r] = h[r].cur; h_out[4 * r + 1] = h[r].op_mode; h_out[4 * r + 2] = h[r].rs_flag; h_out[4 * r + 3] = h[r].unsafe; }
   return MPC_OK;
 }
 

@@ -86,6 +86,51 @@ class BatchedLocomotion:
         _lib.check(_lib.lib().mpc_ctrl_set_gait(self._handle, gi.ctypes.data, stream), "mpc_ctrl_set_gait")
         torch.cuda.current_stream(self.device).synchronize()
 
+    # ---- control FSM (RobotRunnerFSM) --------------------------------------------------------------------
+    PASSIVE, LOCOMOTION, RECOVERY_STAND = 0, 4, 6          # FSM_StateName (MPC_Controller/utils.py:26-30)
+
+    def fsm_init(self, control_mode, operating_mode=1, check_safety=True):
+        """``RobotRunnerFSM.init`` for every robot: fresh controller objects and ``ControlFSM.initialize`` into
+        ``control_mode[r]`` (per-robot ``Parameters.control_mode``); operating_mode 0 TEST / 1 NORMAL."""
+        import torch
+        cm = np.ascontiguousarray(control_mode, dtype=np.int32)
+        if len(cm) != self.n:
+            raise ValueError("control_mode must have one entry per robot")
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.lib().mpc_ctrl_fsm_init(self._handle, cm.ctypes.data, int(operating_mode), int(bool(check_safety)), stream), "mpc_ctrl_fsm_init")
+
+    def run_fsm(self, dof_states, body_states, commands, request, torques=None):
+        """The batched ``RobotRunnerFSM.run(dof_states, body_states, commands)`` (robot_runner/RobotRunnerFSM.py:44-71);
+        ``request`` [N] cuda int32 is the control mode requested for each robot this tick."""
+        import torch
+        for name, t, numel in (("dof_states", dof_states, self.n * 24), ("body_states", body_states, self.n * 13), ("commands", commands, self.n * 16)):
+            if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or t.numel() != numel:
+                raise ValueError(f"{name} must be a contiguous cuda float32 tensor with {numel} elements")
+        if request.dtype != torch.int32 or not request.is_cuda or not request.is_contiguous() or request.numel() != self.n:
+            raise ValueError("request must be a contiguous cuda int32 tensor with one entry per robot")
+        torques = self.torques if torques is None else torques
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.lib().mpc_ctrl_run_fsm(self._handle, dof_states.data_ptr(), body_states.data_ptr(), commands.data_ptr(),
+                                               request.data_ptr(), torques.data_ptr(), stream), "mpc_ctrl_run_fsm")
+        return torques
+
+    def fsm_reset(self, env_ids=None, control_mode=None):
+        """``RobotRunnerFSM.reset`` (= ``ControlFSM.initialize``) for the given robots (all if None)."""
+        import torch
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        cm = None if control_mode is None else np.ascontiguousarray(control_mode, dtype=np.int32)
+        ids = None
+        if env_ids is not None:
+            ids = np.ascontiguousarray(env_ids.detach().cpu().numpy() if hasattr(env_ids, "detach") else env_ids, dtype=np.int32)
+        _lib.check(_lib.lib().mpc_ctrl_fsm_reset(self._handle, None if ids is None else ids.ctypes.data, 0 if ids is None else len(ids),
+                                                 None if cm is None else cm.ctypes.data, stream), "mpc_ctrl_fsm_reset")
+
+    def fsm_state(self):
+        """[N, 4] int32: FSM state name, operating mode, RecoveryStand flag, unsafe flag."""
+        out = np.zeros((self.n, 4), dtype=np.int32)
+        _lib.check(_lib.lib().mpc_ctrl_fsm_state(self._handle, out.ctypes.data), "mpc_ctrl_fsm_state")
+        return out
+
     def estimate(self):
         """(est [n,18], ground_normal_yaw [n,3]) of the last ``run``: the StateEstimate the reference passes to
         ``WeightPolicy.compute_observations`` (vBody, omegaBody, rpyBody, ground_R_body_frame; StateEstimator.py:99-143)."""

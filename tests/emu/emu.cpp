@@ -89,6 +89,55 @@ int emu_ctrl_replay(int n, int ticks, const double *robot_table, const int *robo
   return 0;
 }
 
+// ---- RobotRunnerFSM.run replay (estimator -> fsm_tick -> [ctrl_pre -> emulated solve -> ctrl_post] | joint PD), horizon 10 ----
+// init_mode [n], request [T][n]: FSM_StateName values; fsm_out [T][n][3] = (state, operating mode, recovery flag) after the tick.
+int emu_fsm_replay(int n, int ticks, const double *robot_table, const int *robot_type, const int *gait_id, const int *gait_off,
+                   const int *gait_dur, int flat_ground, double dt, int iters_between_mpc, double alpha, int check_safety, int op_mode,
+                   const int *init_mode, const float *dof, const float *body, const float *cmd, const int *request, float *torques,
+                   int *fsm_out) {
+  constexpr int H = 10;
+  GaitTable gt;
+  gt.n_seg = H;
+  for (int g = 0; g < kNumGaitIds; ++g) for (int j = 0; j < 4; ++j) { gt.offsets[g][j] = (float)gait_off[4 * g + j]; gt.durations[g][j] = (float)gait_dur[4 * g + j]; }
+  CtrlParams cp{dt, iters_between_mpc, dt * iters_between_mpc, H, flat_ground};
+  const FsmParams P = fsm_params(dt, check_safety);
+  const int inlen = 56 + 4 * H, sl = 64 * H + 2;
+  std::vector<double> Pg((size_t)12 * H * 12 * H);
+  for (int r = 0; r < n; ++r) {
+    const double *row = robot_table + 25 * robot_type[r];
+    RobotConst rc;
+    rc.abad = row[0]; rc.hip = row[1]; rc.knee = row[2];
+    for (int k = 0; k < 3; ++k) rc.hiploc[k] = (float)row[3 + k];
+    rc.body_height = row[10]; rc.mu = (float)row[11];
+    for (int k = 0; k < 13; ++k) rc.weights[k] = (float)row[12 + k];
+    const double inertia9[9] = {row[7], 0, 0, 0, row[8], 0, 0, 0, row[9]};
+    const RobotModel mdl = make_model(row[6], inertia9, cp.dt_mpc, alpha);
+    CtrlState st;
+    FsmState f;
+    ctrl_init(st, rc, robot_type[r], gait_id[r]);
+    fsm_init(f, init_mode[r], op_mode, st, rc, 0.f);          // fresh StateEstimate: rBody = 0
+    std::vector<double> state(sl, 0.0), forces(12 * H, 0.0);
+    std::vector<float> rec(inlen);
+    for (int t = 0; t < ticks; ++t) {
+      const size_t idx = (size_t)t * n + r;
+      float est[kEstLen];
+      estimator_update(body + idx * 13, st.normal, est);
+      fsm_tick(f, st, rc, P, dof + idx * 24, body + idx * 13, request[idx]);
+      if (f.entered_loco) std::fill(state.begin(), state.end(), 0.0);     // cMPC.initialize builds a new ConvexMpc
+      if (f.run_loco) {
+        ctrl_pre(st, rc, gt, cp, dof + idx * 24, est, cmd + idx * 16, rec.data());
+        int info[kInfoLen] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (st.do_solve) solve_one<H>(mdl, rec.data(), state.data(), Pg.data(), forces.data(), info, false, nullptr);
+        ctrl_post(st, rc, forces.data(), info[1] == kStSolved, torques + idx * 12);
+      } else {
+        fsm_joint_torques(f, st, torques + idx * 12);
+      }
+      fsm_out[idx * 3] = f.cur; fsm_out[idx * 3 + 1] = f.op_mode; fsm_out[idx * 3 + 2] = f.rs_flag;
+    }
+  }
+  return 0;
+}
+
 // StateEstimator.update restatement: body [n][13], normal [n][3] -> est [n][18]
 int emu_estimator_update(int n, const float *body, const float *normal, float *est) {
   for (int r = 0; r < n; ++r) estimator_update(body + 13 * r, normal + 3 * r, est + kEstLen * r);

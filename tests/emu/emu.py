@@ -71,3 +71,27 @@ def estimator_update(body, normal):
     L.emu_estimator_update.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.emu_estimator_update(n, p(body), p(normal), p(est))
     return est
+
+
+def fsm_replay(robot_type, gait_id, init_mode, dof, body, cmd, request, flat_ground=False, dt=0.01, iters_between_mpc=2, alpha=1e-5,
+               check_safety=True, op_mode=1):
+    """RobotRunnerFSM.run for every robot and tick (host emulation, horizon 10).
+    dof [T,n,12,2], body [T,n,13], cmd [T,n,16], request [T,n] -> torques [T,n,12], fsm [T,n,3] (state, op mode, recovery flag)."""
+    import rl_mpc_locomotion_amd  # noqa: F401
+    from rl_mpc_locomotion_amd.gait import gait_arrays
+    from rl_mpc_locomotion_amd.quadruped import ROBOT_TABLE64
+    L = lib()
+    T, n = dof.shape[0], dof.shape[1]
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    tab = np.ascontiguousarray(ROBOT_TABLE64, dtype=np.float64)
+    rt = np.ascontiguousarray(robot_type, dtype=np.int32); gi = np.ascontiguousarray(gait_id, dtype=np.int32)
+    im = np.ascontiguousarray(init_mode, dtype=np.int32); rq = np.ascontiguousarray(request, dtype=np.int32)
+    off, dur = gait_arrays(10)
+    off = np.ascontiguousarray(off, dtype=np.int32); dur = np.ascontiguousarray(dur, dtype=np.int32)
+    dof = np.ascontiguousarray(dof, dtype=np.float32); body = np.ascontiguousarray(body, dtype=np.float32); cmd = np.ascontiguousarray(cmd, dtype=np.float32)
+    tau = np.zeros((T, n, 12), np.float32); fsm = np.zeros((T, n, 3), np.int32)
+    L.emu_fsm_replay.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int] + [C.c_void_p] * 7
+    rc = L.emu_fsm_replay(n, T, p(tab), p(rt), p(gi), p(off), p(dur), int(flat_ground), dt, iters_between_mpc, alpha, int(check_safety), int(op_mode),
+                          p(im), p(dof), p(body), p(cmd), p(rq), p(tau), p(fsm))
+    assert rc == 0
+    return tau, fsm
