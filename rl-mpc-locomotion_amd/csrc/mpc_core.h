@@ -92,7 +92,8 @@ struct Cfg {
   static constexpr int IN_LEN = 56 + 4 * H;
   static constexpr int NTASK = 78 + (H - 1) * 144;       // P assembly tasks (d, a, b)
   static_assert(T <= 1024, "workgroup too large");
-  static constexpr int PARTLEN0 = (N * G > 14 * 64) ? N * G : 14 * 64;   // part[] doubles as the reduction scratch ...
+  static constexpr int NP = N + 2;                       // row stride of part[] (doubles)
+  static constexpr int PARTLEN0 = (NP * G > 14 * 64) ? NP * G : 14 * 64;   // part[] doubles as the reduction scratch ...
   static constexpr int PARTLEN = PARTLEN0 > H * 156 ? PARTLEN0 : H * 156;  // ... and as W A^k B during assembly
 };
 
@@ -155,7 +156,6 @@ struct Shared {
       MPC_V dt_[C::N]; MPC_V et_[C::M]; MPC_V cn_[C::N];   // Ruiz pass temporaries
     };
     struct {
-      MPC_V Ax[C::M]; MPC_V Aty[C::N]; MPC_V rp[C::M]; MPC_V rd[C::N];
       int act[C::M];
       MPC_V Nb[C::NF * 9]; MPC_V Gm[C::NF * 9];         // per foot: null basis rows (3 x 3, zero padded), Gamma
       int nnull[C::NF], isnull[C::N], rowmask[C::G];      // rowmask: isnull of a tile row's 6 coordinates, one bit each
@@ -212,7 +212,7 @@ struct Solver {
   using C = Cfg<H>;
   using Th = Thread<H>;
   using Sh = Shared<H>;
-  static constexpr int N = C::N, M = C::M, NF = C::NF, T = C::T, TS = C::TS, G = C::G, TE = C::TE;
+  static constexpr int N = C::N, M = C::M, NF = C::NF, T = C::T, TS = C::TS, G = C::G, TE = C::TE, NP = C::NP;
 
   Exec &ex;
   Sh &s;
@@ -250,7 +250,8 @@ struct Solver {
     for (int r = 0; r < 5; ++r) t += a[3 * r] * v[5 * f + r];
     return t;
   }
-  // Partial results of the tile products live in part[slot * N + row]: row i of tile row I gets slot J from the
+  // Partial results of the tile products live in part[slot * NP + row] (NP = N + 2: the pad spreads the six-double runs
+  // that consecutive lanes store into different slots over the LDS banks): row i of tile row I gets slot J from the
   // tile (I, J) itself (J <= I) and slot J > I from the transpose of tile (J, I) -- G slots per row, each written
   // by exactly one thread, six consecutive doubles per thread and slot.
   // part <- partial products of (-Mx) v, both orientations of the tile
@@ -266,7 +267,7 @@ struct Solver {
         ar[a] += m * vc[b];
         ac[b] += m * vr[a];
       }
-    double *pd = s.part + t.tj * N + TS * t.ti, *pt = s.part + t.ti * N + TS * t.tj;
+    double *pd = s.part + t.tj * NP + TS * t.ti, *pt = s.part + t.ti * NP + TS * t.tj;
 #pragma unroll
     for (int a = 0; a < TS; ++a) pd[a] = -ar[a];
     if (!t.dia) {
@@ -278,7 +279,7 @@ struct Solver {
   static MPC_HD double fold_parts(const Sh &s, int row) {   // fixed pairwise order (short dependency chains)
     double v[G];
 #pragma unroll
-    for (int k = 0; k < G; ++k) v[k] = s.part[k * N + row];
+    for (int k = 0; k < G; ++k) v[k] = s.part[k * NP + row];
 #pragma unroll
     for (int w = 1; w < G; w *= 2)
 #pragma unroll
@@ -303,7 +304,7 @@ struct Solver {
         mr[a] = fmax(mr[a], m * dc[b]);
         mc[b] = fmax(mc[b], m * dr[a]);
       }
-    double *pd = s.part + t.tj * N + TS * t.ti, *pt = s.part + t.ti * N + TS * t.tj;
+    double *pd = s.part + t.tj * NP + TS * t.ti, *pt = s.part + t.ti * NP + TS * t.tj;
 #pragma unroll
     for (int a = 0; a < TS; ++a) pd[a] = mr[a] * dr[a];
     if (!t.dia) {
@@ -959,7 +960,7 @@ struct Solver {
             ar[a] += m * vc[b];
             ac[b] += m * vr[a];
           }
-        double *pd = s.part + t.tj * N + TS * t.ti, *pt = s.part + t.ti * N + TS * t.tj;
+        double *pd = s.part + t.tj * NP + TS * t.ti, *pt = s.part + t.ti * NP + TS * t.tj;
 #pragma unroll
         for (int a = 0; a < TS; ++a) pd[a] = ar[a];
         if (!t.dia) {
@@ -984,13 +985,11 @@ struct Solver {
         for (int k = 0; k < 14; ++k) mx[k] = 0;
         for (int i = t.tid; i < M; i += kRedW) {
           const double ax = a_row_dot(s, i, x), r = ax - z[i], ei = s.Einv[i];
-          s.Ax[i] = ax; s.rp[i] = r;
           mx[0] = dmax(mx[0], fabs(ei * r)); mx[1] = dmax(mx[1], fabs(ei * z[i])); mx[2] = dmax(mx[2], fabs(ei * ax));
           mx[3] = dmax(mx[3], fabs(r)); mx[4] = dmax(mx[4], fabs(z[i])); mx[5] = dmax(mx[5], fabs(ax));
         }
         for (int j = t.tid; j < N; j += kRedW) {
           const double aty = at_col_dot(s, j, y), px = Px[j], qv = s.qs[j], r = qv + px + aty, di = s.Dinv[j];
-          s.Aty[j] = aty; s.rd[j] = r;
           mx[6] = dmax(mx[6], fabs(di * r)); mx[7] = dmax(mx[7], fabs(di * qv)); mx[8] = dmax(mx[8], fabs(di * aty));
           mx[9] = dmax(mx[9], fabs(di * px)); mx[10] = dmax(mx[10], fabs(r)); mx[11] = dmax(mx[11], fabs(qv));
           mx[12] = dmax(mx[12], fabs(aty)); mx[13] = dmax(mx[13], fabs(px));
