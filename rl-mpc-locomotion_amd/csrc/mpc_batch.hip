@@ -50,13 +50,13 @@ __global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= MPC_MIN_WAVES_MAX_T ? MPC_
                                                                const float *__restrict__ in, double *__restrict__ state,
                                                                double *__restrict__ scratch, double *__restrict__ forces,
                                                                int *__restrict__ info, long long *__restrict__ prof,
-                                                               const int *__restrict__ active) {
+                                                               const int *__restrict__ active, const int *__restrict__ order) {
   // static LDS: absolute addresses fold into the ds_* offset fields (a dynamic-LDS base costs an SGPR
   // per array and the hot loops spill)
   __shared__ __attribute__((aligned(16))) Shared<H> sh;
   using C = Cfg<H>;
-  const int robot = blockIdx.x;
-  if (robot >= n) return;
+  if ((int)blockIdx.x >= n) return;
+  const int robot = order ? order[blockIdx.x] : (int)blockIdx.x;   // longest-expected solves first (order_kernel)
   if (active && !active[robot]) return;   // robots whose controller is between two MPC updates
   Thread<H> th;
   th.init(threadIdx.x);
@@ -85,10 +85,33 @@ __global__ void reset_kernel(double *state, int state_len, const int *ids, int k
 
 template <int H>
 int launch(int n, const RobotModel *models, const float *in, double *state, double *scratch, double *forces, int *info,
-           long long *prof, const int *active, hipStream_t stream) {
-  hipLaunchKernelGGL(mpc_solve_kernel<H>, dim3(n), dim3(Cfg<H>::T), 0, stream, n, models, in, state, scratch, forces, info, prof, active);
+           long long *prof, const int *active, const int *order, hipStream_t stream) {
+  hipLaunchKernelGGL(mpc_solve_kernel<H>, dim3(n), dim3(Cfg<H>::T), 0, stream, n, models, in, state, scratch, forces, info, prof, active, order);
   HIP_TRY(hipGetLastError());
   return MPC_OK;
+}
+
+// Workgroup -> robot order for the NEXT launch: robots sorted by the shader cycles their last solve took, longest first.
+// Warm-started robots repeat their iteration counts from step to step, and solve times differ 3x between a 25-iteration
+// and a 75-iteration robot; dispatching the long ones first keeps the tail of the launch short (a counting sort over
+// cycles / 8192 in one workgroup; the order inside a bucket is arbitrary, results do not depend on it).
+constexpr int kOrderBuckets = 1024;
+__global__ void order_kernel(int n, const long long *__restrict__ prof, int *__restrict__ order) {
+  __shared__ int cnt[kOrderBuckets], base[kOrderBuckets];
+  for (int b = threadIdx.x; b < kOrderBuckets; b += blockDim.x) cnt[b] = 0;
+  __syncthreads();
+  auto bucket = [&](int r) {
+    const long long c = prof[(size_t)r * kProfLen + kProfLen - 1] >> 13;
+    return (int)(c < 0 ? 0 : (c >= kOrderBuckets ? kOrderBuckets - 1 : c));
+  };
+  for (int r = threadIdx.x; r < n; r += blockDim.x) atomicAdd(&cnt[bucket(r)], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int b = kOrderBuckets - 1; b >= 0; --b) { base[b] = acc; acc += cnt[b]; }
+  }
+  __syncthreads();
+  for (int r = threadIdx.x; r < n; r += blockDim.x) order[atomicAdd(&base[bucket(r)], 1)] = r;
 }
 
 }  // namespace
@@ -100,8 +123,27 @@ struct mpc_batch {
   double *d_state = nullptr, *d_scratch = nullptr;
   int *d_info = nullptr;   // used when the caller passes no info buffer
   long long *d_prof = nullptr;   // per-robot section cycle counts of the last solve
+  int *d_order = nullptr;        // workgroup -> robot map for the next launch (order_kernel)
+  bool order_valid = false;
   long long bytes = 0;
 };
+
+
+// one solver launch on b's robots (+ the dispatch order for the next one)
+static int launch_solver(mpc_batch *b, const float *d_in, double *d_forces, int *d_info, const int *d_active, hipStream_t st) {
+  const int *order = b->order_valid ? b->d_order : nullptr;
+  int rc = MPC_E_HORIZON;
+  switch (b->h) {
+    case 10: rc = launch<10>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, d_forces, d_info, b->d_prof, d_active, order, st); break;
+    case 16: rc = launch<16>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, d_forces, d_info, b->d_prof, d_active, order, st); break;
+  }
+  if (rc == MPC_E_HORIZON) return fail(MPC_E_HORIZON, "solver launch: horizon not compiled in");
+  if (rc != MPC_OK) return rc;
+  hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, st, b->n, b->d_prof, b->d_order);
+  HIP_TRY(hipGetLastError());
+  b->order_valid = true;
+  return MPC_OK;
+}
 
 extern "C" {
 
@@ -134,6 +176,7 @@ int mpc_batch_create(mpc_batch **out, int n, int horizon, double timestep, doubl
       (e = hipMalloc(&b->d_scratch, sizeof(double) * (size_t)n * pg_len)) != hipSuccess ||
       (e = hipMalloc(&b->d_info, sizeof(int) * (size_t)n * kInfoLen)) != hipSuccess ||
       (e = hipMalloc(&b->d_prof, sizeof(long long) * (size_t)n * kProfLen)) != hipSuccess ||
+      (e = hipMalloc(&b->d_order, sizeof(int) * (size_t)n)) != hipSuccess ||
       (e = hipMemcpy(b->d_models, models.data(), sizeof(RobotModel) * n, hipMemcpyHostToDevice)) != hipSuccess ||
       (e = hipMemset(b->d_state, 0, sizeof(double) * (size_t)n * b->state_len)) != hipSuccess) {
     cleanup();
@@ -151,6 +194,7 @@ void mpc_batch_destroy(mpc_batch *b) {
   if (b->d_scratch) (void)hipFree(b->d_scratch);
   if (b->d_info) (void)hipFree(b->d_info);
   if (b->d_prof) (void)hipFree(b->d_prof);
+  if (b->d_order) (void)hipFree(b->d_order);
   delete b;
 }
 
@@ -158,11 +202,7 @@ int mpc_batch_solve(mpc_batch *b, const float *d_in, double *d_forces, int *d_in
   if (!b || !d_in || !d_forces) return fail(MPC_E_ARG, "mpc_batch_solve: bad argument");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int *info = d_info ? d_info : b->d_info;
-  switch (b->h) {
-    case 10: return launch<10>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, d_forces, info, b->d_prof, nullptr, st);
-    case 16: return launch<16>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, d_forces, info, b->d_prof, nullptr, st);
-  }
-  return fail(MPC_E_HORIZON, "mpc_batch_solve: horizon not compiled in");
+  return launch_solver(b, d_in, d_forces, info, nullptr, st);
 }
 
 int mpc_batch_reset(mpc_batch *b, const int *ids, int k, void *stream) {
@@ -399,11 +439,7 @@ int mpc_ctrl_step(mpc_ctrl *c, const float *d_dof, const float *d_est, const flo
   hipLaunchKernelGGL(ctrl_pre_kernel, dim3(blocks), dim3(128), 0, st, n, c->d_state, c->d_rc, c->gt, c->cp, d_dof, d_est, d_cmd, c->d_rec, c->d_active);
   HIP_TRY(hipGetLastError());
   mpc_batch *b = c->solver;
-  int rc = MPC_E_HORIZON;
-  switch (b->h) {
-    case 10: rc = launch<10>(b->n, b->d_models, c->d_rec, b->d_state, b->d_scratch, c->d_forces, c->d_info, b->d_prof, c->d_active, st); break;
-    case 16: rc = launch<16>(b->n, b->d_models, c->d_rec, b->d_state, b->d_scratch, c->d_forces, c->d_info, b->d_prof, c->d_active, st); break;
-  }
+  int rc = launch_solver(b, c->d_rec, c->d_forces, c->d_info, c->d_active, st);
   if (rc != MPC_OK) return rc;
   hipLaunchKernelGGL(ctrl_post_kernel, dim3(blocks), dim3(128), 0, st, n, c->d_state, c->d_rc, c->cp.horizon, c->d_forces, c->d_info, d_torques);
   HIP_TRY(hipGetLastError());
@@ -499,11 +535,7 @@ int mpc_ctrl_run_fsm(mpc_ctrl *c, const float *d_dof, const float *d_body, const
   hipLaunchKernelGGL(fsm_pre_kernel, dim3(blocks), dim3(128), 0, st, n, c->d_state, c->d_fsm, c->d_rc, c->gt, c->cp, c->fp, d_dof, d_body, c->d_est, d_cmd,
                      d_request, c->d_rec, c->d_active, b->d_state, b->state_len);
   HIP_TRY(hipGetLastError());
-  int rc = MPC_E_HORIZON;
-  switch (b->h) {
-    case 10: rc = launch<10>(b->n, b->d_models, c->d_rec, b->d_state, b->d_scratch, c->d_forces, c->d_info, b->d_prof, c->d_active, st); break;
-    case 16: rc = launch<16>(b->n, b->d_models, c->d_rec, b->d_state, b->d_scratch, c->d_forces, c->d_info, b->d_prof, c->d_active, st); break;
-  }
+  int rc = launch_solver(b, c->d_rec, c->d_forces, c->d_info, c->d_active, st);
   if (rc != MPC_OK) return rc;
   hipLaunchKernelGGL(fsm_post_kernel, dim3(blocks), dim3(128), 0, st, n, c->d_state, c->d_fsm, c->d_rc, c->cp.horizon, c->d_forces, c->d_info, d_torques);
   HIP_TRY(hipGetLastError());
