@@ -94,14 +94,14 @@ int launch(int n, const RobotModel *models, const float *in, double *state, doub
 // Workgroup -> robot order for the NEXT launch: robots sorted by the shader cycles their last solve took, longest first.
 // Warm-started robots repeat their iteration counts from step to step, and solve times differ 3x between a 25-iteration
 // and a 75-iteration robot; dispatching the long ones first keeps the tail of the launch short (a counting sort over
-// cycles / 8192 in one workgroup; the order inside a bucket is arbitrary, results do not depend on it).
-constexpr int kOrderBuckets = 1024;
+// cycles / 16384 in one workgroup; the order inside a bucket is arbitrary, results do not depend on it).
+constexpr int kOrderBuckets = 256;
 __global__ void order_kernel(int n, const long long *__restrict__ prof, int *__restrict__ order) {
   __shared__ int cnt[kOrderBuckets], base[kOrderBuckets];
   for (int b = threadIdx.x; b < kOrderBuckets; b += blockDim.x) cnt[b] = 0;
   __syncthreads();
   auto bucket = [&](int r) {
-    const long long c = prof[(size_t)r * kProfLen + kProfLen - 1] >> 13;
+    const long long c = prof[(size_t)r * kProfLen + kProfLen - 1] >> 14;
     return (int)(c < 0 ? 0 : (c >= kOrderBuckets ? kOrderBuckets - 1 : c));
   };
   for (int r = threadIdx.x; r < n; r += blockDim.x) atomicAdd(&cnt[bucket(r)], 1);
