@@ -171,10 +171,10 @@ def main():
                                   "note": "operations the OSQP-faithful kernel executes (all 12h variables kept; bench.py executed_flops), "
                                           "for orientation only -- `achieved` / `frac` above use the SURVEY 8(d) minimal-algorithm count"}},
     }
-    if not args.no_control_loop:
+    if not args.no_control_loop and world == 1:      # secondary legs: single-GPU runs only
         out["control_loop"] = control_loop_leg(n, h, dev)
         out["policy"] = policy_leg(n, dev)
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
         out["cpu_baseline"] = cpu_baseline(wl, batches, W, h, gpu_first_forces=first_forces)
         out["max_grf_err_vs_osqp"] = out["cpu_baseline"].pop("_gpu_err", None)
     print(json.dumps(out))
