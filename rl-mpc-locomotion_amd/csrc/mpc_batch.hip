@@ -100,18 +100,30 @@ __global__ void order_kernel(int n, const long long *__restrict__ prof, int *__r
   __shared__ int cnt[kOrderBuckets], base[kOrderBuckets];
   for (int b = threadIdx.x; b < kOrderBuckets; b += blockDim.x) cnt[b] = 0;
   __syncthreads();
-  auto bucket = [&](int r) {
-    const long long c = prof[(size_t)r * kProfLen + kProfLen - 1] >> 14;
-    return (int)(c < 0 ? 0 : (c >= kOrderBuckets ? kOrderBuckets - 1 : c));
-  };
-  for (int r = threadIdx.x; r < n; r += blockDim.x) atomicAdd(&cnt[bucket(r)], 1);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int acc = 0;
-    for (int b = kOrderBuckets - 1; b >= 0; --b) { base[b] = acc; acc += cnt[b]; }
+  constexpr int kPer = 8;                         // robots per thread held in registers (n <= 8192 per pass)
+  for (int r0 = 0; r0 < n; r0 += kPer * blockDim.x) {
+    int bk[kPer], rank[kPer];
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      const int r = r0 + i * blockDim.x + threadIdx.x;
+      bk[i] = -1;
+      if (r < n) {
+        const long long c = prof[(size_t)r * kProfLen + kProfLen - 1] >> 14;
+        bk[i] = (int)(c < 0 ? 0 : (c >= kOrderBuckets ? kOrderBuckets - 1 : c));
+        rank[i] = atomicAdd(&cnt[bk[i]], 1);      // rank inside the bucket (within this pass)
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int acc = r0;                               // earlier passes fill the front of `order` (only n > 8192 has several)
+      for (int b = kOrderBuckets - 1; b >= 0; --b) { base[b] = acc; acc += cnt[b]; cnt[b] = 0; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kPer; ++i)
+      if (bk[i] >= 0) order[base[bk[i]] + rank[i]] = r0 + i * blockDim.x + threadIdx.x;
+    __syncthreads();
   }
-  __syncthreads();
-  for (int r = threadIdx.x; r < n; r += blockDim.x) order[atomicAdd(&base[bucket(r)], 1)] = r;
 }
 
 }  // namespace

@@ -157,3 +157,24 @@ def test_bad_arguments_raise():
         g.solve(torch.zeros((1, 95), dtype=torch.float32, device="cuda:0"))              # wrong record length
     with pytest.raises(ValueError):
         g.solve(torch.zeros((1, 96), dtype=torch.float64, device="cuda:0"))              # wrong dtype
+
+
+@pytest.mark.gpu
+def test_dispatch_order_does_not_change_results():
+    """After the first launch the workgroup -> robot map is re-sorted by solve time (longest first, order_kernel; two
+    counting-sort passes above 8192 robots).  Per-robot results must not depend on it: a robot solved inside a large batch
+    equals the same robot solved alone, bit for bit, over several warm-started steps."""
+    import torch
+    n, h = 8200, 10
+    wl = make_solver_workload(n, h=h, seed=21, config=3)
+    big = _gpu(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
+    pick = [0, 17, 4095, 8191, 8199]
+    solo = [_gpu(wl.mass[i:i + 1], wl.inertia_diag[i:i + 1], h, wl.dt_mpc, wl.alpha) for i in pick]
+    w = wl
+    for step in range(3):
+        f, info = _solve(big, w.inputs)
+        assert (info[:, 1] == 1).all()
+        for i, s in zip(pick, solo):
+            fs, infos = _solve(s, w.inputs[i:i + 1])
+            assert np.array_equal(fs[0], f[i]) and np.array_equal(infos[0], info[i])
+        w = perturb_workload(w, 300 + step)
