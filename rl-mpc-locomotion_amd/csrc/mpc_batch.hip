@@ -148,6 +148,7 @@ static int launch_solver(mpc_batch *b, const float *d_in, double *d_forces, int 
   switch (b->h) {
     case 10: rc = launch<10>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, d_forces, d_info, b->d_prof, d_active, order, st); break;
     case 16: rc = launch<16>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, d_forces, d_info, b->d_prof, d_active, order, st); break;
+    case 20: rc = launch<20>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, d_forces, d_info, b->d_prof, d_active, order, st); break;
   }
   if (rc == MPC_E_HORIZON) return fail(MPC_E_HORIZON, "solver launch: horizon not compiled in");
   if (rc != MPC_OK) return rc;
@@ -162,7 +163,7 @@ extern "C" {
 const char *mpc_last_error(void) { return g_err.c_str(); }
 int mpc_input_len(int horizon) { return 56 + 4 * horizon; }
 int mpc_supported_horizons(int *out, int cap) {
-  const int hs[] = {10, 16};
+  const int hs[] = {10, 16, 20};
   const int cnt = (int)(sizeof hs / sizeof *hs);
   for (int i = 0; i < cnt && i < cap; ++i) out[i] = hs[i];
   return cnt;
@@ -171,13 +172,13 @@ int mpc_supported_horizons(int *out, int cap) {
 int mpc_batch_create(mpc_batch **out, int n, int horizon, double timestep, double alpha, const double *mass,
                      const double *inertia9) {
   if (!out || n <= 0 || !mass || !inertia9) return fail(MPC_E_ARG, "mpc_batch_create: bad argument");
-  if (horizon != 10 && horizon != 16) return fail(MPC_E_HORIZON, "mpc_batch_create: horizon not compiled in (10, 16)");
+  if (horizon != 10 && horizon != 16 && horizon != 20) return fail(MPC_E_HORIZON, "mpc_batch_create: horizon not compiled in (10, 16, 20)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MPC_E_NODEVICE, "mpc_batch_create: no HIP device");
   mpc_batch *b = new mpc_batch();
   b->n = n;
   b->h = horizon;
-  const size_t pg_len = horizon == 10 ? Cfg<10>::PG_LEN : Cfg<16>::PG_LEN;   // P_s scratch, lower-triangle tiles
+  const size_t pg_len = horizon == 10 ? Cfg<10>::PG_LEN : horizon == 16 ? Cfg<16>::PG_LEN : Cfg<20>::PG_LEN;   // P_s scratch, lower-triangle tiles
   b->state_len = (int)(64 * horizon + 2);
   std::vector<RobotModel> models(n);
   for (int i = 0; i < n; ++i) models[i] = make_model(mass[i], inertia9 + 9 * (size_t)i, timestep, alpha);

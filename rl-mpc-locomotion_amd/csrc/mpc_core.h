@@ -94,6 +94,10 @@ struct Cfg {
   static_assert(T <= 1024, "workgroup too large");
   static constexpr int NP = N + 2;                       // row stride of part[] (doubles)
   static constexpr int PARTLEN0 = (NP * G > 14 * 64) ? NP * G : 14 * 64;   // part[] doubles as the reduction scratch ...
+  // Large horizons are LDS-tight (one workgroup per CU, 160 KB): A^k B moves next to W A^k B inside part[] where both fit,
+  // and rho / 1/rho come from the three per-type values instead of per-row arrays.
+  static constexpr bool kAnbInPart = 2 * H * 156 <= PARTLEN0;
+  static constexpr bool kCompact = H > 16;
   static constexpr int PARTLEN = PARTLEN0 > H * 156 ? PARTLEN0 : H * 156;  // ... and as W A^k B during assembly
 };
 
@@ -131,14 +135,15 @@ struct Shared {
   MPC_V qs[C::N]; MPC_V ls[C::M]; MPC_V us[C::M]; MPC_V As[C::NF * 15];   // scaled problem
   MPC_V D[C::N]; MPC_V Dinv[C::N]; MPC_V E[C::M]; MPC_V Einv[C::M];
   double c, cinv, rho, ctmp;
-  MPC_V rho_vec[C::M]; MPC_V rho_inv[C::M];
+  MPC_V rho_vec[C::kCompact ? 2 : C::M]; MPC_V rho_inv[C::kCompact ? 2 : C::M];   // per row (or unused: rho3 / rinv3 below)
+  double rho3[4], rinv3[4];                             // rho and 1/rho of a loose / inequality / equality row (index type + 1)
   int ctype[C::M];
   MPC_V x[C::N]; MPC_V xt[C::N]; MPC_V Px[C::N];        // Px = P_s x, carried through the ADMM iterations
   MPC_V zz[1][C::M]; MPC_V yy[1][C::M]; MPC_V rr[1][C::N];   // z, y, rhs
   union {
     MPC_V part[C::PARTLEN];                             // [slot][row] partial sums / maxima of the tile products
     struct { MPC_V tm[C::M]; MPC_V rzt[C::M]; };        // R z - y and R z~ of the current ADMM iteration (part is dead then)
-    MPC_V wanb[H * 156];                                // assembly: diag(w) A^k B (part is not in use yet)
+    struct { MPC_V wanb[H * 156]; MPC_V anb_p[C::kAnbInPart ? H * 156 : 2]; };   // assembly: diag(w) A^k B [, A^k B] (part is not in use yet)
   };
   MPC_V prow[2][C::N];                                  // sweep pivot row (double buffered)
   MPC_V piv[2][2];                                      // current pivot and its reciprocal (double buffered)
@@ -150,7 +155,7 @@ struct Shared {
     struct {
       MPC_V in[C::IN_LEN];
       MPC_V x0[13]; MPC_V xref[13 * H]; MPC_V sdiff[13 * H]; MPC_V xk[13 * H];
-      MPC_V a_dt[169]; MPC_V b_dt[156]; MPC_V a_exp[169]; MPC_V b_exp[156]; MPC_V anb[H * 156];
+      MPC_V a_dt[169]; MPC_V b_dt[156]; MPC_V a_exp[169]; MPC_V b_exp[156]; MPC_V anb_u[C::kAnbInPart ? 2 : H * 156];
       MPC_V cone[15];
       MPC_V l[C::M]; MPC_V u[C::M];                     // unscaled bounds
       MPC_V dt_[C::N]; MPC_V et_[C::M]; MPC_V cn_[C::N];   // Ruiz pass temporaries
@@ -227,6 +232,15 @@ struct Solver {
   MPC_HD double *cz() { return s.zz[pp]; }
   MPC_HD double *cy() { return s.yy[pp]; }
   MPC_HD double *crhs() { return s.rr[pp]; }
+  MPC_HD double *anb() { if constexpr (C::kAnbInPart) return s.anb_p; else return s.anb_u; }
+  MPC_HD double rho_at(int i) const {
+    if constexpr (C::kCompact) { const int ty = s.ctype[i]; return ty == 1 ? s.rho3[2] : (ty == 0 ? s.rho3[1] : s.rho3[0]); }
+    else return s.rho_vec[i];
+  }
+  MPC_HD double rinv_at(int i) const {
+    if constexpr (C::kCompact) { const int ty = s.ctype[i]; return ty == 1 ? s.rinv3[2] : (ty == 0 ? s.rinv3[1] : s.rinv3[0]); }
+    else return s.rho_inv[i];
+  }
   long long tc[kProfLen] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = 0;
   // Diagnostic builds (-DMPC_PROFILE_SUB=<section>) split one section into slots 9..13 of the profile record:
@@ -507,7 +521,7 @@ struct Solver {
       for (int e = t.tid; e < H * 156; e += T) {
         const int k = e / 156, rc = e - 156 * k, r = rc / 12;
         const double v = r < 6 ? s.b_exp[rc] + (double)k * s.b_dt[rc] : s.b_exp[rc];
-        s.anb[e] = v;
+        anb()[e] = v;
         s.wanb[e] = s.in[IN_W + r] * v;
       }
       for (int e = t.tid; e < 13 * (H - 1); e += T) {   // (this overwrites the set-up scratch, which is dead by now)
@@ -555,7 +569,7 @@ struct Solver {
         // tile (2 J + b / 6, 2 I + a / 6), position (b % 6, a % 6); a diagonal tile also takes the mirrored entry
         const int ah = a / TS, bh = b / TS, lo = (b - TS * bh) * TS + (a - TS * ah), lom = (a - TS * ah) * TS + (b - TS * bh);
         const bool mirror = d == 0 && ah == bh && a != b;
-        const double *xa = s.wanb + d * 156 + a, *yb = s.anb + b;
+        const double *xa = s.wanb + d * 156 + a, *yb = anb() + b;
         double acc = 0;
         const int ns = H - d;
         for (int sidx = 0; sidx < ns; sidx += 2) {   // two horizon offsets per trip: four independent FMA chains
@@ -719,7 +733,13 @@ struct Solver {
 
   MPC_HD void set_rho_vec() {   // phase: rho_vec from (ctype, rho)  (auxil.c:79-96, osqp.c:1267-1310)
     ex.par([&](Th &t) {
-      if (t.tid < M) {
+      if constexpr (C::kCompact) {
+        if (t.tid < 3) {
+          const double rv = t.tid == 0 ? kRhoMin : (t.tid == 2 ? kRhoEqOverIneq * s.rho : s.rho);
+          s.rho3[t.tid] = rv;
+          s.rinv3[t.tid] = 1.0 / rv;
+        }
+      } else if (t.tid < M) {
         const int ty = s.ctype[t.tid];
         const double rv = ty == -1 ? kRhoMin : (ty == 1 ? kRhoEqOverIneq * s.rho : s.rho);
         s.rho_vec[t.tid] = rv;
@@ -738,13 +758,13 @@ struct Solver {
 #pragma unroll
           for (int fr = 0; fr < 2; ++fr) {
             const int f = 2 * t.ti + fr;
-            const double *a = s.As + 15 * f, *rv = s.rho_vec + 5 * f;
+            const double *a = s.As + 15 * f;
 #pragma unroll
             for (int c1 = 0; c1 < 3; ++c1)
 #pragma unroll
               for (int c2 = 0; c2 < 3; ++c2) {
                 double g = 0;
-                for (int r = 0; r < 5; ++r) g += a[3 * r + c1] * rv[r] * a[3 * r + c2];
+                for (int r = 0; r < 5; ++r) g += a[3 * r + c1] * rho_at(5 * f + r) * a[3 * r + c2];
                 if (c1 == c2) g += kSigma;
                 t.Mx[(3 * fr + c1) * TS + 3 * fr + c2] += g;
               }
@@ -882,7 +902,7 @@ struct Solver {
         const double *a = s.As + 15 * f;
         double tm[5];
 #pragma unroll
-        for (int r = 0; r < 5; ++r) tm[r] = s.rho_vec[5 * f + r] * cz()[5 * f + r] - cy()[5 * f + r];
+        for (int r = 0; r < 5; ++r) tm[r] = rho_at(5 * f + r) * cz()[5 * f + r] - cy()[5 * f + r];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           double acc = 0;
@@ -914,9 +934,9 @@ struct Solver {
         const int i = t.tid, f = i / 5, r = i - 5 * f;
         const double *a = s.As + 15 * f + 3 * r, *xt = s.xt + 3 * f;
         const double zt = a[0] * xt[0] + a[1] * xt[1] + a[2] * xt[2];
-        const double zp = cz()[i], yv = cy()[i], rv = s.rho_vec[i];
+        const double zp = cz()[i], yv = cy()[i], rv = rho_at(i);
         const double zr = kAlphaRelax * zt + (1.0 - kAlphaRelax) * zp;
-        const double zn = clampd(zr + s.rho_inv[i] * yv, s.ls[i], s.us[i]);
+        const double zn = clampd(zr + rinv_at(i) * yv, s.ls[i], s.us[i]);
         const double yn = yv + rv * (zr - zn);
         cz()[i] = zn;
         cy()[i] = yn;

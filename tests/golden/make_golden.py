@@ -26,11 +26,16 @@ CASES = [  # name, n, h, config, seed, steps
     ("solver_h10_cfg2", 48, 10, 2, 0, 3),      # Aliengo trot flat (BASELINE configs[1] shape)
     ("solver_h10_cfg3", 48, 10, 3, 1, 3),      # Go1/A1/Aliengo x trot/walk/bound (configs[2])
     ("solver_h16_cfg4", 12, 16, 4, 2, 2),      # h=16, random ground normals (configs[3])
+    ("solver_h20_cfg5", 8, 20, 5, 3, 2),       # h=20, random ground normals (configs[4])
 ]
+ONLY = sys.argv[1:]                            # optional: regenerate only the named cases
+
 
 
 def main():
     for name, n, h, cfg, seed, steps in CASES:
+        if ONLY and name not in ONLY:
+            continue
         wl = make_solver_workload(n, h=h, seed=seed, config=cfg)
         ref = RefBatch(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
         out = dict(h=h, config=cfg, seed=seed, dt_mpc=wl.dt_mpc, alpha=wl.alpha, mass=wl.mass,
