@@ -61,7 +61,7 @@ __global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= MPC_MIN_WAVES_MAX_T ? MPC_
   Thread<H> th;
   th.init(threadIdx.x);
 #pragma unroll
-  for (int j = 0; j < C::TE; ++j) th.Mx[j] = 0;
+  for (int j = 0; j < C::NT * C::TE; ++j) th.Mx[j] = 0;
   DeviceExec<H> ex{th};
   const RobotModel &mdl = models[robot];   // (uniform loads; a by-value copy indexed at run time would sit in scratch)
   Solver<H, DeviceExec<H>> sv{ex,

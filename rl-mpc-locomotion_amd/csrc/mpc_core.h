@@ -81,13 +81,16 @@ struct Cfg {
   static constexpr int N = 12 * H, M = 20 * H, NF = 4 * H;
   static constexpr int TS = 6;                           // register tile side (2 feet)
   static constexpr int G = N / TS;                       // tile grid G x G, lower triangle stored
-  static constexpr int MT = G * (G + 1) / 2;             // threads that hold a tile
+  static constexpr int MT = G * (G + 1) / 2;             // lower-triangle tiles
+  static constexpr int NT = H > 16 ? 2 : 1;              // tiles per thread: two for the longest horizon keeps the workgroup at
+                                                         // <= 2 waves per SIMD, i.e. 256 VGPRs per lane instead of 168 / 128
+  static constexpr int MTH = (MT + NT - 1) / NT;         // threads that hold tiles
   static constexpr int TE = TS * TS;                     // tile elements per thread
   static constexpr int PG_LEN = MT * TE;                 // doubles of P_s scratch per robot (tile-major)
 #ifdef MPC_FORCE_T
   static constexpr int T = MPC_FORCE_T;                  // (register-budget experiments)
 #else
-  static constexpr int T = (((MT > M ? MT : M) + 63) / 64) * 64;   // workgroup size
+  static constexpr int T = (((MTH > M ? MTH : M) + 63) / 64) * 64;   // workgroup size
 #endif
   static constexpr int IN_LEN = 56 + 4 * H;
   static constexpr int NTASK = 78 + (H - 1) * 144;       // P assembly tasks (d, a, b)
@@ -177,15 +180,28 @@ struct Shared {
 template <int H>
 struct Thread {
   using C = Cfg<H>;
-  int tid, ti, tj;          // thread id; tile row / tile column (tj <= ti)
-  bool mact, dia;           // holds a matrix tile (tid < MT); the tile sits on the diagonal
-  double Mx[C::TE];         // tile of the current symmetric n x n matrix (P_s, K, -Kinv, H, -Hinv), row-major 6 x 6
+  int tid;                        // thread id
+  int ti[C::NT], tj[C::NT];       // my tiles: tile row / tile column (tj <= ti); tile u has index tid + u * MTH
+  bool mact[C::NT], dia[C::NT];   // tile u exists; it sits on the diagonal
+  double Mx[C::NT * C::TE];       // my tiles of the current symmetric n x n matrix (P_s, K, -Kinv, H, -Hinv), row-major 6 x 6 each
   MPC_HD void init(int id) {
-    tid = id; mact = id < C::MT;
-    int r = 0;
-    while ((r + 1) * (r + 2) / 2 <= id) ++r;
-    ti = r; tj = id - r * (r + 1) / 2; dia = ti == tj;
+    tid = id;
+    for (int u = 0; u < C::NT; ++u) {
+      const int tile = id + u * C::MTH;
+      mact[u] = id < C::MTH && tile < C::MT;
+      int r = 0;
+      while ((r + 1) * (r + 2) / 2 <= tile) ++r;
+      ti[u] = r; tj[u] = tile - r * (r + 1) / 2; dia[u] = ti[u] == tj[u];
+    }
   }
+};
+
+// One tile of a thread, as the tile routines see it (built by Solver::for_tiles with a static tile slot, so Mx stays a
+// statically indexed register array)
+struct TileView {
+  int ti, tj, index;
+  bool dia;
+  double *Mx;
 };
 
 MPC_HD double limit_scaling(double v) {  // scaling.c:7-14
@@ -232,6 +248,16 @@ struct Solver {
   MPC_HD double *cz() { return s.zz[pp]; }
   MPC_HD double *cy() { return s.yy[pp]; }
   MPC_HD double *crhs() { return s.rr[pp]; }
+  using Tv = TileView;
+  template <class F>
+  MPC_HD void for_tiles(Th &t, F &&f) {
+#pragma unroll
+    for (int u = 0; u < C::NT; ++u)
+      if (t.mact[u]) {
+        Tv v{t.ti[u], t.tj[u], t.tid + u * C::MTH, t.dia[u], t.Mx + u * TE};
+        f(v, u);
+      }
+  }
   MPC_HD double *anb() { if constexpr (C::kAnbInPart) return s.anb_p; else return s.anb_u; }
   MPC_HD double rho_at(int i) const {
     if constexpr (C::kCompact) { const int ty = s.ctype[i]; return ty == 1 ? s.rho3[2] : (ty == 0 ? s.rho3[1] : s.rho3[0]); }
@@ -269,7 +295,7 @@ struct Solver {
   // tile (I, J) itself (J <= I) and slot J > I from the transpose of tile (J, I) -- G slots per row, each written
   // by exactly one thread, six consecutive doubles per thread and slot.
   // part <- partial products of (-Mx) v, both orientations of the tile
-  MPC_HD void tile_matvec_neg(const Th &t, const double *v) {
+  MPC_HD void tile_matvec_neg(const Tv &t, const double *v) {
     double vc[TS], vr[TS], ar[TS], ac[TS];
 #pragma unroll
     for (int b = 0; b < TS; ++b) { vc[b] = v[TS * t.tj + b]; vr[b] = v[TS * t.ti + b]; ar[b] = 0; ac[b] = 0; }
@@ -306,7 +332,7 @@ struct Solver {
   // (entries are norms: >= 0, never NaN since fmax drops NaNs)
   static MPC_HD double max_parts(const Sh &s, int row) { return fold_parts<true>(s, row); }
   // part <- D_i max_j (|m_ij| D_j) over the tile, for its rows and (transposed) for its columns; D = 1 if null
-  MPC_HD void tile_rownorms(const Th &t, const double *D) {
+  MPC_HD void tile_rownorms(const Tv &t, const double *D) {
     double dc[TS], dr[TS], mr[TS], mc[TS];
 #pragma unroll
     for (int b = 0; b < TS; ++b) { dc[b] = D ? D[TS * t.tj + b] : 1.0; dr[b] = D ? D[TS * t.ti + b] : 1.0; mr[b] = 0; mc[b] = 0; }
@@ -326,14 +352,14 @@ struct Solver {
       for (int b = 0; b < TS; ++b) pt[b] = mc[b] * dc[b];
     }
   }
-  // P_s in HBM is tile-major: thread tid's tile is the 36 doubles at G[36 tid]
-  MPC_HD void load_tile(Th &t, const double *Gm) {
-    const double *g = Gm + (size_t)t.tid * TE;
+  // P_s in HBM is tile-major: tile `index` is the 36 doubles at G[36 index]
+  MPC_HD void load_tile(Tv &t, const double *Gm) {
+    const double *g = Gm + (size_t)t.index * TE;
 #pragma unroll
     for (int e = 0; e < TE; ++e) t.Mx[e] = g[e];
   }
-  MPC_HD void store_tile(const Th &t, double *Gm) {
-    double *g = Gm + (size_t)t.tid * TE;
+  MPC_HD void store_tile(const Tv &t, double *Gm) {
+    double *g = Gm + (size_t)t.index * TE;
 #pragma unroll
     for (int e = 0; e < TE; ++e) g[e] = t.Mx[e];
   }
@@ -636,7 +662,7 @@ struct Solver {
   MPC_HD void scale() {
     lap(2);
     ex.par([&](Th &t) {
-      if (t.mact) { load_tile(t, Pg); tile_rownorms(t, nullptr); }
+      for_tiles(t, [&](Tv &v, int) { load_tile(v, Pg); tile_rownorms(v, nullptr); });
       if (t.tid < N) {
         s.qs[t.tid] = s.first ? s.q[t.tid] : s.xt[t.tid];   // osqp_update_P_A equilibrates with the PREVIOUS q
         s.D[t.tid] = 1.0;
@@ -670,7 +696,7 @@ struct Solver {
       MPC_SUBLAP(2, 9);
       ex.par([&](Th &t) {   // A <- E A D, q <- D (c_temp q), c <- c_temp c; new row norms of D P D and A
         const double ct = s.ctmp;
-        if (t.mact) tile_rownorms(t, s.D);
+        for_tiles(t, [&](Tv &v, int) { tile_rownorms(v, s.D); });
         if (t.tid < M) {
           const int f = t.tid / 5;
           double *a = s.As + 3 * t.tid;
@@ -697,15 +723,15 @@ struct Solver {
     }
     ex.par([&](Th &t) {   // the last pass's cost scale; P_s = c D P D
       const double ct = pending_cost_scale(), cf = s.c * ct;
-      if (t.mact) {
+      for_tiles(t, [&](Tv &v, int) {
         double dc[TS], ra[TS];
 #pragma unroll
-        for (int b = 0; b < TS; ++b) { dc[b] = s.D[TS * t.tj + b]; ra[b] = s.D[TS * t.ti + b] * cf; }
+        for (int b = 0; b < TS; ++b) { dc[b] = s.D[TS * v.tj + b]; ra[b] = s.D[TS * v.ti + b] * cf; }
 #pragma unroll
         for (int a = 0; a < TS; ++a)
 #pragma unroll
-          for (int b = 0; b < TS; ++b) t.Mx[a * TS + b] = (t.Mx[a * TS + b] * dc[b]) * ra[a];
-      }
+          for (int b = 0; b < TS; ++b) v.Mx[a * TS + b] = (v.Mx[a * TS + b] * dc[b]) * ra[a];
+      });
       if (t.tid < N) s.qs[t.tid] *= ct;
       if (t.tid == T - 1) s.ctmp = cf;   // (s.c is still being read in this phase)
     });
@@ -726,7 +752,7 @@ struct Solver {
         const int ty = (s.ls[i] < -kInfty * kMinScaling && s.us[i] > kInfty * kMinScaling) ? -1 : (s.us[i] - s.ls[i] < kRhoTol ? 1 : 0);
         s.ctype[i] = ty;
       }
-      if (t.mact) store_tile(t, Pg);   // keep P_s for residuals, re-factorisations and polish
+      for_tiles(t, [&](Tv &v, int) { store_tile(v, Pg); });   // keep P_s for residuals, re-factorisations and polish
     });
     lap(5);
   }
@@ -752,12 +778,12 @@ struct Solver {
   // A^T R A is block diagonal (3 x 3 per foot): only the diagonal tiles (feet 2 ti, 2 ti + 1) change.
   MPC_HD void factor(bool reload) {
     ex.par([&](Th &t) {
-      if (t.mact) {
-        if (reload) load_tile(t, Pg);
-        if (t.dia) {
+      for_tiles(t, [&](Tv &v, int) {
+        if (reload) load_tile(v, Pg);
+        if (v.dia) {
 #pragma unroll
           for (int fr = 0; fr < 2; ++fr) {
-            const int f = 2 * t.ti + fr;
+            const int f = 2 * v.ti + fr;
             const double *a = s.As + 15 * f;
 #pragma unroll
             for (int c1 = 0; c1 < 3; ++c1)
@@ -766,11 +792,11 @@ struct Solver {
                 double g = 0;
                 for (int r = 0; r < 5; ++r) g += a[3 * r + c1] * rho_at(5 * f + r) * a[3 * r + c2];
                 if (c1 == c2) g += kSigma;
-                t.Mx[(3 * fr + c1) * TS + 3 * fr + c2] += g;
+                v.Mx[(3 * fr + c1) * TS + 3 * fr + c2] += g;
               }
           }
         }
-      }
+      });
     });
     lap(6);
     sweep_all(false);
@@ -791,7 +817,7 @@ struct Solver {
   // The pivot loop is unrolled by TS = 6 so that the pivot's position inside its tile is static.
   MPC_HD void sweep_all(bool masked) {
     int buf = 0;
-    ex.par([&](Th &t) { if (t.mact) publish<0>(t, 0, 0); });
+    ex.par([&](Th &t) { for_tiles(t, [&](Tv &v, int) { publish<0>(v, 0, 0); }); });
     for (int kt = 0; kt < G; ++kt) {
       // bit A: pivot 6 kt + A is swept; bit 6: so is the first pivot of the next tile row (one LDS read per six steps)
       int bits = kt + 1 < G ? 0x7f : 0x3f;
@@ -819,37 +845,37 @@ struct Solver {
     const bool pub = (bits >> (A + 1)) & 1;          // the next pivot row is only needed if that pivot is used
     if (!active && !pub) return;
     ex.par([&](Th &t) {
-      if (t.mact) {
+      for_tiles(t, [&](Tv &v, int) {   // (a thread with two tiles finishes one before it starts the other: 24 live VGPRs of g / pc, not 48)
         double g[TS], pc[TS];
         if (active) {
           const double p = s.piv[buf][0], pinv = s.piv[buf][1];
           const double *pr = s.prow[buf];
 #pragma unroll
-          for (int a = 0; a < TS; ++a) { g[a] = pr[TS * t.ti + a] * pinv; pc[a] = pr[TS * t.tj + a]; }
+          for (int a = 0; a < TS; ++a) { g[a] = pr[TS * v.ti + a] * pinv; pc[a] = pr[TS * v.tj + a]; }
 #pragma unroll
-          for (int b = 0; b < TS; ++b) t.Mx[AN * TS + b] -= g[AN] * pc[b];
+          for (int b = 0; b < TS; ++b) v.Mx[AN * TS + b] -= g[AN] * pc[b];
 #pragma unroll
           for (int a = 0; a < TS; ++a)
-            if (a != AN) t.Mx[a * TS + AN] -= g[a] * pc[AN];
-          if (t.tid == 0 && !(p > 0)) s.bad = 1;     // not positive definite
+            if (a != AN) v.Mx[a * TS + AN] -= g[a] * pc[AN];
+          if (v.index == 0 && !(p > 0)) s.bad = 1;     // not positive definite
         }
-        if (pub) publish<AN>(t, buf ^ 1, ktn);
+        if (pub) publish<AN>(v, buf ^ 1, ktn);
         MPC_SCHED_FENCE();
         if (active) {
 #pragma unroll
           for (int a = 0; a < TS; ++a)
 #pragma unroll
             for (int b = 0; b < TS; ++b)
-              if (a != AN && b != AN) t.Mx[a * TS + b] -= g[a] * pc[b];
+              if (a != AN && b != AN) v.Mx[a * TS + b] -= g[a] * pc[b];
         }
-      }
+      });
     });
   }
   // Row k = 6 kt + A of the matrix -> prow[b]: the tiles of tile row kt hold its part left of (and on) the
   // diagonal as their row A, the tiles of tile column kt hold the rest as their column A.  Slot k itself
   // gets (pivot - 1), and piv[b] = {pivot, 1 / pivot}.
   template <int A>
-  MPC_HD void publish(const Th &t, int b, int kt) {
+  MPC_HD void publish(const Tv &t, int b, int kt) {
     if (t.ti == kt) {
       double *pn = s.prow[b] + TS * t.tj;
 #pragma unroll
@@ -921,7 +947,7 @@ struct Solver {
   //   X: x update, P_s x recursion, next rhs_j = sigma x_j - q_j + (A^T tm)_j   (one thread per variable)
   MPC_HD void admm_iter() {
     ex.par([&](Th &t) {
-      if (t.mact) tile_matvec_neg(t, crhs());
+      for_tiles(t, [&](Tv &v, int) { tile_matvec_neg(v, crhs()); });
     });
 #ifdef MPC_PROFILE_ADMM
     lap(9);
@@ -967,11 +993,11 @@ struct Solver {
   // P_s v -> out (P_s tiles read from HBM scratch, each used in both orientations).  Two phases.
   MPC_HD void mul_P(const double *v, double *out) {
     ex.par([&](Th &t) {
-      if (t.mact) {
-        const double *g = Pg + (size_t)t.tid * TE;
+      for_tiles(t, [&](Tv &tv, int) {
+        const double *g = Pg + (size_t)tv.index * TE;
         double vc[TS], vr[TS], ar[TS], ac[TS];
 #pragma unroll
-        for (int b = 0; b < TS; ++b) { vc[b] = v[TS * t.tj + b]; vr[b] = v[TS * t.ti + b]; ar[b] = 0; ac[b] = 0; }
+        for (int b = 0; b < TS; ++b) { vc[b] = v[TS * tv.tj + b]; vr[b] = v[TS * tv.ti + b]; ar[b] = 0; ac[b] = 0; }
 #pragma unroll
         for (int a = 0; a < TS; ++a)
 #pragma unroll
@@ -980,14 +1006,14 @@ struct Solver {
             ar[a] += m * vc[b];
             ac[b] += m * vr[a];
           }
-        double *pd = s.part + t.tj * NP + TS * t.ti, *pt = s.part + t.ti * NP + TS * t.tj;
+        double *pd = s.part + tv.tj * NP + TS * tv.ti, *pt = s.part + tv.ti * NP + TS * tv.tj;
 #pragma unroll
         for (int a = 0; a < TS; ++a) pd[a] = ar[a];
-        if (!t.dia) {
+        if (!tv.dia) {
 #pragma unroll
           for (int b = 0; b < TS; ++b) pt[b] = ac[b];
         }
-      }
+      });
     });
     ex.par([&](Th &t) { if (t.tid < N) out[t.tid] = sum_parts(s, t.tid); });
   }
@@ -1173,13 +1199,13 @@ struct Solver {
     // Tile-local: 2 row feet x 2 column feet of 3 x 3 blocks, all register indices static.
     ex.par([&](Th &t) {
       if (t.tid < N) s.g[t.tid] = -s.qs[t.tid] - s.Pu[t.tid];
-      if (t.mact) {
-        load_tile(t, Pg);
+      for_tiles(t, [&](Tv &tv, int) {
+        load_tile(tv, Pg);
 #pragma unroll
         for (int fr = 0; fr < 2; ++fr)
 #pragma unroll
           for (int fc = 0; fc < 2; ++fc) {
-            const int rf = 2 * t.ti + fr, cf = 2 * t.tj + fc;
+            const int rf = 2 * tv.ti + fr, cf = 2 * tv.tj + fc;
             const double *nr = s.Nb + 9 * rf, *nc = s.Nb + 9 * cf;   // row k = null vector k (zero rows beyond nnull)
             const int nnr = s.nnull[rf], nnc = s.nnull[cf];
             double T1[9];
@@ -1187,18 +1213,18 @@ struct Solver {
             for (int r = 0; r < 3; ++r)
 #pragma unroll
               for (int k2 = 0; k2 < 3; ++k2)
-                T1[3 * r + k2] = t.Mx[(3 * fr + r) * TS + 3 * fc] * nc[3 * k2] + t.Mx[(3 * fr + r) * TS + 3 * fc + 1] * nc[3 * k2 + 1] +
-                                 t.Mx[(3 * fr + r) * TS + 3 * fc + 2] * nc[3 * k2 + 2];
+                T1[3 * r + k2] = tv.Mx[(3 * fr + r) * TS + 3 * fc] * nc[3 * k2] + tv.Mx[(3 * fr + r) * TS + 3 * fc + 1] * nc[3 * k2 + 1] +
+                                 tv.Mx[(3 * fr + r) * TS + 3 * fc + 2] * nc[3 * k2 + 2];
 #pragma unroll
             for (int k1 = 0; k1 < 3; ++k1)
 #pragma unroll
               for (int k2 = 0; k2 < 3; ++k2) {
                 double v = (k1 < nnr && k2 < nnc) ? nr[3 * k1] * T1[k2] + nr[3 * k1 + 1] * T1[3 + k2] + nr[3 * k1 + 2] * T1[6 + k2] : 0.0;
                 if (k1 == k2 && rf == cf) v = (k1 < nnr) ? v + kDelta : 1.0;
-                t.Mx[(3 * fr + k1) * TS + 3 * fc + k2] = v;
+                tv.Mx[(3 * fr + k1) * TS + 3 * fc + k2] = v;
               }
           }
-      }
+      });
     });
     MPC_SUBLAP(3, 12);
     sweep_all(true);   // Mx <- -(H + delta I)^{-1} on the null coordinates
@@ -1215,7 +1241,7 @@ struct Solver {
       }
     });
     for (int it = 0; it <= kPolishRefine; ++it) {
-      ex.par([&](Th &t) { if (t.mact) tile_matvec_neg(t, s.rw); });
+      ex.par([&](Th &t) { for_tiles(t, [&](Tv &v, int) { tile_matvec_neg(v, s.rw); }); });
       ex.par([&](Th &t) {
         if (t.tid < N && s.isnull[t.tid]) {
           const double dw = inv_combine(s, t.tid, s.rw);

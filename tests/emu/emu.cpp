@@ -22,7 +22,7 @@ struct HostExec {
   explicit HostExec(bool rev) : th(Cfg<H>::T), reverse(rev) {
     for (int i = 0; i < Cfg<H>::T; ++i) {
       th[i].init(i);
-      for (int j = 0; j < Cfg<H>::TE; ++j) th[i].Mx[j] = 0;
+      for (int j = 0; j < Cfg<H>::NT * Cfg<H>::TE; ++j) th[i].Mx[j] = 0;
     }
   }
   template <class F> void par(F &&f) {
