@@ -143,11 +143,6 @@ struct Shared {
   int ctype[C::M];
   MPC_V x[C::N]; MPC_V xt[C::N]; MPC_V Px[C::N];        // Px = P_s x, carried through the ADMM iterations
   MPC_V zz[1][C::M]; MPC_V yy[1][C::M]; MPC_V rr[1][C::N];   // z, y, rhs
-  union {
-    MPC_V part[C::PARTLEN];                             // [slot][row] partial sums / maxima of the tile products
-    struct { MPC_V tm[C::M]; MPC_V rzt[C::M]; };        // R z - y and R z~ of the current ADMM iteration (part is dead then)
-    struct { MPC_V wanb[H * 156]; MPC_V anb_p[C::kAnbInPart ? H * 156 : 2]; };   // assembly: diag(w) A^k B [, A^k B] (part is not in use yet)
-  };
   MPC_V prow[2][C::N];                                  // sweep pivot row (double buffered)
   MPC_V piv[2][2];                                      // current pivot and its reciprocal (double buffered)
   unsigned long long red[16];                           // max-reductions (bit pattern of doubles >= 0)
@@ -170,6 +165,12 @@ struct Shared {
       MPC_V u0[C::N]; MPC_V Pu[C::N]; MPC_V g[C::N]; MPC_V xN[C::N]; MPC_V PxN[C::N]; MPC_V wv[C::N]; MPC_V rw[C::N];
       MPC_V ypol[C::M]; MPC_V zpol[C::M];
     };
+  };
+  // (last: the big arrays sit above the statically addressable 64 KB, the small hot ones below)
+  union {
+    MPC_V part[C::PARTLEN];                             // [slot][row] partial sums / maxima of the tile products
+    struct { MPC_V tm[C::M]; MPC_V rzt[C::M]; };        // R z - y and R z~ of the current ADMM iteration (part is dead then)
+    struct { MPC_V wanb[H * 156]; MPC_V anb_p[C::kAnbInPart ? H * 156 : 2]; };   // assembly: diag(w) A^k B [, A^k B] (part is not in use yet)
   };
 #ifdef MPC_LDS_PAD
   char pad[MPC_LDS_PAD];                                // occupancy experiments only
