@@ -10,7 +10,8 @@ from rl_mpc_locomotion_amd.batched import BatchedConvexMpc
 from rl_mpc_locomotion_amd.synthetic import make_solver_workload, perturb_workload
 from oracle.refmpc import RefBatch
 
-cases = [("config2_h10_aliengo_trot", 2, 10, 4096), ("config3_h10_mixed", 3, 10, 4096), ("config4_h16_normals", 4, 16, 1024)]
+cases = [("config2_h10_aliengo_trot", 2, 10, 4096), ("config3_h10_mixed", 3, 10, 4096), ("config4_h16_normals", 4, 16, 1024),
+         ("config5_h20_normals", 5, 20, 256)]
 seeds = [int(a) for a in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1, 2, 3, 4]
 threads = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 out = {}
