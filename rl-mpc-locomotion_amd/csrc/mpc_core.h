@@ -271,7 +271,7 @@ struct Solver {
   long long tc[kProfLen] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = 0;
   // Diagnostic builds (-DMPC_PROFILE_SUB=<section>) split one section into slots 9..13 of the profile record:
-  // 1 = dynamics, 2 = one scaling pass, 3 = polish set-up, 4 = A dt / B dt set-up.
+  // 1 = dynamics, 2 = one scaling pass, 3 = polish set-up, 4 = A dt / B dt set-up, 5 = the four phases of an ADMM iteration.
 #ifndef MPC_PROFILE_SUB
 #define MPC_PROFILE_SUB 0
 #endif
@@ -950,20 +950,24 @@ struct Solver {
     ex.par([&](Th &t) {
       for_tiles(t, [&](Tv &v, int) { tile_matvec_neg(v, crhs()); });
     });
+    MPC_SUBLAP(5, 9);
 #ifdef MPC_PROFILE_ADMM
     lap(9);
 #endif
     ex.par([&](Th &t) {
       if (t.tid < N) s.xt[t.tid] = inv_combine(s, t.tid, crhs());
     });
+    MPC_SUBLAP(5, 10);
     ex.par([&](Th &t) {
-      if (t.tid < M) {
+      if (t.tid < M) {   // (all LDS loads first, as one batch: a single round trip per phase)
         const int i = t.tid, f = i / 5, r = i - 5 * f;
         const double *a = s.As + 15 * f + 3 * r, *xt = s.xt + 3 * f;
-        const double zt = a[0] * xt[0] + a[1] * xt[1] + a[2] * xt[2];
-        const double zp = cz()[i], yv = cy()[i], rv = rho_at(i);
+        const double a0 = a[0], a1 = a[1], a2 = a[2], x0 = xt[0], x1 = xt[1], x2 = xt[2];
+        const double zp = cz()[i], yv = cy()[i], rv = rho_at(i), ri = rinv_at(i), lo = s.ls[i], hi = s.us[i];
+        MPC_SCHED_FENCE();
+        const double zt = a0 * x0 + a1 * x1 + a2 * x2;
         const double zr = kAlphaRelax * zt + (1.0 - kAlphaRelax) * zp;
-        const double zn = clampd(zr + rinv_at(i) * yv, s.ls[i], s.us[i]);
+        const double zn = clampd(zr + ri * yv, lo, hi);
         const double yn = yv + rv * (zr - zn);
         cz()[i] = zn;
         cy()[i] = yn;
@@ -971,21 +975,27 @@ struct Solver {
         s.rzt[i] = rv * zt;
       }
     });
+    MPC_SUBLAP(5, 11);
     ex.par([&](Th &t) {
       if (t.tid < N) {
         const int j = t.tid, f = j / 3, c = j - 3 * f;
         const double *a = s.As + 15 * f + c, *tm = s.tm + 5 * f, *rz = s.rzt + 5 * f;
+        double av[5], tv[5], rzv[5];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) { av[r] = a[3 * r]; tv[r] = tm[r]; rzv[r] = rz[r]; }
+        const double xt = s.xt[j], xp = s.x[j], rh = crhs()[j], px = s.Px[j], qv = s.qs[j];
+        MPC_SCHED_FENCE();
         double acc = 0, arz = 0;
 #pragma unroll
-        for (int r = 0; r < 5; ++r) { acc += a[3 * r] * tm[r]; arz += a[3 * r] * rz[r]; }
-        const double xt = s.xt[j], xp = s.x[j];
+        for (int r = 0; r < 5; ++r) { acc += av[r] * tv[r]; arz += av[r] * rzv[r]; }
         // P_s x without a matrix product: K x~ = rhs gives P_s x~ = rhs - sigma x~ - A^T R z~, and x is affine in x~
-        s.Px[j] = kAlphaRelax * (crhs()[j] - kSigma * xt - arz) + (1.0 - kAlphaRelax) * s.Px[j];
+        s.Px[j] = kAlphaRelax * (rh - kSigma * xt - arz) + (1.0 - kAlphaRelax) * px;
         const double xn = kAlphaRelax * xt + (1.0 - kAlphaRelax) * xp;
         s.x[j] = xn;
-        crhs()[j] = kSigma * xn - s.qs[j] + acc;
+        crhs()[j] = kSigma * xn - qv + acc;
       }
     });
+    MPC_SUBLAP(5, 12);
 #ifdef MPC_PROFILE_ADMM
     lap(8);
 #endif
