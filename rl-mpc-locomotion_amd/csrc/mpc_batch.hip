@@ -136,6 +136,8 @@ struct mpc_batch {
   int *d_info = nullptr;   // used when the caller passes no info buffer
   long long *d_prof = nullptr;   // per-robot section cycle counts of the last solve
   int *d_order = nullptr;        // workgroup -> robot map for the next launch (order_kernel)
+  float *d_host_in = nullptr;    // staging for mpc_batch_solve_host
+  double *d_host_f = nullptr;
   bool order_valid = false;
   long long bytes = 0;
 };
@@ -208,6 +210,8 @@ void mpc_batch_destroy(mpc_batch *b) {
   if (b->d_info) (void)hipFree(b->d_info);
   if (b->d_prof) (void)hipFree(b->d_prof);
   if (b->d_order) (void)hipFree(b->d_order);
+  if (b->d_host_in) (void)hipFree(b->d_host_in);
+  if (b->d_host_f) (void)hipFree(b->d_host_f);
   delete b;
 }
 
@@ -238,21 +242,17 @@ int mpc_batch_reset(mpc_batch *b, const int *ids, int k, void *stream) {
 int mpc_batch_solve_host(mpc_batch *b, const float *h_in, double *h_forces, int *h_info) {
   if (!b || !h_in || !h_forces) return fail(MPC_E_ARG, "mpc_batch_solve_host: bad argument");
   const size_t inlen = 56 + 4 * (size_t)b->h, N = 12 * (size_t)b->h;
-  float *d_in = nullptr;
-  double *d_f = nullptr;
-  HIP_TRY(hipMalloc(&d_in, sizeof(float) * b->n * inlen));
-  HIP_TRY(hipMalloc(&d_f, sizeof(double) * b->n * N));
-  HIP_TRY(hipMemcpy(d_in, h_in, sizeof(float) * b->n * inlen, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_f, h_forces, sizeof(double) * b->n * N, hipMemcpyHostToDevice));
-  int rc = mpc_batch_solve(b, d_in, d_f, nullptr, nullptr);
-  if (rc == MPC_OK) {
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(h_forces, d_f, sizeof(double) * b->n * N, hipMemcpyDeviceToHost));
-    if (h_info) HIP_TRY(hipMemcpy(h_info, b->d_info, sizeof(int) * b->n * kInfoLen, hipMemcpyDeviceToHost));
+  if (!b->d_host_in) {   // staging buffers of the host-pointer entry point, kept for the life of the handle
+    HIP_TRY(hipMalloc(&b->d_host_in, sizeof(float) * b->n * inlen));
+    HIP_TRY(hipMalloc(&b->d_host_f, sizeof(double) * b->n * N));
   }
-  (void)hipFree(d_in);
-  (void)hipFree(d_f);
-  return rc;
+  HIP_TRY(hipMemcpy(b->d_host_in, h_in, sizeof(float) * b->n * inlen, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b->d_host_f, h_forces, sizeof(double) * b->n * N, hipMemcpyHostToDevice));   // rows of unsolved robots stay as passed in
+  const int rc = mpc_batch_solve(b, b->d_host_in, b->d_host_f, nullptr, nullptr);
+  if (rc != MPC_OK) return rc;
+  HIP_TRY(hipMemcpy(h_forces, b->d_host_f, sizeof(double) * b->n * N, hipMemcpyDeviceToHost));     // (synchronises with the null stream)
+  if (h_info) HIP_TRY(hipMemcpy(h_info, b->d_info, sizeof(int) * b->n * kInfoLen, hipMemcpyDeviceToHost));
+  return MPC_OK;
 }
 
 int mpc_batch_size(const mpc_batch *b) { return b ? b->n : 0; }
