@@ -142,3 +142,30 @@ def test_hip_controller_reset_and_gait_switch():
     a.set_gait(np.full(n, 1, dtype=np.int32))
     out = run(a, 6)
     assert np.isfinite(out).all()
+
+
+@pytest.mark.gpu
+def test_env_bridge_equals_manual_composition():
+    """MpcEnvBridge.pre_physics_step = rescale + command record + controller.run (aliengo.py:237-258), reset_idx = per-robot reset."""
+    import torch
+    import rl_mpc_locomotion_amd  # noqa: F401
+    from rl_mpc_locomotion_amd.env_bridge import MpcEnvBridge
+    from rl_mpc_locomotion_amd.locomotion import BatchedLocomotion
+    from rl_mpc_locomotion_amd.synthetic import TickStream
+    n = 96
+    ts = TickStream(n, seed=9, config=3)
+    br = MpcEnvBridge(ts.robot_type, ts.gait_id, horizon=10)
+    ref = BatchedLocomotion(ts.robot_type, ts.gait_id, horizon=10)
+    rng = np.random.default_rng(4)
+    scale = np.array([4, 4, 4, 20, 20, 20, 1, 1, 1, 1, 1, 1], np.float32); const = np.array([5, 5, 5, 50, 50, 50, 1, 1, 1, 1, 1, 1], np.float32)
+    for k in range(6):
+        dof, body, cmd16 = ts.tick(k)
+        act = rng.uniform(-1, 1, (n, 12)).astype(np.float32)
+        cmd = cmd16.copy(); cmd[:, 3:15] = act * scale + const; cmd[:, 15] = 0
+        t_ref = ref.run(torch.from_numpy(dof).cuda(), torch.from_numpy(body).cuda(), torch.from_numpy(cmd).cuda()).clone()
+        t_br = br.pre_physics_step(torch.from_numpy(act).cuda(), torch.from_numpy(dof.reshape(n * 12, 2)).cuda(), torch.from_numpy(body).cuda(),
+                                   torch.from_numpy(np.ascontiguousarray(cmd16[:, :3])).cuda())
+        assert torch.equal(t_ref, t_br)
+        if k == 2:
+            ids = torch.tensor([1, 5, 40], dtype=torch.int64, device="cuda")
+            br.reset_idx(ids); ref.reset(ids)
