@@ -168,6 +168,10 @@ int mpc_ctrl_fsm_state(mpc_ctrl *c, int *h_out);
  *   mpc_ctrl_estimate        <- the StateEstimate the reference hands to compute_observations: copies the result of
  *                               the last mpc_ctrl_run's StateEstimator.update ([n, 18]) and the controller's
  *                               ground_normal_yaw ([n, 3], StateEstimator.py:99-143) to caller buffers (either may be NULL).
+ *   mpc_ctrl_update_estimate <- StateEstimator.update(body_states) alone (StateEstimator.py:57-97), for callers that need
+ *                               the estimate before the controller runs (RobotRunnerPolicy.run, robot_runner/
+ *                               RobotRunnerPolicy.py:62-92: update, observations, policy, then the FSM); mpc_ctrl_run /
+ *                               mpc_ctrl_run_fsm recompute the same estimate from the same body_states.
  *   mpc_pack_commands        <- np.concatenate((commands, actions_rescale, [0.0])) (RL_Environment/tasks/aliengo.py:251):
  *                               [n, 3] + [n, 12] -> the [n, 16] command record of mpc_ctrl_step / mpc_ctrl_run.
  */
@@ -178,6 +182,7 @@ void mpc_policy_destroy(mpc_policy *p);
 int mpc_policy_step(mpc_policy *p, int n, const float *d_obs, float *d_actions, float *d_weights, void *stream);
 int mpc_policy_observations(int n, const float *d_dof, const float *d_est, const float *d_ground_normal, const float *d_cmd3,
                             const float *d_prev_actions, const float *scales4, float *d_obs, void *stream);
+int mpc_ctrl_update_estimate(mpc_ctrl *c, const float *d_body, void *stream);
 int mpc_ctrl_estimate(mpc_ctrl *c, float *d_est, float *d_ground_normal, void *stream);
 int mpc_pack_commands(int n, const float *d_cmd3, const float *d_weights12, float *d_cmd16, void *stream);
 

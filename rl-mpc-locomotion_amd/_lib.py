@@ -15,7 +15,7 @@ SYMBOLS = [
     "mpc_batch_state_len", "mpc_batch_get_state", "mpc_batch_set_state", "mpc_batch_get_profile", "mpc_last_error",
     "mpc_ctrl_create", "mpc_ctrl_destroy", "mpc_ctrl_step", "mpc_ctrl_run", "mpc_ctrl_reset", "mpc_ctrl_set_gait", "mpc_ctrl_solver_info",
     "mpc_ctrl_fsm_init", "mpc_ctrl_run_fsm", "mpc_ctrl_fsm_reset", "mpc_ctrl_fsm_state",
-    "mpc_policy_create", "mpc_policy_destroy", "mpc_policy_step", "mpc_policy_observations", "mpc_ctrl_estimate", "mpc_pack_commands",
+    "mpc_policy_create", "mpc_policy_destroy", "mpc_policy_step", "mpc_policy_observations", "mpc_ctrl_estimate", "mpc_ctrl_update_estimate", "mpc_pack_commands",
 ]
 
 
@@ -61,6 +61,7 @@ def lib():
         L.mpc_policy_destroy.argtypes = [vp]; L.mpc_policy_destroy.restype = None
         L.mpc_policy_step.argtypes = [vp, ci, vp, vp, vp, vp]; L.mpc_policy_step.restype = ci
         L.mpc_policy_observations.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, vp]; L.mpc_policy_observations.restype = ci
+        L.mpc_ctrl_update_estimate.argtypes = [vp, vp, vp]; L.mpc_ctrl_update_estimate.restype = ci
         L.mpc_ctrl_estimate.argtypes = [vp, vp, vp, vp]; L.mpc_ctrl_estimate.restype = ci
         L.mpc_pack_commands.argtypes = [ci, vp, vp, vp, vp]; L.mpc_pack_commands.restype = ci
         L.mpc_last_error.argtypes = []; L.mpc_last_error.restype = C.c_char_p

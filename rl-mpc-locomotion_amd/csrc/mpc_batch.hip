@@ -656,6 +656,13 @@ int mpc_pack_commands(int n, const float *d_cmd3, const float *d_weights12, floa
   return MPC_OK;
 }
 
+int mpc_ctrl_update_estimate(mpc_ctrl *c, const float *d_body, void *stream) {
+  if (!c || !d_body) return fail(MPC_E_ARG, "mpc_ctrl_update_estimate: bad argument");
+  hipLaunchKernelGGL(estimator_kernel, dim3((c->n + 127) / 128), dim3(128), 0, (hipStream_t)stream, c->n, c->d_state, d_body, c->d_est);
+  HIP_TRY(hipGetLastError());
+  return MPC_OK;
+}
+
 int mpc_ctrl_estimate(mpc_ctrl *c, float *d_est, float *d_ground_normal, void *stream) {
   if (!c || (!d_est && !d_ground_normal)) return fail(MPC_E_ARG, "mpc_ctrl_estimate: bad argument");
   hipLaunchKernelGGL(ctrl_estimate_kernel, dim3((c->n + 127) / 128), dim3(128), 0, (hipStream_t)stream, c->n, c->d_state, c->d_est, d_est, d_ground_normal);

@@ -131,6 +131,21 @@ class BatchedLocomotion:
         _lib.check(_lib.lib().mpc_ctrl_fsm_state(self._handle, out.ctypes.data), "mpc_ctrl_fsm_state")
         return out
 
+    def run_policy(self, policy, dof_states, body_states, commands3, prev_weights, request):
+        """The batched ``RobotRunnerPolicy.run`` (robot_runner/RobotRunnerPolicy.py:62-92): StateEstimator.update, the weight
+        policy on the fresh estimate (its "previous actions" observation slot carries the previous WEIGHTS, as there:
+        ``compute_observations(dof, result, commands, self.weights)``), then the control FSM with those weights.
+        ``policy`` is a ``weight_policy.WeightPolicy``; returns (torques [N,12], weights [N,12])."""
+        import torch
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        if body_states.dtype != torch.float32 or not body_states.is_cuda or not body_states.is_contiguous() or body_states.numel() != self.n * 13:
+            raise ValueError("body_states must be a contiguous cuda float32 tensor with %d elements" % (self.n * 13))
+        _lib.check(_lib.lib().mpc_ctrl_update_estimate(self._handle, body_states.data_ptr(), stream), "mpc_ctrl_update_estimate")
+        est, nrm = self.estimate()
+        obs = policy.compute_observations(dof_states, est, nrm, commands3, prev_weights)
+        weights = policy.step(obs)
+        return self.run_fsm(dof_states, body_states, policy.pack_commands(commands3, weights), request), weights
+
     def estimate(self):
         """(est [n,18], ground_normal_yaw [n,3]) of the last ``run``: the StateEstimate the reference passes to
         ``WeightPolicy.compute_observations`` (vBody, omegaBody, rpyBody, ground_R_body_frame; StateEstimator.py:99-143)."""

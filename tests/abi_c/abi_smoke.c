@@ -19,7 +19,8 @@ static const char *kSymbols[] = {
     "mpc_batch_get_state", "mpc_batch_set_state", "mpc_batch_get_profile", "mpc_last_error", "mpc_ctrl_create", "mpc_ctrl_destroy",
     "mpc_ctrl_step", "mpc_ctrl_run", "mpc_ctrl_reset", "mpc_ctrl_set_gait", "mpc_ctrl_solver_info", "mpc_ctrl_fsm_init",
     "mpc_ctrl_run_fsm", "mpc_ctrl_fsm_reset", "mpc_ctrl_fsm_state", "mpc_policy_create",
-    "mpc_policy_destroy", "mpc_policy_step", "mpc_policy_observations", "mpc_ctrl_estimate", "mpc_pack_commands"};
+    "mpc_policy_destroy", "mpc_policy_step", "mpc_policy_observations", "mpc_ctrl_estimate", "mpc_ctrl_update_estimate",
+    "mpc_pack_commands"};
 
 typedef int (*create_fn)(mpc_batch **, int, int, double, double, const double *, const double *);
 typedef int (*solve_host_fn)(mpc_batch *, const float *, double *, int *);
