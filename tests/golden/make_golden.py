@@ -27,6 +27,7 @@ CASES = [  # name, n, h, config, seed, steps
     ("solver_h10_cfg3", 48, 10, 3, 1, 3),      # Go1/A1/Aliengo x trot/walk/bound (configs[2])
     ("solver_h16_cfg4", 12, 16, 4, 2, 2),      # h=16, random ground normals (configs[3])
     ("solver_h20_cfg5", 8, 20, 5, 3, 2),       # h=20, random ground normals (configs[4])
+    ("solver_h10_stress", 24, 10, 3, 5, 2),    # weights x 1e3 .. 1e9, velocities x 30: 100 - 400 ADMM iterations, many rho updates
 ]
 ONLY = sys.argv[1:]                            # optional: regenerate only the named cases
 
@@ -37,6 +38,11 @@ def main():
         if ONLY and name not in ONLY:
             continue
         wl = make_solver_workload(n, h=h, seed=seed, config=cfg)
+        if name.endswith("stress"):
+            inp = wl.inputs.copy()
+            inp[:, 0:13] *= np.float32(10.0) ** (3 + 2 * (np.arange(n) % 4))[:, None]      # weights x 1e3, 1e5, 1e7, 1e9
+            inp[:, 16:19] *= np.where(np.arange(n) % 2 == 0, 30.0, 1.0).astype(np.float32)[:, None]
+            wl.inputs = inp                       # (perturb_workload keeps the scaled weights / velocities for the warm step)
         ref = RefBatch(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
         out = dict(h=h, config=cfg, seed=seed, dt_mpc=wl.dt_mpc, alpha=wl.alpha, mass=wl.mass,
                    inertia_diag=wl.inertia_diag, robot_type=wl.robot_type, gait_id=wl.gait_id)

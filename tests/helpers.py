@@ -10,6 +10,14 @@ HAVE_REFERENCE = os.path.isdir("/root/reference/MPC_Controller")
 # over the first-step 12 forces.  BASELINE.json's bar is 1e-3; the fp64 kernel
 # reproduces OSQP's iterates, so the tests hold it to 1e-5 (observed <= 3e-7).
 GRF_RTOL = 1e-5
+# The stress fixture scales the weights by up to 1e9: the QP's conditioning amplifies the rounding difference between the
+# reference's sparse LDL^T and the explicit inverse used here.  Decisions (iterations, status, polish, rho updates) must still
+# be identical; forces are held to 2e-4 (BASELINE's bar is 1e-3).
+GRF_RTOL_STRESS = 2e-4
+
+
+def grf_rtol(name):
+    return GRF_RTOL_STRESS if name.endswith("stress") else GRF_RTOL
 
 
 def load_golden(name):
