@@ -48,7 +48,7 @@ struct DeviceExec {
 template <int H>
 __global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= MPC_MIN_WAVES_MAX_T ? MPC_MIN_WAVES : 1)) void mpc_solve_kernel(int n, const RobotModel *__restrict__ models,
                                                                const float *__restrict__ in, double *__restrict__ state,
-                                                               double *__restrict__ scratch, double *__restrict__ forces,
+                                                               double *__restrict__ scratch, const double *__restrict__ qp, double *__restrict__ forces,
                                                                int *__restrict__ info, long long *__restrict__ prof,
                                                                const int *__restrict__ active, const int *__restrict__ order) {
   // static LDS: absolute addresses fold into the ds_* offset fields (a dynamic-LDS base costs an SGPR
@@ -67,13 +67,32 @@ __global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= MPC_MIN_WAVES_MAX_T ? MPC_
   Solver<H, DeviceExec<H>> sv{ex,
                               sh,
                               mdl,
-                              in + (size_t)robot * C::IN_LEN,
                               state + (size_t)robot * state_len<H>(),
                               scratch + (size_t)robot * C::PG_LEN,
+                              qp + (size_t)robot * C::QP_LEN,
                               forces + (size_t)robot * C::N,
                               info + (size_t)robot * kInfoLen,
                               prof ? prof + (size_t)robot * kProfLen : nullptr};
   sv.run();
+}
+
+// Assembly kernel (mpc_core.h Assembler): q, bounds, cone block and P of every active robot -> HBM
+template <int H>
+__global__ __launch_bounds__(Cfg<H>::T) void mpc_assemble_kernel(int n, const RobotModel *__restrict__ models, const float *__restrict__ in,
+                                                                 double *__restrict__ scratch, double *__restrict__ qp,
+                                                                 long long *__restrict__ prof, const int *__restrict__ active) {
+  __shared__ __attribute__((aligned(16))) AsmShared<H> sh;
+  using C = Cfg<H>;
+  const int robot = blockIdx.x;
+  if (robot >= n) return;
+  if (active && !active[robot]) return;
+  Thread<H> th;
+  th.init(threadIdx.x);
+  DeviceExec<H> ex{th};
+  const RobotModel &mdl = models[robot];
+  Assembler<H, DeviceExec<H>> am{ex, sh, mdl, in + (size_t)robot * C::IN_LEN, scratch + (size_t)robot * C::PG_LEN,
+                                 qp + (size_t)robot * C::QP_LEN, prof ? prof + (size_t)robot * kProfLen : nullptr};
+  am.run();
 }
 
 __global__ void reset_kernel(double *state, int state_len, const int *ids, int k, int n) {
@@ -84,9 +103,10 @@ __global__ void reset_kernel(double *state, int state_len, const int *ids, int k
 }
 
 template <int H>
-int launch(int n, const RobotModel *models, const float *in, double *state, double *scratch, double *forces, int *info,
+int launch(int n, const RobotModel *models, const float *in, double *state, double *scratch, double *qp, double *forces, int *info,
            long long *prof, const int *active, const int *order, hipStream_t stream) {
-  hipLaunchKernelGGL(mpc_solve_kernel<H>, dim3(n), dim3(Cfg<H>::T), 0, stream, n, models, in, state, scratch, forces, info, prof, active, order);
+  hipLaunchKernelGGL(mpc_assemble_kernel<H>, dim3(n), dim3(Cfg<H>::T), 0, stream, n, models, in, scratch, qp, prof, active);
+  hipLaunchKernelGGL(mpc_solve_kernel<H>, dim3(n), dim3(Cfg<H>::T), 0, stream, n, models, in, state, scratch, qp, forces, info, prof, active, order);
   HIP_TRY(hipGetLastError());
   return MPC_OK;
 }
@@ -132,7 +152,7 @@ struct mpc_batch {
   int n = 0, h = 0;
   int state_len = 0;
   RobotModel *d_models = nullptr;
-  double *d_state = nullptr, *d_scratch = nullptr;
+  double *d_state = nullptr, *d_scratch = nullptr, *d_qp = nullptr;   // warm start, P tiles, QP record (q, l, u, cone)
   int *d_info = nullptr;   // used when the caller passes no info buffer
   long long *d_prof = nullptr;   // per-robot section cycle counts of the last solve
   int *d_order = nullptr;        // workgroup -> robot map for the next launch (order_kernel)
@@ -148,9 +168,9 @@ static int launch_solver(mpc_batch *b, const float *d_in, double *d_forces, int 
   const int *order = b->order_valid ? b->d_order : nullptr;
   int rc = MPC_E_HORIZON;
   switch (b->h) {
-    case 10: rc = launch<10>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, d_forces, d_info, b->d_prof, d_active, order, st); break;
-    case 16: rc = launch<16>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, d_forces, d_info, b->d_prof, d_active, order, st); break;
-    case 20: rc = launch<20>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, d_forces, d_info, b->d_prof, d_active, order, st); break;
+    case 10: rc = launch<10>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, b->d_qp, d_forces, d_info, b->d_prof, d_active, order, st); break;
+    case 16: rc = launch<16>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, b->d_qp, d_forces, d_info, b->d_prof, d_active, order, st); break;
+    case 20: rc = launch<20>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, b->d_qp, d_forces, d_info, b->d_prof, d_active, order, st); break;
   }
   if (rc == MPC_E_HORIZON) return fail(MPC_E_HORIZON, "solver launch: horizon not compiled in");
   if (rc != MPC_OK) return rc;
@@ -181,6 +201,7 @@ int mpc_batch_create(mpc_batch **out, int n, int horizon, double timestep, doubl
   b->n = n;
   b->h = horizon;
   const size_t pg_len = horizon == 10 ? Cfg<10>::PG_LEN : horizon == 16 ? Cfg<16>::PG_LEN : Cfg<20>::PG_LEN;   // P_s scratch, lower-triangle tiles
+  const size_t qp_len = 52 * (size_t)horizon + 16;                                                     // Cfg<H>::QP_LEN
   b->state_len = (int)(64 * horizon + 2);
   std::vector<RobotModel> models(n);
   for (int i = 0; i < n; ++i) models[i] = make_model(mass[i], inertia9 + 9 * (size_t)i, timestep, alpha);
@@ -189,6 +210,7 @@ int mpc_batch_create(mpc_batch **out, int n, int horizon, double timestep, doubl
   if ((e = hipMalloc(&b->d_models, sizeof(RobotModel) * n)) != hipSuccess ||
       (e = hipMalloc(&b->d_state, sizeof(double) * (size_t)n * b->state_len)) != hipSuccess ||
       (e = hipMalloc(&b->d_scratch, sizeof(double) * (size_t)n * pg_len)) != hipSuccess ||
+      (e = hipMalloc(&b->d_qp, sizeof(double) * (size_t)n * qp_len)) != hipSuccess ||
       (e = hipMalloc(&b->d_info, sizeof(int) * (size_t)n * kInfoLen)) != hipSuccess ||
       (e = hipMalloc(&b->d_prof, sizeof(long long) * (size_t)n * kProfLen)) != hipSuccess ||
       (e = hipMalloc(&b->d_order, sizeof(int) * (size_t)n)) != hipSuccess ||
@@ -197,7 +219,7 @@ int mpc_batch_create(mpc_batch **out, int n, int horizon, double timestep, doubl
     cleanup();
     return fail(MPC_E_HIP, std::string("mpc_batch_create: ") + hipGetErrorString(e));
   }
-  b->bytes = (long long)(sizeof(RobotModel) * n + sizeof(double) * (size_t)n * (b->state_len + pg_len) + sizeof(int) * (size_t)n * kInfoLen);
+  b->bytes = (long long)(sizeof(RobotModel) * n + sizeof(double) * (size_t)n * (b->state_len + pg_len + qp_len) + sizeof(int) * (size_t)n * kInfoLen);
   *out = b;
   return MPC_OK;
 }
@@ -207,6 +229,7 @@ void mpc_batch_destroy(mpc_batch *b) {
   if (b->d_models) (void)hipFree(b->d_models);
   if (b->d_state) (void)hipFree(b->d_state);
   if (b->d_scratch) (void)hipFree(b->d_scratch);
+  if (b->d_qp) (void)hipFree(b->d_qp);
   if (b->d_info) (void)hipFree(b->d_info);
   if (b->d_prof) (void)hipFree(b->d_prof);
   if (b->d_order) (void)hipFree(b->d_order);

@@ -1,5 +1,6 @@
-// mpc_core.h -- one robot's convex-MPC contact-force solve, written once as a sequence of
-// barrier-separated phases over the threads of one workgroup.
+// mpc_core.h -- one robot's convex-MPC contact-force solve, written once as sequences of
+// barrier-separated phases over the threads of one workgroup: Assembler (QP assembly, its own kernel) and
+// Solver (the OSQP algorithm).
 //
 //   Device build (mpc_batch.hip): Exec::par(f) = { f(thread); __syncthreads(); } -- the per-thread
 //   state lives in VGPRs, Shared<H> in LDS.
@@ -96,12 +97,12 @@ struct Cfg {
   static constexpr int NTASK = 78 + (H - 1) * 144;       // P assembly tasks (d, a, b)
   static_assert(T <= 1024, "workgroup too large");
   static constexpr int NP = N + 2;                       // row stride of part[] (doubles)
-  static constexpr int PARTLEN0 = (NP * G > 14 * 64) ? NP * G : 14 * 64;   // part[] doubles as the reduction scratch ...
-  // Large horizons are LDS-tight (one workgroup per CU, 160 KB): A^k B moves next to W A^k B inside part[] where both fit,
-  // and rho / 1/rho come from the three per-type values instead of per-row arrays.
-  static constexpr bool kAnbInPart = 2 * H * 156 <= PARTLEN0;
+  static constexpr int PARTLEN = (NP * G > 14 * 64) ? NP * G : 14 * 64;   // part[] doubles as the reduction scratch
+  // The longest horizon is LDS-tight (one workgroup per CU, 160 KB): rho / 1/rho come from the three per-type values
+  // instead of per-row arrays.
   static constexpr bool kCompact = H > 16;
-  static constexpr int PARTLEN = PARTLEN0 > H * 156 ? PARTLEN0 : H * 156;  // ... and as W A^k B during assembly
+  // The QP record the assembly kernel hands to the solve kernel (doubles per robot): q[N] l[M] u[M] cone[15] pad
+  static constexpr int QP_Q = 0, QP_L = N, QP_U = N + M, QP_CONE = N + 2 * M, QP_LEN = N + 2 * M + 16;
 };
 
 // Flat input record offsets (include/mpc_batch.h, layout.py)
@@ -148,13 +149,10 @@ struct Shared {
   unsigned long long red[16];                           // max-reductions (bit pattern of doubles >= 0)
   int first, iter, status, status_polish, rho_updates, nfact, done, bad;   // control (uniform)
   double pri_res, dua_res, rho_new;
-  // ---- phase-local storage: assembly + scaling, then residuals + polish share the same LDS ------
+  // ---- phase-local storage: scaling, then polish share the same LDS ---------------------------------------------
   union {
     struct {
-      MPC_V in[C::IN_LEN];
-      MPC_V x0[13]; MPC_V xref[13 * H]; MPC_V sdiff[13 * H]; MPC_V xk[13 * H];
-      MPC_V a_dt[169]; MPC_V b_dt[156]; MPC_V a_exp[169]; MPC_V b_exp[156]; MPC_V anb_u[C::kAnbInPart ? 2 : H * 156];
-      MPC_V cone[15];
+      MPC_V cone[16];
       MPC_V l[C::M]; MPC_V u[C::M];                     // unscaled bounds
       MPC_V dt_[C::N]; MPC_V et_[C::M]; MPC_V cn_[C::N];   // Ruiz pass temporaries
     };
@@ -170,11 +168,19 @@ struct Shared {
   union {
     MPC_V part[C::PARTLEN];                             // [slot][row] partial sums / maxima of the tile products
     struct { MPC_V tm[C::M]; MPC_V rzt[C::M]; };        // R z - y and R z~ of the current ADMM iteration (part is dead then)
-    struct { MPC_V wanb[H * 156]; MPC_V anb_p[C::kAnbInPart ? H * 156 : 2]; };   // assembly: diag(w) A^k B [, A^k B] (part is not in use yet)
   };
 #ifdef MPC_LDS_PAD
   char pad[MPC_LDS_PAD];                                // occupancy experiments only
 #endif
+};
+// LDS of the assembly kernel (one workgroup per robot, its own launch: see Assembler)
+template <int H>
+struct AsmShared {
+  using C = Cfg<H>;
+  MPC_V in[C::IN_LEN];
+  MPC_V x0[13]; MPC_V xref[13 * H]; MPC_V sdiff[13 * H]; MPC_V xk[13 * H];
+  MPC_V a_dt[169]; MPC_V b_dt[156]; MPC_V a_exp[169]; MPC_V b_exp[156];
+  MPC_V anb[H * 156]; MPC_V wanb[H * 156];              // A^k B and diag(w) A^k B
 };
 #undef MPC_V
 
@@ -229,6 +235,300 @@ MPC_HD double bitsd(unsigned long long u) {
 // The solver.  `Exec` provides: par(f), amax(&slot, value) (LDS atomic max on a double >= 0).
 // `Pg` is this robot's n*n fp64 scratch in HBM (holds P, then the scaled P_s).
 // ------------------------------------------------------------------------------------------------
+// Diagnostic builds (-DMPC_PROFILE_SUB=<section>) split one section into slots 9..13 of the profile record:
+// 1 = dynamics, 2 = one scaling pass, 3 = polish set-up, 4 = A dt / B dt set-up, 5 = the four phases of an ADMM iteration.
+#ifndef MPC_PROFILE_SUB
+#define MPC_PROFILE_SUB 0
+#endif
+#define MPC_SUBLAP(sec, k) do { if (MPC_PROFILE_SUB == (sec)) lap(k); } while (0)
+
+// ============================================================================================================
+// 1. Assembly (mpc_osqp.cc:606-688), a kernel of its own: one workgroup per robot builds q, the bounds, the cone block
+// and P (tile-major, unscaled) and leaves them in HBM for the solve kernel.  It needs 38 KB of LDS that the solver does
+// not (four robots per CU instead of two) and is bound by LDS latency / bandwidth, not by fp64 issue.
+// ============================================================================================================
+template <int H, class Exec>
+struct Assembler {
+  using C = Cfg<H>;
+  using Th = Thread<H>;
+  static constexpr int N = C::N, M = C::M, NF = C::NF, T = C::T, TS = C::TS, TE = C::TE;
+
+  Exec &ex;
+  AsmShared<H> &s;
+  const RobotModel &mdl;
+  const float *in;     // [IN_LEN]
+  double *Pg;          // [PG_LEN]   out: P, lower-triangle tiles
+  double *qp;          // [QP_LEN]   out: q, l, u, cone
+  long long *prof;     // [kProfLen] slots 1 (dynamics) and 2 (q + P) are written here (may be null)
+  long long tc[3] = {0, 0, 0};
+  long long tlast = 0;
+  MPC_HD void lap(int k) { const long long now = MPC_CLOCK(); tc[k] += now - tlast; tlast = now; }
+
+  static MPC_HD double mat3e(const double *a, const double *b, int e) {   // entry e = 3 i + j of the 3 x 3 product a b
+    const int i = e / 3, j = e - 3 * i;
+    return a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+  }
+  static MPC_HD void mat3(const double *a, const double *b, double *c) {
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) c[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+  }
+
+  static MPC_HD size_t pg_index(int r, int c) {   // offset of entry (r, c) in the tile-major store; needs r / 6 >= c / 6
+    const int I = r / TS, J = c / TS;
+    return (size_t)(I * (I + 1) / 2 + J) * TE + (r - TS * I) * TS + (c - TS * J);
+  }
+
+  // ================================ 1. assembly =================================================
+  MPC_HD void run() {
+    tlast = MPC_CLOCK();
+    ex.par([&](Th &t) {
+      for (int i = t.tid; i < C::IN_LEN; i += T) s.in[i] = (double)in[i];
+      for (int i = t.tid; i < 169; i += T) s.a_dt[i] = 0;
+      for (int i = t.tid; i < 156; i += T) s.b_dt[i] = 0;
+    });
+    // ---- A dt, B dt (mpc_osqp.cc:299-336, 606-617, 661-673): every 3 x 3 product is one entry per thread, all
+    // operands in LDS (a thread-local array indexed by a runtime entry number would live in scratch memory).
+    // The intermediates use the not yet used xk / sdiff areas:
+    //   xk:    tan(pitch); m1 = Rx Ry; m2 = Rz Ry; rxyz; rzyx; fw[12]; t2 = rzyx I^-1; iw
+    //   sdiff: [26..53) Rx, Ry, Rz; [53..62) I^-1 (body)
+    double *const tp_ = s.xk, *const m1 = s.xk + 7, *const m2 = s.xk + 16, *const rxyz = s.xk + 25, *const rzyx = s.xk + 34,
+                 *const fw = s.xk + 43, *const t2 = s.xk + 55, *const iw = s.xk + 64;
+    double *const rxm = s.sdiff + 26, *const rym = s.sdiff + 35, *const rzm = s.sdiff + 44, *const iib = s.sdiff + 53;
+    static_assert(13 * H >= 73, "xk / sdiff too small for the set-up scratch");
+    ex.par([&](Th &t) {
+      if (t.tid < 27) {   // entry k of rotation `which` about x / y / z: 0, 1, cos, sin or -sin of its angle
+        const int which = t.tid / 9, k = t.tid - 9 * which;
+        const int ax = which, u = (ax + 1) % 3, v = (ax + 2) % 3, r = k / 3, c = k - 3 * r;
+        const double ang = s.in[IN_RPY + which];
+        double val;
+        if (r == ax || c == ax) val = (r == c) ? 1.0 : 0.0;
+        else if (r == c) val = cos(ang);
+        else val = (r == v && c == u) ? sin(ang) : -sin(ang);     // R[u][v] = -sin, R[v][u] = +sin
+        rxm[t.tid] = val;
+      } else if (t.tid == 64) {
+        tp_[0] = tan(s.in[IN_RPY + 1]);
+      } else if (t.tid >= 96 && t.tid < 105) {
+        iib[t.tid - 96] = mdl.inv_inertia[t.tid - 96];
+      }
+    });
+    MPC_SUBLAP(4, 9);
+    ex.par([&](Th &t) {   // m1 = Rx Ry (feet, :606-609), m2 = Rz Ry (inertia, :283-291)
+      if (t.tid < 18) {
+        const int e = t.tid % 9;
+        (t.tid < 9 ? m1 : m2)[e] = mat3e(t.tid < 9 ? rxm : rzm, rym, e);
+      }
+      // x0 (:630-633)
+      if (t.tid >= 32 && t.tid < 45) {
+        const int i = t.tid - 32;
+        s.x0[i] = i < 3 ? s.in[IN_RPY + i] : i < 6 ? s.in[IN_POS + i - 3] : i < 9 ? s.in[IN_ANG + i - 6] : i < 12 ? s.in[IN_VEL + i - 9] : -kGravity;
+      }
+      // bounds (:449-477, 685-688, 720-721)
+      if (t.tid < M) {
+        const int i = t.tid, f = i / 5, r = i - 5 * f;
+        const double cst = s.in[IN_CONTACT + f];
+        const double fzmax = mdl.mass * kGravity * kMaxScale, fzmin = mdl.mass * kGravity * kMinScale;
+        const double mu0 = s.in[in_fric<H>()];
+        qp[C::QP_L + i] = dmax(r < 4 ? 0.0 : fzmin * cst, -kInfty);
+        qp[C::QP_U + i] = dmin(r < 4 ? (mu0 + 1) * fzmax * cst : fzmax * cst, kInfty);
+      }
+    });
+    MPC_SUBLAP(4, 10);
+    ex.par([&](Th &t) {   // rxyz = (Rx Ry) Rz, rzyx = (Rz Ry) Rx
+      if (t.tid < 18) {
+        const int e = t.tid % 9;
+        (t.tid < 9 ? rxyz : rzyx)[e] = mat3e(t.tid < 9 ? m1 : m2, t.tid < 9 ? rzm : rxm, e);
+      }
+      // x_ref (:635-659): row r of step i is base_r + dt (i + 1) slope_r  (slope 0 for the constant rows)
+      for (int k = t.tid; k < 13 * H; k += T) {
+        const int i = k / 13, r = k - 13 * i;
+        const double tt = mdl.dt * (i + 1);
+        const int drpy = in_drpy<H>(), dvel = in_dvel<H>(), dang = in_dang<H>(), dpos = in_dpos<H>();
+        const int bi = r < 2 ? drpy + r : r == 2 ? IN_RPY + 2 : r < 5 ? IN_POS + r - 3 : r == 5 ? dpos + 2 : r < 9 ? dang + r - 6 : dvel + (r < 11 ? r - 9 : 0);
+        const int si = r == 2 ? dang + 2 : dvel + (r == 4 ? 1 : 0);
+        const double base = s.in[bi], slope = s.in[si];
+        const double v = (r == 2 || r == 3 || r == 4) ? tt * slope + base : base;
+        s.xref[k] = r == 11 ? 0.0 : r == 12 ? -kGravity : v;
+      }
+    });
+    MPC_SUBLAP(4, 11);
+    ex.par([&](Th &t) {   // feet in the world frame; t2 = rzyx I^-1 (:670)
+      if (t.tid < 12) {
+        const int i = t.tid / 3, r = t.tid - 3 * i;
+        const double *fb = s.in + in_foot<H>();
+        fw[t.tid] = rxyz[3 * r] * fb[3 * i] + rxyz[3 * r + 1] * fb[3 * i + 1] + rxyz[3 * r + 2] * fb[3 * i + 2];
+      } else if (t.tid < 21) {
+        t2[t.tid - 12] = mat3e(rzyx, iib, t.tid - 12);
+      }
+    });
+    MPC_SUBLAP(4, 12);
+    ex.par([&](Th &t) {   // iw = t2 rzyx^T (:671)
+      if (t.tid < 9) {
+        const int i = t.tid / 3, j = t.tid - 3 * i;
+        iw[t.tid] = t2[3 * i] * rzyx[3 * j] + t2[3 * i + 1] * rzyx[3 * j + 1] + t2[3 * i + 2] * rzyx[3 * j + 2];
+      }
+    });
+    ex.par([&](Th &t) {
+      const double dt = mdl.dt;
+      if (t.tid < 36) {   // B rows 6-8: I_w^-1 [r_i]x (:324-336); [v]x = {0, -v2, v1; v2, 0, -v0; -v1, v0, 0}
+        const int i = t.tid / 9, e = t.tid - 9 * i, r = e / 3, c = e - 3 * r;
+        const double *v = fw + 3 * i;
+        double acc = 0;
+        for (int k = 0; k < 3; ++k) {   // same left-to-right sum as the 3 x 3 product, with skew[k][c] formed on the fly
+          const double sk = (k == c) ? 0.0 : (((c - k + 3) % 3 == 1) ? -v[3 - k - c] : v[3 - k - c]);
+          const double term = iw[3 * r + k] * sk;
+          acc = k == 0 ? term : acc + term;
+        }
+        s.b_dt[(6 + r) * 12 + 3 * i + c] = acc * dt;
+      } else if (t.tid < 48) {   // B rows 9-11: I / m
+        const int k = t.tid - 36, i = k / 3, r = k - 3 * i;
+        s.b_dt[(9 + r) * 12 + 3 * i + r] = mdl.inv_mass * dt;
+      } else if (t.tid < 57) {   // A rows 0-2: omega -> rpy rates (:311-312): {cy/cp, sy/cp, 0; -sy, cy, 0; cy tp, sy tp, 1}
+        const int e = t.tid - 48, r = e / 3, c = e - 3 * r;
+        const double cp = rym[0], cy = rzm[0], sy = rzm[3], tp = tp_[0];
+        const double num = c == 0 ? cy : sy;
+        double val;
+        if (c == 2) val = r == 2 ? 1.0 : 0.0;
+        else if (r == 0) val = num / cp;
+        else if (r == 1) val = c == 0 ? -sy : cy;
+        else val = num * tp;
+        s.a_dt[r * 13 + 6 + c] = val * dt;
+      } else if (t.tid < 60) {
+        const int r = t.tid - 57;
+        s.a_dt[(3 + r) * 13 + 9 + r] = dt;
+        s.a_dt[(9 + r) * 13 + 12] = s.in[IN_NRM + r] * dt;
+      } else if (t.tid == 60) {
+        const double *fr = s.in + in_fric<H>();
+        const double cb[15] = {-1, 0, fr[0], 1, 0, fr[1], 0, -1, fr[2], 0, 1, fr[3], 0, 0, 1};   // :437-447
+        for (int k = 0; k < 15; ++k) qp[C::QP_CONE + k] = cb[k];
+      }
+    });
+    MPC_SUBLAP(1, 9);
+    MPC_SUBLAP(4, 13);
+    // exact exponential (mpc_osqp.cc:338-351; M^3 = 0): A_exp = I + A dt + (A dt)^2/2, B_exp = B dt + (A dt)(B dt)/2.
+    // A dt is nonzero only at rows 0-2 x cols 6-8, (3+i, 9+i) and rows 9-11 x col 12; the dense products of the
+    // reference add exact zeros elsewhere, so only the nonzero terms are formed (same order, same values).
+    ex.par([&](Th &t) {
+      for (int k = t.tid; k < 169 + 156; k += T) {
+        if (k < 169) {
+          const int r = k / 13, c = k - 13 * r;
+          const double acc = (r >= 3 && r < 6 && c == 12) ? s.a_dt[r * 13 + r + 6] * s.a_dt[(r + 6) * 13 + 12] : 0.0;
+          s.a_exp[k] = (r == c ? 1.0 : 0.0) + s.a_dt[k] + acc / 2;
+        } else {
+          const int kk = k - 169, r = kk / 12, c = kk - 12 * r;
+          double acc = 0;
+          if (r < 3) { for (int j = 6; j < 9; ++j) acc += s.a_dt[r * 13 + j] * s.b_dt[j * 12 + c]; }
+          else if (r < 6) acc += s.a_dt[r * 13 + r + 6] * s.b_dt[(r + 6) * 12 + c];
+          s.b_exp[kk] = s.b_dt[kk] + acc / 2;
+        }
+      }
+    });
+    MPC_SUBLAP(1, 10);
+    // A^k B (:368-373) and the free response A^{i+1} x0, i < H-1 (:360-364; the last A_qp block stays 0).
+    // A dt is nilpotent, so A_exp^k = exp(k A dt) = I + k A dt + k^2 (A dt)^2 / 2 exactly, and (A dt)^2 B_exp = 0
+    // (its only column, 12, meets the zero row 12 of B_exp):  A_exp^k B_exp = B_exp + k U,  U = (A dt) B_exp,
+    // which is nonzero in rows 0-5 only.  All k are formed at once (the reference multiplies k times; the two
+    // agree to rounding).  U overwrites b_dt, (A dt) x0 and (A dt)^2 x0 go to the first 26 slots of sdiff.
+    ex.par([&](Th &t) {
+      if (t.tid < 72) {
+        const int r = t.tid / 12, c = t.tid - 12 * r;
+        double acc = 0;
+        if (r < 3) { for (int j = 6; j < 9; ++j) acc += s.a_dt[r * 13 + j] * s.b_exp[j * 12 + c]; }
+        else acc = s.a_dt[r * 13 + r + 6] * s.b_exp[(r + 6) * 12 + c];
+        s.b_dt[t.tid] = acc;
+      } else if (t.tid < 72 + 13) {
+        const int r = t.tid - 72;
+        double a1 = 0, a2 = 0;
+        if (r < 3) { for (int j = 6; j < 9; ++j) a1 += s.a_dt[r * 13 + j] * s.x0[j]; }
+        else if (r < 6) { a1 = s.a_dt[r * 13 + r + 6] * s.x0[r + 6]; a2 = (s.a_dt[r * 13 + r + 6] * s.a_dt[(r + 6) * 13 + 12]) * s.x0[12]; }
+        else if (r >= 9 && r < 12) a1 = s.a_dt[r * 13 + 12] * s.x0[12];
+        s.sdiff[r] = a1; s.sdiff[13 + r] = a2;
+      }
+    });
+    ex.par([&](Th &t) {
+      for (int e = t.tid; e < H * 156; e += T) {
+        const int k = e / 156, rc = e - 156 * k, r = rc / 12;
+        const double v = r < 6 ? s.b_exp[rc] + (double)k * s.b_dt[rc] : s.b_exp[rc];
+        s.anb[e] = v;
+        s.wanb[e] = s.in[IN_W + r] * v;
+      }
+      for (int e = t.tid; e < 13 * (H - 1); e += T) {   // (this overwrites the set-up scratch, which is dead by now)
+        const int i = e / 13, r = e - 13 * i;
+        const double kk = i + 1;
+        s.xk[e] = s.x0[r] + kk * s.sdiff[r] + (kk * kk / 2) * s.sdiff[13 + r];
+      }
+    });
+    MPC_SUBLAP(1, 11);
+    ex.par([&](Th &t) {   // state_diff (:681)
+      for (int k = t.tid; k < 13 * H; k += T) s.sdiff[k] = (k < 13 * (H - 1) ? s.xk[k] : 0.0) - s.xref[k];
+    });
+    lap(1);
+    // q (:683) and P (:387-434) -> Pg (unscaled, lower-triangle tiles)
+    ex.par([&](Th &t) {
+      if (t.tid < N) {
+        const int j = t.tid / 12, c = t.tid - 12 * j;
+        double acc = 0;
+        for (int i = j; i < H; ++i) {
+          const double *bk = s.wanb + (i - j) * 156 + c, *sd = s.sdiff + 13 * i;
+          double e = 0, o = 0;   // two FMA chains per horizon step
+#pragma unroll
+          for (int r = 0; r < 13; ++r) {
+            if (r & 1) o += bk[r * 12] * sd[r];
+            else e += bk[r * 12] * sd[r];
+          }
+          acc += e + o;
+        }
+        qp[C::QP_Q + t.tid] = 2 * acc;
+      }
+      for (int task = t.tid; task < C::NTASK; task += T) {
+        int d, a, b;
+        if (task < 78) {          // diagonal blocks: a <= b only, mirrored
+          d = 0;
+          int k = task; a = 0;
+          while (k >= 12 - a) { k -= 12 - a; ++a; }
+          b = a + k;
+        } else {
+          const int k = task - 78;
+          d = 1 + k / 144;
+          const int ab = k - (d - 1) * 144;
+          a = ab / 12; b = ab - 12 * a;
+        }
+        // entry (12 I + a, 12 J + b), I = J - d <= J, lives at row 12 J + b, column 12 I + a of the lower triangle:
+        // tile (2 J + b / 6, 2 I + a / 6), position (b % 6, a % 6); a diagonal tile also takes the mirrored entry
+        const int ah = a / TS, bh = b / TS, lo = (b - TS * bh) * TS + (a - TS * ah), lom = (a - TS * ah) * TS + (b - TS * bh);
+        const bool mirror = d == 0 && ah == bh && a != b;
+        const double *xa = s.wanb + d * 156 + a, *yb = s.anb + b;
+        double acc = 0;
+        const int ns = H - d;
+        for (int sidx = 0; sidx < ns; sidx += 2) {   // two horizon offsets per trip: four independent FMA chains
+          const int s1 = sidx + 1 < ns ? sidx + 1 : sidx;
+          const double *x0 = xa + sidx * 156, *y0 = yb + sidx * 156, *x1 = xa + s1 * 156, *y1 = yb + s1 * 156;
+          double e0 = 0, o0 = 0, e1 = 0, o1 = 0;
+#pragma unroll
+          for (int r = 0; r < 13; ++r) {
+            if (r & 1) { o0 += x0[r * 12] * y0[r * 12]; o1 += x1[r * 12] * y1[r * 12]; }
+            else { e0 += x0[r * 12] * y0[r * 12]; e1 += x1[r * 12] * y1[r * 12]; }
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            if (u == 1 && sidx + 1 >= ns) break;
+            acc += u == 0 ? e0 + o0 : e1 + o1;
+            const int J = H - 1 - (sidx + u), I = J - d;
+            const int tr = 2 * J + bh, tix = tr * (tr + 1) / 2 + 2 * I + ah;
+            double v = 2.0 * acc;
+            if (d == 0 && a == b) v += mdl.alpha;
+            Pg[(size_t)tix * TE + lo] = v;
+            if (mirror) Pg[(size_t)tix * TE + lom] = v;
+          }
+        }
+      }
+    });
+    lap(2);
+    if (prof) {
+      ex.par([&](Th &t) { if (t.tid == 0) { prof[1] = tc[1]; prof[2] = tc[2]; } });
+    }
+  }
+};
+
 template <int H, class Exec>
 struct Solver {
   using C = Cfg<H>;
@@ -239,9 +539,9 @@ struct Solver {
   Exec &ex;
   Sh &s;
   const RobotModel &mdl;
-  const float *in;     // [IN_LEN]
   double *state;       // [state_len<H>()]
-  double *Pg;          // [N*N]
+  double *Pg;          // [PG_LEN]  P (unscaled) from the assembly kernel; P_s after scaling
+  const double *qp;    // [QP_LEN]  q, l, u, cone from the assembly kernel
   double *forces;      // [N]   out: -D x (all horizon steps), untouched on failure
   int *info;           // [kInfoLen]
   long long *prof;     // [kProfLen] shader-clock cycles per section (may be null)
@@ -259,7 +559,6 @@ struct Solver {
         f(v, u);
       }
   }
-  MPC_HD double *anb() { if constexpr (C::kAnbInPart) return s.anb_p; else return s.anb_u; }
   MPC_HD double rho_at(int i) const {
     if constexpr (C::kCompact) { const int ty = s.ctype[i]; return ty == 1 ? s.rho3[2] : (ty == 0 ? s.rho3[1] : s.rho3[0]); }
     else return s.rho_vec[i];
@@ -270,12 +569,6 @@ struct Solver {
   }
   long long tc[kProfLen] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = 0;
-  // Diagnostic builds (-DMPC_PROFILE_SUB=<section>) split one section into slots 9..13 of the profile record:
-  // 1 = dynamics, 2 = one scaling pass, 3 = polish set-up, 4 = A dt / B dt set-up, 5 = the four phases of an ADMM iteration.
-#ifndef MPC_PROFILE_SUB
-#define MPC_PROFILE_SUB 0
-#endif
-#define MPC_SUBLAP(sec, k) do { if (MPC_PROFILE_SUB == (sec)) lap(k); } while (0)
   MPC_HD void lap(int k) { const long long now = MPC_CLOCK(); tc[k] += now - tlast; tlast = now; }
 
   // ---- helpers valid inside a phase ------------------------------------------------------------
@@ -364,275 +657,25 @@ struct Solver {
 #pragma unroll
     for (int e = 0; e < TE; ++e) g[e] = t.Mx[e];
   }
-  static MPC_HD size_t pg_index(int r, int c) {   // offset of entry (r, c) in the tile-major store; needs r / 6 >= c / 6
-    const int I = r / TS, J = c / TS;
-    return (size_t)(I * (I + 1) / 2 + J) * TE + (r - TS * I) * TS + (c - TS * J);
-  }
 
-  // ================================ 1. assembly =================================================
-  MPC_HD void assemble() {
+  // ================================ 1. load: the QP record of the assembly kernel + the warm-start state =====
+  MPC_HD void load() {
     ex.par([&](Th &t) {
-      for (int i = t.tid; i < C::IN_LEN; i += T) s.in[i] = (double)in[i];
-      for (int i = t.tid; i < 169; i += T) s.a_dt[i] = 0;
-      for (int i = t.tid; i < 156; i += T) s.b_dt[i] = 0;
-      // warm-start state (scaled iterates of the previous call; zeros on the first call)
-      for (int i = t.tid; i < N; i += T) { s.x[i] = state[i]; s.xt[i] = state[N + 2 * M + i]; /* q_old */ }
-      for (int i = t.tid; i < M; i += T) { s.zz[0][i] = state[N + i]; s.yy[0][i] = state[N + M + i]; }
+      for (int i = t.tid; i < N; i += T) { s.q[i] = qp[C::QP_Q + i]; s.x[i] = state[i]; s.xt[i] = state[N + 2 * M + i]; /* q_old */ }
+      for (int i = t.tid; i < M; i += T) {
+        s.l[i] = qp[C::QP_L + i]; s.u[i] = qp[C::QP_U + i];
+        s.zz[0][i] = state[N + i]; s.yy[0][i] = state[N + M + i];   // scaled iterates of the previous call; zeros on the first call
+      }
+      if (t.tid < 15) s.cone[t.tid] = qp[C::QP_CONE + t.tid];
       if (t.tid == 0) {
-        s.rho = state[2 * N + 2 * M];
-        s.first = state[2 * N + 2 * M + 1] == 0.0;
+        const bool first = state[2 * N + 2 * M + 1] == 0.0;
+        s.first = first;
+        s.rho = first ? kRho0 : state[2 * N + 2 * M];
         s.status = kStUnsolved; s.status_polish = 0; s.rho_updates = 0; s.nfact = 0; s.iter = 0; s.done = 0; s.bad = 0;
       }
     });
     lap(0);
-    // ---- A dt, B dt (mpc_osqp.cc:299-336, 606-617, 661-673): every 3 x 3 product is one entry per thread, all
-    // operands in LDS (a thread-local array indexed by a runtime entry number would live in scratch memory).
-    // The intermediates use the not yet used xk / sdiff areas:
-    //   xk:    tan(pitch); m1 = Rx Ry; m2 = Rz Ry; rxyz; rzyx; fw[12]; t2 = rzyx I^-1; iw
-    //   sdiff: [26..53) Rx, Ry, Rz; [53..62) I^-1 (body)
-    double *const tp_ = s.xk, *const m1 = s.xk + 7, *const m2 = s.xk + 16, *const rxyz = s.xk + 25, *const rzyx = s.xk + 34,
-                 *const fw = s.xk + 43, *const t2 = s.xk + 55, *const iw = s.xk + 64;
-    double *const rxm = s.sdiff + 26, *const rym = s.sdiff + 35, *const rzm = s.sdiff + 44, *const iib = s.sdiff + 53;
-    static_assert(13 * H >= 73, "xk / sdiff too small for the set-up scratch");
-    ex.par([&](Th &t) {
-      if (t.tid < 27) {   // entry k of rotation `which` about x / y / z: 0, 1, cos, sin or -sin of its angle
-        const int which = t.tid / 9, k = t.tid - 9 * which;
-        const int ax = which, u = (ax + 1) % 3, v = (ax + 2) % 3, r = k / 3, c = k - 3 * r;
-        const double ang = s.in[IN_RPY + which];
-        double val;
-        if (r == ax || c == ax) val = (r == c) ? 1.0 : 0.0;
-        else if (r == c) val = cos(ang);
-        else val = (r == v && c == u) ? sin(ang) : -sin(ang);     // R[u][v] = -sin, R[v][u] = +sin
-        rxm[t.tid] = val;
-      } else if (t.tid == 64) {
-        tp_[0] = tan(s.in[IN_RPY + 1]);
-      } else if (t.tid >= 96 && t.tid < 105) {
-        iib[t.tid - 96] = mdl.inv_inertia[t.tid - 96];
-      }
-      if (t.tid == 128 % T && s.first) s.rho = kRho0;
-    });
-    MPC_SUBLAP(4, 9);
-    ex.par([&](Th &t) {   // m1 = Rx Ry (feet, :606-609), m2 = Rz Ry (inertia, :283-291)
-      if (t.tid < 18) {
-        const int e = t.tid % 9;
-        (t.tid < 9 ? m1 : m2)[e] = mat3e(t.tid < 9 ? rxm : rzm, rym, e);
-      }
-      // x0 (:630-633)
-      if (t.tid >= 32 && t.tid < 45) {
-        const int i = t.tid - 32;
-        s.x0[i] = i < 3 ? s.in[IN_RPY + i] : i < 6 ? s.in[IN_POS + i - 3] : i < 9 ? s.in[IN_ANG + i - 6] : i < 12 ? s.in[IN_VEL + i - 9] : -kGravity;
-      }
-      // bounds (:449-477, 685-688, 720-721)
-      if (t.tid < M) {
-        const int i = t.tid, f = i / 5, r = i - 5 * f;
-        const double cst = s.in[IN_CONTACT + f];
-        const double fzmax = mdl.mass * kGravity * kMaxScale, fzmin = mdl.mass * kGravity * kMinScale;
-        const double mu0 = s.in[in_fric<H>()];
-        s.l[i] = dmax(r < 4 ? 0.0 : fzmin * cst, -kInfty);
-        s.u[i] = dmin(r < 4 ? (mu0 + 1) * fzmax * cst : fzmax * cst, kInfty);
-      }
-    });
-    MPC_SUBLAP(4, 10);
-    ex.par([&](Th &t) {   // rxyz = (Rx Ry) Rz, rzyx = (Rz Ry) Rx
-      if (t.tid < 18) {
-        const int e = t.tid % 9;
-        (t.tid < 9 ? rxyz : rzyx)[e] = mat3e(t.tid < 9 ? m1 : m2, t.tid < 9 ? rzm : rxm, e);
-      }
-      // x_ref (:635-659): row r of step i is base_r + dt (i + 1) slope_r  (slope 0 for the constant rows)
-      for (int k = t.tid; k < 13 * H; k += T) {
-        const int i = k / 13, r = k - 13 * i;
-        const double tt = mdl.dt * (i + 1);
-        const int drpy = in_drpy<H>(), dvel = in_dvel<H>(), dang = in_dang<H>(), dpos = in_dpos<H>();
-        const int bi = r < 2 ? drpy + r : r == 2 ? IN_RPY + 2 : r < 5 ? IN_POS + r - 3 : r == 5 ? dpos + 2 : r < 9 ? dang + r - 6 : dvel + (r < 11 ? r - 9 : 0);
-        const int si = r == 2 ? dang + 2 : dvel + (r == 4 ? 1 : 0);
-        const double base = s.in[bi], slope = s.in[si];
-        const double v = (r == 2 || r == 3 || r == 4) ? tt * slope + base : base;
-        s.xref[k] = r == 11 ? 0.0 : r == 12 ? -kGravity : v;
-      }
-    });
-    MPC_SUBLAP(4, 11);
-    ex.par([&](Th &t) {   // feet in the world frame; t2 = rzyx I^-1 (:670)
-      if (t.tid < 12) {
-        const int i = t.tid / 3, r = t.tid - 3 * i;
-        const double *fb = s.in + in_foot<H>();
-        fw[t.tid] = rxyz[3 * r] * fb[3 * i] + rxyz[3 * r + 1] * fb[3 * i + 1] + rxyz[3 * r + 2] * fb[3 * i + 2];
-      } else if (t.tid < 21) {
-        t2[t.tid - 12] = mat3e(rzyx, iib, t.tid - 12);
-      }
-    });
-    MPC_SUBLAP(4, 12);
-    ex.par([&](Th &t) {   // iw = t2 rzyx^T (:671)
-      if (t.tid < 9) {
-        const int i = t.tid / 3, j = t.tid - 3 * i;
-        iw[t.tid] = t2[3 * i] * rzyx[3 * j] + t2[3 * i + 1] * rzyx[3 * j + 1] + t2[3 * i + 2] * rzyx[3 * j + 2];
-      }
-    });
-    ex.par([&](Th &t) {
-      const double dt = mdl.dt;
-      if (t.tid < 36) {   // B rows 6-8: I_w^-1 [r_i]x (:324-336); [v]x = {0, -v2, v1; v2, 0, -v0; -v1, v0, 0}
-        const int i = t.tid / 9, e = t.tid - 9 * i, r = e / 3, c = e - 3 * r;
-        const double *v = fw + 3 * i;
-        double acc = 0;
-        for (int k = 0; k < 3; ++k) {   // same left-to-right sum as the 3 x 3 product, with skew[k][c] formed on the fly
-          const double sk = (k == c) ? 0.0 : (((c - k + 3) % 3 == 1) ? -v[3 - k - c] : v[3 - k - c]);
-          const double term = iw[3 * r + k] * sk;
-          acc = k == 0 ? term : acc + term;
-        }
-        s.b_dt[(6 + r) * 12 + 3 * i + c] = acc * dt;
-      } else if (t.tid < 48) {   // B rows 9-11: I / m
-        const int k = t.tid - 36, i = k / 3, r = k - 3 * i;
-        s.b_dt[(9 + r) * 12 + 3 * i + r] = mdl.inv_mass * dt;
-      } else if (t.tid < 57) {   // A rows 0-2: omega -> rpy rates (:311-312): {cy/cp, sy/cp, 0; -sy, cy, 0; cy tp, sy tp, 1}
-        const int e = t.tid - 48, r = e / 3, c = e - 3 * r;
-        const double cp = rym[0], cy = rzm[0], sy = rzm[3], tp = tp_[0];
-        const double num = c == 0 ? cy : sy;
-        double val;
-        if (c == 2) val = r == 2 ? 1.0 : 0.0;
-        else if (r == 0) val = num / cp;
-        else if (r == 1) val = c == 0 ? -sy : cy;
-        else val = num * tp;
-        s.a_dt[r * 13 + 6 + c] = val * dt;
-      } else if (t.tid < 60) {
-        const int r = t.tid - 57;
-        s.a_dt[(3 + r) * 13 + 9 + r] = dt;
-        s.a_dt[(9 + r) * 13 + 12] = s.in[IN_NRM + r] * dt;
-      } else if (t.tid == 60) {
-        const double *fr = s.in + in_fric<H>();
-        const double cb[15] = {-1, 0, fr[0], 1, 0, fr[1], 0, -1, fr[2], 0, 1, fr[3], 0, 0, 1};   // :437-447
-        for (int k = 0; k < 15; ++k) s.cone[k] = cb[k];
-      }
-    });
-    MPC_SUBLAP(1, 9);
-    MPC_SUBLAP(4, 13);
-    // exact exponential (mpc_osqp.cc:338-351; M^3 = 0): A_exp = I + A dt + (A dt)^2/2, B_exp = B dt + (A dt)(B dt)/2.
-    // A dt is nonzero only at rows 0-2 x cols 6-8, (3+i, 9+i) and rows 9-11 x col 12; the dense products of the
-    // reference add exact zeros elsewhere, so only the nonzero terms are formed (same order, same values).
-    ex.par([&](Th &t) {
-      for (int k = t.tid; k < 169 + 156; k += T) {
-        if (k < 169) {
-          const int r = k / 13, c = k - 13 * r;
-          const double acc = (r >= 3 && r < 6 && c == 12) ? s.a_dt[r * 13 + r + 6] * s.a_dt[(r + 6) * 13 + 12] : 0.0;
-          s.a_exp[k] = (r == c ? 1.0 : 0.0) + s.a_dt[k] + acc / 2;
-        } else {
-          const int kk = k - 169, r = kk / 12, c = kk - 12 * r;
-          double acc = 0;
-          if (r < 3) { for (int j = 6; j < 9; ++j) acc += s.a_dt[r * 13 + j] * s.b_dt[j * 12 + c]; }
-          else if (r < 6) acc += s.a_dt[r * 13 + r + 6] * s.b_dt[(r + 6) * 12 + c];
-          s.b_exp[kk] = s.b_dt[kk] + acc / 2;
-        }
-      }
-    });
-    MPC_SUBLAP(1, 10);
-    // A^k B (:368-373) and the free response A^{i+1} x0, i < H-1 (:360-364; the last A_qp block stays 0).
-    // A dt is nilpotent, so A_exp^k = exp(k A dt) = I + k A dt + k^2 (A dt)^2 / 2 exactly, and (A dt)^2 B_exp = 0
-    // (its only column, 12, meets the zero row 12 of B_exp):  A_exp^k B_exp = B_exp + k U,  U = (A dt) B_exp,
-    // which is nonzero in rows 0-5 only.  All k are formed at once (the reference multiplies k times; the two
-    // agree to rounding).  U overwrites b_dt, (A dt) x0 and (A dt)^2 x0 go to the first 26 slots of sdiff.
-    ex.par([&](Th &t) {
-      if (t.tid < 72) {
-        const int r = t.tid / 12, c = t.tid - 12 * r;
-        double acc = 0;
-        if (r < 3) { for (int j = 6; j < 9; ++j) acc += s.a_dt[r * 13 + j] * s.b_exp[j * 12 + c]; }
-        else acc = s.a_dt[r * 13 + r + 6] * s.b_exp[(r + 6) * 12 + c];
-        s.b_dt[t.tid] = acc;
-      } else if (t.tid < 72 + 13) {
-        const int r = t.tid - 72;
-        double a1 = 0, a2 = 0;
-        if (r < 3) { for (int j = 6; j < 9; ++j) a1 += s.a_dt[r * 13 + j] * s.x0[j]; }
-        else if (r < 6) { a1 = s.a_dt[r * 13 + r + 6] * s.x0[r + 6]; a2 = (s.a_dt[r * 13 + r + 6] * s.a_dt[(r + 6) * 13 + 12]) * s.x0[12]; }
-        else if (r >= 9 && r < 12) a1 = s.a_dt[r * 13 + 12] * s.x0[12];
-        s.sdiff[r] = a1; s.sdiff[13 + r] = a2;
-      }
-    });
-    ex.par([&](Th &t) {
-      for (int e = t.tid; e < H * 156; e += T) {
-        const int k = e / 156, rc = e - 156 * k, r = rc / 12;
-        const double v = r < 6 ? s.b_exp[rc] + (double)k * s.b_dt[rc] : s.b_exp[rc];
-        anb()[e] = v;
-        s.wanb[e] = s.in[IN_W + r] * v;
-      }
-      for (int e = t.tid; e < 13 * (H - 1); e += T) {   // (this overwrites the set-up scratch, which is dead by now)
-        const int i = e / 13, r = e - 13 * i;
-        const double kk = i + 1;
-        s.xk[e] = s.x0[r] + kk * s.sdiff[r] + (kk * kk / 2) * s.sdiff[13 + r];
-      }
-    });
-    MPC_SUBLAP(1, 11);
-    ex.par([&](Th &t) {   // state_diff (:681)
-      for (int k = t.tid; k < 13 * H; k += T) s.sdiff[k] = (k < 13 * (H - 1) ? s.xk[k] : 0.0) - s.xref[k];
-    });
-    lap(1);
-    // q (:683) and P (:387-434) -> Pg (unscaled, lower-triangle tiles)
-    ex.par([&](Th &t) {
-      if (t.tid < N) {
-        const int j = t.tid / 12, c = t.tid - 12 * j;
-        double acc = 0;
-        for (int i = j; i < H; ++i) {
-          const double *bk = s.wanb + (i - j) * 156 + c, *sd = s.sdiff + 13 * i;
-          double e = 0, o = 0;   // two FMA chains per horizon step
-#pragma unroll
-          for (int r = 0; r < 13; ++r) {
-            if (r & 1) o += bk[r * 12] * sd[r];
-            else e += bk[r * 12] * sd[r];
-          }
-          acc += e + o;
-        }
-        s.q[t.tid] = 2 * acc;
-      }
-      for (int task = t.tid; task < C::NTASK; task += T) {
-        int d, a, b;
-        if (task < 78) {          // diagonal blocks: a <= b only, mirrored
-          d = 0;
-          int k = task; a = 0;
-          while (k >= 12 - a) { k -= 12 - a; ++a; }
-          b = a + k;
-        } else {
-          const int k = task - 78;
-          d = 1 + k / 144;
-          const int ab = k - (d - 1) * 144;
-          a = ab / 12; b = ab - 12 * a;
-        }
-        // entry (12 I + a, 12 J + b), I = J - d <= J, lives at row 12 J + b, column 12 I + a of the lower triangle:
-        // tile (2 J + b / 6, 2 I + a / 6), position (b % 6, a % 6); a diagonal tile also takes the mirrored entry
-        const int ah = a / TS, bh = b / TS, lo = (b - TS * bh) * TS + (a - TS * ah), lom = (a - TS * ah) * TS + (b - TS * bh);
-        const bool mirror = d == 0 && ah == bh && a != b;
-        const double *xa = s.wanb + d * 156 + a, *yb = anb() + b;
-        double acc = 0;
-        const int ns = H - d;
-        for (int sidx = 0; sidx < ns; sidx += 2) {   // two horizon offsets per trip: four independent FMA chains
-          const int s1 = sidx + 1 < ns ? sidx + 1 : sidx;
-          const double *x0 = xa + sidx * 156, *y0 = yb + sidx * 156, *x1 = xa + s1 * 156, *y1 = yb + s1 * 156;
-          double e0 = 0, o0 = 0, e1 = 0, o1 = 0;
-#pragma unroll
-          for (int r = 0; r < 13; ++r) {
-            if (r & 1) { o0 += x0[r * 12] * y0[r * 12]; o1 += x1[r * 12] * y1[r * 12]; }
-            else { e0 += x0[r * 12] * y0[r * 12]; e1 += x1[r * 12] * y1[r * 12]; }
-          }
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            if (u == 1 && sidx + 1 >= ns) break;
-            acc += u == 0 ? e0 + o0 : e1 + o1;
-            const int J = H - 1 - (sidx + u), I = J - d;
-            const int tr = 2 * J + bh, tix = tr * (tr + 1) / 2 + 2 * I + ah;
-            double v = 2.0 * acc;
-            if (d == 0 && a == b) v += mdl.alpha;
-            Pg[(size_t)tix * TE + lo] = v;
-            if (mirror) Pg[(size_t)tix * TE + lom] = v;
-          }
-        }
-      }
-    });
   }
-  // (lap(2) is taken at the start of scale())
-  static MPC_HD double mat3e(const double *a, const double *b, int e) {   // entry e = 3 i + j of the 3 x 3 product a b
-    const int i = e / 3, j = e - 3 * i;
-    return a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
-  }
-  static MPC_HD void mat3(const double *a, const double *b, double *c) {
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) c[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
-  }
-
   // ================================ 2. scaling (scaling.c:44-156) ===============================
   // One Ruiz pass is three phases.  P itself stays UNSCALED in the tile registers for all passes: a pass only
   // needs the row norms of c D P D, which are c D_i max_j(|P_ij| D_j) with the cumulative D and c (tile_rownorms); D, c, q, A, E are updated incrementally as in
@@ -1314,7 +1357,7 @@ struct Solver {
   MPC_HD void run() {
     const long long t0 = MPC_CLOCK();
     tlast = t0;
-    assemble();
+    load();
     scale();
     set_rho_vec();
     factor(false);
@@ -1362,7 +1405,7 @@ struct Solver {
         state[2 * N + 2 * M + 1] = 1.0;
         info[0] = s.iter; info[1] = s.bad ? kStNonCvx : s.status; info[2] = s.status_polish; info[3] = s.rho_updates;
         info[4] = s.nfact; info[5] = s.first; info[6] = 0; info[7] = 0;
-        if (prof) for (int k = 0; k < kProfLen; ++k) prof[k] = tc[k];
+        if (prof) for (int k = 0; k < kProfLen; ++k) if (k != 1 && k != 2) prof[k] = tc[k];   // (1, 2: the assembly kernel's)
       }
     });
   }

@@ -41,7 +41,15 @@ static void solve_one(const RobotModel &mdl, const float *in, double *state, dou
   HostExec<H> ex(reverse);
   Shared<H> *sh = new Shared<H>();
   std::memset(sh, 0, sizeof(Shared<H>));
-  Solver<H, HostExec<H>> sv{ex, *sh, mdl, in, state, Pg, forces, info, nullptr};
+  std::vector<double> qp(Cfg<H>::QP_LEN, 0.0);
+  {
+    AsmShared<H> *as = new AsmShared<H>();
+    std::memset(as, 0, sizeof(AsmShared<H>));
+    Assembler<H, HostExec<H>> am{ex, *as, mdl, in, Pg, qp.data(), nullptr};
+    am.run();
+    delete as;
+  }
+  Solver<H, HostExec<H>> sv{ex, *sh, mdl, state, Pg, qp.data(), forces, info, nullptr};
   sv.run();
   if (phases) *phases = ex.phases;
   delete sh;
