@@ -28,23 +28,25 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6    # datasheet fp64 vector rate (half the fp32 ra
 
 
 def algorithmic_flops(h, contact, iters, nfact):
-    """SURVEY.md 8(d) minimal-algorithm flop count per control step, summed over the batch.
+    """SURVEY.md 8(d) minimal-algorithm flop count per control step, summed over the batch, split by kernel:
+    (assembly kernel: A^k B, P recursion, q;  solve kernel: F factorisations + I ADMM iterations).
     n_r = 3 * (stance leg-steps in the horizon); I = ADMM iterations executed; F = factorisations."""
     n_r = 3.0 * contact.reshape(len(contact), -1).sum(1)
     fixed = 4056.0 * (h - 1) + 3900.0 * h * (h + 1) / 2 + 2.0 * 13 * h * (13 + 12 * h)
-    per = fixed + nfact * n_r ** 3 / 3.0 + iters * (2.0 * n_r ** 2 + 40.0 * n_r)
-    return float(per.sum())
+    per = nfact * n_r ** 3 / 3.0 + iters * (2.0 * n_r ** 2 + 40.0 * n_r)
+    return float(fixed * len(n_r)), float(per.sum())
 
 
 def executed_flops(h, iters, nfact, polished):
     """fp64 operations the kernel actually executes per batch: the OSQP-faithful algorithm keeps all
     n = 12 h variables.  Per robot: nfact_K full symmetric sweeps (n pivots x MT tiles x (36 FMA + 6 mul)), the masked
     polish sweep counted as half a sweep, `iters` ADMM iterations (tile mat-vec 2 x 36 FMA per tile + ~45 flops per
-    variable + ~15 per constraint row), 10 Ruiz passes (4 ops per tile entry), three P_s products and the assembly."""
+    variable + ~15 per constraint row), 10 Ruiz passes (4 ops per tile entry) and three P_s products (the assembly kernel's
+    work is not counted here)."""
     n, m, mt = 12 * h, 20 * h, h * (2 * h + 1)
     sweep = n * mt * (72.0 + 6.0)
     it = mt * 144.0 + 45.0 * n + 15.0 * m
-    fixed = 10 * mt * 144.0 + 3 * mt * 144.0 + 4056.0 * (h - 1) + 3900.0 * h * (h + 1) / 2 + 2.0 * 13 * h * (13 + 12 * h)
+    fixed = 10 * mt * 144.0 + 3 * mt * 144.0
     n_k = nfact - polished                       # factorisations of K (the polish one is counted in info[4])
     return float((n_k * sweep + polished * 0.5 * sweep + iters * it + fixed).sum())
 
@@ -88,6 +90,7 @@ def main():
     d_in = [torch.from_numpy(b).to(dev) for b in batches]          # resident in HBM before timing
     inertia9 = np.zeros((n, 9)); inertia9[:, 0], inertia9[:, 4], inertia9[:, 8] = wl.inertia_diag.T
     solver = BatchedConvexMpc(wl.mass, inertia9, h, wl.dt_mpc, wl.alpha, device=dev)
+    solver.enable_timing()                       # HIP events inside the library, around each kernel, on the launch stream
     infos = [torch.zeros((n, 8), dtype=torch.int32, device=dev) for _ in range(K)]
 
     for s in range(W):
@@ -111,15 +114,18 @@ def main():
         from rl_mpc_locomotion_amd.sharding import max_over_ranks
         elapsed = max_over_ranks(elapsed, dev)
 
-    kernel_ms = np.array([a.elapsed_time(b) for a, b in ev])
+    step_ms = np.array([a.elapsed_time(b) for a, b in ev])        # assembly + solve + dispatch-order kernels of one step
+    kt = min(K, 64)
+    assemble_ms, kernel_ms = (a.astype(np.float64) for a in solver.kernel_times(kt))   # the dominant kernel (mpc_solve_kernel) alone
     first_forces = first_out.cpu().numpy()
     info = torch.stack(infos).cpu().numpy()                         # [K, n, 8]
     solved = int((info[..., 1] == 1).sum())
-    flops = 0.0
+    flops = asm_flops = 0.0
     for s in range(K):
         contact = batches[W + s][:, L.IN_CONTACT:L.IN_CONTACT + 4 * h]
-        flops += algorithmic_flops(h, contact, info[s, :, 0].astype(np.float64), info[s, :, 4].astype(np.float64))
-    flops_per_launch = flops / K
+        fa, fs = algorithmic_flops(h, contact, info[s, :, 0].astype(np.float64), info[s, :, 4].astype(np.float64))
+        flops += fs; asm_flops += fa
+    flops_per_launch = flops / K                                     # of the dominant kernel (mpc_solve_kernel)
     exec_flops = sum(executed_flops(h, info[s, :, 0].astype(np.float64), info[s, :, 4].astype(np.float64),
                                     (info[s, :, 2] != 0).astype(np.float64)) for s in range(K)) / K
     achieved_tflops = flops_per_launch / (kernel_ms.mean() * 1e-3) / 1e12
@@ -163,8 +169,10 @@ def main():
                      "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_note": "HBM-side bytes per launch from rocprofv3 PMC (profiles/*_pmc_summary.json, measured offline on this command)",
                      "note": "vector-FP bound, no MFMA/HBM roofline applies (SURVEY 8d): algorithmic flops (n_r formula) / "
-                             "mean kernel time from HIP events; kernel arithmetic is fp64 (peak 78.6 TF)",
-                     "kernel_ms": float(kernel_ms.mean()), "flops_per_launch": flops_per_launch,
+                             "mean duration of mpc_solve_kernel from HIP events; kernel arithmetic is fp64 (peak 78.6 TF)",
+                     "kernel": "mpc_solve_kernel", "kernel_ms": float(kernel_ms.mean()), "assemble_kernel_ms": float(assemble_ms.mean()),
+                     "step_ms_all_kernels": float(step_ms.mean()), "flops_per_launch": flops_per_launch,
+                     "assemble_kernel_flops_per_launch": asm_flops / K,
                      "frac_fp64_peak": achieved_tflops / FP64_VECTOR_PEAK_TFLOPS,
                      "executed": {"flops_per_launch": exec_flops, "tflops": exec_flops / (kernel_ms.mean() * 1e-3) / 1e12,
                                   "frac_fp64_peak": exec_flops / (kernel_ms.mean() * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,

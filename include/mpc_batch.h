@@ -85,6 +85,11 @@ long long mpc_batch_device_bytes(const mpc_batch *b);
 int mpc_batch_state_len(const mpc_batch *b);
 int mpc_batch_get_state(mpc_batch *b, double *h_state);
 int mpc_batch_set_state(mpc_batch *b, const double *h_state);
+/* Kernel timing (benchmarks): after mpc_batch_enable_timing every launch records HIP events on its stream around the
+ * assembly kernel and the solve kernel; mpc_batch_kernel_times synchronises and returns the durations (ms) of the last
+ * `last_k` launches (oldest first, at most 64). */
+int mpc_batch_enable_timing(mpc_batch *b);
+int mpc_batch_kernel_times(mpc_batch *b, int last_k, float *ms_assemble, float *ms_solve);
 /* Shader-clock cycles the last solve spent per section, [n, 16] int64 (sections: csrc/mpc_core.h kProfLen). */
 int mpc_batch_get_profile(mpc_batch *b, long long *h_prof);
 

@@ -73,6 +73,15 @@ class BatchedConvexMpc:
         _lib.check(_lib.lib().mpc_batch_get_state(self._handle, out.ctypes.data), "mpc_batch_get_state")
         return out
 
+    def enable_timing(self):
+        _lib.check(_lib.lib().mpc_batch_enable_timing(self._handle), "mpc_batch_enable_timing")
+
+    def kernel_times(self, last_k):
+        """(assembly_ms [k], solve_ms [k]) of the last k launches, from HIP events recorded on the launch stream."""
+        a = np.zeros(last_k, dtype=np.float32); b = np.zeros(last_k, dtype=np.float32)
+        _lib.check(_lib.lib().mpc_batch_kernel_times(self._handle, int(last_k), a.ctypes.data, b.ctypes.data), "mpc_batch_kernel_times")
+        return a, b
+
     def get_profile(self):
         """Shader-clock cycles of the last solve per robot, 16 sections (csrc/mpc_core.h kProfLen)."""
         out = np.zeros((self.n, 16), dtype=np.int64)

@@ -104,9 +104,12 @@ __global__ void reset_kernel(double *state, int state_len, const int *ids, int k
 
 template <int H>
 int launch(int n, const RobotModel *models, const float *in, double *state, double *scratch, double *qp, double *forces, int *info,
-           long long *prof, const int *active, const int *order, hipStream_t stream) {
+           long long *prof, const int *active, const int *order, hipEvent_t *ev, hipStream_t stream) {
+  if (ev) (void)hipEventRecord(ev[0], stream);
   hipLaunchKernelGGL(mpc_assemble_kernel<H>, dim3(n), dim3(Cfg<H>::T), 0, stream, n, models, in, scratch, qp, prof, active);
+  if (ev) (void)hipEventRecord(ev[1], stream);
   hipLaunchKernelGGL(mpc_solve_kernel<H>, dim3(n), dim3(Cfg<H>::T), 0, stream, n, models, in, state, scratch, qp, forces, info, prof, active, order);
+  if (ev) (void)hipEventRecord(ev[2], stream);
   HIP_TRY(hipGetLastError());
   return MPC_OK;
 }
@@ -148,6 +151,8 @@ __global__ void order_kernel(int n, const long long *__restrict__ prof, int *__r
 
 }  // namespace
 
+constexpr int kTimingRing = 64;
+
 struct mpc_batch {
   int n = 0, h = 0;
   int state_len = 0;
@@ -156,6 +161,9 @@ struct mpc_batch {
   int *d_info = nullptr;   // used when the caller passes no info buffer
   long long *d_prof = nullptr;   // per-robot section cycle counts of the last solve
   int *d_order = nullptr;        // workgroup -> robot map for the next launch (order_kernel)
+  bool timing = false;           // mpc_batch_enable_timing: HIP events around the two kernels of each launch
+  hipEvent_t ev[kTimingRing][3];
+  long long launches = 0;
   float *d_host_in = nullptr;    // staging for mpc_batch_solve_host
   double *d_host_f = nullptr;
   bool order_valid = false;
@@ -166,17 +174,19 @@ struct mpc_batch {
 // one solver launch on b's robots (+ the dispatch order for the next one)
 static int launch_solver(mpc_batch *b, const float *d_in, double *d_forces, int *d_info, const int *d_active, hipStream_t st) {
   const int *order = b->order_valid ? b->d_order : nullptr;
+  hipEvent_t *ev = b->timing ? b->ev[b->launches % kTimingRing] : nullptr;
   int rc = MPC_E_HORIZON;
   switch (b->h) {
-    case 10: rc = launch<10>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, b->d_qp, d_forces, d_info, b->d_prof, d_active, order, st); break;
-    case 16: rc = launch<16>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, b->d_qp, d_forces, d_info, b->d_prof, d_active, order, st); break;
-    case 20: rc = launch<20>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, b->d_qp, d_forces, d_info, b->d_prof, d_active, order, st); break;
+    case 10: rc = launch<10>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, b->d_qp, d_forces, d_info, b->d_prof, d_active, order, ev, st); break;
+    case 16: rc = launch<16>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, b->d_qp, d_forces, d_info, b->d_prof, d_active, order, ev, st); break;
+    case 20: rc = launch<20>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, b->d_qp, d_forces, d_info, b->d_prof, d_active, order, ev, st); break;
   }
   if (rc == MPC_E_HORIZON) return fail(MPC_E_HORIZON, "solver launch: horizon not compiled in");
   if (rc != MPC_OK) return rc;
   hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, st, b->n, b->d_prof, b->d_order);
   HIP_TRY(hipGetLastError());
   b->order_valid = true;
+  b->launches++;
   return MPC_OK;
 }
 
@@ -233,6 +243,7 @@ void mpc_batch_destroy(mpc_batch *b) {
   if (b->d_info) (void)hipFree(b->d_info);
   if (b->d_prof) (void)hipFree(b->d_prof);
   if (b->d_order) (void)hipFree(b->d_order);
+  if (b->timing) for (auto &e3 : b->ev) for (auto &e : e3) (void)hipEventDestroy(e);
   if (b->d_host_in) (void)hipFree(b->d_host_in);
   if (b->d_host_f) (void)hipFree(b->d_host_f);
   delete b;
@@ -278,6 +289,26 @@ int mpc_batch_solve_host(mpc_batch *b, const float *h_in, double *h_forces, int 
   return MPC_OK;
 }
 
+int mpc_batch_enable_timing(mpc_batch *b) {
+  if (!b) return fail(MPC_E_ARG, "mpc_batch_enable_timing: bad argument");
+  if (!b->timing) {
+    for (auto &e3 : b->ev) for (auto &e : e3) HIP_TRY(hipEventCreate(&e));
+    b->timing = true;
+    b->launches = 0;
+  }
+  return MPC_OK;
+}
+int mpc_batch_kernel_times(mpc_batch *b, int last_k, float *ms_assemble, float *ms_solve) {
+  if (!b || !b->timing || last_k <= 0 || last_k > kTimingRing || last_k > b->launches || !ms_assemble || !ms_solve)
+    return fail(MPC_E_ARG, "mpc_batch_kernel_times: bad argument (enable timing first; at most 64 launches back)");
+  HIP_TRY(hipDeviceSynchronize());
+  for (int i = 0; i < last_k; ++i) {
+    hipEvent_t *e = b->ev[(b->launches - last_k + i) % kTimingRing];
+    HIP_TRY(hipEventElapsedTime(ms_assemble + i, e[0], e[1]));
+    HIP_TRY(hipEventElapsedTime(ms_solve + i, e[1], e[2]));
+  }
+  return MPC_OK;
+}
 int mpc_batch_size(const mpc_batch *b) { return b ? b->n : 0; }
 int mpc_batch_horizon(const mpc_batch *b) { return b ? b->h : 0; }
 long long mpc_batch_device_bytes(const mpc_batch *b) { return b ? b->bytes : 0; }

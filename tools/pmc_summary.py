@@ -9,7 +9,7 @@ h = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 per = defaultdict(lambda: defaultdict(float))   # counter -> dispatch -> value
 for f in sorted(glob.glob(os.path.join(src, "*pmc_*.csv"))):
     for row in csv.DictReader(open(f)):
-        if "mpc_solve_kernel" not in row["Kernel_Name"]:
+        if "mpc_solve_kernel" not in row["Kernel_Name"]:   # the dominant kernel
             continue
         per[row["Counter_Name"]][int(row["Dispatch_Id"])] += float(row["Counter_Value"])
 counters = {}
