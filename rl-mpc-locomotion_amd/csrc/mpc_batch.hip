@@ -433,6 +433,8 @@ struct mpc_ctrl {
   double *d_forces = nullptr;
   GaitTable gt;
   CtrlParams cp;
+  std::vector<int> h_iter;        // host mirror of every robot's iterationCounter (deterministic outside the FSM): lets a tick
+  bool mirror_valid = true;       // on which no robot is due for an MPC update skip the solver launches
   FsmState *d_fsm = nullptr;      // control FSM (allocated by mpc_ctrl_fsm_init)
   int *d_fsm_mode = nullptr;      // per-robot control mode of the last (re)initialisation
   FsmParams fp{};
@@ -503,11 +505,19 @@ int mpc_ctrl_step(mpc_ctrl *c, const float *d_dof, const float *d_est, const flo
   if (!c || !d_dof || !d_est || !d_cmd || !d_torques) return fail(MPC_E_ARG, "mpc_ctrl_step: bad argument");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int n = c->n, blocks = (n + 127) / 128;
+  bool any_due = true;
+  if (c->mirror_valid) {   // ConvexMPCLocomotion.run: iterationCounter += 1, MPC update when it is a multiple of iterationsBetweenMPC
+    if ((int)c->h_iter.size() != n) c->h_iter.assign(n, 0);
+    any_due = false;
+    for (int r = 0; r < n; ++r) any_due |= (++c->h_iter[r] % c->cp.iters_between_mpc) == 0;
+  }
   hipLaunchKernelGGL(ctrl_pre_kernel, dim3(blocks), dim3(128), 0, st, n, c->d_state, c->d_rc, c->gt, c->cp, d_dof, d_est, d_cmd, c->d_rec, c->d_active);
   HIP_TRY(hipGetLastError());
   mpc_batch *b = c->solver;
-  int rc = launch_solver(b, c->d_rec, c->d_forces, c->d_info, c->d_active, st);
-  if (rc != MPC_OK) return rc;
+  if (any_due) {
+    int rc = launch_solver(b, c->d_rec, c->d_forces, c->d_info, c->d_active, st);
+    if (rc != MPC_OK) return rc;
+  }
   hipLaunchKernelGGL(ctrl_post_kernel, dim3(blocks), dim3(128), 0, st, n, c->d_state, c->d_rc, c->cp.horizon, c->d_forces, c->d_info, d_torques);
   HIP_TRY(hipGetLastError());
   return MPC_OK;
@@ -523,6 +533,8 @@ int mpc_ctrl_run(mpc_ctrl *c, const float *d_dof, const float *d_body, const flo
 
 int mpc_ctrl_reset(mpc_ctrl *c, const int *ids, int k, void *stream) {
   if (!c) return fail(MPC_E_ARG, "mpc_ctrl_reset: bad argument");
+  if (!ids) c->h_iter.assign(c->n, 0);
+  else for (int i = 0; i < k; ++i) if (ids[i] >= 0 && ids[i] < c->n && (int)c->h_iter.size() == c->n) c->h_iter[ids[i]] = 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int rc = mpc_batch_reset(c->solver, ids, k, stream);   // new ConvexMpc object = cold solver (ConvexMPCLocomotion.py:102-108)
   if (rc != MPC_OK) return rc;
@@ -561,6 +573,7 @@ int mpc_ctrl_fsm_init(mpc_ctrl *c, const int *control_mode, int operating_mode, 
     HIP_TRY(hipMalloc(&c->d_fsm, sizeof(FsmState) * c->n));
     HIP_TRY(hipMalloc(&c->d_fsm_mode, sizeof(int) * c->n));
   }
+  c->mirror_valid = false;       // from here on the device decides which robots run the locomotion controller
   c->fp = fsm_params(c->cp.dt, check_safety);
   c->fsm_op_mode = operating_mode;
   HIP_TRY(hipMemcpyAsync(c->d_fsm_mode, control_mode, sizeof(int) * c->n, hipMemcpyHostToDevice, st));
