@@ -994,9 +994,6 @@ struct Solver {
       for_tiles(t, [&](Tv &v, int) { tile_matvec_neg(v, crhs()); });
     });
     MPC_SUBLAP(5, 9);
-#ifdef MPC_PROFILE_ADMM
-    lap(9);
-#endif
     ex.par([&](Th &t) {
       if (t.tid < N) s.xt[t.tid] = inv_combine(s, t.tid, crhs());
     });
@@ -1039,9 +1036,6 @@ struct Solver {
       }
     });
     MPC_SUBLAP(5, 12);
-#ifdef MPC_PROFILE_ADMM
-    lap(8);
-#endif
   }
 
   // P_s v -> out (P_s tiles read from HBM scratch, each used in both orientations).  Two phases.
