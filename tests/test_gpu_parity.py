@@ -178,3 +178,28 @@ def test_dispatch_order_does_not_change_results():
             fs, infos = _solve(s, w.inputs[i:i + 1])
             assert np.array_equal(fs[0], f[i]) and np.array_equal(infos[0], info[i])
         w = perturb_workload(w, 300 + step)
+
+
+@pytest.mark.parametrize("config,h,n", [(4, 16, 4096), (5, 20, 8192)])
+def test_full_size_properties_long_horizons(config, h, n):
+    """BASELINE configs[3] / configs[4] at their per-GPU size (32768 / 8 and 65536 / 8 robots): permutation equivariance
+    (robot i's result does not depend on where it sits in the batch, bit for bit), every solve OSQP_SOLVED, swing forces
+    vanish, and a 24-robot sample agrees with the oracle."""
+    from oracle.refmpc import RefBatch
+    wl = make_solver_workload(n, h=h, seed=31, config=config)
+    a = _gpu(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
+    fa, ia = _solve(a, wl.inputs)
+    assert (ia[:, 1] == 1).all()
+    perm = np.random.default_rng(0).permutation(n)
+    b = _gpu(wl.mass[perm], wl.inertia_diag[perm], h, wl.dt_mpc, wl.alpha)
+    fb, ib = _solve(b, wl.inputs[perm])
+    assert np.array_equal(fb, fa[perm]) and np.array_equal(ib, ia[perm])
+    from rl_mpc_locomotion_amd import layout as L
+    c = wl.inputs[:, L.IN_CONTACT:L.IN_CONTACT + 4 * h].astype(bool)
+    f = fa.reshape(n, 4 * h, 3)
+    assert (np.abs(f[~c]) < 2e-3 * (wl.mass * 98.0).max()).all()
+    pick = np.arange(0, n, n // 24)[:24]
+    ref = RefBatch(wl.mass[pick], wl.inertia_diag[pick], h, wl.dt_mpc, wl.alpha)
+    fr = ref.solve(wl.inputs[pick], nthreads=8)
+    assert np.array_equal(ref.info[:, :4], ia[pick][:, :4])
+    assert grf_relerr(fa[pick], fr, first_step_only=False).max() < GRF_RTOL
