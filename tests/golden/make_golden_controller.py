@@ -97,5 +97,8 @@ def run_case(name, n, ticks, seed, flat_ground):
 
 
 if __name__ == "__main__":
-    run_case("controller_h10_slope", 9, 48, 5, flat_ground=False)
-    run_case("controller_h10_flat", 6, 48, 6, flat_ground=True)
+    only = sys.argv[1:]
+    for case in (("controller_h10_slope", 9, 48, 5, False), ("controller_h10_flat", 6, 48, 6, True),
+                 ("controller_h10_config1", 1, 1000, 7, False)):      # one Aliengo, trot, 1000 ticks of open-loop replay
+        if not only or case[0] in only:
+            run_case(case[0], case[1], case[2], case[3], flat_ground=case[4])
