@@ -94,7 +94,7 @@ struct Cfg {
   static constexpr int T = (((MTH > M ? MTH : M) + 63) / 64) * 64;   // workgroup size
 #endif
   static constexpr int IN_LEN = 56 + 4 * H;
-  static constexpr int NTASK = 78 + (H - 1) * 144;       // P assembly tasks (d, a, b)
+  static constexpr int NTASK2 = 21 + (H - 1) * 36;       // P assembly tasks (d, 2 x 2 block of (a, b))
   static_assert(T <= 1024, "workgroup too large");
   static constexpr int NP = N + 2;                       // row stride of part[] (doubles)
   static constexpr int PARTLEN = (NP * G > 14 * 64) ? NP * G : 14 * 64;   // part[] doubles as the reduction scratch
@@ -479,45 +479,50 @@ struct Assembler {
         }
         qp[C::QP_Q + t.tid] = 2 * acc;
       }
-      for (int task = t.tid; task < C::NTASK; task += T) {
-        int d, a, b;
-        if (task < 78) {          // diagonal blocks: a <= b only, mirrored
+      // P: 2 x 2 register blocks of (a, b) -- four outputs share two 16-byte loads per term (one LDS byte per flop
+      // instead of two: with four robots per CU this phase is LDS-bandwidth bound).  Tasks: for d = 0 the block pairs
+      // a2 <= b2 (21), for d >= 1 all 36; d-major, so a thread's second task is a short one.
+      for (int task = t.tid; task < C::NTASK2; task += T) {
+        int d, a2, b2;
+        if (task < 21) {
           d = 0;
-          int k = task; a = 0;
-          while (k >= 12 - a) { k -= 12 - a; ++a; }
-          b = a + k;
+          int k = task; a2 = 0;
+          while (k >= 6 - a2) { k -= 6 - a2; ++a2; }
+          b2 = a2 + k;
         } else {
-          const int k = task - 78;
-          d = 1 + k / 144;
-          const int ab = k - (d - 1) * 144;
-          a = ab / 12; b = ab - 12 * a;
+          const int k = task - 21;
+          d = 1 + k / 36;
+          const int ab = k - (d - 1) * 36;
+          a2 = ab / 6; b2 = ab - 6 * a2;
         }
+        const int a0 = 2 * a2, b0 = 2 * b2, ah = a0 / TS, bh = b0 / TS, ar = a0 - TS * ah, br = b0 - TS * bh;
         // entry (12 I + a, 12 J + b), I = J - d <= J, lives at row 12 J + b, column 12 I + a of the lower triangle:
         // tile (2 J + b / 6, 2 I + a / 6), position (b % 6, a % 6); a diagonal tile also takes the mirrored entry
-        const int ah = a / TS, bh = b / TS, lo = (b - TS * bh) * TS + (a - TS * ah), lom = (a - TS * ah) * TS + (b - TS * bh);
-        const bool mirror = d == 0 && ah == bh && a != b;
-        const double *xa = s.wanb + d * 156 + a, *yb = s.anb + b;
-        double acc = 0;
+        const bool dtile = d == 0 && ah == bh;
+        const double *xa = s.wanb + d * 156 + a0, *yb = s.anb + b0;
+        double acc[4] = {0, 0, 0, 0};
         const int ns = H - d;
-        for (int sidx = 0; sidx < ns; sidx += 2) {   // two horizon offsets per trip: four independent FMA chains
-          const int s1 = sidx + 1 < ns ? sidx + 1 : sidx;
-          const double *x0 = xa + sidx * 156, *y0 = yb + sidx * 156, *x1 = xa + s1 * 156, *y1 = yb + s1 * 156;
-          double e0 = 0, o0 = 0, e1 = 0, o1 = 0;
+        for (int sidx = 0; sidx < ns; ++sidx) {
+          const double *x = xa + sidx * 156, *y = yb + sidx * 156;
+          double e[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0};   // even / odd terms: eight independent FMA chains
 #pragma unroll
           for (int r = 0; r < 13; ++r) {
-            if (r & 1) { o0 += x0[r * 12] * y0[r * 12]; o1 += x1[r * 12] * y1[r * 12]; }
-            else { e0 += x0[r * 12] * y0[r * 12]; e1 += x1[r * 12] * y1[r * 12]; }
+            const double x0 = x[r * 12], x1 = x[r * 12 + 1], y0 = y[r * 12], y1 = y[r * 12 + 1];
+            double *w = (r & 1) ? o : e;
+            w[0] += x0 * y0; w[1] += x1 * y0; w[2] += x0 * y1; w[3] += x1 * y1;      // index ia + 2 ib
           }
+          const int J = H - 1 - sidx, I = J - d;
+          const int tr = 2 * J + bh;
+          double *tile = Pg + (size_t)(tr * (tr + 1) / 2 + 2 * I + ah) * TE;
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            if (u == 1 && sidx + 1 >= ns) break;
-            acc += u == 0 ? e0 + o0 : e1 + o1;
-            const int J = H - 1 - (sidx + u), I = J - d;
-            const int tr = 2 * J + bh, tix = tr * (tr + 1) / 2 + 2 * I + ah;
-            double v = 2.0 * acc;
-            if (d == 0 && a == b) v += mdl.alpha;
-            Pg[(size_t)tix * TE + lo] = v;
-            if (mirror) Pg[(size_t)tix * TE + lom] = v;
+          for (int q = 0; q < 4; ++q) {
+            const int ia = q & 1, ib = q >> 1;
+            acc[q] += e[q] + o[q];
+            if (d == 0 && a0 + ia > b0 + ib) continue;       // below the diagonal of a diagonal block: its mirror is computed
+            double v = 2.0 * acc[q];
+            if (d == 0 && a0 + ia == b0 + ib) v += mdl.alpha;
+            tile[(br + ib) * TS + ar + ia] = v;
+            if (dtile && a0 + ia != b0 + ib) tile[(ar + ia) * TS + br + ib] = v;
           }
         }
       }
