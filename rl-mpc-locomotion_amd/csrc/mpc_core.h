@@ -48,6 +48,12 @@
 #define MPC_LAUNDER(x) ((void)0)
 #define MPC_SCHED_FENCE() ((void)0)
 #endif
+#ifndef MPC_EXIT_FENCE_UPTO
+#define MPC_EXIT_FENCE_UPTO 12
+#endif
+#ifndef MPC_NT2_FROM
+#define MPC_NT2_FROM 17
+#endif
 #define MPC_CHUNK 10   // columns between scheduling fences
 // A value that is the same in every lane, moved to a scalar register (so that branches on it are scalar branches)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -83,7 +89,7 @@ struct Cfg {
   static constexpr int TS = 6;                           // register tile side (2 feet)
   static constexpr int G = N / TS;                       // tile grid G x G, lower triangle stored
   static constexpr int MT = G * (G + 1) / 2;             // lower-triangle tiles
-  static constexpr int NT = H > 16 ? 2 : 1;              // tiles per thread: two for the longest horizon keeps the workgroup at
+  static constexpr int NT = H >= MPC_NT2_FROM ? 2 : 1;              // tiles per thread: two for the longest horizon keeps the workgroup at
                                                          // <= 2 waves per SIMD, i.e. 256 VGPRs per lane instead of 168 / 128
   static constexpr int MTH = (MT + NT - 1) / NT;         // threads that hold tiles
   static constexpr int TE = TS * TS;                     // tile elements per thread
@@ -101,6 +107,15 @@ struct Cfg {
   // The longest horizon is LDS-tight (one workgroup per CU, 160 KB): rho / 1/rho come from the three per-type values
   // instead of per-row arrays.
   static constexpr bool kCompact = H > 16;
+  static constexpr bool kLoopExitFence = H <= MPC_EXIT_FENCE_UPTO;
+  // Live-range split points of the tile registers (Solver::pin_tiles): bit 0 / 1 before / after a sweep, 2 / 3 around the
+  // 25 ADMM iterations, 4 inside the sweep loop.  Chosen per horizon by measurement (round 1: h = 16 0.12 -> 0.60 M steps/s,
+  // h = 20 36 k -> 106 k).
+#ifdef MPC_PIN_MASK
+  static constexpr int kPinMask = MPC_PIN_MASK;
+#else
+  static constexpr int kPinMask = H > 16 ? 3 : 19;
+#endif   // scheduling fence after the ADMM loop (see Solver::run)
   // The QP record the assembly kernel hands to the solve kernel (doubles per robot): q[N] l[M] u[M] cone[15] pad
   static constexpr int QP_Q = 0, QP_L = N, QP_U = N + M, QP_CONE = N + 2 * M, QP_LEN = N + 2 * M + 16;
 };
@@ -262,7 +277,11 @@ struct Assembler {
   long long *prof;     // [kProfLen] slots 1 (dynamics) and 2 (q + P) are written here (may be null)
   long long tc[3] = {0, 0, 0};
   long long tlast = 0;
+#ifndef MPC_SECTION_PROFILE   // per-section counters cost ~30 SGPRs (and push uniform values into VGPRs): opt-in, tools/section_profile.py
+  MPC_HD void lap(int) {}
+#else
   MPC_HD void lap(int k) { const long long now = MPC_CLOCK(); tc[k] += now - tlast; tlast = now; }
+#endif
 
   static MPC_HD double mat3e(const double *a, const double *b, int e) {   // entry e = 3 i + j of the 3 x 3 product a b
     const int i = e / 3, j = e - 3 * i;
@@ -564,6 +583,17 @@ struct Solver {
         f(v, u);
       }
   }
+  // A register-allocation hint, no code: every tile element passes through an empty asm, which ends its live range and
+  // starts a new one.  The tile lives from load() to polish(); without such split points the allocator treats a
+  // tile register pair as one range over the whole kernel and, once some phase is over budget, spills it in the hot
+  // loops as well (h = 16: 12 of the 36 elements went through scratch on every sweep step with 70 VGPRs idle).
+  MPC_HD void pin_tiles(int site) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (!((C::kPinMask >> site) & 1)) return;
+#pragma unroll
+    for (int e = 0; e < C::NT * TE; ++e) MPC_LAUNDER(ex.th.Mx[e]);
+#endif
+  }
   MPC_HD double rho_at(int i) const {
     if constexpr (C::kCompact) { const int ty = s.ctype[i]; return ty == 1 ? s.rho3[2] : (ty == 0 ? s.rho3[1] : s.rho3[0]); }
     else return s.rho_vec[i];
@@ -574,7 +604,11 @@ struct Solver {
   }
   long long tc[kProfLen] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = 0;
+#ifndef MPC_SECTION_PROFILE   // per-section counters cost ~30 SGPRs (and push uniform values into VGPRs): opt-in, tools/section_profile.py
+  MPC_HD void lap(int) {}
+#else
   MPC_HD void lap(int k) { const long long now = MPC_CLOCK(); tc[k] += now - tlast; tlast = now; }
+#endif
 
   // ---- helpers valid inside a phase ------------------------------------------------------------
   static MPC_HD double a_row_dot(const Sh &s, int i, const double *v) {  // row i of scaled A times v
@@ -866,13 +900,16 @@ struct Solver {
   // The pivot loop is unrolled by TS = 6 so that the pivot's position inside its tile is static.
   MPC_HD void sweep_all(bool masked) {
     int buf = 0;
+    pin_tiles(0);
     ex.par([&](Th &t) { for_tiles(t, [&](Tv &v, int) { publish<0>(v, 0, 0); }); });
     for (int kt = 0; kt < G; ++kt) {
+      pin_tiles(4);
       // bit A: pivot 6 kt + A is swept; bit 6: so is the first pivot of the next tile row (one LDS read per six steps)
       int bits = kt + 1 < G ? 0x7f : 0x3f;
       if (masked) bits = MPC_UNIFORM_INT(s.rowmask[kt] | (kt + 1 < G ? (s.rowmask[kt + 1] & 1) << TS : 0));
       sweep_steps<0>(bits, kt, buf);
     }
+    pin_tiles(1);
   }
   template <int A>
   MPC_HD void sweep_steps(int bits, int kt, int &buf) {
@@ -1365,25 +1402,33 @@ struct Solver {
     lap(9);
     admm_prepare();
     lap(8);
+    // kCheck iterations between termination checks (osqp.c:417-517 checks when iter % 25 == 0): the iterations
+    // run in their own inner loop so that the register allocator keeps the tile resident across them and places
+    // its live-range splits around the check / refactor code, which runs 25x less often.
+    static_assert(kMaxIter % kCheck == 0, "the check falls on the last iteration");
     int iter = 0;
     while (!s.done && !s.bad && iter < kMaxIter) {
-      ++iter;
-      admm_iter();
-      if (iter % kCheck == 0) {
+      pin_tiles(2);
+      for (int k = 0; k < kCheck; ++k) admm_iter();
+      pin_tiles(3);
+      iter += kCheck;
+      lap(8);
+      residuals(s.x, cz(), cy(), s.Px);
+      check_and_adapt(iter);
+      lap(10);
+      if (!s.done && s.rho_new > 0) {          // osqp_update_rho: new rho_vec, refactor
+        ex.par([&](Th &t) { if (t.tid == 0) { s.rho = s.rho_new; s.rho_updates++; } });
+        set_rho_vec();
+        factor(true);
+        admm_prepare();
         lap(8);
-        residuals(s.x, cz(), cy(), s.Px);
-        check_and_adapt(iter);
-        lap(10);
-        if (!s.done && s.rho_new > 0) {          // osqp_update_rho: new rho_vec, refactor
-          ex.par([&](Th &t) { if (t.tid == 0) { s.rho = s.rho_new; s.rho_updates++; } });
-          set_rho_vec();
-          factor(true);
-          admm_prepare();
-          lap(8);
-        }
       }
     }
-    lap(8);
+    if (C::kLoopExitFence) lap(8);   // (the clock read of an instrumented build is a fence too)
+    // Register allocation of the whole kernel hinges on whether the scheduler may move code across the loop exit
+    // (measured, hipcc 7.2): with a fence here h = 10 fits 210 VGPRs without spills (256 + 7 spills and 3.5 % slower
+    // without); h = 16 / 20 spill 1830 / 4998 registers with it and 283 / 2493 without (h = 16: 2.0x faster).
+    if (C::kLoopExitFence) MPC_SCHED_FENCE();
     if (!s.done && !s.bad) {   // max_iter reached (osqp.c:564-568): only SOLVED counts for the reference
       ex.par([&](Th &t) { if (t.tid == 0) s.status = kStMaxIter; });
     }

@@ -1,4 +1,9 @@
-"""Per-section shader-cycle breakdown of the solve kernel (in-kernel s_memtime laps), 4096 robots."""
+"""Per-section shader-cycle breakdown of the solve kernel (in-kernel s_memtime laps), 4096 robots.
+
+The section counters are compiled out of the product library; build and select an instrumented copy first:
+  tools/build_variant.sh prof -DMPC_SECTION_PROFILE
+  MPC_LIB_PATH=rl-mpc-locomotion_amd/csrc/variants/libmpc_batch_prof.so python tools/section_profile.py
+"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,8 +12,9 @@ import rl_mpc_locomotion_amd  # noqa
 from rl_mpc_locomotion_amd.batched import BatchedConvexMpc
 from rl_mpc_locomotion_amd.synthetic import make_solver_workload, perturb_workload
 
-n, h = int(sys.argv[1]) if len(sys.argv) > 1 else 4096, 10
-wl = make_solver_workload(n, h=h, seed=1000, config=2)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+h = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+wl = make_solver_workload(n, h=h, seed=1000, config={10: 2, 16: 4, 20: 5}[h])
 inertia9 = np.zeros((n, 9)); inertia9[:, 0], inertia9[:, 4], inertia9[:, 8] = wl.inertia_diag.T
 sv = BatchedConvexMpc(wl.mass, inertia9, h, wl.dt_mpc, wl.alpha)
 names = ["load", "dyn", "qP", "sc-load", "sc-loop", "sc-store", "Kform", "sweep", "admm", "r-mulP", "r-rest", "p-setup", "p-H", "p-refine", "p-fin", "total"]
