@@ -338,11 +338,13 @@ int mpc_batch_set_state(mpc_batch *b, const double *h_state) {
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-__global__ void ctrl_init_kernel(int n, CtrlState *st, const RobotConst *rc, const int *robot_type, const int *gait_id) {
+constexpr int kCtrlThreads = 64;   // one wave per workgroup: 4096 robots spread over 64 CUs, and the register cap is 512 (no spills)
+
+__global__ __launch_bounds__(kCtrlThreads) void ctrl_init_kernel(int n, CtrlState *st, const RobotConst *rc, const int *robot_type, const int *gait_id) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r < n) ctrl_init(st[r], rc[robot_type[r]], robot_type[r], gait_id[r]);
 }
-__global__ void ctrl_reset_kernel(int n, CtrlState *st, const RobotConst *rc, const int *ids, int k) {
+__global__ __launch_bounds__(kCtrlThreads) void ctrl_reset_kernel(int n, CtrlState *st, const RobotConst *rc, const int *ids, int k) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= k) return;
   const int r = ids ? ids[i] : i;
@@ -352,7 +354,7 @@ __global__ void ctrl_set_gait_kernel(int n, CtrlState *st, const int *gait_id) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r < n) st[r].gait_id = gait_id[r];
 }
-__global__ void ctrl_pre_kernel(int n, CtrlState *st, const RobotConst *rc, GaitTable gt, CtrlParams cp, const float *dof,
+__global__ __launch_bounds__(kCtrlThreads) void ctrl_pre_kernel(int n, CtrlState *st, const RobotConst *rc, GaitTable gt, CtrlParams cp, const float *dof,
                                 const float *est, const float *cmd, float *rec, int *active) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
@@ -362,7 +364,7 @@ __global__ void ctrl_pre_kernel(int n, CtrlState *st, const RobotConst *rc, Gait
   active[r] = s.do_solve;
   st[r] = s;
 }
-__global__ void estimator_kernel(int n, const CtrlState *st, const float *body, float *est) {
+__global__ __launch_bounds__(kCtrlThreads) void estimator_kernel(int n, const CtrlState *st, const float *body, float *est) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   const float nrm[3] = {st[r].normal[0], st[r].normal[1], st[r].normal[2]};
@@ -370,7 +372,7 @@ __global__ void estimator_kernel(int n, const CtrlState *st, const float *body, 
   estimator_update(body + (size_t)r * 13, nrm, e);
   for (int k = 0; k < kEstLen; ++k) est[(size_t)r * kEstLen + k] = e[k];
 }
-__global__ void fsm_init_kernel(int n, CtrlState *st, FsmState *fs, const RobotConst *rc, const int *mode, int op_mode, const int *ids, int k, int fresh) {
+__global__ __launch_bounds__(kCtrlThreads) void fsm_init_kernel(int n, CtrlState *st, FsmState *fs, const RobotConst *rc, const int *mode, int op_mode, const int *ids, int k, int fresh) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= k) return;
   const int r = ids ? ids[i] : i;
@@ -382,7 +384,7 @@ __global__ void fsm_init_kernel(int n, CtrlState *st, FsmState *fs, const RobotC
   st[r] = s; fs[r] = f;
 }
 // RobotRunnerFSM.run up to the solver launch: fsm_tick, then ctrl_pre for the robots whose state runs the locomotion controller
-__global__ void fsm_pre_kernel(int n, CtrlState *st, FsmState *fs, const RobotConst *rc, GaitTable gt, CtrlParams cp, FsmParams fp,
+__global__ __launch_bounds__(kCtrlThreads) void fsm_pre_kernel(int n, CtrlState *st, FsmState *fs, const RobotConst *rc, GaitTable gt, CtrlParams cp, FsmParams fp,
                                const float *dof, const float *body, const float *est, const float *cmd, const int *request, float *rec,
                                int *active, double *solver_state, int state_len) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -400,7 +402,7 @@ __global__ void fsm_pre_kernel(int n, CtrlState *st, FsmState *fs, const RobotCo
   active[r] = act;
   st[r] = s; fs[r] = f;
 }
-__global__ void fsm_post_kernel(int n, CtrlState *st, const FsmState *fs, const RobotConst *rc, int horizon, const double *forces, const int *info,
+__global__ __launch_bounds__(kCtrlThreads) void fsm_post_kernel(int n, CtrlState *st, const FsmState *fs, const RobotConst *rc, int horizon, const double *forces, const int *info,
                                 float *torques) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
@@ -412,7 +414,7 @@ __global__ void fsm_post_kernel(int n, CtrlState *st, const FsmState *fs, const 
     fsm_joint_torques(fs[r], st[r], torques + (size_t)r * 12);
   }
 }
-__global__ void ctrl_post_kernel(int n, CtrlState *st, const RobotConst *rc, int horizon, const double *forces, const int *info,
+__global__ __launch_bounds__(kCtrlThreads) void ctrl_post_kernel(int n, CtrlState *st, const RobotConst *rc, int horizon, const double *forces, const int *info,
                                  float *torques) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
@@ -495,7 +497,7 @@ int mpc_ctrl_create(mpc_ctrl **out, int n, int horizon, double controller_dt, in
     mpc_ctrl_destroy(c);
     return fail(MPC_E_HIP, std::string("mpc_ctrl_create: ") + hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(ctrl_init_kernel, dim3((n + 127) / 128), dim3(128), 0, nullptr, n, c->d_state, c->d_rc, c->d_robot_type, c->d_gait);
+  hipLaunchKernelGGL(ctrl_init_kernel, dim3((n + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, nullptr, n, c->d_state, c->d_rc, c->d_robot_type, c->d_gait);
   if ((e = hipDeviceSynchronize()) != hipSuccess) { mpc_ctrl_destroy(c); return fail(MPC_E_HIP, std::string("mpc_ctrl_create: ") + hipGetErrorString(e)); }
   *out = c;
   return MPC_OK;
@@ -504,21 +506,21 @@ int mpc_ctrl_create(mpc_ctrl **out, int n, int horizon, double controller_dt, in
 int mpc_ctrl_step(mpc_ctrl *c, const float *d_dof, const float *d_est, const float *d_cmd, float *d_torques, void *stream) {
   if (!c || !d_dof || !d_est || !d_cmd || !d_torques) return fail(MPC_E_ARG, "mpc_ctrl_step: bad argument");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int n = c->n, blocks = (n + 127) / 128;
+  const int n = c->n, blocks = (n + kCtrlThreads - 1) / kCtrlThreads;
   bool any_due = true;
   if (c->mirror_valid) {   // ConvexMPCLocomotion.run: iterationCounter += 1, MPC update when it is a multiple of iterationsBetweenMPC
     if ((int)c->h_iter.size() != n) c->h_iter.assign(n, 0);
     any_due = false;
     for (int r = 0; r < n; ++r) any_due |= (++c->h_iter[r] % c->cp.iters_between_mpc) == 0;
   }
-  hipLaunchKernelGGL(ctrl_pre_kernel, dim3(blocks), dim3(128), 0, st, n, c->d_state, c->d_rc, c->gt, c->cp, d_dof, d_est, d_cmd, c->d_rec, c->d_active);
+  hipLaunchKernelGGL(ctrl_pre_kernel, dim3(blocks), dim3(kCtrlThreads), 0, st, n, c->d_state, c->d_rc, c->gt, c->cp, d_dof, d_est, d_cmd, c->d_rec, c->d_active);
   HIP_TRY(hipGetLastError());
   mpc_batch *b = c->solver;
   if (any_due) {
     int rc = launch_solver(b, c->d_rec, c->d_forces, c->d_info, c->d_active, st);
     if (rc != MPC_OK) return rc;
   }
-  hipLaunchKernelGGL(ctrl_post_kernel, dim3(blocks), dim3(128), 0, st, n, c->d_state, c->d_rc, c->cp.horizon, c->d_forces, c->d_info, d_torques);
+  hipLaunchKernelGGL(ctrl_post_kernel, dim3(blocks), dim3(kCtrlThreads), 0, st, n, c->d_state, c->d_rc, c->cp.horizon, c->d_forces, c->d_info, d_torques);
   HIP_TRY(hipGetLastError());
   return MPC_OK;
 }
@@ -526,7 +528,7 @@ int mpc_ctrl_step(mpc_ctrl *c, const float *d_dof, const float *d_est, const flo
 int mpc_ctrl_run(mpc_ctrl *c, const float *d_dof, const float *d_body, const float *d_cmd, float *d_torques, void *stream) {
   if (!c || !d_dof || !d_body || !d_cmd || !d_torques) return fail(MPC_E_ARG, "mpc_ctrl_run: bad argument");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(estimator_kernel, dim3((c->n + 127) / 128), dim3(128), 0, st, c->n, c->d_state, d_body, c->d_est);
+  hipLaunchKernelGGL(estimator_kernel, dim3((c->n + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, st, c->n, c->d_state, d_body, c->d_est);
   HIP_TRY(hipGetLastError());
   return mpc_ctrl_step(c, d_dof, c->d_est, d_cmd, d_torques, stream);
 }
@@ -539,7 +541,7 @@ int mpc_ctrl_reset(mpc_ctrl *c, const int *ids, int k, void *stream) {
   int rc = mpc_batch_reset(c->solver, ids, k, stream);   // new ConvexMpc object = cold solver (ConvexMPCLocomotion.py:102-108)
   if (rc != MPC_OK) return rc;
   if (!ids) {
-    hipLaunchKernelGGL(ctrl_reset_kernel, dim3((c->n + 127) / 128), dim3(128), 0, st, c->n, c->d_state, c->d_rc, (const int *)nullptr, c->n);
+    hipLaunchKernelGGL(ctrl_reset_kernel, dim3((c->n + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, st, c->n, c->d_state, c->d_rc, (const int *)nullptr, c->n);
     HIP_TRY(hipGetLastError());
     return MPC_OK;
   }
@@ -547,7 +549,7 @@ int mpc_ctrl_reset(mpc_ctrl *c, const int *ids, int k, void *stream) {
   int *d_ids = nullptr;
   HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&d_ids), sizeof(int) * k, st));
   HIP_TRY(hipMemcpyAsync(d_ids, ids, sizeof(int) * k, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(ctrl_reset_kernel, dim3((k + 127) / 128), dim3(128), 0, st, c->n, c->d_state, c->d_rc, d_ids, k);
+  hipLaunchKernelGGL(ctrl_reset_kernel, dim3((k + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, st, c->n, c->d_state, c->d_rc, d_ids, k);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipFreeAsync(d_ids, st));
   return MPC_OK;
@@ -558,7 +560,7 @@ int mpc_ctrl_set_gait(mpc_ctrl *c, const int *gait_id, void *stream) {
   for (int r = 0; r < c->n; ++r) if (gait_id[r] < 0 || gait_id[r] >= kNumGaitIds) return fail(MPC_E_ARG, "mpc_ctrl_set_gait: gait id out of range");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   HIP_TRY(hipMemcpyAsync(c->d_gait, gait_id, sizeof(int) * c->n, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(ctrl_set_gait_kernel, dim3((c->n + 127) / 128), dim3(128), 0, st, c->n, c->d_state, c->d_gait);
+  hipLaunchKernelGGL(ctrl_set_gait_kernel, dim3((c->n + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, st, c->n, c->d_state, c->d_gait);
   HIP_TRY(hipGetLastError());
   return MPC_OK;
 }
@@ -579,8 +581,8 @@ int mpc_ctrl_fsm_init(mpc_ctrl *c, const int *control_mode, int operating_mode, 
   HIP_TRY(hipMemcpyAsync(c->d_fsm_mode, control_mode, sizeof(int) * c->n, hipMemcpyHostToDevice, st));
   int rc = mpc_batch_reset(c->solver, nullptr, 0, stream);   // RobotRunnerFSM.init builds fresh objects
   if (rc != MPC_OK) return rc;
-  hipLaunchKernelGGL(ctrl_init_kernel, dim3((c->n + 127) / 128), dim3(128), 0, st, c->n, c->d_state, c->d_rc, c->d_robot_type, c->d_gait);
-  hipLaunchKernelGGL(fsm_init_kernel, dim3((c->n + 127) / 128), dim3(128), 0, st, c->n, c->d_state, c->d_fsm, c->d_rc, c->d_fsm_mode, operating_mode,
+  hipLaunchKernelGGL(ctrl_init_kernel, dim3((c->n + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, st, c->n, c->d_state, c->d_rc, c->d_robot_type, c->d_gait);
+  hipLaunchKernelGGL(fsm_init_kernel, dim3((c->n + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, st, c->n, c->d_state, c->d_fsm, c->d_rc, c->d_fsm_mode, operating_mode,
                      (const int *)nullptr, c->n, 1);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(st));                          // control_mode is a host buffer
@@ -598,7 +600,7 @@ int mpc_ctrl_fsm_reset(mpc_ctrl *c, const int *ids, int k, const int *control_mo
     HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&d_ids), sizeof(int) * k, st));
     HIP_TRY(hipMemcpyAsync(d_ids, ids, sizeof(int) * k, hipMemcpyHostToDevice, st));
   }
-  hipLaunchKernelGGL(fsm_init_kernel, dim3((cnt + 127) / 128), dim3(128), 0, st, c->n, c->d_state, c->d_fsm, c->d_rc, c->d_fsm_mode, c->fsm_op_mode, d_ids, cnt, 0);
+  hipLaunchKernelGGL(fsm_init_kernel, dim3((cnt + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, st, c->n, c->d_state, c->d_fsm, c->d_rc, c->d_fsm_mode, c->fsm_op_mode, d_ids, cnt, 0);
   HIP_TRY(hipGetLastError());
   if (d_ids) HIP_TRY(hipFreeAsync(d_ids, st));
   HIP_TRY(hipStreamSynchronize(st));
@@ -609,15 +611,15 @@ int mpc_ctrl_run_fsm(mpc_ctrl *c, const float *d_dof, const float *d_body, const
   if (!c || !d_dof || !d_body || !d_cmd || !d_request || !d_torques) return fail(MPC_E_ARG, "mpc_ctrl_run_fsm: bad argument");
   if (!c->d_fsm) return fail(MPC_E_ARG, "mpc_ctrl_run_fsm: call mpc_ctrl_fsm_init first");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int n = c->n, blocks = (n + 127) / 128;
+  const int n = c->n, blocks = (n + kCtrlThreads - 1) / kCtrlThreads;
   mpc_batch *b = c->solver;
-  hipLaunchKernelGGL(estimator_kernel, dim3(blocks), dim3(128), 0, st, n, c->d_state, d_body, c->d_est);
-  hipLaunchKernelGGL(fsm_pre_kernel, dim3(blocks), dim3(128), 0, st, n, c->d_state, c->d_fsm, c->d_rc, c->gt, c->cp, c->fp, d_dof, d_body, c->d_est, d_cmd,
+  hipLaunchKernelGGL(estimator_kernel, dim3(blocks), dim3(kCtrlThreads), 0, st, n, c->d_state, d_body, c->d_est);
+  hipLaunchKernelGGL(fsm_pre_kernel, dim3(blocks), dim3(kCtrlThreads), 0, st, n, c->d_state, c->d_fsm, c->d_rc, c->gt, c->cp, c->fp, d_dof, d_body, c->d_est, d_cmd,
                      d_request, c->d_rec, c->d_active, b->d_state, b->state_len);
   HIP_TRY(hipGetLastError());
   int rc = launch_solver(b, c->d_rec, c->d_forces, c->d_info, c->d_active, st);
   if (rc != MPC_OK) return rc;
-  hipLaunchKernelGGL(fsm_post_kernel, dim3(blocks), dim3(128), 0, st, n, c->d_state, c->d_fsm, c->d_rc, c->cp.horizon, c->d_forces, c->d_info, d_torques);
+  hipLaunchKernelGGL(fsm_post_kernel, dim3(blocks), dim3(kCtrlThreads), 0, st, n, c->d_state, c->d_fsm, c->d_rc, c->cp.horizon, c->d_forces, c->d_info, d_torques);
   HIP_TRY(hipGetLastError());
   return MPC_OK;
 }
@@ -725,14 +727,14 @@ int mpc_pack_commands(int n, const float *d_cmd3, const float *d_weights12, floa
 
 int mpc_ctrl_update_estimate(mpc_ctrl *c, const float *d_body, void *stream) {
   if (!c || !d_body) return fail(MPC_E_ARG, "mpc_ctrl_update_estimate: bad argument");
-  hipLaunchKernelGGL(estimator_kernel, dim3((c->n + 127) / 128), dim3(128), 0, (hipStream_t)stream, c->n, c->d_state, d_body, c->d_est);
+  hipLaunchKernelGGL(estimator_kernel, dim3((c->n + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, (hipStream_t)stream, c->n, c->d_state, d_body, c->d_est);
   HIP_TRY(hipGetLastError());
   return MPC_OK;
 }
 
 int mpc_ctrl_estimate(mpc_ctrl *c, float *d_est, float *d_ground_normal, void *stream) {
   if (!c || (!d_est && !d_ground_normal)) return fail(MPC_E_ARG, "mpc_ctrl_estimate: bad argument");
-  hipLaunchKernelGGL(ctrl_estimate_kernel, dim3((c->n + 127) / 128), dim3(128), 0, (hipStream_t)stream, c->n, c->d_state, c->d_est, d_est, d_ground_normal);
+  hipLaunchKernelGGL(ctrl_estimate_kernel, dim3((c->n + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, (hipStream_t)stream, c->n, c->d_state, c->d_est, d_est, d_ground_normal);
   HIP_TRY(hipGetLastError());
   return MPC_OK;
 }

@@ -51,6 +51,9 @@
 #ifndef MPC_EXIT_FENCE_UPTO
 #define MPC_EXIT_FENCE_UPTO 12
 #endif
+#ifndef MPC_PROW_SKEW
+#define MPC_PROW_SKEW 0
+#endif
 #ifndef MPC_NT2_FROM
 #define MPC_NT2_FROM 17
 #endif
@@ -159,7 +162,11 @@ struct Shared {
   int ctype[C::M];
   MPC_V x[C::N]; MPC_V xt[C::N]; MPC_V Px[C::N];        // Px = P_s x, carried through the ADMM iterations
   MPC_V zz[1][C::M]; MPC_V yy[1][C::M]; MPC_V rr[1][C::N];   // z, y, rhs
-  MPC_V prow[2][C::N];                                  // sweep pivot row (double buffered)
+  // sweep pivot row (double buffered).  With MPC_PROW_SKEW = 1 the row starts 8 bytes off the 16-byte grid, so that publish()
+  // stores it as ds_write2_b64 (two independent 64-bit sources) instead of ds_write_b128, whose 128-bit source ties pairs of
+  // tile elements into register quads.
+  MPC_V prow_raw[2][C::N + 2];
+  MPC_HD double *prow(int b) { return prow_raw[b] + MPC_PROW_SKEW; }
   MPC_V piv[2][2];                                      // current pivot and its reciprocal (double buffered)
   unsigned long long red[16];                           // max-reductions (bit pattern of doubles >= 0)
   int first, iter, status, status_polish, rho_updates, nfact, done, bad;   // control (uniform)
@@ -935,7 +942,7 @@ struct Solver {
         double g[TS], pc[TS];
         if (active) {
           const double p = s.piv[buf][0], pinv = s.piv[buf][1];
-          const double *pr = s.prow[buf];
+          const double *pr = s.prow(buf);
 #pragma unroll
           for (int a = 0; a < TS; ++a) { g[a] = pr[TS * v.ti + a] * pinv; pc[a] = pr[TS * v.tj + a]; }
 #pragma unroll
@@ -963,7 +970,7 @@ struct Solver {
   template <int A>
   MPC_HD void publish(const Tv &t, int b, int kt) {
     if (t.ti == kt) {
-      double *pn = s.prow[b] + TS * t.tj;
+      double *pn = s.prow(b) + TS * t.tj;
 #pragma unroll
       for (int bb = 0; bb < TS; ++bb)
         if (bb != A) pn[bb] = t.Mx[A * TS + bb];
@@ -974,7 +981,7 @@ struct Solver {
         s.piv[b][1] = fast_recip(pivot);
       }
     } else if (t.tj == kt) {
-      double *pn = s.prow[b] + TS * t.ti;
+      double *pn = s.prow(b) + TS * t.ti;
 #pragma unroll
       for (int a = 0; a < TS; ++a) pn[a] = t.Mx[a * TS + A];
     }
