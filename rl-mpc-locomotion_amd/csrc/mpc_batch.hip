@@ -21,7 +21,7 @@ using namespace mpc;
 #define MPC_MIN_WAVES 2
 #endif
 #ifndef MPC_MIN_WAVES_MAX_T
-#define MPC_MIN_WAVES_MAX_T 256   // larger workgroups (h = 16) run one per CU
+#define MPC_MIN_WAVES_MAX_T 256   // larger workgroups (h = 16), and the four-tiles-per-thread layout (h = 20), run one per CU
 #endif
 
 namespace {
@@ -46,7 +46,7 @@ struct DeviceExec {
 };
 
 template <int H>
-__global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= MPC_MIN_WAVES_MAX_T ? MPC_MIN_WAVES : 1)) void mpc_solve_kernel(int n, const RobotModel *__restrict__ models,
+__global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= MPC_MIN_WAVES_MAX_T && Cfg<H>::NT == 1 ? MPC_MIN_WAVES : 1)) void mpc_solve_kernel(int n, const RobotModel *__restrict__ models,
                                                                const float *__restrict__ in, double *__restrict__ state,
                                                                double *__restrict__ scratch, const double *__restrict__ qp, double *__restrict__ forces,
                                                                int *__restrict__ info, long long *__restrict__ prof,
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= MPC_MIN_WAVES_MAX_T ? MPC_
 
 // Assembly kernel (mpc_core.h Assembler): q, bounds, cone block and P of every active robot -> HBM
 template <int H>
-__global__ __launch_bounds__(Cfg<H>::T) void mpc_assemble_kernel(int n, const RobotModel *__restrict__ models, const float *__restrict__ in,
+__global__ __launch_bounds__(Cfg<H>::TA) void mpc_assemble_kernel(int n, const RobotModel *__restrict__ models, const float *__restrict__ in,
                                                                  double *__restrict__ scratch, double *__restrict__ qp,
                                                                  long long *__restrict__ prof, const int *__restrict__ active) {
   __shared__ __attribute__((aligned(16))) AsmShared<H> sh;
@@ -106,7 +106,7 @@ template <int H>
 int launch(int n, const RobotModel *models, const float *in, double *state, double *scratch, double *qp, double *forces, int *info,
            long long *prof, const int *active, const int *order, hipEvent_t *ev, hipStream_t stream) {
   if (ev) (void)hipEventRecord(ev[0], stream);
-  hipLaunchKernelGGL(mpc_assemble_kernel<H>, dim3(n), dim3(Cfg<H>::T), 0, stream, n, models, in, scratch, qp, prof, active);
+  hipLaunchKernelGGL(mpc_assemble_kernel<H>, dim3(n), dim3(Cfg<H>::TA), 0, stream, n, models, in, scratch, qp, prof, active);
   if (ev) (void)hipEventRecord(ev[1], stream);
   hipLaunchKernelGGL(mpc_solve_kernel<H>, dim3(n), dim3(Cfg<H>::T), 0, stream, n, models, in, state, scratch, qp, forces, info, prof, active, order);
   if (ev) (void)hipEventRecord(ev[2], stream);

@@ -54,6 +54,9 @@
 #ifndef MPC_PROW_SKEW
 #define MPC_PROW_SKEW 0
 #endif
+#ifndef MPC_NT_LONG
+#define MPC_NT_LONG 4
+#endif
 #ifndef MPC_NT2_FROM
 #define MPC_NT2_FROM 17
 #endif
@@ -92,16 +95,21 @@ struct Cfg {
   static constexpr int TS = 6;                           // register tile side (2 feet)
   static constexpr int G = N / TS;                       // tile grid G x G, lower triangle stored
   static constexpr int MT = G * (G + 1) / 2;             // lower-triangle tiles
-  static constexpr int NT = H >= MPC_NT2_FROM ? 2 : 1;              // tiles per thread: two for the longest horizon keeps the workgroup at
-                                                         // <= 2 waves per SIMD, i.e. 256 VGPRs per lane instead of 168 / 128
+  // Tiles per thread.  Up to h = 16 every thread holds one tile.  The longest horizon has 820 tiles: with one or two per
+  // thread the workgroup runs 2-4 waves per SIMD, i.e. at most 256 / 128 registers per lane, and the tile spills to scratch
+  // in every hot loop (measured: spill traffic, not arithmetic, bounded the kernel).  Four tiles per thread make it a
+  // 256-thread workgroup, one wave per SIMD, with the full 512-register budget (256 VGPRs + 256 AGPRs as spill space).
+  static constexpr int NT = H >= MPC_NT2_FROM ? MPC_NT_LONG : 1;
   static constexpr int MTH = (MT + NT - 1) / NT;         // threads that hold tiles
   static constexpr int TE = TS * TS;                     // tile elements per thread
   static constexpr int PG_LEN = MT * TE;                 // doubles of P_s scratch per robot (tile-major)
 #ifdef MPC_FORCE_T
   static constexpr int T = MPC_FORCE_T;                  // (register-budget experiments)
 #else
-  static constexpr int T = (((MTH > M ? MTH : M) + 63) / 64) * 64;   // workgroup size
+  static constexpr int T = (((MTH > N ? MTH : N) + 63) / 64) * 64;   // solve-kernel workgroup: a thread per tile slot and per variable
 #endif
+  static constexpr int MR = (M + T - 1) / T;             // constraint rows per thread (Solver::for_rows): 1, or 2 at h = 20
+  static constexpr int TA = ((M > 256 ? M : 256) + 63) / 64 * 64;   // assembly-kernel workgroup (>= M threads)
   static constexpr int IN_LEN = 56 + 4 * H;
   static constexpr int NTASK2 = 21 + (H - 1) * 36;       // P assembly tasks (d, 2 x 2 block of (a, b))
   static_assert(T <= 1024, "workgroup too large");
@@ -273,7 +281,7 @@ template <int H, class Exec>
 struct Assembler {
   using C = Cfg<H>;
   using Th = Thread<H>;
-  static constexpr int N = C::N, M = C::M, NF = C::NF, T = C::T, TS = C::TS, TE = C::TE;
+  static constexpr int N = C::N, M = C::M, NF = C::NF, T = C::TA, TS = C::TS, TE = C::TE;
 
   Exec &ex;
   AsmShared<H> &s;
@@ -590,6 +598,15 @@ struct Solver {
         f(v, u);
       }
   }
+  // The constraint rows of a thread: tid, tid + T, ... (one row per thread unless the workgroup is smaller than M).
+  template <class F>
+  MPC_HD void for_rows(const Th &t, F &&f) {
+#pragma unroll
+    for (int p = 0; p < C::MR; ++p) {
+      const int i = t.tid + p * T;
+      if (i < M) f(i);
+    }
+  }
   // A register-allocation hint, no code: every tile element passes through an empty asm, which ends its live range and
   // starts a new one.  The tile lives from load() to polish(); without such split points the allocator treats a
   // tile register pair as one range over the whole kernel and, once some phase is over budget, spills it in the hot
@@ -757,11 +774,11 @@ struct Solver {
         s.qs[t.tid] = s.first ? s.q[t.tid] : s.xt[t.tid];   // osqp_update_P_A equilibrates with the PREVIOUS q
         s.D[t.tid] = 1.0;
       }
-      if (t.tid < M) {
-        const double *a = s.cone + 3 * (t.tid % 5);
-        s.E[t.tid] = 1.0;
-        s.et_[t.tid] = row_scale3(a[0], a[1], a[2]);
-      }
+      for_rows(t, [&](int i) {
+        const double *a = s.cone + 3 * (i % 5);
+        s.E[i] = 1.0;
+        s.et_[i] = row_scale3(a[0], a[1], a[2]);
+      });
       for (int k = t.tid; k < NF * 15; k += T) s.As[k] = s.cone[k % 15];
       if (t.tid == 0) s.c = 1.0;
     });
@@ -787,16 +804,16 @@ struct Solver {
       ex.par([&](Th &t) {   // A <- E A D, q <- D (c_temp q), c <- c_temp c; new row norms of D P D and A
         const double ct = s.ctmp;
         for_tiles(t, [&](Tv &v, int) { tile_rownorms(v, s.D); });
-        if (t.tid < M) {
-          const int f = t.tid / 5;
-          double *a = s.As + 3 * t.tid;
-          const double e = s.et_[t.tid], a0 = a[0], a1 = a[1], a2 = a[2];
-          const double d0 = s.dt_[3 * f], d1 = s.dt_[3 * f + 1], d2 = s.dt_[3 * f + 2], eo = s.E[t.tid];
+        for_rows(t, [&](int i) {
+          const int f = i / 5;
+          double *a = s.As + 3 * i;
+          const double e = s.et_[i], a0 = a[0], a1 = a[1], a2 = a[2];
+          const double d0 = s.dt_[3 * f], d1 = s.dt_[3 * f + 1], d2 = s.dt_[3 * f + 2], eo = s.E[i];
           const double n0 = (a0 * e) * d0, n1 = (a1 * e) * d1, n2 = (a2 * e) * d2;
           a[0] = n0; a[1] = n1; a[2] = n2;
-          s.E[t.tid] = eo * e;
-          s.et_[t.tid] = row_scale3(n0, n1, n2);   // row scale of the next pass
-        }
+          s.E[i] = eo * e;
+          s.et_[i] = row_scale3(n0, n1, n2);   // row scale of the next pass
+        });
         if (t.tid < N) s.qs[t.tid] = (s.qs[t.tid] * ct) * s.dt_[t.tid];
         if (t.tid == T - 1) s.c *= ct;
       });
@@ -833,15 +850,14 @@ struct Solver {
         s.Dinv[t.tid] = 1.0 / s.D[t.tid];
         if (!s.first) s.qs[t.tid] = (s.D[t.tid] * s.q[t.tid]) * cf;      // osqp_update_lin_cost (osqp.c:765-770)
       }
-      if (t.tid < M) {
-        const int i = t.tid;
+      for_rows(t, [&](int i) {
         s.Einv[i] = 1.0 / s.E[i];
         s.ls[i] = s.E[i] * s.l[i];
         s.us[i] = s.E[i] * s.u[i];
         // set_rho_vec / update_rho_vec (auxil.c:79-141): rho_vec is a function of (type, rho) in both
         const int ty = (s.ls[i] < -kInfty * kMinScaling && s.us[i] > kInfty * kMinScaling) ? -1 : (s.us[i] - s.ls[i] < kRhoTol ? 1 : 0);
         s.ctype[i] = ty;
-      }
+      });
       for_tiles(t, [&](Tv &v, int) { store_tile(v, Pg); });   // keep P_s for residuals, re-factorisations and polish
     });
     lap(5);
@@ -855,11 +871,13 @@ struct Solver {
           s.rho3[t.tid] = rv;
           s.rinv3[t.tid] = 1.0 / rv;
         }
-      } else if (t.tid < M) {
-        const int ty = s.ctype[t.tid];
-        const double rv = ty == -1 ? kRhoMin : (ty == 1 ? kRhoEqOverIneq * s.rho : s.rho);
-        s.rho_vec[t.tid] = rv;
-        s.rho_inv[t.tid] = 1.0 / rv;
+      } else {
+        for_rows(t, [&](int i) {
+          const int ty = s.ctype[i];
+          const double rv = ty == -1 ? kRhoMin : (ty == 1 ? kRhoEqOverIneq * s.rho : s.rho);
+          s.rho_vec[i] = rv;
+          s.rho_inv[i] = 1.0 / rv;
+        });
       }
     });
   }
@@ -1048,8 +1066,8 @@ struct Solver {
     });
     MPC_SUBLAP(5, 10);
     ex.par([&](Th &t) {
-      if (t.tid < M) {   // (all LDS loads first, as one batch: a single round trip per phase)
-        const int i = t.tid, f = i / 5, r = i - 5 * f;
+      for_rows(t, [&](int i) {   // (all LDS loads first, as one batch: a single round trip per phase)
+        const int f = i / 5, r = i - 5 * f;
         const double *a = s.As + 15 * f + 3 * r, *xt = s.xt + 3 * f;
         const double a0 = a[0], a1 = a[1], a2 = a[2], x0 = xt[0], x1 = xt[1], x2 = xt[2];
         const double zp = cz()[i], yv = cy()[i], rv = rho_at(i), ri = rinv_at(i), lo = s.ls[i], hi = s.us[i];
@@ -1062,7 +1080,7 @@ struct Solver {
         cy()[i] = yn;
         s.tm[i] = rv * zn - yn;
         s.rzt[i] = rv * zt;
-      }
+      });
     });
     MPC_SUBLAP(5, 11);
     ex.par([&](Th &t) {
@@ -1179,10 +1197,7 @@ struct Solver {
   MPC_HD void polish() {
     // active set (polish.c:36-52) and per-foot bases
     ex.par([&](Th &t) {
-      if (t.tid < M) {
-        const int i = t.tid;
-        s.act[i] = (cz()[i] - s.ls[i] < -cy()[i]) ? -1 : ((s.us[i] - cz()[i] < cy()[i]) ? 1 : 0);
-      }
+      for_rows(t, [&](int i) { s.act[i] = (cz()[i] - s.ls[i] < -cy()[i]) ? -1 : ((s.us[i] - cz()[i] < cy()[i]) ? 1 : 0); });
     });
     ex.par([&](Th &t) {
       if (t.tid < NF) {
@@ -1367,14 +1382,13 @@ struct Solver {
       }
     });
     ex.par([&](Th &t) {
-      if (t.tid < M) {
-        const int i = t.tid;
+      for_rows(t, [&](int i) {
         const double yv = s.act[i] ? a_row_dot(s, i, s.rw) : 0.0;
         const double tt = a_row_dot(s, i, s.xt) + yv;
         const double zc = clampd(tt, s.ls[i], s.us[i]);
         s.zpol[i] = zc;
         s.ypol[i] = tt - zc;
-      }
+      });
     });
     // residuals at the polished point, acceptance (polish.c:306-345)
     const double pri0 = s.pri_res, dua0 = s.dua_res;
@@ -1391,7 +1405,7 @@ struct Solver {
     ex.par([&](Th &t) {
       if (s.status_polish == 1) {
         if (t.tid < N) s.x[t.tid] = s.xt[t.tid];
-        if (t.tid < M) { cz()[t.tid] = s.zpol[t.tid]; cy()[t.tid] = s.ypol[t.tid]; }
+        for_rows(t, [&](int i) { cz()[i] = s.zpol[i]; cy()[i] = s.ypol[i]; });
       }
     });
   }
@@ -1450,7 +1464,7 @@ struct Solver {
         state[t.tid] = s.x[t.tid];
         state[N + 2 * M + t.tid] = s.q[t.tid];
       }
-      if (t.tid < M) { state[N + t.tid] = cz()[t.tid]; state[N + M + t.tid] = cy()[t.tid]; }
+      for_rows(t, [&](int i) { state[N + i] = cz()[i]; state[N + M + i] = cy()[i]; });
       if (t.tid == 0) {
         state[2 * N + 2 * M] = s.rho;
         state[2 * N + 2 * M + 1] = 1.0;

@@ -14,21 +14,21 @@
 
 using namespace mpc;
 
-template <int H>
+template <int H, int NTHREADS = Cfg<H>::T>
 struct HostExec {
   std::vector<Thread<H>> th;
   bool reverse;
   long phases = 0;
-  explicit HostExec(bool rev) : th(Cfg<H>::T), reverse(rev) {
-    for (int i = 0; i < Cfg<H>::T; ++i) {
+  explicit HostExec(bool rev) : th(NTHREADS), reverse(rev) {
+    for (int i = 0; i < NTHREADS; ++i) {
       th[i].init(i);
       for (int j = 0; j < Cfg<H>::NT * Cfg<H>::TE; ++j) th[i].Mx[j] = 0;
     }
   }
   template <class F> void par(F &&f) {
     ++phases;
-    if (!reverse) for (int i = 0; i < Cfg<H>::T; ++i) f(th[i]);
-    else for (int i = Cfg<H>::T - 1; i >= 0; --i) f(th[i]);
+    if (!reverse) for (int i = 0; i < NTHREADS; ++i) f(th[i]);
+    else for (int i = NTHREADS - 1; i >= 0; --i) f(th[i]);
   }
   void amax(unsigned long long *slot, double v) {
     const unsigned long long b = dbits(v);
@@ -45,8 +45,10 @@ static void solve_one(const RobotModel &mdl, const float *in, double *state, dou
   {
     AsmShared<H> *as = new AsmShared<H>();
     std::memset(as, 0, sizeof(AsmShared<H>));
-    Assembler<H, HostExec<H>> am{ex, *as, mdl, in, Pg, qp.data(), nullptr};
+    HostExec<H, Cfg<H>::TA> exa(reverse);   // (the assembly kernel has its own workgroup size)
+    Assembler<H, HostExec<H, Cfg<H>::TA>> am{exa, *as, mdl, in, Pg, qp.data(), nullptr};
     am.run();
+    ex.phases += exa.phases;
     delete as;
   }
   Solver<H, HostExec<H>> sv{ex, *sh, mdl, state, Pg, qp.data(), forces, info, nullptr};
