@@ -15,10 +15,10 @@
 
 using namespace mpc;
 
-// minimum waves per SIMD the register allocator must leave room for (256-thread workgroups:
-// 2 -> two robots per CU)
+// minimum waves per SIMD the register allocator must leave room for: 3 -> a 256-thread workgroup (h = 10) gets 168 VGPRs
+// and three robots share a CU (3 x 52 KB of LDS)
 #ifndef MPC_MIN_WAVES
-#define MPC_MIN_WAVES 2
+#define MPC_MIN_WAVES 3
 #endif
 #ifndef MPC_MIN_WAVES_MAX_T
 #define MPC_MIN_WAVES_MAX_T 256   // larger workgroups (h = 16), and the four-tiles-per-thread layout (h = 20), run one per CU

@@ -49,13 +49,16 @@
 #define MPC_SCHED_FENCE() ((void)0)
 #endif
 #ifndef MPC_EXIT_FENCE_UPTO
-#define MPC_EXIT_FENCE_UPTO 12
+#define MPC_EXIT_FENCE_UPTO 16
 #endif
 #ifndef MPC_PROW_SKEW
 #define MPC_PROW_SKEW 0
 #endif
 #ifndef MPC_NT_LONG
 #define MPC_NT_LONG 4
+#endif
+#ifndef MPC_NT_MID
+#define MPC_NT_MID 1
 #endif
 #ifndef MPC_NT2_FROM
 #define MPC_NT2_FROM 17
@@ -99,7 +102,7 @@ struct Cfg {
   // thread the workgroup runs 2-4 waves per SIMD, i.e. at most 256 / 128 registers per lane, and the tile spills to scratch
   // in every hot loop (measured: spill traffic, not arithmetic, bounded the kernel).  Four tiles per thread make it a
   // 256-thread workgroup, one wave per SIMD, with the full 512-register budget (256 VGPRs + 256 AGPRs as spill space).
-  static constexpr int NT = H >= MPC_NT2_FROM ? MPC_NT_LONG : 1;
+  static constexpr int NT = H >= MPC_NT2_FROM ? MPC_NT_LONG : (H > 12 ? MPC_NT_MID : 1);
   static constexpr int MTH = (MT + NT - 1) / NT;         // threads that hold tiles
   static constexpr int TE = TS * TS;                     // tile elements per thread
   static constexpr int PG_LEN = MT * TE;                 // doubles of P_s scratch per robot (tile-major)
@@ -114,10 +117,15 @@ struct Cfg {
   static constexpr int NTASK2 = 21 + (H - 1) * 36;       // P assembly tasks (d, 2 x 2 block of (a, b))
   static_assert(T <= 1024, "workgroup too large");
   static constexpr int NP = N + 2;                       // row stride of part[] (doubles)
-  static constexpr int PARTLEN = (NP * G > 14 * 64) ? NP * G : 14 * 64;   // part[] doubles as the reduction scratch
-  // The longest horizon is LDS-tight (one workgroup per CU, 160 KB): rho / 1/rho come from the three per-type values
-  // instead of per-row arrays.
-  static constexpr bool kCompact = H > 16;
+  static constexpr int MEVEN = (M + 1) & ~1;
+  static constexpr int PARTLEN = (NP * G > 14 * 64 + 2 * MEVEN) ? NP * G : 14 * 64 + 2 * MEVEN;   // part[] doubles as the reduction scratch
+                                                         // [0, 14 * 64) and, above it, holds z_pol / y_pol at the end of polish
+  // LDS diet of the short horizon (three robots per CU need <= 54.6 KB each): q stays in the HBM record and rho per row
+  // is a three-way select on the row type.  h = 16 keeps both in LDS -- it runs one robot per CU whatever its LDS size,
+  // and the leaner forms cost it 9 % each (measured; they lengthen live ranges in a kernel that is at its register cap).
+  // h = 20 needs the per-type rho to fit 160 KB.
+  static constexpr bool kQInLds = H > 12;
+  static constexpr bool kRhoPerType = H <= 12 || H > 16;
   static constexpr bool kLoopExitFence = H <= MPC_EXIT_FENCE_UPTO;
   // Live-range split points of the tile registers (Solver::pin_tiles): bit 0 / 1 before / after a sweep, 2 / 3 around the
   // 25 ADMM iterations, 4 inside the sweep loop.  Chosen per horizon by measurement (round 1: h = 16 0.12 -> 0.60 M steps/s,
@@ -125,7 +133,7 @@ struct Cfg {
 #ifdef MPC_PIN_MASK
   static constexpr int kPinMask = MPC_PIN_MASK;
 #else
-  static constexpr int kPinMask = H > 16 ? 3 : 19;
+  static constexpr int kPinMask = H > 16 ? 3 : 17;
 #endif   // scheduling fence after the ADMM loop (see Solver::run)
   // The QP record the assembly kernel hands to the solve kernel (doubles per robot): q[N] l[M] u[M] cone[15] pad
   static constexpr int QP_Q = 0, QP_L = N, QP_U = N + M, QP_CONE = N + 2 * M, QP_LEN = N + 2 * M + 16;
@@ -161,13 +169,16 @@ template <int H>
 struct Shared {
   using C = Cfg<H>;
   // ---- alive for the whole solve -------------------------------------------------------------
-  MPC_V q[C::N];                                        // unscaled q (becomes q_old of the next call)
+  // (LDS is what limits the robots per CU at h = 10 -- three fit in 160 KB below 54.6 KB each -- so nothing is stored that
+  //  is cheap to re-derive: the unscaled q stays in the HBM record, 1/D and 1/E are divided out where the residuals need
+  //  them (every 25 iterations), rho per row is a three-way select on the row type.)
+  MPC_V q[C::kQInLds ? C::N : 2];                       // unscaled q (becomes q_old of the next call), unless it is re-read from HBM
   MPC_V qs[C::N]; MPC_V ls[C::M]; MPC_V us[C::M]; MPC_V As[C::NF * 15];   // scaled problem
-  MPC_V D[C::N]; MPC_V Dinv[C::N]; MPC_V E[C::M]; MPC_V Einv[C::M];
+  MPC_V D[C::N]; MPC_V E[C::M];
   double c, cinv, rho, ctmp;
-  MPC_V rho_vec[C::kCompact ? 2 : C::M]; MPC_V rho_inv[C::kCompact ? 2 : C::M];   // per row (or unused: rho3 / rinv3 below)
+  MPC_V rho_vec[C::kRhoPerType ? 2 : C::M]; MPC_V rho_inv[C::kRhoPerType ? 2 : C::M];   // per row, or unused: rho3 / rinv3
   double rho3[4], rinv3[4];                             // rho and 1/rho of a loose / inequality / equality row (index type + 1)
-  int ctype[C::M];
+  signed char ctype[C::M];                              // -1 loose, 0 inequality, 1 equality (auxil.c:79-96)
   MPC_V x[C::N]; MPC_V xt[C::N]; MPC_V Px[C::N];        // Px = P_s x, carried through the ADMM iterations
   MPC_V zz[1][C::M]; MPC_V yy[1][C::M]; MPC_V rr[1][C::N];   // z, y, rhs
   // sweep pivot row (double buffered).  With MPC_PROW_SKEW = 1 the row starts 8 bytes off the 16-byte grid, so that publish()
@@ -187,11 +198,11 @@ struct Shared {
       MPC_V dt_[C::N]; MPC_V et_[C::M]; MPC_V cn_[C::N];   // Ruiz pass temporaries
     };
     struct {
-      int act[C::M];
+      signed char act[C::M];
       MPC_V Nb[C::NF * 9]; MPC_V Gm[C::NF * 9];         // per foot: null basis rows (3 x 3, zero padded), Gamma
       int nnull[C::NF], isnull[C::N], rowmask[C::G];      // rowmask: isnull of a tile row's 6 coordinates, one bit each
-      MPC_V u0[C::N]; MPC_V Pu[C::N]; MPC_V g[C::N]; MPC_V xN[C::N]; MPC_V PxN[C::N]; MPC_V wv[C::N]; MPC_V rw[C::N];
-      MPC_V ypol[C::M]; MPC_V zpol[C::M];
+      MPC_V u0[C::N]; MPC_V Pu[C::N]; MPC_V g[C::N]; MPC_V xN[C::N]; MPC_V PxN[C::N];
+      // (the other polish vectors reuse storage that is dead by then: Solver::wv / rw / zpol / ypol)
     };
   };
   // (last: the big arrays sit above the statically addressable 64 KB, the small hot ones below)
@@ -588,6 +599,13 @@ struct Solver {
   MPC_HD double *cz() { return s.zz[pp]; }
   MPC_HD double *cy() { return s.yy[pp]; }
   MPC_HD double *crhs() { return s.rr[pp]; }
+  // polish vectors in storage that is dead during polish: the ADMM right-hand side, P_s x (re-derived by the next call), and
+  // the upper part of part[] -- z_pol / y_pol live from after the last tile product to the acceptance test, and residuals()
+  // in between uses part[0 .. 14 * 64) only.
+  MPC_HD double *rw() { return s.rr[0]; }
+  MPC_HD double *wv() { return s.Px; }
+  MPC_HD double *zpol() { return s.part + 14 * 64; }
+  MPC_HD double *ypol() { return s.part + 14 * 64 + C::MEVEN; }
   using Tv = TileView;
   template <class F>
   MPC_HD void for_tiles(Th &t, F &&f) {
@@ -618,13 +636,23 @@ struct Solver {
     for (int e = 0; e < C::NT * TE; ++e) MPC_LAUNDER(ex.th.Mx[e]);
 #endif
   }
+  MPC_HD double q_at(int i) const {
+    if constexpr (C::kQInLds) return s.q[i];
+    else return qp[C::QP_Q + i];
+  }
   MPC_HD double rho_at(int i) const {
-    if constexpr (C::kCompact) { const int ty = s.ctype[i]; return ty == 1 ? s.rho3[2] : (ty == 0 ? s.rho3[1] : s.rho3[0]); }
-    else return s.rho_vec[i];
+    if constexpr (C::kRhoPerType) {
+      const double r0 = s.rho3[0], r1 = s.rho3[1], r2 = s.rho3[2];   // (uniform loads, independent of the row type)
+      const int ty = s.ctype[i];
+      return ty == 1 ? r2 : (ty == 0 ? r1 : r0);
+    } else return s.rho_vec[i];
   }
   MPC_HD double rinv_at(int i) const {
-    if constexpr (C::kCompact) { const int ty = s.ctype[i]; return ty == 1 ? s.rinv3[2] : (ty == 0 ? s.rinv3[1] : s.rinv3[0]); }
-    else return s.rho_inv[i];
+    if constexpr (C::kRhoPerType) {
+      const double r0 = s.rinv3[0], r1 = s.rinv3[1], r2 = s.rinv3[2];
+      const int ty = s.ctype[i];
+      return ty == 1 ? r2 : (ty == 0 ? r1 : r0);
+    } else return s.rho_inv[i];
   }
   long long tc[kProfLen] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = 0;
@@ -724,7 +752,7 @@ struct Solver {
   // ================================ 1. load: the QP record of the assembly kernel + the warm-start state =====
   MPC_HD void load() {
     ex.par([&](Th &t) {
-      for (int i = t.tid; i < N; i += T) { s.q[i] = qp[C::QP_Q + i]; s.x[i] = state[i]; s.xt[i] = state[N + 2 * M + i]; /* q_old */ }
+      for (int i = t.tid; i < N; i += T) { if constexpr (C::kQInLds) s.q[i] = qp[C::QP_Q + i]; s.x[i] = state[i]; s.xt[i] = state[N + 2 * M + i]; /* q_old */ }
       for (int i = t.tid; i < M; i += T) {
         s.l[i] = qp[C::QP_L + i]; s.u[i] = qp[C::QP_U + i];
         s.zz[0][i] = state[N + i]; s.yy[0][i] = state[N + M + i];   // scaled iterates of the previous call; zeros on the first call
@@ -771,7 +799,7 @@ struct Solver {
     ex.par([&](Th &t) {
       for_tiles(t, [&](Tv &v, int) { load_tile(v, Pg); tile_rownorms(v, nullptr); });
       if (t.tid < N) {
-        s.qs[t.tid] = s.first ? s.q[t.tid] : s.xt[t.tid];   // osqp_update_P_A equilibrates with the PREVIOUS q
+        s.qs[t.tid] = s.first ? q_at(t.tid) : s.xt[t.tid];   // osqp_update_P_A equilibrates with the PREVIOUS q
         s.D[t.tid] = 1.0;
       }
       for_rows(t, [&](int i) {
@@ -847,11 +875,9 @@ struct Solver {
       const double cf = s.ctmp;
       if (t.tid == 0) { s.c = cf; s.cinv = 1.0 / cf; }
       if (t.tid < N) {
-        s.Dinv[t.tid] = 1.0 / s.D[t.tid];
-        if (!s.first) s.qs[t.tid] = (s.D[t.tid] * s.q[t.tid]) * cf;      // osqp_update_lin_cost (osqp.c:765-770)
+        if (!s.first) s.qs[t.tid] = (s.D[t.tid] * q_at(t.tid)) * cf;      // osqp_update_lin_cost (osqp.c:765-770)
       }
       for_rows(t, [&](int i) {
-        s.Einv[i] = 1.0 / s.E[i];
         s.ls[i] = s.E[i] * s.l[i];
         s.us[i] = s.E[i] * s.u[i];
         // set_rho_vec / update_rho_vec (auxil.c:79-141): rho_vec is a function of (type, rho) in both
@@ -865,7 +891,7 @@ struct Solver {
 
   MPC_HD void set_rho_vec() {   // phase: rho_vec from (ctype, rho)  (auxil.c:79-96, osqp.c:1267-1310)
     ex.par([&](Th &t) {
-      if constexpr (C::kCompact) {
+      if constexpr (C::kRhoPerType) {
         if (t.tid < 3) {
           const double rv = t.tid == 0 ? kRhoMin : (t.tid == 2 ? kRhoEqOverIneq * s.rho : s.rho);
           s.rho3[t.tid] = rv;
@@ -893,12 +919,16 @@ struct Solver {
           for (int fr = 0; fr < 2; ++fr) {
             const int f = 2 * v.ti + fr;
             const double *a = s.As + 15 * f;
+            double rv[5];
+#pragma unroll
+            for (int r = 0; r < 5; ++r) rv[r] = rho_at(5 * f + r);
 #pragma unroll
             for (int c1 = 0; c1 < 3; ++c1)
 #pragma unroll
               for (int c2 = 0; c2 < 3; ++c2) {
                 double g = 0;
-                for (int r = 0; r < 5; ++r) g += a[3 * r + c1] * rho_at(5 * f + r) * a[3 * r + c2];
+#pragma unroll
+                for (int r = 0; r < 5; ++r) g += a[3 * r + c1] * rv[r] * a[3 * r + c2];
                 if (c1 == c2) g += kSigma;
                 v.Mx[(3 * fr + c1) * TS + 3 * fr + c2] += g;
               }
@@ -1145,12 +1175,12 @@ struct Solver {
 #pragma unroll
         for (int k = 0; k < 14; ++k) mx[k] = 0;
         for (int i = t.tid; i < M; i += kRedW) {
-          const double ax = a_row_dot(s, i, x), r = ax - z[i], ei = s.Einv[i];
+          const double ax = a_row_dot(s, i, x), r = ax - z[i], ei = 1.0 / s.E[i];
           mx[0] = dmax(mx[0], fabs(ei * r)); mx[1] = dmax(mx[1], fabs(ei * z[i])); mx[2] = dmax(mx[2], fabs(ei * ax));
           mx[3] = dmax(mx[3], fabs(r)); mx[4] = dmax(mx[4], fabs(z[i])); mx[5] = dmax(mx[5], fabs(ax));
         }
         for (int j = t.tid; j < N; j += kRedW) {
-          const double aty = at_col_dot(s, j, y), px = Px[j], qv = s.qs[j], r = qv + px + aty, di = s.Dinv[j];
+          const double aty = at_col_dot(s, j, y), px = Px[j], qv = s.qs[j], r = qv + px + aty, di = 1.0 / s.D[j];
           mx[6] = dmax(mx[6], fabs(di * r)); mx[7] = dmax(mx[7], fabs(di * qv)); mx[8] = dmax(mx[8], fabs(di * aty));
           mx[9] = dmax(mx[9], fabs(di * px)); mx[10] = dmax(mx[10], fabs(r)); mx[11] = dmax(mx[11], fabs(qv));
           mx[12] = dmax(mx[12], fabs(aty)); mx[13] = dmax(mx[13], fabs(px));
@@ -1295,7 +1325,7 @@ struct Solver {
         }
         const double *G = s.Gm + 9 * f + 3 * (j - 3 * f);
         s.u0[j] = G[0] * v[0] + G[1] * v[1] + G[2] * v[2];
-        s.xN[j] = 0; s.PxN[j] = 0; s.wv[j] = 0;
+        s.xN[j] = 0; s.PxN[j] = 0; wv()[j] = 0;
         if (j % TS == 0) {
           int m = 0;
           for (int b = 0; b < TS; ++b) m |= (s.isnull[j + b] ? 1 : 0) << b;
@@ -1349,16 +1379,16 @@ struct Solver {
       if (t.tid < N) {
         const int j = t.tid, f = j / 3, k = j - 3 * f;
         const double *nv = s.Nb + 9 * f + 3 * k;
-        s.rw[j] = (k < s.nnull[f]) ? nv[0] * s.g[3 * f] + nv[1] * s.g[3 * f + 1] + nv[2] * s.g[3 * f + 2] : 0.0;
+        rw()[j] = (k < s.nnull[f]) ? nv[0] * s.g[3 * f] + nv[1] * s.g[3 * f + 1] + nv[2] * s.g[3 * f + 2] : 0.0;
       }
     });
     for (int it = 0; it <= kPolishRefine; ++it) {
-      ex.par([&](Th &t) { for_tiles(t, [&](Tv &v, int) { tile_matvec_neg(v, s.rw); }); });
+      ex.par([&](Th &t) { for_tiles(t, [&](Tv &v, int) { tile_matvec_neg(v, rw()); }); });
       ex.par([&](Th &t) {
         if (t.tid < N && s.isnull[t.tid]) {
-          const double dw = inv_combine(s, t.tid, s.rw);
-          s.wv[t.tid] += dw;
-          s.rw[t.tid] = kDelta * dw;
+          const double dw = inv_combine(s, t.tid, rw());
+          wv()[t.tid] += dw;
+          rw()[t.tid] = kDelta * dw;
         }
       });
     }
@@ -1366,7 +1396,7 @@ struct Solver {
       if (t.tid < N) {
         const int j = t.tid, f = j / 3, c = j - 3 * f;
         double v = 0;
-        for (int k = 0; k < 3; ++k) if (k < s.nnull[f]) v += s.Nb[9 * f + 3 * k + c] * s.wv[3 * f + k];
+        for (int k = 0; k < 3; ++k) if (k < s.nnull[f]) v += s.Nb[9 * f + 3 * k + c] * wv()[3 * f + k];
         s.xN[j] = v;
       }
     });
@@ -1378,22 +1408,22 @@ struct Solver {
         const int j = t.tid, f = j / 3;
         s.xt[j] = s.u0[j] + s.xN[j];                                   // polished x (scaled)
         const double *G = s.Gm + 9 * f + 3 * (j - 3 * f);
-        s.rw[j] = G[0] * (s.g[3 * f] - s.PxN[3 * f]) + G[1] * (s.g[3 * f + 1] - s.PxN[3 * f + 1]) + G[2] * (s.g[3 * f + 2] - s.PxN[3 * f + 2]);
+        rw()[j] = G[0] * (s.g[3 * f] - s.PxN[3 * f]) + G[1] * (s.g[3 * f + 1] - s.PxN[3 * f + 1]) + G[2] * (s.g[3 * f + 2] - s.PxN[3 * f + 2]);
       }
     });
     ex.par([&](Th &t) {
       for_rows(t, [&](int i) {
-        const double yv = s.act[i] ? a_row_dot(s, i, s.rw) : 0.0;
+        const double yv = s.act[i] ? a_row_dot(s, i, rw()) : 0.0;
         const double tt = a_row_dot(s, i, s.xt) + yv;
         const double zc = clampd(tt, s.ls[i], s.us[i]);
-        s.zpol[i] = zc;
-        s.ypol[i] = tt - zc;
+        zpol()[i] = zc;
+        ypol()[i] = tt - zc;
       });
     });
     // residuals at the polished point, acceptance (polish.c:306-345)
     const double pri0 = s.pri_res, dua0 = s.dua_res;
     ex.par([&](Th &t) { if (t.tid < N) s.Pu[t.tid] += s.PxN[t.tid]; });   // P_s x_pol
-    residuals(s.xt, s.zpol, s.ypol, s.Pu);
+    residuals(s.xt, zpol(), ypol(), s.Pu);
     ex.par([&](Th &t) {
       if (t.tid == 0) {
         const double pri = bitsd(s.red[0]), dua = s.cinv * bitsd(s.red[6]);
@@ -1405,7 +1435,7 @@ struct Solver {
     ex.par([&](Th &t) {
       if (s.status_polish == 1) {
         if (t.tid < N) s.x[t.tid] = s.xt[t.tid];
-        for_rows(t, [&](int i) { cz()[i] = s.zpol[i]; cy()[i] = s.ypol[i]; });
+        for_rows(t, [&](int i) { cz()[i] = zpol()[i]; cy()[i] = ypol()[i]; });
       }
     });
   }
@@ -1462,7 +1492,7 @@ struct Solver {
       if (t.tid < N) {
         if (solved) forces[t.tid] = -(s.D[t.tid] * s.x[t.tid]);
         state[t.tid] = s.x[t.tid];
-        state[N + 2 * M + t.tid] = s.q[t.tid];
+        state[N + 2 * M + t.tid] = q_at(t.tid);
       }
       for_rows(t, [&](int i) { state[N + i] = cz()[i]; state[N + M + i] = cy()[i]; });
       if (t.tid == 0) {

@@ -44,3 +44,40 @@ def loops(path, H):
 
 if len(sys.argv) > 3:
     loops(sys.argv[1], int(sys.argv[3]))
+
+
+def spill_cost(path, H):
+    """Estimated scratch instructions executed per wave and solve: per-block static counts weighted by the trip counts of
+    the enclosing loops (sweep loops G, the Ruiz loop 10, the ADMM inner loop 50, the check loop 2, other loops 4)."""
+    txt = open(path).read()
+    m = re.search(r'\n(_ZN[^\n]*mpc_solve_kernelILi%dE[^\n:]*):[^\n]*\n(.*?)\n\.Lfunc_end' % H, txt, re.S)
+    blocks = re.split(r'\n(?=\.LBB\d+_\d+:)', m.group(2))
+    info = {}
+    for b in blocks:                      # loop key -> barriers
+        first = b.split('\n')[0]; lab = b.split(':')[0]
+        h = re.search(r'Header=(BB\d+_\d+) Depth=(\d+)', first)
+        key = lab[2:] if 'Loop Header' in first else (h.group(1) if h else None)
+        if key: info[key] = info.get(key, 0) + b.count('\ts_barrier')
+    G = 2 * H
+    def trips(key):
+        nb = info.get(key, 0)
+        return {6: G, 4: 50, 15: 2, 3: 10}.get(nb, 4)
+    total = 0; detail = {}
+    for b in blocks:
+        first = b.split('\n')[0]; lab = b.split(':')[0]
+        sc = sum(1 for l in b.split('\n') if l.startswith('\tscratch'))
+        if not sc: continue
+        w = 1
+        h = re.search(r'Header=(BB\d+_\d+) Depth=(\d+)', first)
+        par = re.search(r'Parent Loop (BB\d+_\d+) Depth=(\d+)', b.split('\n')[0])
+        if 'Loop Header' in first: w = trips(lab[2:])
+        elif h: w = trips(h.group(1))
+        if (h and h.group(2) == '2') or ('Depth=2' in first): w *= 2          # nested in the check loop
+        total += sc * w
+        k = (lab[2:] if 'Loop Header' in first else (h.group(1) if h else 'straight'))
+        detail[k] = detail.get(k, 0) + sc * w
+    print(f"H={H}: weighted scratch ops per wave-solve ~ {total}  " + ' '.join(f"{k}:{v}" for k, v in sorted(detail.items(), key=lambda x: -x[1])[:6]))
+
+
+if len(sys.argv) > 4 and sys.argv[4] == 'cost':
+    spill_cost(sys.argv[1], int(sys.argv[3]))
