@@ -44,7 +44,10 @@
 // The slice loops are fully unrolled (static register indices); without a fence every few columns the
 // scheduler hoists all 60 LDS/HBM loads above the FMAs and the live set overflows the register file.
 #define MPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// A 64-bit LDS store that the load/store vectoriser leaves alone (volatile, address space 3 spelled out so that it stays a ds_write)
+#define MPC_LDS_STORE64(p, v) (*(volatile __attribute__((address_space(3))) double *)(p) = (v))
 #else
+#define MPC_LDS_STORE64(p, v) (*(p) = (v))
 #define MPC_LAUNDER(x) ((void)0)
 #define MPC_SCHED_FENCE() ((void)0)
 #endif
@@ -127,6 +130,14 @@ struct Cfg {
   static constexpr bool kQInLds = H > 12;
   static constexpr bool kRhoPerType = H <= 12 || H > 16;
   static constexpr bool kLoopExitFence = H <= MPC_EXIT_FENCE_UPTO;
+  // publish() stores a tile column as six 64-bit LDS stores instead of three 128-bit ones (no v_mov packing: -9 % VALU
+  // instructions per sweep step; +2..3 % at h = 10 / 20).  h = 16 sits at its 168-register cap, where any change of the
+  // code shape moves the allocator's spill decisions: measured 0.54 M steps/s with the packed stores, 0.34 M without.
+#ifdef MPC_COLUMN_STORE64
+  static constexpr bool kColumnStore64 = MPC_COLUMN_STORE64;
+#else
+  static constexpr bool kColumnStore64 = H != 16;
+#endif
   // Live-range split points of the tile registers (Solver::pin_tiles): bit 0 / 1 before / after a sweep, 2 / 3 around the
   // 25 ADMM iterations, 4 inside the sweep loop.  Chosen per horizon by measurement (round 1: h = 16 0.12 -> 0.60 M steps/s,
   // h = 20 36 k -> 106 k).
@@ -1029,9 +1040,15 @@ struct Solver {
         s.piv[b][1] = fast_recip(pivot);
       }
     } else if (t.tj == kt) {
+      // (a column of the tile: its elements are not register neighbours, and a 128-bit store would first copy each pair
+      //  into an aligned register quad -- four v_mov per store on the VALU, which is the busy unit.  Volatile keeps the
+      //  six 64-bit stores apart (MPC_LDS_STORE64); they go to the LDS queue, which has slack.)
       double *pn = s.prow(b) + TS * t.ti;
 #pragma unroll
-      for (int a = 0; a < TS; ++a) pn[a] = t.Mx[a * TS + A];
+      for (int a = 0; a < TS; ++a) {
+        if constexpr (C::kColumnStore64) MPC_LDS_STORE64(pn + a, t.Mx[a * TS + A]);
+        else pn[a] = t.Mx[a * TS + A];
+      }
     }
   }
   static MPC_HD double fast_rsqrt(double d) {   // 1 / sqrt(d), d > 0 finite: v_rsq_f64 + two Newton steps (to the last ulp or two)
