@@ -139,7 +139,7 @@ struct Cfg {
   static constexpr bool kColumnStore64 = H != 16;
 #endif
   // Live-range split points of the tile registers (Solver::pin_tiles): bit 0 / 1 before / after a sweep, 2 / 3 around the
-  // 25 ADMM iterations, 4 inside the sweep loop.  Chosen per horizon by measurement (round 1: h = 16 0.12 -> 0.60 M steps/s,
+  // 25 ADMM iterations, 4 inside the sweep loop, 5 / 6 before / after the Ruiz passes, 7 inside them.  Chosen per horizon by measurement (round 1: h = 16 0.12 -> 0.60 M steps/s,
   // h = 20 36 k -> 106 k).
 #ifdef MPC_PIN_MASK
   static constexpr int kPinMask = MPC_PIN_MASK;
@@ -822,7 +822,9 @@ struct Solver {
       if (t.tid == 0) s.c = 1.0;
     });
     lap(3);
+    pin_tiles(5);
     for (int it = 0; it < kScalingIters; ++it) {
+      pin_tiles(7);
       ex.par([&](Th &t) {   // column scales from |column|_inf of [c P ; A]; D <- D_temp D
         if (t.tid < N) {
           const int j = t.tid, f = j / 3, c = j - 3 * f;
@@ -881,6 +883,7 @@ struct Solver {
       if (t.tid < N) s.qs[t.tid] *= ct;
       if (t.tid == T - 1) s.ctmp = cf;   // (s.c is still being read in this phase)
     });
+    pin_tiles(6);
     lap(4);
     ex.par([&](Th &t) {
       const double cf = s.ctmp;
