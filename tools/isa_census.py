@@ -1,83 +1,126 @@
-"""Per-basic-block census of the solve kernels' ISA: fp64 ops, LDS ops, scratch (spill) traffic.
+"""Census of the solve kernels' ISA: fp64 ops, LDS ops and scratch (register spill) instructions per basic block and per loop.
+
+The solve kernel keeps a 6x6 fp64 tile per thread in registers for its whole life; whether hipcc's allocator spills part of it
+inside the hot loops decides the kernel's speed by integer factors, and the decision moves with any change
+of the code shape.  This tool reads the assembly and says where the scratch instructions are.
+
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -S --cuda-device-only rl-mpc-locomotion_amd/csrc/mpc_batch.hip -o /tmp/all.s
-  python tools/isa_census.py /tmp/all.s [min_scratch_ops]"""
-import re, sys
-txt = open(sys.argv[1]).read()
-thr = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-for m in re.finditer(r'\n(_ZN[^\n]*mpc_solve_kernelILi(\d+)E[^\n:]*):[^\n]*\n(.*?)\n\.Lfunc_end', txt, re.S):
-    H, body = m.group(2), m.group(3)
-    blocks = re.split(r'\n(?=\.LBB\d+_\d+:)', body)
-    tot = [0, 0, 0]
-    print(f"H={H}: {len(blocks)} blocks")
-    for b in blocks:
-        lab = b.split(':')[0].strip()[:12]
-        ins = [l for l in b.split('\n') if l.startswith('\t') and not l.startswith('\t.') and not l.startswith('\t;')]
-        f64 = sum(1 for l in ins if re.match(r'\tv_(fma|mul|add|div_fmas|div_fixup|rcp|rsq|min|max)_f64', l))
-        lds = sum(1 for l in ins if l.startswith('\tds_'))
-        sl = sum(1 for l in ins if l.startswith('\tscratch_load')); ss = sum(1 for l in ins if l.startswith('\tscratch_store'))
-        tot[0] += f64; tot[1] += sl; tot[2] += ss
-        if sl + ss >= thr: print(f"   {lab:12s} ins {len(ins):5d} f64 {f64:5d} lds {lds:4d} scratch ld {sl:4d} st {ss:4d}")
-    print(f"   total f64 {tot[0]} scratch ld {tot[1]} st {tot[2]}")
+  python tools/isa_census.py /tmp/all.s                 # per horizon: loops, weighted spill estimate
+  python tools/isa_census.py /tmp/all.s --blocks 8      # also every block with >= 8 scratch instructions
+
+Loops are recognised by the assembler's "in Loop: Header=.. Depth=.." comments and classified by their barrier count:
+6 = a sweep loop (six pivot steps per trip), 4 = the ADMM iteration, 3 = a Ruiz pass, 15 = the check / refactor loop.
+(tests/test_isa_budget.py asserts the hot loops of the benchmark horizon stay free of scratch traffic.)"""
+import re
+import subprocess
+import sys
+
+KERNEL_RE = r'\n(_ZN[^\n]*mpc_solve_kernelILi%sE[^\n:]*):[^\n]*\n(.*?)\n\.Lfunc_end'
+ROLE = {6: "sweep", 4: "admm-iteration", 3: "ruiz-pass", 15: "check-loop"}
 
 
-def loops(path, H):
-    """Aggregate per innermost loop (the assembler's 'in Loop: Header=.. Depth=..' comments)."""
-    txt = open(path).read()
-    m = re.search(r'\n(_ZN[^\n]*mpc_solve_kernelILi%dE[^\n:]*):[^\n]*\n(.*?)\n\.Lfunc_end' % H, txt, re.S)
+def compile_to_asm(src, out, include_dir, extra=()):
+    """hipcc cross-compiles gfx950 without a GPU."""
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{include_dir}", "-S", "--cuda-device-only", *extra, src, "-o", out]
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return out
+
+
+def horizons(txt):
+    return sorted(int(h) for h in set(re.findall(r'mpc_solve_kernelILi(\d+)E', txt)))
+
+
+def _blocks(txt, H):
+    m = re.search(KERNEL_RE % H, txt, re.S)
+    if not m:
+        raise KeyError(f"no mpc_solve_kernel<{H}> in the assembly")
+    return re.split(r'\n(?=\.LBB\d+_\d+:)', m.group(2))
+
+
+def _instructions(block):
+    return [l for l in block.split('\n') if l.startswith('\t') and not l.startswith('\t.') and not l.startswith('\t;')]
+
+
+def _loop_of(block):
+    """(header label, depth) of the innermost loop a block belongs to, or None."""
+    first = block.split('\n')[0]
+    lab = block.split(':')[0]
+    if 'Loop Header' in first:
+        return lab[2:], int(re.search(r'Depth=(\d+)', first).group(1))
+    h = re.search(r'Header=(BB\d+_\d+) Depth=(\d+)', first)
+    return (h.group(1), int(h.group(2))) if h else None
+
+
+def block_stats(txt, H):
+    """[(label, n_instructions, n_f64, n_lds, scratch_loads, scratch_stores)] for every basic block."""
+    out = []
+    for b in _blocks(txt, H):
+        ins = _instructions(b)
+        out.append((b.split(':')[0].strip(), len(ins),
+                    sum(1 for l in ins if re.match(r'\tv_(fma|fmac|mul|add|div_fmas|div_fixup|rcp|rsq|min|max)_f64', l)),
+                    sum(1 for l in ins if l.startswith('\tds_')),
+                    sum(1 for l in ins if l.startswith('\tscratch_load')),
+                    sum(1 for l in ins if l.startswith('\tscratch_store'))))
+    return out
+
+
+def loop_stats(txt, H):
+    """{header: dict(depth, ins, f64, lds, scratch, barriers, role)} aggregated over the blocks of each innermost loop."""
     agg = {}
-    for b in re.split(r'\n(?=\.LBB\d+_\d+:)', m.group(2)):
-        first = b.split('\n')[0]
-        lab = b.split(':')[0]
-        h = re.search(r'Header=(BB\d+_\d+) Depth=(\d+)', first)
-        if 'Loop Header' in first:
-            d = re.search(r'Depth=(\d+)', first).group(1); key = (lab[2:], d)
-        elif h: key = (h.group(1), h.group(2))
-        else: continue
-        ins = [l for l in b.split('\n') if l.startswith('\t') and not l.startswith('\t.') and not l.startswith('\t;')]
-        a = agg.setdefault(key, [0, 0, 0, 0, 0])
-        a[0] += len(ins); a[1] += sum(1 for l in ins if re.match(r'\tv_(fma|mul|add|fmac)_f64', l))
-        a[2] += sum(1 for l in ins if l.startswith('\tds_')); a[3] += sum(1 for l in ins if l.startswith('\tscratch'))
-        a[4] += sum(1 for l in ins if l.startswith('\ts_barrier'))
-    for k, a in agg.items():
-        if a[0] > 60: print(f"   loop {k[0]:10s} depth {k[1]} ins {a[0]:5d} f64 {a[1]:4d} lds {a[2]:4d} scratch {a[3]:4d} barriers {a[4]}")
+    for b in _blocks(txt, H):
+        key = _loop_of(b)
+        if key is None:
+            continue
+        ins = _instructions(b)
+        a = agg.setdefault(key[0], dict(depth=key[1], ins=0, f64=0, lds=0, scratch=0, barriers=0))
+        a["ins"] += len(ins)
+        a["f64"] += sum(1 for l in ins if re.match(r'\tv_(fma|mul|add|fmac)_f64', l))
+        a["lds"] += sum(1 for l in ins if l.startswith('\tds_'))
+        a["scratch"] += sum(1 for l in ins if l.startswith('\tscratch'))
+        a["barriers"] += sum(1 for l in ins if l.startswith('\ts_barrier'))
+    for a in agg.values():
+        a["role"] = ROLE.get(a["barriers"], "")
+    return agg
 
 
-if len(sys.argv) > 3:
-    loops(sys.argv[1], int(sys.argv[3]))
-
-
-def spill_cost(path, H):
-    """Estimated scratch instructions executed per wave and solve: per-block static counts weighted by the trip counts of
-    the enclosing loops (sweep loops G, the Ruiz loop 10, the ADMM inner loop 50, the check loop 2, other loops 4)."""
-    txt = open(path).read()
-    m = re.search(r'\n(_ZN[^\n]*mpc_solve_kernelILi%dE[^\n:]*):[^\n]*\n(.*?)\n\.Lfunc_end' % H, txt, re.S)
-    blocks = re.split(r'\n(?=\.LBB\d+_\d+:)', m.group(2))
-    info = {}
-    for b in blocks:                      # loop key -> barriers
-        first = b.split('\n')[0]; lab = b.split(':')[0]
-        h = re.search(r'Header=(BB\d+_\d+) Depth=(\d+)', first)
-        key = lab[2:] if 'Loop Header' in first else (h.group(1) if h else None)
-        if key: info[key] = info.get(key, 0) + b.count('\ts_barrier')
-    G = 2 * H
-    def trips(key):
-        nb = info.get(key, 0)
-        return {6: G, 4: 50, 15: 2, 3: 10}.get(nb, 4)
-    total = 0; detail = {}
-    for b in blocks:
-        first = b.split('\n')[0]; lab = b.split(':')[0]
-        sc = sum(1 for l in b.split('\n') if l.startswith('\tscratch'))
-        if not sc: continue
-        w = 1
-        h = re.search(r'Header=(BB\d+_\d+) Depth=(\d+)', first)
-        par = re.search(r'Parent Loop (BB\d+_\d+) Depth=(\d+)', b.split('\n')[0])
-        if 'Loop Header' in first: w = trips(lab[2:])
-        elif h: w = trips(h.group(1))
-        if (h and h.group(2) == '2') or ('Depth=2' in first): w *= 2          # nested in the check loop
+def spill_cost(txt, H):
+    """Estimated scratch instructions executed per wave and solve: static counts weighted by rough trip counts (a sweep loop
+    runs 2H trips, the Ruiz loop 10, the ADMM iteration ~50, the check loop ~2, anything else 4; straight-line code once)."""
+    loops = loop_stats(txt, H)
+    trips = {"sweep": 2 * H, "admm-iteration": 50, "check-loop": 2, "ruiz-pass": 10}
+    total, detail = 0, {}
+    for b in _blocks(txt, H):
+        sc = sum(1 for l in _instructions(b) if l.startswith('\tscratch'))
+        if not sc:
+            continue
+        key = _loop_of(b)
+        w, name = 1, "straight-line"
+        if key is not None:
+            a = loops[key[0]]
+            w = trips.get(a["role"], 4) * (2 if a["depth"] == 2 else 1)   # depth 2: nested in the check loop
+            name = f"{key[0]}({a['role'] or 'loop'})"
         total += sc * w
-        k = (lab[2:] if 'Loop Header' in first else (h.group(1) if h else 'straight'))
-        detail[k] = detail.get(k, 0) + sc * w
-    print(f"H={H}: weighted scratch ops per wave-solve ~ {total}  " + ' '.join(f"{k}:{v}" for k, v in sorted(detail.items(), key=lambda x: -x[1])[:6]))
+        detail[name] = detail.get(name, 0) + sc * w
+    return total, detail
 
 
-if len(sys.argv) > 4 and sys.argv[4] == 'cost':
-    spill_cost(sys.argv[1], int(sys.argv[3]))
+def main(argv):
+    txt = open(argv[1]).read()
+    thr = int(argv[argv.index("--blocks") + 1]) if "--blocks" in argv else None
+    for H in horizons(txt):
+        bs = block_stats(txt, H)
+        print(f"h={H}: {len(bs)} blocks, fp64 instructions {sum(b[2] for b in bs)}, scratch loads {sum(b[4] for b in bs)} stores {sum(b[5] for b in bs)}")
+        if thr is not None:
+            for lab, n, f64, lds, sl, ss in bs:
+                if sl + ss >= thr:
+                    print(f"   {lab:12s} ins {n:5d} f64 {f64:5d} lds {lds:4d} scratch ld {sl:4d} st {ss:4d}")
+        for k, a in loop_stats(txt, H).items():
+            if a["ins"] > 60:
+                print(f"   loop {k:10s} depth {a['depth']} ins {a['ins']:5d} f64 {a['f64']:4d} lds {a['lds']:4d} scratch {a['scratch']:4d} barriers {a['barriers']:2d} {a['role']}")
+        total, detail = spill_cost(txt, H)
+        print(f"   weighted scratch instructions per wave and solve ~ {total}: " +
+              ' '.join(f"{k}:{v}" for k, v in sorted(detail.items(), key=lambda x: -x[1])[:6]))
+
+
+if __name__ == "__main__":
+    main(sys.argv)
