@@ -129,7 +129,7 @@ struct Cfg {
   // h = 20 needs the per-type rho to fit 160 KB.
   static constexpr bool kQInLds = H > 12;
   static constexpr bool kRhoPerType = H <= 12 || H > 16;
-  static constexpr bool kLoopExitFence = H <= MPC_EXIT_FENCE_UPTO;
+  static constexpr bool kLoopExitFence = H <= MPC_EXIT_FENCE_UPTO;   // scheduling fence after the ADMM loop (see Solver::run)
   // publish() stores a tile column as six 64-bit LDS stores instead of three 128-bit ones (no v_mov packing: -9 % VALU
   // instructions per sweep step; +2..3 % at h = 10 / 20).  h = 16 sits at its 168-register cap, where any change of the
   // code shape moves the allocator's spill decisions: measured 0.54 M steps/s with the packed stores, 0.34 M without.
@@ -139,13 +139,15 @@ struct Cfg {
   static constexpr bool kColumnStore64 = H != 16;
 #endif
   // Live-range split points of the tile registers (Solver::pin_tiles): bit 0 / 1 before / after a sweep, 2 / 3 around the
-  // 25 ADMM iterations, 4 inside the sweep loop, 5 / 6 before / after the Ruiz passes, 7 inside them.  Chosen per horizon by measurement (round 1: h = 16 0.12 -> 0.60 M steps/s,
-  // h = 20 36 k -> 106 k).
+  // 25 ADMM iterations, 4 inside the sweep loop, 5 / 6 before / after the Ruiz passes, 7 inside them.  Set by measurement:
+  // 17 (before each sweep and once per six pivot steps) has the fewest scratch instructions in the hot loops of every horizon
+  // (tools/isa_census.py) and is the fastest at h = 10 / 16; h = 20 measures 231 k steps/s with 3 against 207 k with 17,
+  // census notwithstanding.
 #ifdef MPC_PIN_MASK
   static constexpr int kPinMask = MPC_PIN_MASK;
 #else
   static constexpr int kPinMask = H > 16 ? 3 : 17;
-#endif   // scheduling fence after the ADMM loop (see Solver::run)
+#endif
   // The QP record the assembly kernel hands to the solve kernel (doubles per robot): q[N] l[M] u[M] cone[15] pad
   static constexpr int QP_Q = 0, QP_L = N, QP_U = N + M, QP_CONE = N + 2 * M, QP_LEN = N + 2 * M + 16;
 };
