@@ -21,12 +21,16 @@
 //
 // Thread layout: every n x n matrix on the path (P_s, K, -K^{-1}, H, -H^{-1}; n = 12 H) is SYMMETRIC and is
 // held as the lower triangle of a G x G grid (G = 2 H) of 6 x 6 register tiles (2 feet x 2 feet), one tile
-// per thread (two at h = 20): tile index ti (ti + 1) / 2 + tj holds tile (ti, tj), tj <= ti; thread tid owns tiles
+// per thread (four at h = 20): tile index ti (ti + 1) / 2 + tj holds tile (ti, tj), tj <= ti; thread tid owns tiles
 // tid, tid + MTH, ...; a diagonal tile is stored in full.  An off-diagonal tile stands for itself and for its transpose, so
 //   * a symmetric sweep step costs 36 FMAs per thread (half of a full-matrix update) for 12 LDS reads,
 //   * a matrix-vector product uses every tile twice (T v_cols -> rows, T^T v_rows -> cols),
 //   * P_s in HBM is one contiguous 288-byte run per thread (tile-major), half the bytes of the full matrix.
-// Vector phases use tid < n / tid < m.
+// Vector phases use tid < n and the constraint rows tid, tid + T, ... < m (Solver::for_rows).
+//
+// Per-horizon tuning knobs (Cfg: NT, kPinMask, kLoopExitFence, kColumnStore64, kQInLds, kRhoPerType) exist because the kernel
+// lives at the edge of the register file: they do not change any arithmetic, only how the compiler allocates registers, and
+// are set from measurements (tools/isa_census.py; tests/test_isa_budget.py guards the outcome).
 #pragma once
 
 #include <math.h>
