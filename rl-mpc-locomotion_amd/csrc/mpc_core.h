@@ -55,20 +55,21 @@
 #define MPC_LAUNDER(x) ((void)0)
 #define MPC_SCHED_FENCE() ((void)0)
 #endif
+// Tuning hooks for tools/build_variant.sh experiments (the product build uses the defaults; see Cfg for what they mean):
+//   MPC_NT_H16 / MPC_NT_H20   tiles per thread at h = 16 / 20          MPC_EXIT_FENCE_UPTO  largest h with the loop-exit fence
+//   MPC_PIN_MASK              live-range split points (all horizons)   MPC_COLUMN_STORE64   0 / 1 for all horizons
+//   MPC_PROW_SKEW             1: pivot rows 8 bytes off the 16-byte grid (ds_write2_b64 instead of ds_write_b128)
 #ifndef MPC_EXIT_FENCE_UPTO
 #define MPC_EXIT_FENCE_UPTO 16
 #endif
 #ifndef MPC_PROW_SKEW
 #define MPC_PROW_SKEW 0
 #endif
-#ifndef MPC_NT_LONG
-#define MPC_NT_LONG 4
+#ifndef MPC_NT_H20
+#define MPC_NT_H20 4
 #endif
-#ifndef MPC_NT_MID
-#define MPC_NT_MID 1
-#endif
-#ifndef MPC_NT2_FROM
-#define MPC_NT2_FROM 17
+#ifndef MPC_NT_H16
+#define MPC_NT_H16 1
 #endif
 #define MPC_CHUNK 10   // columns between scheduling fences
 // A value that is the same in every lane, moved to a scalar register (so that branches on it are scalar branches)
@@ -109,15 +110,11 @@ struct Cfg {
   // thread the workgroup runs 2-4 waves per SIMD, i.e. at most 256 / 128 registers per lane, and the tile spills to scratch
   // in every hot loop (measured: spill traffic, not arithmetic, bounded the kernel).  Four tiles per thread make it a
   // 256-thread workgroup, one wave per SIMD, with the full 512-register budget (256 VGPRs + 256 AGPRs as spill space).
-  static constexpr int NT = H >= MPC_NT2_FROM ? MPC_NT_LONG : (H > 12 ? MPC_NT_MID : 1);
+  static constexpr int NT = H > 16 ? MPC_NT_H20 : (H > 12 ? MPC_NT_H16 : 1);
   static constexpr int MTH = (MT + NT - 1) / NT;         // threads that hold tiles
   static constexpr int TE = TS * TS;                     // tile elements per thread
   static constexpr int PG_LEN = MT * TE;                 // doubles of P_s scratch per robot (tile-major)
-#ifdef MPC_FORCE_T
-  static constexpr int T = MPC_FORCE_T;                  // (register-budget experiments)
-#else
   static constexpr int T = (((MTH > N ? MTH : N) + 63) / 64) * 64;   // solve-kernel workgroup: a thread per tile slot and per variable
-#endif
   static constexpr int MR = (M + T - 1) / T;             // constraint rows per thread (Solver::for_rows): 1, or 2 at h = 20
   static constexpr int TA = ((M > 256 ? M : 256) + 63) / 64 * 64;   // assembly-kernel workgroup (>= M threads)
   static constexpr int IN_LEN = 56 + 4 * H;
@@ -227,9 +224,6 @@ struct Shared {
     MPC_V part[C::PARTLEN];                             // [slot][row] partial sums / maxima of the tile products
     struct { MPC_V tm[C::M]; MPC_V rzt[C::M]; };        // R z - y and R z~ of the current ADMM iteration (part is dead then)
   };
-#ifdef MPC_LDS_PAD
-  char pad[MPC_LDS_PAD];                                // occupancy experiments only
-#endif
 };
 // LDS of the assembly kernel (one workgroup per robot, its own launch: see Assembler)
 template <int H>
