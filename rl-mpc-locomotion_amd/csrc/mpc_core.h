@@ -1497,8 +1497,8 @@ struct Solver {
     }
     if (C::kLoopExitFence) lap(8);   // (the clock read of an instrumented build is a fence too)
     // Register allocation of the whole kernel hinges on whether the scheduler may move code across the loop exit
-    // (measured, hipcc 7.2): with a fence here h = 10 fits 210 VGPRs without spills (256 + 7 spills and 3.5 % slower
-    // without); h = 16 / 20 spill 1830 / 4998 registers with it and 283 / 2493 without (h = 16: 2.0x faster).
+    // (measured, hipcc 7.2, and re-measured whenever the code around it changes): a fence here is worth 3.5 % at h = 10 and,
+    // with the current code, takes h = 16 from 0.38 to 0.54 M steps/s; h = 20 is faster without it.
     if (C::kLoopExitFence) MPC_SCHED_FENCE();
     if (!s.done && !s.bad) {   // max_iter reached (osqp.c:564-568): only SOLVED counts for the reference
       ex.par([&](Th &t) { if (t.tid == 0) s.status = kStMaxIter; });
