@@ -31,6 +31,10 @@ def lib():
             raise MpcLibraryError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        # The Python host hands torch device tensors to the library, so both must sit on ONE HIP runtime: torch ships its own
+        # libamdhip64 and has to be loaded first -- a library that pulled in /opt/rocm's copy before `import torch` ends up
+        # with a second runtime that sees no device ("mpc_batch_create: no HIP device").
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         vp, ci, cd = C.c_void_p, C.c_int, C.c_double
         L.mpc_input_len.argtypes = [ci]; L.mpc_input_len.restype = ci
