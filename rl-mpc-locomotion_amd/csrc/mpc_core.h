@@ -653,15 +653,19 @@ struct Solver {
   }
   MPC_HD double rho_at(int i) const {
     if constexpr (C::kRhoPerType) {
-      const double r0 = s.rho3[0], r1 = s.rho3[1], r2 = s.rho3[2];   // (uniform loads, independent of the row type)
+      // (three uniform loads issued together with the row type; the empty asm keeps the compiler from sinking them into
+      //  branches on the type, which would make them a second, dependent LDS round trip in every ADMM iteration)
+      double r0 = s.rho3[0], r1 = s.rho3[1], r2 = s.rho3[2];
       const int ty = s.ctype[i];
+      MPC_LAUNDER(r0); MPC_LAUNDER(r1); MPC_LAUNDER(r2);
       return ty == 1 ? r2 : (ty == 0 ? r1 : r0);
     } else return s.rho_vec[i];
   }
   MPC_HD double rinv_at(int i) const {
     if constexpr (C::kRhoPerType) {
-      const double r0 = s.rinv3[0], r1 = s.rinv3[1], r2 = s.rinv3[2];
+      double r0 = s.rinv3[0], r1 = s.rinv3[1], r2 = s.rinv3[2];
       const int ty = s.ctype[i];
+      MPC_LAUNDER(r0); MPC_LAUNDER(r1); MPC_LAUNDER(r2);
       return ty == 1 ? r2 : (ty == 0 ? r1 : r0);
     } else return s.rho_inv[i];
   }
