@@ -142,12 +142,13 @@ struct Cfg {
   // Live-range split points of the tile registers (Solver::pin_tiles): bit 0 / 1 before / after a sweep, 2 / 3 around the
   // 25 ADMM iterations, 4 inside the sweep loop, 5 / 6 before / after the Ruiz passes, 7 inside them.  Set by measurement:
   // 17 (before each sweep and once per six pivot steps) has the fewest scratch instructions in the hot loops of every horizon
-  // (tools/isa_census.py) and is the fastest at h = 10 / 16; h = 20 measures 231 k steps/s with 3 against 207 k with 17,
-  // census notwithstanding.
+  // (tools/isa_census.py) and is the fastest at h = 10; h = 20 measures 231 k steps/s with 3 against 207 k with 17, census
+  // notwithstanding; h = 16, at its register cap, is re-tuned whenever the kernel changes (last scan of 16 masks: 0.10 ...
+  // 0.55 M steps/s, best 151 = sites 0, 1, 2, 4, 7).
 #ifdef MPC_PIN_MASK
   static constexpr int kPinMask = MPC_PIN_MASK;
 #else
-  static constexpr int kPinMask = H > 16 ? 3 : 17;
+  static constexpr int kPinMask = H > 16 ? 3 : (H > 12 ? 151 : 17);
 #endif
   // The QP record the assembly kernel hands to the solve kernel (doubles per robot): q[N] l[M] u[M] cone[15] pad
   static constexpr int QP_Q = 0, QP_L = N, QP_U = N + M, QP_CONE = N + 2 * M, QP_LEN = N + 2 * M + 16;
@@ -694,8 +695,8 @@ struct Solver {
   // that consecutive lanes store into different slots over the LDS banks): row i of tile row I gets slot J from the
   // tile (I, J) itself (J <= I) and slot J > I from the transpose of tile (J, I) -- G slots per row, each written
   // by exactly one thread, six consecutive doubles per thread and slot.
-  // part <- partial products of (-Mx) v, both orientations of the tile
-  MPC_HD void tile_matvec_neg(const Tv &t, const double *v) {
+  // part <- partial products of Mx v, both orientations of the tile (Mx holds the NEGATED inverse: inv_combine flips the sign)
+  MPC_HD void tile_matvec(const Tv &t, const double *v) {
     double vc[TS], vr[TS], ar[TS], ac[TS];
 #pragma unroll
     for (int b = 0; b < TS; ++b) { vc[b] = v[TS * t.tj + b]; vr[b] = v[TS * t.ti + b]; ar[b] = 0; ac[b] = 0; }
@@ -709,10 +710,10 @@ struct Solver {
       }
     double *pd = s.part + t.tj * NP + TS * t.ti, *pt = s.part + t.ti * NP + TS * t.tj;
 #pragma unroll
-    for (int a = 0; a < TS; ++a) pd[a] = -ar[a];
+    for (int a = 0; a < TS; ++a) pd[a] = ar[a];     // (un-negated: inv_combine subtracts the sum -- exact, and twelve v_xor fewer per tile)
     if (!t.dia) {
 #pragma unroll
-      for (int b = 0; b < TS; ++b) pt[b] = -ac[b];
+      for (int b = 0; b < TS; ++b) pt[b] = ac[b];
     }
   }
   template <bool MAX>
@@ -728,7 +729,7 @@ struct Solver {
   }
   static MPC_HD double sum_parts(const Sh &s, int row) { return fold_parts<false>(s, row); }
   // combine the partial products of (-Minv) v for a swept row: see sweep_all()
-  static MPC_HD double inv_combine(const Sh &s, int row, const double *v) { return sum_parts(s, row) + 2.0 * v[row]; }
+  static MPC_HD double inv_combine(const Sh &s, int row, const double *v) { return 2.0 * v[row] - sum_parts(s, row); }
   // (entries are norms: >= 0, never NaN since fmax drops NaNs)
   static MPC_HD double max_parts(const Sh &s, int row) { return fold_parts<true>(s, row); }
   // part <- D_i max_j (|m_ij| D_j) over the tile, for its rows and (transposed) for its columns; D = 1 if null
@@ -1112,7 +1113,7 @@ struct Solver {
   //   X: x update, P_s x recursion, next rhs_j = sigma x_j - q_j + (A^T tm)_j   (one thread per variable)
   MPC_HD void admm_iter() {
     ex.par([&](Th &t) {
-      for_tiles(t, [&](Tv &v, int) { tile_matvec_neg(v, crhs()); });
+      for_tiles(t, [&](Tv &v, int) { tile_matvec(v, crhs()); });
     });
     MPC_SUBLAP(5, 9);
     ex.par([&](Th &t) {
@@ -1407,7 +1408,7 @@ struct Solver {
       }
     });
     for (int it = 0; it <= kPolishRefine; ++it) {
-      ex.par([&](Th &t) { for_tiles(t, [&](Tv &v, int) { tile_matvec_neg(v, rw()); }); });
+      ex.par([&](Th &t) { for_tiles(t, [&](Tv &v, int) { tile_matvec(v, rw()); }); });
       ex.par([&](Th &t) {
         if (t.tid < N && s.isnull[t.tid]) {
           const double dw = inv_combine(s, t.tid, rw());
