@@ -56,7 +56,7 @@ __global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= MPC_MIN_WAVES_MAX_T && Cfg
   __shared__ __attribute__((aligned(16))) Shared<H> sh;
   using C = Cfg<H>;
   if ((int)blockIdx.x >= n) return;
-  const int robot = order ? order[blockIdx.x] : (int)blockIdx.x;   // longest-expected solves first (order_kernel)
+  const int robot = order ? order[blockIdx.x] : (int)blockIdx.x;   // longest-expected solves first (order_block)
   if (active && !active[robot]) return;   // robots whose controller is between two MPC updates
   Thread<H> th;
   th.init(threadIdx.x);
@@ -76,50 +76,13 @@ __global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= MPC_MIN_WAVES_MAX_T && Cfg
   sv.run();
 }
 
-// Assembly kernel (mpc_core.h Assembler): q, bounds, cone block and P of every active robot -> HBM
-template <int H>
-__global__ __launch_bounds__(Cfg<H>::TA) void mpc_assemble_kernel(int n, const RobotModel *__restrict__ models, const float *__restrict__ in,
-                                                                 double *__restrict__ scratch, double *__restrict__ qp,
-                                                                 long long *__restrict__ prof, const int *__restrict__ active) {
-  __shared__ __attribute__((aligned(16))) AsmShared<H> sh;
-  using C = Cfg<H>;
-  const int robot = blockIdx.x;
-  if (robot >= n) return;
-  if (active && !active[robot]) return;
-  Thread<H> th;
-  th.init(threadIdx.x);
-  DeviceExec<H> ex{th};
-  const RobotModel &mdl = models[robot];
-  Assembler<H, DeviceExec<H>> am{ex, sh, mdl, in + (size_t)robot * C::IN_LEN, scratch + (size_t)robot * C::PG_LEN,
-                                 qp + (size_t)robot * C::QP_LEN, prof ? prof + (size_t)robot * kProfLen : nullptr};
-  am.run();
-}
-
-__global__ void reset_kernel(double *state, int state_len, const int *ids, int k, int n) {
-  const int r = blockIdx.x;
-  const int robot = ids ? ids[r] : r;
-  if (r >= k || robot < 0 || robot >= n) return;
-  for (int i = threadIdx.x; i < state_len; i += blockDim.x) state[(size_t)robot * state_len + i] = 0.0;
-}
-
-template <int H>
-int launch(int n, const RobotModel *models, const float *in, double *state, double *scratch, double *qp, double *forces, int *info,
-           long long *prof, const int *active, const int *order, hipEvent_t *ev, hipStream_t stream) {
-  if (ev) (void)hipEventRecord(ev[0], stream);
-  hipLaunchKernelGGL(mpc_assemble_kernel<H>, dim3(n), dim3(Cfg<H>::TA), 0, stream, n, models, in, scratch, qp, prof, active);
-  if (ev) (void)hipEventRecord(ev[1], stream);
-  hipLaunchKernelGGL(mpc_solve_kernel<H>, dim3(n), dim3(Cfg<H>::T), 0, stream, n, models, in, state, scratch, qp, forces, info, prof, active, order);
-  if (ev) (void)hipEventRecord(ev[2], stream);
-  HIP_TRY(hipGetLastError());
-  return MPC_OK;
-}
-
-// Workgroup -> robot order for the NEXT launch: robots sorted by the shader cycles their last solve took, longest first.
+// Workgroup -> robot order for the solve kernel of THIS launch: robots sorted by the shader cycles their previous solve took,
+// longest first.  Runs as one extra workgroup of the assembly kernel (blockIdx.x == 0), i.e. hidden behind the assembly.
 // Warm-started robots repeat their iteration counts from step to step, and solve times differ 3x between a 25-iteration
 // and a 75-iteration robot; dispatching the long ones first keeps the tail of the launch short (a counting sort over
 // cycles / 16384 in one workgroup; the order inside a bucket is arbitrary, results do not depend on it).
 constexpr int kOrderBuckets = 256;
-__global__ void order_kernel(int n, const long long *__restrict__ prof, int *__restrict__ order) {
+__device__ void order_block(int n, const long long *__restrict__ prof, int *__restrict__ order) {
   __shared__ int cnt[kOrderBuckets], base[kOrderBuckets];
   for (int b = threadIdx.x; b < kOrderBuckets; b += blockDim.x) cnt[b] = 0;
   __syncthreads();
@@ -149,6 +112,50 @@ __global__ void order_kernel(int n, const long long *__restrict__ prof, int *__r
   }
 }
 
+// Assembly kernel (mpc_core.h Assembler): q, bounds, cone block and P of every active robot -> HBM
+template <int H>
+__global__ __launch_bounds__(Cfg<H>::TA) void mpc_assemble_kernel(int n, const RobotModel *__restrict__ models, const float *__restrict__ in,
+                                                                 double *__restrict__ scratch, double *__restrict__ qp,
+                                                                 long long *__restrict__ prof, const int *__restrict__ active,
+                                                                 int *__restrict__ order) {
+  __shared__ __attribute__((aligned(16))) AsmShared<H> sh;
+  using C = Cfg<H>;
+  if (blockIdx.x == 0) {      // the extra workgroup (first, so that it starts at once): dispatch order of the solve kernel that follows
+    if (order) order_block(n, prof, order);
+    return;
+  }
+  const int robot = (int)blockIdx.x - 1;
+  if (robot >= n) return;
+  if (active && !active[robot]) return;
+  Thread<H> th;
+  th.init(threadIdx.x);
+  DeviceExec<H> ex{th};
+  const RobotModel &mdl = models[robot];
+  Assembler<H, DeviceExec<H>> am{ex, sh, mdl, in + (size_t)robot * C::IN_LEN, scratch + (size_t)robot * C::PG_LEN,
+                                 qp + (size_t)robot * C::QP_LEN, prof ? prof + (size_t)robot * kProfLen : nullptr};
+  am.run();
+}
+
+__global__ void reset_kernel(double *state, int state_len, const int *ids, int k, int n) {
+  const int r = blockIdx.x;
+  const int robot = ids ? ids[r] : r;
+  if (r >= k || robot < 0 || robot >= n) return;
+  for (int i = threadIdx.x; i < state_len; i += blockDim.x) state[(size_t)robot * state_len + i] = 0.0;
+}
+
+template <int H>
+int launch(int n, const RobotModel *models, const float *in, double *state, double *scratch, double *qp, double *forces, int *info,
+           long long *prof, const int *active, const int *order, hipEvent_t *ev, hipStream_t stream) {
+  if (ev) (void)hipEventRecord(ev[0], stream);
+  hipLaunchKernelGGL(mpc_assemble_kernel<H>, dim3(n + 1), dim3(Cfg<H>::TA), 0, stream, n, models, in, scratch, qp, prof, active, const_cast<int *>(order));
+  if (ev) (void)hipEventRecord(ev[1], stream);
+  hipLaunchKernelGGL(mpc_solve_kernel<H>, dim3(n), dim3(Cfg<H>::T), 0, stream, n, models, in, state, scratch, qp, forces, info, prof, active, order);
+  if (ev) (void)hipEventRecord(ev[2], stream);
+  HIP_TRY(hipGetLastError());
+  return MPC_OK;
+}
+
+
 }  // namespace
 
 constexpr int kTimingRing = 64;
@@ -160,7 +167,7 @@ struct mpc_batch {
   double *d_state = nullptr, *d_scratch = nullptr, *d_qp = nullptr;   // warm start, P tiles, QP record (q, l, u, cone)
   int *d_info = nullptr;   // used when the caller passes no info buffer
   long long *d_prof = nullptr;   // per-robot section cycle counts of the last solve
-  int *d_order = nullptr;        // workgroup -> robot map for the next launch (order_kernel)
+  int *d_order = nullptr;        // workgroup -> robot map of the solve kernel (order_block, written by the assembly launch)
   bool timing = false;           // mpc_batch_enable_timing: HIP events around the two kernels of each launch
   hipEvent_t ev[kTimingRing][3];
   long long launches = 0;
@@ -183,9 +190,7 @@ static int launch_solver(mpc_batch *b, const float *d_in, double *d_forces, int 
   }
   if (rc == MPC_E_HORIZON) return fail(MPC_E_HORIZON, "solver launch: horizon not compiled in");
   if (rc != MPC_OK) return rc;
-  hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, st, b->n, b->d_prof, b->d_order);
-  HIP_TRY(hipGetLastError());
-  b->order_valid = true;
+  b->order_valid = true;     // from the second launch on there are cycle counts to sort by
   b->launches++;
   return MPC_OK;
 }
