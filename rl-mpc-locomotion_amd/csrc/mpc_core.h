@@ -50,8 +50,12 @@
 #define MPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // A 64-bit LDS store that the load/store vectoriser leaves alone (volatile, address space 3 spelled out so that it stays a ds_write)
 #define MPC_LDS_STORE64(p, v) (*(volatile __attribute__((address_space(3))) double *)(p) = (v))
+// A 64-bit LDS load that is not paired into ds_read2_b64: the pairs' 8-bit offsets (2 KB reach) force one base register per
+// pair for the 20 slots of a partial-sum row, whereas single loads take 16-bit immediates off one base.
+#define MPC_LDS_LOAD64(p) (*(const volatile __attribute__((address_space(3))) double *)(p))
 #else
 #define MPC_LDS_STORE64(p, v) (*(p) = (v))
+#define MPC_LDS_LOAD64(p) (*(p))
 #define MPC_LAUNDER(x) ((void)0)
 #define MPC_SCHED_FENCE() ((void)0)
 #endif
@@ -720,7 +724,7 @@ struct Solver {
   static MPC_HD double fold_parts(const Sh &s, int row) {   // fixed pairwise order (short dependency chains)
     double v[G];
 #pragma unroll
-    for (int k = 0; k < G; ++k) v[k] = s.part[k * NP + row];
+    for (int k = 0; k < G; ++k) v[k] = MPC_LDS_LOAD64(s.part + k * NP + row);   // (one base register + immediates: see the macro)
 #pragma unroll
     for (int w = 1; w < G; w *= 2)
 #pragma unroll
