@@ -136,23 +136,20 @@ struct Cfg {
   static constexpr bool kRhoPerType = H <= 12 || H > 16;
   static constexpr bool kLoopExitFence = H <= MPC_EXIT_FENCE_UPTO;   // scheduling fence after the ADMM loop (see Solver::run)
   // publish() stores a tile column as six 64-bit LDS stores instead of three 128-bit ones (no v_mov packing: -9 % VALU
-  // instructions per sweep step; +2..3 % at h = 10 / 20).  h = 16 sits at its 168-register cap, where any change of the
-  // code shape moves the allocator's spill decisions: measured 0.54 M steps/s with the packed stores, 0.34 M without.
+  // instructions per sweep step; +2..3 %).
 #ifdef MPC_COLUMN_STORE64
   static constexpr bool kColumnStore64 = MPC_COLUMN_STORE64;
 #else
-  static constexpr bool kColumnStore64 = H != 16;
+  static constexpr bool kColumnStore64 = true;
 #endif
   // Live-range split points of the tile registers (Solver::pin_tiles): bit 0 / 1 before / after a sweep, 2 / 3 around the
-  // 25 ADMM iterations, 4 inside the sweep loop, 5 / 6 before / after the Ruiz passes, 7 inside them.  Set by measurement:
-  // 17 (before each sweep and once per six pivot steps) has the fewest scratch instructions in the hot loops of every horizon
-  // (tools/isa_census.py) and is the fastest at h = 10; h = 20 measures 231 k steps/s with 3 against 207 k with 17, census
-  // notwithstanding; h = 16, at its register cap, is re-tuned whenever the kernel changes (last scan of 16 masks: 0.10 ...
-  // 0.55 M steps/s, best 151 = sites 0, 1, 2, 4, 7).
+  // 25 ADMM iterations, 4 inside the sweep loop, 5 / 6 before / after the Ruiz passes, 7 inside them.  They mattered by
+  // factors while the kernel carried ~20 hoisted LDS base registers (see MPC_LDS_LOAD64); since those are gone h = 10 / 16 are
+  // within 2 % for every mask tried, and h = 20 still prefers 3 (246 k steps/s against 220-235 k).
 #ifdef MPC_PIN_MASK
   static constexpr int kPinMask = MPC_PIN_MASK;
 #else
-  static constexpr int kPinMask = H > 16 ? 3 : (H > 12 ? 151 : 17);
+  static constexpr int kPinMask = H > 16 ? 3 : 17;
 #endif
   // The QP record the assembly kernel hands to the solve kernel (doubles per robot): q[N] l[M] u[M] cone[15] pad
   static constexpr int QP_Q = 0, QP_L = N, QP_U = N + M, QP_CONE = N + 2 * M, QP_LEN = N + 2 * M + 16;
