@@ -161,7 +161,7 @@ def test_bad_arguments_raise():
 
 @pytest.mark.gpu
 def test_dispatch_order_does_not_change_results():
-    """After the first launch the workgroup -> robot map is re-sorted by solve time (longest first, order_kernel; two
+    """After the first launch the workgroup -> robot map is re-sorted by solve time (longest first, order_block in the assembly launch; two
     counting-sort passes above 8192 robots).  Per-robot results must not depend on it: a robot solved inside a large batch
     equals the same robot solved alone, bit for bit, over several warm-started steps."""
     import torch
