@@ -43,10 +43,12 @@ def _instructions(block):
 
 def _loop_of(block):
     """(header label, depth) of the innermost loop a block belongs to, or None."""
-    first = block.split('\n')[0]
+    lines = block.split('\n')
+    first = lines[0]
     lab = block.split(':')[0]
-    if 'Loop Header' in first:
-        return lab[2:], int(re.search(r'Depth=(\d+)', first).group(1))
+    head = ' '.join(lines[:2])          # an inner loop header carries "Parent Loop .." first and "=> This Inner Loop Header" on the next line
+    if 'Loop Header' in head:
+        return lab[2:], int(re.findall(r'Loop Header: Depth=(\d+)', head)[-1])
     h = re.search(r'Header=(BB\d+_\d+) Depth=(\d+)', first)
     return (h.group(1), int(h.group(2))) if h else None
 
