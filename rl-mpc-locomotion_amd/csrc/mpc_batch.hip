@@ -1,5 +1,6 @@
 // mpc_batch.hip -- gfx950 kernels + the C ABI of include/mpc_batch.h.
-// One workgroup per robot; the algorithm itself is mpc_core.h (phase-structured, fp64).
+// One workgroup per robot and kernel: assembly and Ruiz scaling (mpc_core.h, dense P in register tiles), then the OSQP
+// iteration in the wrench space (mpc_wrench.h; one wavefront per robot at h = 10).  All arithmetic fp64.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -11,17 +12,22 @@
 #include "controller.h"
 #include "mpc_core.h"
 #include "mpc_model.h"
+#include "mpc_wrench.h"
 #include "policy_mlp.h"
 
 using namespace mpc;
 
-// minimum waves per SIMD the register allocator must leave room for: 3 -> a 256-thread workgroup (h = 10) gets 168 VGPRs
-// and three robots share a CU (3 x 52 KB of LDS)
-#ifndef MPC_MIN_WAVES
-#define MPC_MIN_WAVES 3
+// minimum waves per SIMD the register allocator must leave room for in the scaling kernel: 4 -> a 256-thread workgroup
+// (h = 10) gets 128 VGPRs and four robots share a CU
+#ifndef MPC_SCALE_MIN_WAVES
+#define MPC_SCALE_MIN_WAVES 4
 #endif
 #ifndef MPC_MIN_WAVES_MAX_T
 #define MPC_MIN_WAVES_MAX_T 256   // larger workgroups (h = 16), and the four-tiles-per-thread layout (h = 20), run one per CU
+#endif
+// waves per SIMD of the solve kernel (h = 10: one wave per robot; 2 -> 256 registers per lane, eight robots per CU)
+#ifndef MPC_SOLVE_MIN_WAVES
+#define MPC_SOLVE_MIN_WAVES 2
 #endif
 
 namespace {
@@ -34,46 +40,64 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
     if (e_ != hipSuccess) return fail(MPC_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
-template <int H>
+template <class TH>
 struct DeviceExec {
-  Thread<H> &th;
+  TH &th;
   template <class F>
   __device__ __forceinline__ void par(F &&f) {
     f(th);
-    __syncthreads();
+    __syncthreads();   // (a single-wave workgroup -- the h = 10 solve kernel -- needs no s_barrier: the compiler drops it)
   }
-  __device__ __forceinline__ void amax(unsigned long long *slot, double v) { atomicMax(slot, dbits(v)); }
 };
 
+// Solve kernel (mpc_wrench.h Solver): ADMM + polish of every active robot, from the QP and scale records
 template <int H>
-__global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= MPC_MIN_WAVES_MAX_T && Cfg<H>::NT == 1 ? MPC_MIN_WAVES : 1)) void mpc_solve_kernel(int n, const RobotModel *__restrict__ models,
-                                                               const float *__restrict__ in, double *__restrict__ state,
-                                                               double *__restrict__ scratch, const double *__restrict__ qp, double *__restrict__ forces,
-                                                               int *__restrict__ info, long long *__restrict__ prof,
-                                                               const int *__restrict__ active, const int *__restrict__ order) {
-  // static LDS: absolute addresses fold into the ds_* offset fields (a dynamic-LDS base costs an SGPR
-  // per array and the hot loops spill)
+__global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES : 1)) void mpc_solve_kernel(
+    int n, const RobotModel *__restrict__ models, double *__restrict__ state, const double *__restrict__ qp,
+    const double *__restrict__ sc, double *__restrict__ forces, int *__restrict__ info, long long *__restrict__ prof,
+    const int *__restrict__ active, const int *__restrict__ order) {
+  // static LDS: absolute addresses fold into the ds_* offset fields
   __shared__ __attribute__((aligned(16))) Shared<H> sh;
   using C = Cfg<H>;
   if ((int)blockIdx.x >= n) return;
   const int robot = order ? order[blockIdx.x] : (int)blockIdx.x;   // longest-expected solves first (order_block)
   if (active && !active[robot]) return;   // robots whose controller is between two MPC updates
+  WThread<H> th;
+  th.init(threadIdx.x);
+#pragma unroll
+  for (int j = 0; j < C::TE; ++j) th.Mx[j] = 0;
+  DeviceExec<WThread<H>> ex{th};
+  const RobotModel &mdl = models[robot];   // (uniform loads; a by-value copy indexed at run time would sit in scratch)
+  Solver<H, DeviceExec<WThread<H>>> sv{ex,
+                                       sh,
+                                       mdl,
+                                       state + (size_t)robot * state_len<H>(),
+                                       qp + (size_t)robot * C::QP_LEN,
+                                       sc + (size_t)robot * C::SC_LEN,
+                                       forces + (size_t)robot * C::N,
+                                       info + (size_t)robot * kInfoLen,
+                                       prof ? prof + (size_t)robot * kProfLen : nullptr};
+  sv.run();
+}
+
+// Scaling kernel (mpc_core.h Scaler): OSQP's Ruiz equilibration of every active robot -> the scale record
+template <int H>
+__global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= MPC_MIN_WAVES_MAX_T && Cfg<H>::NT == 1 ? MPC_SCALE_MIN_WAVES : 1)) void mpc_scale_kernel(
+    int n, const double *__restrict__ state, const double *__restrict__ scratch, const double *__restrict__ qp,
+    double *__restrict__ sc, const int *__restrict__ active) {
+  __shared__ __attribute__((aligned(16))) ScaleShared<H> sh;
+  using C = Cfg<H>;
+  const int robot = (int)blockIdx.x;
+  if (robot >= n) return;
+  if (active && !active[robot]) return;
   Thread<H> th;
   th.init(threadIdx.x);
 #pragma unroll
   for (int j = 0; j < C::NT * C::TE; ++j) th.Mx[j] = 0;
-  DeviceExec<H> ex{th};
-  const RobotModel &mdl = models[robot];   // (uniform loads; a by-value copy indexed at run time would sit in scratch)
-  Solver<H, DeviceExec<H>> sv{ex,
-                              sh,
-                              mdl,
-                              state + (size_t)robot * state_len<H>(),
-                              scratch + (size_t)robot * C::PG_LEN,
-                              qp + (size_t)robot * C::QP_LEN,
-                              forces + (size_t)robot * C::N,
-                              info + (size_t)robot * kInfoLen,
-                              prof ? prof + (size_t)robot * kProfLen : nullptr};
-  sv.run();
+  DeviceExec<Thread<H>> ex{th};
+  Scaler<H, DeviceExec<Thread<H>>> sk{ex, sh, state + (size_t)robot * state_len<H>(), scratch + (size_t)robot * C::PG_LEN,
+                                      qp + (size_t)robot * C::QP_LEN, sc + (size_t)robot * C::SC_LEN};
+  sk.run();
 }
 
 // Workgroup -> robot order for the solve kernel of THIS launch: robots sorted by the shader cycles their previous solve took,
@@ -129,9 +153,9 @@ __global__ __launch_bounds__(Cfg<H>::TA) void mpc_assemble_kernel(int n, const R
   if (active && !active[robot]) return;
   Thread<H> th;
   th.init(threadIdx.x);
-  DeviceExec<H> ex{th};
+  DeviceExec<Thread<H>> ex{th};
   const RobotModel &mdl = models[robot];
-  Assembler<H, DeviceExec<H>> am{ex, sh, mdl, in + (size_t)robot * C::IN_LEN, scratch + (size_t)robot * C::PG_LEN,
+  Assembler<H, DeviceExec<Thread<H>>> am{ex, sh, mdl, in + (size_t)robot * C::IN_LEN, scratch + (size_t)robot * C::PG_LEN,
                                  qp + (size_t)robot * C::QP_LEN, prof ? prof + (size_t)robot * kProfLen : nullptr};
   am.run();
 }
@@ -144,13 +168,15 @@ __global__ void reset_kernel(double *state, int state_len, const int *ids, int k
 }
 
 template <int H>
-int launch(int n, const RobotModel *models, const float *in, double *state, double *scratch, double *qp, double *forces, int *info,
+int launch(int n, const RobotModel *models, const float *in, double *state, double *scratch, double *qp, double *sc, double *forces, int *info,
            long long *prof, const int *active, const int *order, hipEvent_t *ev, hipStream_t stream) {
   if (ev) (void)hipEventRecord(ev[0], stream);
   hipLaunchKernelGGL(mpc_assemble_kernel<H>, dim3(n + 1), dim3(Cfg<H>::TA), 0, stream, n, models, in, scratch, qp, prof, active, const_cast<int *>(order));
   if (ev) (void)hipEventRecord(ev[1], stream);
-  hipLaunchKernelGGL(mpc_solve_kernel<H>, dim3(n), dim3(Cfg<H>::T), 0, stream, n, models, in, state, scratch, qp, forces, info, prof, active, order);
+  hipLaunchKernelGGL(mpc_scale_kernel<H>, dim3(n), dim3(Cfg<H>::T), 0, stream, n, state, scratch, qp, sc, active);
   if (ev) (void)hipEventRecord(ev[2], stream);
+  hipLaunchKernelGGL(mpc_solve_kernel<H>, dim3(n), dim3(Cfg<H>::TW), 0, stream, n, models, state, qp, sc, forces, info, prof, active, order);
+  if (ev) (void)hipEventRecord(ev[3], stream);
   HIP_TRY(hipGetLastError());
   return MPC_OK;
 }
@@ -164,12 +190,12 @@ struct mpc_batch {
   int n = 0, h = 0;
   int state_len = 0;
   RobotModel *d_models = nullptr;
-  double *d_state = nullptr, *d_scratch = nullptr, *d_qp = nullptr;   // warm start, P tiles, QP record (q, l, u, cone)
+  double *d_state = nullptr, *d_scratch = nullptr, *d_qp = nullptr, *d_sc = nullptr;   // warm start, P tiles, QP record (q, l, u, cone, wrench form), scale record
   int *d_info = nullptr;   // used when the caller passes no info buffer
   long long *d_prof = nullptr;   // per-robot section cycle counts of the last solve
   int *d_order = nullptr;        // workgroup -> robot map of the solve kernel (order_block, written by the assembly launch)
   bool timing = false;           // mpc_batch_enable_timing: HIP events around the two kernels of each launch
-  hipEvent_t ev[kTimingRing][3];
+  hipEvent_t ev[kTimingRing][4];
   long long launches = 0;
   float *d_host_in = nullptr;    // staging for mpc_batch_solve_host
   double *d_host_f = nullptr;
@@ -184,9 +210,9 @@ static int launch_solver(mpc_batch *b, const float *d_in, double *d_forces, int 
   hipEvent_t *ev = b->timing ? b->ev[b->launches % kTimingRing] : nullptr;
   int rc = MPC_E_HORIZON;
   switch (b->h) {
-    case 10: rc = launch<10>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, b->d_qp, d_forces, d_info, b->d_prof, d_active, order, ev, st); break;
-    case 16: rc = launch<16>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, b->d_qp, d_forces, d_info, b->d_prof, d_active, order, ev, st); break;
-    case 20: rc = launch<20>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, b->d_qp, d_forces, d_info, b->d_prof, d_active, order, ev, st); break;
+    case 10: rc = launch<10>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, b->d_qp, b->d_sc, d_forces, d_info, b->d_prof, d_active, order, ev, st); break;
+    case 16: rc = launch<16>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, b->d_qp, b->d_sc, d_forces, d_info, b->d_prof, d_active, order, ev, st); break;
+    case 20: rc = launch<20>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, b->d_qp, b->d_sc, d_forces, d_info, b->d_prof, d_active, order, ev, st); break;
   }
   if (rc == MPC_E_HORIZON) return fail(MPC_E_HORIZON, "solver launch: horizon not compiled in");
   if (rc != MPC_OK) return rc;
@@ -216,7 +242,8 @@ int mpc_batch_create(mpc_batch **out, int n, int horizon, double timestep, doubl
   b->n = n;
   b->h = horizon;
   const size_t pg_len = horizon == 10 ? Cfg<10>::PG_LEN : horizon == 16 ? Cfg<16>::PG_LEN : Cfg<20>::PG_LEN;   // P_s scratch, lower-triangle tiles
-  const size_t qp_len = 52 * (size_t)horizon + 16;                                                     // Cfg<H>::QP_LEN
+  const size_t qp_len = horizon == 10 ? Cfg<10>::QP_LEN : horizon == 16 ? Cfg<16>::QP_LEN : Cfg<20>::QP_LEN;
+  const size_t sc_len = horizon == 10 ? Cfg<10>::SC_LEN : horizon == 16 ? Cfg<16>::SC_LEN : Cfg<20>::SC_LEN;
   b->state_len = (int)(64 * horizon + 2);
   std::vector<RobotModel> models(n);
   for (int i = 0; i < n; ++i) models[i] = make_model(mass[i], inertia9 + 9 * (size_t)i, timestep, alpha);
@@ -226,6 +253,7 @@ int mpc_batch_create(mpc_batch **out, int n, int horizon, double timestep, doubl
       (e = hipMalloc(&b->d_state, sizeof(double) * (size_t)n * b->state_len)) != hipSuccess ||
       (e = hipMalloc(&b->d_scratch, sizeof(double) * (size_t)n * pg_len)) != hipSuccess ||
       (e = hipMalloc(&b->d_qp, sizeof(double) * (size_t)n * qp_len)) != hipSuccess ||
+      (e = hipMalloc(&b->d_sc, sizeof(double) * (size_t)n * sc_len)) != hipSuccess ||
       (e = hipMalloc(&b->d_info, sizeof(int) * (size_t)n * kInfoLen)) != hipSuccess ||
       (e = hipMalloc(&b->d_prof, sizeof(long long) * (size_t)n * kProfLen)) != hipSuccess ||
       (e = hipMalloc(&b->d_order, sizeof(int) * (size_t)n)) != hipSuccess ||
@@ -234,7 +262,7 @@ int mpc_batch_create(mpc_batch **out, int n, int horizon, double timestep, doubl
     cleanup();
     return fail(MPC_E_HIP, std::string("mpc_batch_create: ") + hipGetErrorString(e));
   }
-  b->bytes = (long long)(sizeof(RobotModel) * n + sizeof(double) * (size_t)n * (b->state_len + pg_len + qp_len) + sizeof(int) * (size_t)n * kInfoLen);
+  b->bytes = (long long)(sizeof(RobotModel) * n + sizeof(double) * (size_t)n * (b->state_len + pg_len + qp_len + sc_len) + sizeof(int) * (size_t)n * kInfoLen);
   *out = b;
   return MPC_OK;
 }
@@ -245,6 +273,7 @@ void mpc_batch_destroy(mpc_batch *b) {
   if (b->d_state) (void)hipFree(b->d_state);
   if (b->d_scratch) (void)hipFree(b->d_scratch);
   if (b->d_qp) (void)hipFree(b->d_qp);
+  if (b->d_sc) (void)hipFree(b->d_sc);
   if (b->d_info) (void)hipFree(b->d_info);
   if (b->d_prof) (void)hipFree(b->d_prof);
   if (b->d_order) (void)hipFree(b->d_order);
@@ -310,7 +339,19 @@ int mpc_batch_kernel_times(mpc_batch *b, int last_k, float *ms_assemble, float *
   for (int i = 0; i < last_k; ++i) {
     hipEvent_t *e = b->ev[(b->launches - last_k + i) % kTimingRing];
     HIP_TRY(hipEventElapsedTime(ms_assemble + i, e[0], e[1]));
-    HIP_TRY(hipEventElapsedTime(ms_solve + i, e[1], e[2]));
+    HIP_TRY(hipEventElapsedTime(ms_solve + i, e[1], e[3]));   // scaling + solve
+  }
+  return MPC_OK;
+}
+int mpc_batch_kernel_times3(mpc_batch *b, int last_k, float *ms_assemble, float *ms_scale, float *ms_solve) {
+  if (!b || !b->timing || last_k <= 0 || last_k > kTimingRing || last_k > b->launches || !ms_assemble || !ms_scale || !ms_solve)
+    return fail(MPC_E_ARG, "mpc_batch_kernel_times3: bad argument (enable timing first; at most 64 launches back)");
+  HIP_TRY(hipDeviceSynchronize());
+  for (int i = 0; i < last_k; ++i) {
+    hipEvent_t *e = b->ev[(b->launches - last_k + i) % kTimingRing];
+    HIP_TRY(hipEventElapsedTime(ms_assemble + i, e[0], e[1]));
+    HIP_TRY(hipEventElapsedTime(ms_scale + i, e[1], e[2]));
+    HIP_TRY(hipEventElapsedTime(ms_solve + i, e[2], e[3]));
   }
   return MPC_OK;
 }

@@ -1,6 +1,7 @@
 // mpc_core.h -- one robot's convex-MPC contact-force solve, written once as sequences of
-// barrier-separated phases over the threads of one workgroup: Assembler (QP assembly, its own kernel) and
-// Solver (the OSQP algorithm).
+// barrier-separated phases over the threads of one workgroup: Assembler (QP assembly, its own kernel),
+// Scaler (OSQP's Ruiz equilibration on the dense P, its own kernel) and -- in mpc_wrench.h -- Solver (the OSQP
+// iteration, re-expressed in the 6 h-dimensional space of the net body wrenches).
 //
 //   Device build (mpc_batch.hip): Exec::par(f) = { f(thread); __syncthreads(); } -- the per-thread
 //   state lives in VGPRs, Shared<H> in LDS.
@@ -12,25 +13,18 @@
 //   1. single-rigid-body QP assembly (mpc_osqp.cc:606-688): x0, x_ref, A/B, exact exp, A^k B, q, P
 //      (P by cumulative diagonal sums = the reference's block recursion :387-434 in the same order)
 //   2. the OSQP 0.6.0 algorithm the reference calls on it (extern/osqp/src): Ruiz scaling
-//      (scaling.c:44-156), ADMM (auxil.c:164-228), residuals/termination (auxil.c:243-362,684-793),
-//      rho adaptation (auxil.c:13-77), polish (polish.c) -- restated for dense algebra:
-//        KKT solve      -> x~ = Kinv (sigma x - q + A^T(R z - y)),  K = P + sigma I + A^T R A,  z~ = A x~
-//        Kinv           -> explicit inverse by symmetric sweeps on register tiles
-//        polish         -> delta-regularised refinement in the null space of the active rows
+//      (scaling.c:44-156) here; ADMM, residuals / termination, rho adaptation and polish in mpc_wrench.h.
 //   All arithmetic is fp64: an fp32 ADMM does not reproduce OSQP's iterates (oracle/README).
 //
-// Thread layout: every n x n matrix on the path (P_s, K, -K^{-1}, H, -H^{-1}; n = 12 H) is SYMMETRIC and is
+// Thread layout of the dense P (n = 12 H, assembly and scaling kernels): P is SYMMETRIC and is
 // held as the lower triangle of a G x G grid (G = 2 H) of 6 x 6 register tiles (2 feet x 2 feet), one tile
 // per thread (four at h = 20): tile index ti (ti + 1) / 2 + tj holds tile (ti, tj), tj <= ti; thread tid owns tiles
-// tid, tid + MTH, ...; a diagonal tile is stored in full.  An off-diagonal tile stands for itself and for its transpose, so
-//   * a symmetric sweep step costs 36 FMAs per thread (half of a full-matrix update) for 12 LDS reads,
-//   * a matrix-vector product uses every tile twice (T v_cols -> rows, T^T v_rows -> cols),
-//   * P_s in HBM is one contiguous 288-byte run per thread (tile-major), half the bytes of the full matrix.
-// Vector phases use tid < n and the constraint rows tid, tid + T, ... < m (Solver::for_rows).
+// tid, tid + MTH, ...; a diagonal tile is stored in full.  An off-diagonal tile stands for itself and for its transpose.
+// Vector phases use tid < n and the constraint rows tid, tid + T, ... < m (Scaler::for_rows).
 //
-// Per-horizon tuning knobs (Cfg: NT, kPinMask, kLoopExitFence, kColumnStore64, kQInLds, kRhoPerType) exist because the kernel
+// Per-horizon tuning knobs (Cfg: NT, kPinMask, kQInLds) exist because the scaling kernel
 // lives at the edge of the register file: they do not change any arithmetic, only how the compiler allocates registers, and
-// are set from measurements (tools/isa_census.py; tests/test_isa_budget.py guards the outcome).
+// are set from measurements (tools/isa_census.py).
 #pragma once
 
 #include <math.h>
@@ -126,8 +120,6 @@ struct Cfg {
   static_assert(T <= 1024, "workgroup too large");
   static constexpr int NP = N + 2;                       // row stride of part[] (doubles)
   static constexpr int MEVEN = (M + 1) & ~1;
-  static constexpr int PARTLEN = (NP * G > 14 * 64 + 2 * MEVEN) ? NP * G : 14 * 64 + 2 * MEVEN;   // part[] doubles as the reduction scratch
-                                                         // [0, 14 * 64) and, above it, holds z_pol / y_pol at the end of polish
   // LDS diet of the short horizon (three robots per CU need <= 54.6 KB each): q stays in the HBM record and rho per row
   // is a three-way select on the row type.  h = 16 keeps both in LDS -- it runs one robot per CU whatever its LDS size,
   // and the leaner forms cost it 9 % each (measured; they lengthen live ranges in a kernel that is at its register cap).
@@ -151,8 +143,17 @@ struct Cfg {
 #else
   static constexpr int kPinMask = H > 16 ? 3 : 17;
 #endif
-  // The QP record the assembly kernel hands to the solve kernel (doubles per robot): q[N] l[M] u[M] cone[15] pad
-  static constexpr int QP_Q = 0, QP_L = N, QP_U = N + M, QP_CONE = N + 2 * M, QP_LEN = N + 2 * M + 16;
+  // The QP record the assembly kernel hands to the scaling and solve kernels (doubles per robot):
+  //   q[N] l[M] u[M] cone[15] pad | B6[6 x 12] th1[6 x 6] th2[6] pad2   (the wrench-space description of P, mpc_wrench.h)
+  static constexpr int QP_Q = 0, QP_L = N, QP_U = N + M, QP_CONE = N + 2 * M, QP_B6 = N + 2 * M + 16, QP_TH1 = QP_B6 + 72,
+                       QP_TH2 = QP_TH1 + 36, QP_LEN = QP_TH2 + 8;
+  // The scale record the scaling kernel hands to the solve kernel: D[N] E[M] q_s[N] A_s[15 NF] l_s[M] u_s[M] c 1/c
+  static constexpr int SC_D = 0, SC_E = N, SC_QS = N + M, SC_AS = 2 * N + M, SC_LS = SC_AS + 15 * NF, SC_US = SC_LS + M,
+                       SC_C = SC_US + M, SC_LEN = SC_C + 2;
+  // ---- wrench grid of the solve kernel (mpc_wrench.h): the 6 H x 6 H core matrix as H x H tiles of 6 x 6, one per thread
+  static constexpr int NW = 6 * H, GW = H, MTW = H * (H + 1) / 2;
+  static constexpr int TW = (((MTW > NW ? MTW : NW) + 63) / 64) * 64;   // solve-kernel workgroup: 64 (h = 10), 192, 256
+  static constexpr int NPW = NW + 2;                     // row stride of the solve kernel's part[]
 };
 
 // Flat input record offsets (include/mpc_batch.h, layout.py)
@@ -181,51 +182,20 @@ struct RobotModel {       // constructor arguments of ConvexMpc (mpc_osqp.cc:508
 // Every vector in LDS starts on a 16-byte boundary so that runs of doubles can move as ds_read_b128 /
 // ds_write_b128 with an immediate address (no per-access address register).
 #define MPC_V alignas(16) double
+// LDS of the scaling kernel
 template <int H>
-struct Shared {
+struct ScaleShared {
   using C = Cfg<H>;
-  // ---- alive for the whole solve -------------------------------------------------------------
-  // (LDS is what limits the robots per CU at h = 10 -- three fit in 160 KB below 54.6 KB each -- so nothing is stored that
-  //  is cheap to re-derive: the unscaled q stays in the HBM record, 1/D and 1/E are divided out where the residuals need
-  //  them (every 25 iterations), rho per row is a three-way select on the row type.)
-  MPC_V q[C::kQInLds ? C::N : 2];                       // unscaled q (becomes q_old of the next call), unless it is re-read from HBM
+  MPC_V q[C::kQInLds ? C::N : 2];                       // unscaled q, unless it is re-read from the HBM record
   MPC_V qs[C::N]; MPC_V ls[C::M]; MPC_V us[C::M]; MPC_V As[C::NF * 15];   // scaled problem
   MPC_V D[C::N]; MPC_V E[C::M];
-  double c, cinv, rho, ctmp;
-  MPC_V rho_vec[C::kRhoPerType ? 2 : C::M]; MPC_V rho_inv[C::kRhoPerType ? 2 : C::M];   // per row, or unused: rho3 / rinv3
-  double rho3[4], rinv3[4];                             // rho and 1/rho of a loose / inequality / equality row (index type + 1)
-  signed char ctype[C::M];                              // -1 loose, 0 inequality, 1 equality (auxil.c:79-96)
-  MPC_V x[C::N]; MPC_V xt[C::N]; MPC_V Px[C::N];        // Px = P_s x, carried through the ADMM iterations
-  MPC_V zz[1][C::M]; MPC_V yy[1][C::M]; MPC_V rr[1][C::N];   // z, y, rhs
-  // sweep pivot row (double buffered).  With MPC_PROW_SKEW = 1 the row starts 8 bytes off the 16-byte grid, so that publish()
-  // stores it as ds_write2_b64 (two independent 64-bit sources) instead of ds_write_b128, whose 128-bit source ties pairs of
-  // tile elements into register quads.
-  MPC_V prow_raw[2][C::N + 2];
-  MPC_HD double *prow(int b) { return prow_raw[b] + MPC_PROW_SKEW; }
-  MPC_V piv[2][2];                                      // current pivot and its reciprocal (double buffered)
-  unsigned long long red[16];                           // max-reductions (bit pattern of doubles >= 0)
-  int first, iter, status, status_polish, rho_updates, nfact, done, bad;   // control (uniform)
-  double pri_res, dua_res, rho_new;
-  // ---- phase-local storage: scaling, then polish share the same LDS ---------------------------------------------
-  union {
-    struct {
-      MPC_V cone[16];
-      MPC_V l[C::M]; MPC_V u[C::M];                     // unscaled bounds
-      MPC_V dt_[C::N]; MPC_V et_[C::M]; MPC_V cn_[C::N];   // Ruiz pass temporaries
-    };
-    struct {
-      signed char act[C::M];
-      MPC_V Nb[C::NF * 9]; MPC_V Gm[C::NF * 9];         // per foot: null basis rows (3 x 3, zero padded), Gamma
-      int nnull[C::NF], isnull[C::N], rowmask[C::G];      // rowmask: isnull of a tile row's 6 coordinates, one bit each
-      MPC_V u0[C::N]; MPC_V Pu[C::N]; MPC_V g[C::N]; MPC_V xN[C::N]; MPC_V PxN[C::N];
-      // (the other polish vectors reuse storage that is dead by then: Solver::wv / rw / zpol / ypol)
-    };
-  };
-  // (last: the big arrays sit above the statically addressable 64 KB, the small hot ones below)
-  union {
-    MPC_V part[C::PARTLEN];                             // [slot][row] partial sums / maxima of the tile products
-    struct { MPC_V tm[C::M]; MPC_V rzt[C::M]; };        // R z - y and R z~ of the current ADMM iteration (part is dead then)
-  };
+  double c, cinv, ctmp;
+  int first;
+  MPC_V xt[C::N];                                       // q of the previous call (osqp_update_P_A scales with it)
+  MPC_V cone[16];
+  MPC_V l[C::M]; MPC_V u[C::M];                         // unscaled bounds
+  MPC_V dt_[C::N]; MPC_V et_[C::M]; MPC_V cn_[C::N];    // Ruiz pass temporaries
+  MPC_V part[C::NP * C::G];                             // [slot][row] partial maxima of the tile row norms
 };
 // LDS of the assembly kernel (one workgroup per robot, its own launch: see Assembler)
 template <int H>
@@ -365,6 +335,7 @@ struct Assembler {
       for (int i = t.tid; i < C::IN_LEN; i += T) s.in[i] = (double)in[i];
       for (int i = t.tid; i < 169; i += T) s.a_dt[i] = 0;
       for (int i = t.tid; i < 156; i += T) s.b_dt[i] = 0;
+      for (int i = t.tid; i < 72; i += T) qp[C::QP_B6 + i] = 0;
     });
     // ---- A dt, B dt (mpc_osqp.cc:299-336, 606-617, 661-673): every 3 x 3 product is one entry per thread, all
     // operands in LDS (a thread-local array indexed by a runtime entry number would live in scratch memory).
@@ -459,9 +430,11 @@ struct Assembler {
           acc = k == 0 ? term : acc + term;
         }
         s.b_dt[(6 + r) * 12 + 3 * i + c] = acc * dt;
+        qp[C::QP_B6 + r * 12 + 3 * i + c] = acc;          // wrench map B6 = [I_w^-1 [r_i]x ; I / m]  (mpc_wrench.h)
       } else if (t.tid < 48) {   // B rows 9-11: I / m
         const int k = t.tid - 36, i = k / 3, r = k - 3 * i;
         s.b_dt[(9 + r) * 12 + 3 * i + r] = mdl.inv_mass * dt;
+        qp[C::QP_B6 + (3 + r) * 12 + 3 * i + r] = mdl.inv_mass;
       } else if (t.tid < 57) {   // A rows 0-2: omega -> rpy rates (:311-312): {cy/cp, sy/cp, 0; -sy, cy, 0; cy tp, sy tp, 1}
         const int e = t.tid - 48, r = e / 3, c = e - 3 * r;
         const double cp = rym[0], cy = rzm[0], sy = rzm[3], tp = tp_[0];
@@ -500,6 +473,21 @@ struct Assembler {
           else if (r < 6) acc += s.a_dt[r * 13 + r + 6] * s.b_dt[(r + 6) * 12 + c];
           s.b_exp[kk] = s.b_dt[kk] + acc / 2;
         }
+      }
+      // The wrench-space description of P (mpc_wrench.h): A_exp^k B_exp = Gamma_k B6 with Gamma_k = [dt^2 (k + 1/2) That ; dt I6],
+      // That = blockdiag(T_rpy, I3) (A dt rows 0-2 hold dt T_rpy), so that 2 Gamma_k^T Q Gamma_k' = (k + 1/2)(k' + 1/2) th1 + diag(th2):
+      //   th1 = 2 dt^4 blockdiag(T^T diag(w0..2) T, diag(w3..5)),  th2 = 2 dt^2 (w6 .. w11)
+      if (t.tid < 36) {
+        const int a = t.tid / 6, b = t.tid - 6 * a;
+        const double dt = mdl.dt, d2 = 2.0 * dt * dt;
+        double v = 0;
+        if (a < 3 && b < 3) {
+          for (int r = 0; r < 3; ++r) v += s.in[IN_W + r] * (s.a_dt[r * 13 + 6 + a] * s.a_dt[r * 13 + 6 + b]);
+          v *= d2;
+        } else if (a == b) v = (d2 * dt * dt) * s.in[IN_W + a];
+        qp[C::QP_TH1 + t.tid] = v;
+      } else if (t.tid < 42) {
+        qp[C::QP_TH2 + t.tid - 36] = (2.0 * mdl.dt * mdl.dt) * s.in[IN_W + 6 + t.tid - 36];
       }
     });
     MPC_SUBLAP(1, 10);
@@ -614,33 +602,25 @@ struct Assembler {
   }
 };
 
+
+// ============================================================================================================
+// 2. Ruiz equilibration + cost scaling (scaling.c:44-156), a kernel of its own: one workgroup per robot holds the dense
+// P as 6 x 6 register tiles (the only consumer of the dense matrix: the solve kernel works in the wrench space, mpc_wrench.h),
+// runs the ten passes and leaves the scaled problem vectors in the robot's scale record.
+// ============================================================================================================
 template <int H, class Exec>
-struct Solver {
+struct Scaler {
   using C = Cfg<H>;
   using Th = Thread<H>;
-  using Sh = Shared<H>;
+  using Sh = ScaleShared<H>;
   static constexpr int N = C::N, M = C::M, NF = C::NF, T = C::T, TS = C::TS, G = C::G, TE = C::TE, NP = C::NP;
 
   Exec &ex;
   Sh &s;
-  const RobotModel &mdl;
-  double *state;       // [state_len<H>()]
-  double *Pg;          // [PG_LEN]  P (unscaled) from the assembly kernel; P_s after scaling
+  const double *state; // [state_len<H>()]  warm-start record (read: q of the previous call, cold flag)
+  const double *Pg;    // [PG_LEN]  P (unscaled, lower-triangle tiles) from the assembly kernel
   const double *qp;    // [QP_LEN]  q, l, u, cone from the assembly kernel
-  double *forces;      // [N]   out: -D x (all horizon steps), untouched on failure
-  int *info;           // [kInfoLen]
-  long long *prof;     // [kProfLen] shader-clock cycles per section (may be null)
-  int pp = 0;          // which half of the z / y / rhs ping-pong buffers is current (uniform)
-  MPC_HD double *cz() { return s.zz[pp]; }
-  MPC_HD double *cy() { return s.yy[pp]; }
-  MPC_HD double *crhs() { return s.rr[pp]; }
-  // polish vectors in storage that is dead during polish: the ADMM right-hand side, P_s x (re-derived by the next call), and
-  // the upper part of part[] -- z_pol / y_pol live from after the last tile product to the acceptance test, and residuals()
-  // in between uses part[0 .. 14 * 64) only.
-  MPC_HD double *rw() { return s.rr[0]; }
-  MPC_HD double *wv() { return s.Px; }
-  MPC_HD double *zpol() { return s.part + 14 * 64; }
-  MPC_HD double *ypol() { return s.part + 14 * 64 + C::MEVEN; }
+  double *sc;          // [SC_LEN]  out: D, E, q_s, A_s, l_s, u_s, c, 1/c
   using Tv = TileView;
   template <class F>
   MPC_HD void for_tiles(Th &t, F &&f) {
@@ -675,70 +655,7 @@ struct Solver {
     if constexpr (C::kQInLds) return s.q[i];
     else return qp[C::QP_Q + i];
   }
-  MPC_HD double rho_at(int i) const {
-    if constexpr (C::kRhoPerType) {
-      // (three uniform loads issued together with the row type; the empty asm keeps the compiler from sinking them into
-      //  branches on the type, which would make them a second, dependent LDS round trip in every ADMM iteration)
-      double r0 = s.rho3[0], r1 = s.rho3[1], r2 = s.rho3[2];
-      const int ty = s.ctype[i];
-      MPC_LAUNDER(r0); MPC_LAUNDER(r1); MPC_LAUNDER(r2);
-      return ty == 1 ? r2 : (ty == 0 ? r1 : r0);
-    } else return s.rho_vec[i];
-  }
-  MPC_HD double rinv_at(int i) const {
-    if constexpr (C::kRhoPerType) {
-      double r0 = s.rinv3[0], r1 = s.rinv3[1], r2 = s.rinv3[2];
-      const int ty = s.ctype[i];
-      MPC_LAUNDER(r0); MPC_LAUNDER(r1); MPC_LAUNDER(r2);
-      return ty == 1 ? r2 : (ty == 0 ? r1 : r0);
-    } else return s.rho_inv[i];
-  }
-  long long tc[kProfLen] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  long long tlast = 0;
-#ifndef MPC_SECTION_PROFILE   // per-section counters cost ~30 SGPRs (and push uniform values into VGPRs): opt-in, tools/section_profile.py
   MPC_HD void lap(int) {}
-#else
-  MPC_HD void lap(int k) { const long long now = MPC_CLOCK(); tc[k] += now - tlast; tlast = now; }
-#endif
-
-  // ---- helpers valid inside a phase ------------------------------------------------------------
-  static MPC_HD double a_row_dot(const Sh &s, int i, const double *v) {  // row i of scaled A times v
-    const int f = i / 5, r = i - 5 * f;
-    const double *a = s.As + 15 * f + 3 * r;
-    return a[0] * v[3 * f] + a[1] * v[3 * f + 1] + a[2] * v[3 * f + 2];
-  }
-  static MPC_HD double at_col_dot(const Sh &s, int j, const double *v) {  // column j of scaled A times v
-    const int f = j / 3, c = j - 3 * f;
-    const double *a = s.As + 15 * f + c;
-    double t = 0;
-    for (int r = 0; r < 5; ++r) t += a[3 * r] * v[5 * f + r];
-    return t;
-  }
-  // Partial results of the tile products live in part[slot * NP + row] (NP = N + 2: the pad spreads the six-double runs
-  // that consecutive lanes store into different slots over the LDS banks): row i of tile row I gets slot J from the
-  // tile (I, J) itself (J <= I) and slot J > I from the transpose of tile (J, I) -- G slots per row, each written
-  // by exactly one thread, six consecutive doubles per thread and slot.
-  // part <- partial products of Mx v, both orientations of the tile (Mx holds the NEGATED inverse: inv_combine flips the sign)
-  MPC_HD void tile_matvec(const Tv &t, const double *v) {
-    double vc[TS], vr[TS], ar[TS], ac[TS];
-#pragma unroll
-    for (int b = 0; b < TS; ++b) { vc[b] = v[TS * t.tj + b]; vr[b] = v[TS * t.ti + b]; ar[b] = 0; ac[b] = 0; }
-#pragma unroll
-    for (int a = 0; a < TS; ++a)
-#pragma unroll
-      for (int b = 0; b < TS; ++b) {   // twelve independent accumulation chains
-        const double m = t.Mx[a * TS + b];
-        ar[a] += m * vc[b];
-        ac[b] += m * vr[a];
-      }
-    double *pd = s.part + t.tj * NP + TS * t.ti, *pt = s.part + t.ti * NP + TS * t.tj;
-#pragma unroll
-    for (int a = 0; a < TS; ++a) pd[a] = ar[a];     // (un-negated: inv_combine subtracts the sum -- exact, and twelve v_xor fewer per tile)
-    if (!t.dia) {
-#pragma unroll
-      for (int b = 0; b < TS; ++b) pt[b] = ac[b];
-    }
-  }
   template <bool MAX>
   static MPC_HD double fold_parts(const Sh &s, int row) {   // fixed pairwise order (short dependency chains)
     double v[G];
@@ -787,24 +704,26 @@ struct Solver {
 #pragma unroll
     for (int e = 0; e < TE; ++e) g[e] = t.Mx[e];
   }
-
-  // ================================ 1. load: the QP record of the assembly kernel + the warm-start state =====
-  MPC_HD void load() {
-    ex.par([&](Th &t) {
-      for (int i = t.tid; i < N; i += T) { if constexpr (C::kQInLds) s.q[i] = qp[C::QP_Q + i]; s.x[i] = state[i]; s.xt[i] = state[N + 2 * M + i]; /* q_old */ }
-      for (int i = t.tid; i < M; i += T) {
-        s.l[i] = qp[C::QP_L + i]; s.u[i] = qp[C::QP_U + i];
-        s.zz[0][i] = state[N + i]; s.yy[0][i] = state[N + M + i];   // scaled iterates of the previous call; zeros on the first call
-      }
-      if (t.tid < 15) s.cone[t.tid] = qp[C::QP_CONE + t.tid];
-      if (t.tid == 0) {
-        const bool first = state[2 * N + 2 * M + 1] == 0.0;
-        s.first = first;
-        s.rho = first ? kRho0 : state[2 * N + 2 * M];
-        s.status = kStUnsolved; s.status_polish = 0; s.rho_updates = 0; s.nfact = 0; s.iter = 0; s.done = 0; s.bad = 0;
-      }
-    });
-    lap(0);
+  static MPC_HD double fast_rsqrt(double d) {   // 1 / sqrt(d), d > 0 finite: v_rsq_f64 + two Newton steps (to the last ulp or two)
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    r = r * (1.5 - h * r * r);
+    r = r * (1.5 - h * r * r);
+    return r;
+#else
+    return 1.0 / sqrt(d);
+#endif
+  }
+  static MPC_HD double fast_recip(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(d);            // v_rcp_f64 + two Newton steps (full double accuracy, not IEEE-rounded)
+    r = r * (2.0 - d * r);
+    r = r * (2.0 - d * r);
+    return r;
+#else
+    return 1.0 / d;
+#endif
   }
   // ================================ 2. scaling (scaling.c:44-156) ===============================
   // One Ruiz pass is three phases.  P itself stays UNSCALED in the tile registers for all passes: a pass only
@@ -897,660 +816,41 @@ struct Solver {
       });
       MPC_SUBLAP(2, 11);
     }
-    ex.par([&](Th &t) {   // the last pass's cost scale; P_s = c D P D
+    ex.par([&](Th &t) {   // the last pass's cost scale (c D P D itself is never formed: the solve kernel works from D, c and the wrench form of P)
       const double ct = pending_cost_scale(), cf = s.c * ct;
-      for_tiles(t, [&](Tv &v, int) {
-        double dc[TS], ra[TS];
-#pragma unroll
-        for (int b = 0; b < TS; ++b) { dc[b] = s.D[TS * v.tj + b]; ra[b] = s.D[TS * v.ti + b] * cf; }
-#pragma unroll
-        for (int a = 0; a < TS; ++a)
-#pragma unroll
-          for (int b = 0; b < TS; ++b) v.Mx[a * TS + b] = (v.Mx[a * TS + b] * dc[b]) * ra[a];
-      });
       if (t.tid < N) s.qs[t.tid] *= ct;
       if (t.tid == T - 1) s.ctmp = cf;   // (s.c is still being read in this phase)
     });
     pin_tiles(6);
-    lap(4);
-    ex.par([&](Th &t) {
+    ex.par([&](Th &t) {   // the scale record
       const double cf = s.ctmp;
-      if (t.tid == 0) { s.c = cf; s.cinv = 1.0 / cf; }
+      if (t.tid == 0) { sc[C::SC_C] = cf; sc[C::SC_C + 1] = 1.0 / cf; }
       if (t.tid < N) {
-        if (!s.first) s.qs[t.tid] = (s.D[t.tid] * q_at(t.tid)) * cf;      // osqp_update_lin_cost (osqp.c:765-770)
+        const double qv = s.first ? s.qs[t.tid] : (s.D[t.tid] * q_at(t.tid)) * cf;      // osqp_update_lin_cost (osqp.c:765-770)
+        sc[C::SC_QS + t.tid] = qv;
+        sc[C::SC_D + t.tid] = s.D[t.tid];
       }
       for_rows(t, [&](int i) {
-        s.ls[i] = s.E[i] * s.l[i];
-        s.us[i] = s.E[i] * s.u[i];
-        // set_rho_vec / update_rho_vec (auxil.c:79-141): rho_vec is a function of (type, rho) in both
-        const int ty = (s.ls[i] < -kInfty * kMinScaling && s.us[i] > kInfty * kMinScaling) ? -1 : (s.us[i] - s.ls[i] < kRhoTol ? 1 : 0);
-        s.ctype[i] = ty;
+        sc[C::SC_E + i] = s.E[i];
+        sc[C::SC_LS + i] = s.E[i] * s.l[i];
+        sc[C::SC_US + i] = s.E[i] * s.u[i];
       });
-      for_tiles(t, [&](Tv &v, int) { store_tile(v, Pg); });   // keep P_s for residuals, re-factorisations and polish
-    });
-    lap(5);
-  }
-
-  MPC_HD void set_rho_vec() {   // phase: rho_vec from (ctype, rho)  (auxil.c:79-96, osqp.c:1267-1310)
-    ex.par([&](Th &t) {
-      if constexpr (C::kRhoPerType) {
-        if (t.tid < 3) {
-          const double rv = t.tid == 0 ? kRhoMin : (t.tid == 2 ? kRhoEqOverIneq * s.rho : s.rho);
-          s.rho3[t.tid] = rv;
-          s.rinv3[t.tid] = 1.0 / rv;
-        }
-      } else {
-        for_rows(t, [&](int i) {
-          const int ty = s.ctype[i];
-          const double rv = ty == -1 ? kRhoMin : (ty == 1 ? kRhoEqOverIneq * s.rho : s.rho);
-          s.rho_vec[i] = rv;
-          s.rho_inv[i] = 1.0 / rv;
-        });
-      }
+      for (int k = t.tid; k < NF * 15; k += T) sc[C::SC_AS + k] = s.As[k];
     });
   }
 
-  // ================================ 3. K = P_s + sigma I + A^T R A ; Mx <- -K^{-1} ==============
-  // A^T R A is block diagonal (3 x 3 per foot): only the diagonal tiles (feet 2 ti, 2 ti + 1) change.
-  MPC_HD void factor(bool reload) {
+  // the QP record of the assembly kernel + what the warm-start record says about the previous call
+  MPC_HD void load() {
     ex.par([&](Th &t) {
-      for_tiles(t, [&](Tv &v, int) {
-        if (reload) load_tile(v, Pg);
-        if (v.dia) {
-#pragma unroll
-          for (int fr = 0; fr < 2; ++fr) {
-            const int f = 2 * v.ti + fr;
-            const double *a = s.As + 15 * f;
-            double rv[5];
-#pragma unroll
-            for (int r = 0; r < 5; ++r) rv[r] = rho_at(5 * f + r);
-#pragma unroll
-            for (int c1 = 0; c1 < 3; ++c1)
-#pragma unroll
-              for (int c2 = 0; c2 < 3; ++c2) {
-                double g = 0;
-#pragma unroll
-                for (int r = 0; r < 5; ++r) g += a[3 * r + c1] * rv[r] * a[3 * r + c2];
-                if (c1 == c2) g += kSigma;
-                v.Mx[(3 * fr + c1) * TS + 3 * fr + c2] += g;
-              }
-          }
-        }
-      });
-    });
-    lap(6);
-    sweep_all(false);
-    ex.par([&](Th &t) { if (t.tid == 0) s.nfact++; });
-    lap(7);
-  }
-
-  // Symmetric sweep of every pivot (masked: the update is skipped for pivots with !isnull[k]).  After
-  // all pivots the matrix equals -inverse.  Per step k:  p = a_kk;  a_ij -= a_ik a_kj / p (i,j != k);
-  // a_ik -> a_ik / p;  a_kk -> -1/p.  The matrix stays symmetric, so both a_ik and a_kj are read from the
-  // published pivot row, and only the lower-triangle tiles are updated.  That row carries (p - 1) in
-  // slot k, which makes the generic update
-  //   a_ij -= (row_k[i] / p) * row_k[j]
-  // produce a_ik / p on column k and a_kj / p on row k with no per-element select; the diagonal element
-  // of a swept row takes the generic update too and ends up as (true value + 2) -- the matrix-vector
-  // products add 2 v[row] back (inv_combine).  Un-swept diagonal elements are exact, so the pivot is
-  // read straight from the diagonal tile.
-  // The pivot loop is unrolled by TS = 6 so that the pivot's position inside its tile is static.
-  MPC_HD void sweep_all(bool masked) {
-    int buf = 0;
-    pin_tiles(0);
-    ex.par([&](Th &t) { for_tiles(t, [&](Tv &v, int) { publish<0>(v, 0, 0); }); });
-    for (int kt = 0; kt < G; ++kt) {
-      pin_tiles(4);
-      // bit A: pivot 6 kt + A is swept; bit 6: so is the first pivot of the next tile row (one LDS read per six steps)
-      int bits = kt + 1 < G ? 0x7f : 0x3f;
-      if (masked) bits = MPC_UNIFORM_INT(s.rowmask[kt] | (kt + 1 < G ? (s.rowmask[kt + 1] & 1) << TS : 0));
-      sweep_steps<0>(bits, kt, buf);
-    }
-    pin_tiles(1);
-  }
-  template <int A>
-  MPC_HD void sweep_steps(int bits, int kt, int &buf) {
-    if constexpr (A < TS) {
-      sweep_step<A>(bits, kt, buf);
-      buf ^= 1;
-      sweep_steps<A + 1>(bits, kt, buf);
-    }
-  }
-  // Pivot step k = 6 kt + A.  Order inside the phase: first the cross through the next pivot (row AN and
-  // column AN of every tile, 11 FMAs), then the tiles of tile row / tile column of the next pivot publish
-  // row k + 1 -- so that the LDS stores and the reciprocal are in flight while the other 25 entries take
-  // their update.
-  template <int A>
-  MPC_HD void sweep_step(int bits, int kt, int buf) {
-    constexpr int AN = (A + 1) % TS;                 // next pivot's position inside its tile
-    const int ktn = (A + 1 < TS) ? kt : kt + 1;      // tile row (= column) of the next pivot
-    const bool active = (bits >> A) & 1;             // uniform
-    const bool pub = (bits >> (A + 1)) & 1;          // the next pivot row is only needed if that pivot is used
-    if (!active && !pub) return;
-    ex.par([&](Th &t) {
-      for_tiles(t, [&](Tv &v, int) {   // (a thread with two tiles finishes one before it starts the other: 24 live VGPRs of g / pc, not 48)
-        double g[TS], pc[TS];
-        if (active) {
-          const double p = s.piv[buf][0], pinv = s.piv[buf][1];
-          const double *pr = s.prow(buf);
-#pragma unroll
-          for (int a = 0; a < TS; ++a) { g[a] = pr[TS * v.ti + a] * pinv; pc[a] = pr[TS * v.tj + a]; }
-#pragma unroll
-          for (int b = 0; b < TS; ++b) v.Mx[AN * TS + b] -= g[AN] * pc[b];
-#pragma unroll
-          for (int a = 0; a < TS; ++a)
-            if (a != AN) v.Mx[a * TS + AN] -= g[a] * pc[AN];
-          if (v.index == 0 && !(p > 0)) s.bad = 1;     // not positive definite
-        }
-        if (pub) publish<AN>(v, buf ^ 1, ktn);
-        MPC_SCHED_FENCE();
-        if (active) {
-#pragma unroll
-          for (int a = 0; a < TS; ++a)
-#pragma unroll
-            for (int b = 0; b < TS; ++b)
-              if (a != AN && b != AN) v.Mx[a * TS + b] -= g[a] * pc[b];
-        }
-      });
+      for (int i = t.tid; i < N; i += T) { if constexpr (C::kQInLds) s.q[i] = qp[C::QP_Q + i]; s.xt[i] = state[N + 2 * M + i]; /* q_old */ }
+      for (int i = t.tid; i < M; i += T) { s.l[i] = qp[C::QP_L + i]; s.u[i] = qp[C::QP_U + i]; }
+      if (t.tid < 15) s.cone[t.tid] = qp[C::QP_CONE + t.tid];
+      if (t.tid == 0) s.first = state[2 * N + 2 * M + 1] == 0.0;
     });
   }
-  // Row k = 6 kt + A of the matrix -> prow[b]: the tiles of tile row kt hold its part left of (and on) the
-  // diagonal as their row A, the tiles of tile column kt hold the rest as their column A.  Slot k itself
-  // gets (pivot - 1), and piv[b] = {pivot, 1 / pivot}.
-  template <int A>
-  MPC_HD void publish(const Tv &t, int b, int kt) {
-    if (t.ti == kt) {
-      double *pn = s.prow(b) + TS * t.tj;
-#pragma unroll
-      for (int bb = 0; bb < TS; ++bb)
-        if (bb != A) pn[bb] = t.Mx[A * TS + bb];
-      const double pivot = t.Mx[A * TS + A];
-      pn[A] = t.dia ? pivot - 1.0 : pivot;
-      if (t.dia) {
-        s.piv[b][0] = pivot;
-        s.piv[b][1] = fast_recip(pivot);
-      }
-    } else if (t.tj == kt) {
-      // (a column of the tile: its elements are not register neighbours, and a 128-bit store would first copy each pair
-      //  into an aligned register quad -- four v_mov per store on the VALU, which is the busy unit.  Volatile keeps the
-      //  six 64-bit stores apart (MPC_LDS_STORE64); they go to the LDS queue, which has slack.)
-      double *pn = s.prow(b) + TS * t.ti;
-#pragma unroll
-      for (int a = 0; a < TS; ++a) {
-        if constexpr (C::kColumnStore64) MPC_LDS_STORE64(pn + a, t.Mx[a * TS + A]);
-        else pn[a] = t.Mx[a * TS + A];
-      }
-    }
-  }
-  static MPC_HD double fast_rsqrt(double d) {   // 1 / sqrt(d), d > 0 finite: v_rsq_f64 + two Newton steps (to the last ulp or two)
-#if defined(__HIP_DEVICE_COMPILE__)
-    double r = __builtin_amdgcn_rsq(d);
-    const double h = 0.5 * d;
-    r = r * (1.5 - h * r * r);
-    r = r * (1.5 - h * r * r);
-    return r;
-#else
-    return 1.0 / sqrt(d);
-#endif
-  }
-  static MPC_HD double fast_recip(double d) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    double r = __builtin_amdgcn_rcp(d);            // v_rcp_f64 + two Newton steps (full double accuracy, not IEEE-rounded)
-    r = r * (2.0 - d * r);
-    r = r * (2.0 - d * r);
-    return r;
-#else
-    return 1.0 / d;
-#endif
-  }
-
-  // ================================ 4. ADMM (auxil.c:164-228) ===================================
-  // Two phases per iteration:
-  //   M: part <- (-Mx) rhs                       (tile threads; Mx = -K^{-1} + 2 I on the diagonal slots)
-  //   V: one thread per foot finishes the iteration for its 3 variables and 5 constraint rows
-  //      (x~ from the partials, x, z~ = A x~, z, y) and forms the next right-hand side
-  //      rhs = sigma x - q + A^T (R z - y).
-  MPC_HD void admm_prepare() {   // rhs for the first iteration / after a rho update
-    ex.par([&](Th &t) {
-      if (t.tid < NF) {
-        const int f = t.tid;
-        const double *a = s.As + 15 * f;
-        double tm[5];
-#pragma unroll
-        for (int r = 0; r < 5; ++r) tm[r] = rho_at(5 * f + r) * cz()[5 * f + r] - cy()[5 * f + r];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          double acc = 0;
-#pragma unroll
-          for (int r = 0; r < 5; ++r) acc += a[3 * r + c] * tm[r];
-          crhs()[3 * f + c] = kSigma * s.x[3 * f + c] - s.qs[3 * f + c] + acc;
-        }
-      }
-    });
-  }
-  // One ADMM iteration = four short phases (each a single LDS round trip; the tile leaves few free
-  // registers, so long per-thread programs serialise into many round trips):
-  //   M: part <- (-Mx) rhs                       (tile threads; Mx = -K^{-1} + 2 I on the diagonal slots)
-  //   C: x~_j = sum of the partials + 2 rhs_j    (one thread per variable)
-  //   R: z~_i = (A x~)_i ; z, y update ; tm_i = rho_i z_i - y_i      (one thread per constraint row)
-  //   X: x update, P_s x recursion, next rhs_j = sigma x_j - q_j + (A^T tm)_j   (one thread per variable)
-  MPC_HD void admm_iter() {
-    ex.par([&](Th &t) {
-      for_tiles(t, [&](Tv &v, int) { tile_matvec(v, crhs()); });
-    });
-    MPC_SUBLAP(5, 9);
-    ex.par([&](Th &t) {
-      if (t.tid < N) s.xt[t.tid] = inv_combine(s, t.tid, crhs());
-    });
-    MPC_SUBLAP(5, 10);
-    ex.par([&](Th &t) {
-      for_rows(t, [&](int i) {   // (all LDS loads first, as one batch: a single round trip per phase)
-        const int f = i / 5, r = i - 5 * f;
-        const double *a = s.As + 15 * f + 3 * r, *xt = s.xt + 3 * f;
-        const double a0 = a[0], a1 = a[1], a2 = a[2], x0 = xt[0], x1 = xt[1], x2 = xt[2];
-        const double zp = cz()[i], yv = cy()[i], rv = rho_at(i), ri = rinv_at(i), lo = s.ls[i], hi = s.us[i];
-        MPC_SCHED_FENCE();
-        const double zt = a0 * x0 + a1 * x1 + a2 * x2;
-        const double zr = kAlphaRelax * zt + (1.0 - kAlphaRelax) * zp;
-        const double zn = clampd(zr + ri * yv, lo, hi);
-        const double yn = yv + rv * (zr - zn);
-        cz()[i] = zn;
-        cy()[i] = yn;
-        s.tm[i] = rv * zn - yn;
-        s.rzt[i] = rv * zt;
-      });
-    });
-    MPC_SUBLAP(5, 11);
-    ex.par([&](Th &t) {
-      if (t.tid < N) {
-        const int j = t.tid, f = j / 3, c = j - 3 * f;
-        const double *a = s.As + 15 * f + c, *tm = s.tm + 5 * f, *rz = s.rzt + 5 * f;
-        double av[5], tv[5], rzv[5];
-#pragma unroll
-        for (int r = 0; r < 5; ++r) { av[r] = a[3 * r]; tv[r] = tm[r]; rzv[r] = rz[r]; }
-        const double xt = s.xt[j], xp = s.x[j], rh = crhs()[j], px = s.Px[j], qv = s.qs[j];
-        MPC_SCHED_FENCE();
-        double acc = 0, arz = 0;
-#pragma unroll
-        for (int r = 0; r < 5; ++r) { acc += av[r] * tv[r]; arz += av[r] * rzv[r]; }
-        // P_s x without a matrix product: K x~ = rhs gives P_s x~ = rhs - sigma x~ - A^T R z~, and x is affine in x~
-        s.Px[j] = kAlphaRelax * (rh - kSigma * xt - arz) + (1.0 - kAlphaRelax) * px;
-        const double xn = kAlphaRelax * xt + (1.0 - kAlphaRelax) * xp;
-        s.x[j] = xn;
-        crhs()[j] = kSigma * xn - qv + acc;
-      }
-    });
-    MPC_SUBLAP(5, 12);
-  }
-
-  // P_s v -> out (P_s tiles read from HBM scratch, each used in both orientations).  Two phases.
-  MPC_HD void mul_P(const double *v, double *out) {
-    ex.par([&](Th &t) {
-      for_tiles(t, [&](Tv &tv, int) {
-        const double *g = Pg + (size_t)tv.index * TE;
-        double vc[TS], vr[TS], ar[TS], ac[TS];
-#pragma unroll
-        for (int b = 0; b < TS; ++b) { vc[b] = v[TS * tv.tj + b]; vr[b] = v[TS * tv.ti + b]; ar[b] = 0; ac[b] = 0; }
-#pragma unroll
-        for (int a = 0; a < TS; ++a)
-#pragma unroll
-          for (int b = 0; b < TS; ++b) {
-            const double m = g[a * TS + b];
-            ar[a] += m * vc[b];
-            ac[b] += m * vr[a];
-          }
-        double *pd = s.part + tv.tj * NP + TS * tv.ti, *pt = s.part + tv.ti * NP + TS * tv.tj;
-#pragma unroll
-        for (int a = 0; a < TS; ++a) pd[a] = ar[a];
-        if (!tv.dia) {
-#pragma unroll
-          for (int b = 0; b < TS; ++b) pt[b] = ac[b];
-        }
-      });
-    });
-    ex.par([&](Th &t) { if (t.tid < N) out[t.tid] = sum_parts(s, t.tid); });
-  }
-
-  // residuals of (x, z, y) (auxil.c:243-306, 563-629) + the norms termination and rho need.
-  // red[] slots: 0 pri_res 1 ||Einv z|| 2 ||Einv Ax|| 3 ||rp|| 4 ||z|| 5 ||Ax||
-  //              6 ||Dinv rd|| 7 ||Dinv q|| 8 ||Dinv Aty|| 9 ||Dinv Px|| 10 ||rd|| 11 ||q|| 12 ||Aty|| 13 ||Px||
-  // 64 threads stride over the rows and keep running maxima in registers; 14 threads finish.
-  static constexpr int kRedW = 64;
-  MPC_HD void residuals(const double *x, const double *z, const double *y, const double *Px) {
-    ex.par([&](Th &t) {
-      if (t.tid < kRedW) {
-        double mx[14];
-#pragma unroll
-        for (int k = 0; k < 14; ++k) mx[k] = 0;
-        for (int i = t.tid; i < M; i += kRedW) {
-          const double ax = a_row_dot(s, i, x), r = ax - z[i], ei = 1.0 / s.E[i];
-          mx[0] = dmax(mx[0], fabs(ei * r)); mx[1] = dmax(mx[1], fabs(ei * z[i])); mx[2] = dmax(mx[2], fabs(ei * ax));
-          mx[3] = dmax(mx[3], fabs(r)); mx[4] = dmax(mx[4], fabs(z[i])); mx[5] = dmax(mx[5], fabs(ax));
-        }
-        for (int j = t.tid; j < N; j += kRedW) {
-          const double aty = at_col_dot(s, j, y), px = Px[j], qv = s.qs[j], r = qv + px + aty, di = 1.0 / s.D[j];
-          mx[6] = dmax(mx[6], fabs(di * r)); mx[7] = dmax(mx[7], fabs(di * qv)); mx[8] = dmax(mx[8], fabs(di * aty));
-          mx[9] = dmax(mx[9], fabs(di * px)); mx[10] = dmax(mx[10], fabs(r)); mx[11] = dmax(mx[11], fabs(qv));
-          mx[12] = dmax(mx[12], fabs(aty)); mx[13] = dmax(mx[13], fabs(px));
-        }
-#pragma unroll
-        for (int k = 0; k < 14; ++k) s.part[k * kRedW + t.tid] = mx[k];
-      }
-    });
-    ex.par([&](Th &t) {
-      if (t.tid < 14) {
-        const double *p = s.part + t.tid * kRedW;
-        double m0 = 0, m1 = 0, m2 = 0, m3 = 0;
-        for (int k = 0; k < kRedW; k += 4) { m0 = dmax(m0, p[k]); m1 = dmax(m1, p[k + 1]); m2 = dmax(m2, p[k + 2]); m3 = dmax(m3, p[k + 3]); }
-        s.red[t.tid] = dbits(dmax(dmax(m0, m1), dmax(m2, m3)));
-      }
-    });
-  }
-
-  // check_termination (auxil.c:684-793; infeasibility certificates not evaluated: the QP is always
-  // feasible and strictly convex) + adapt_rho decision (auxil.c:13-77).  One thread decides.
-  MPC_HD void check_and_adapt(int iter) {
-    ex.par([&](Th &t) {
-      if (t.tid == 0) {
-        const double pri = bitsd(s.red[0]), dua = s.cinv * bitsd(s.red[6]);
-        s.pri_res = pri; s.dua_res = dua; s.iter = iter; s.rho_new = 0;
-        if (pri > kInfty || dua > kInfty) { s.status = kStNonCvx; s.done = 1; }
-        else {
-          const double eps_prim = kEpsAbs + kEpsRel * dmax(bitsd(s.red[1]), bitsd(s.red[2]));
-          const double eps_dual = kEpsAbs + kEpsRel * s.cinv * dmax(dmax(bitsd(s.red[7]), bitsd(s.red[8])), bitsd(s.red[9]));
-          if (pri < eps_prim && dua < eps_dual) { s.status = kStSolved; s.done = 1; }
-          else {
-            double pr = bitsd(s.red[3]) / (dmax(bitsd(s.red[4]), bitsd(s.red[5])) + 1e-10);
-            double dr = bitsd(s.red[10]) / (dmax(dmax(bitsd(s.red[11]), bitsd(s.red[12])), bitsd(s.red[13])) + 1e-10);
-            double rn = s.rho * sqrt(pr / (dr + 1e-10));
-            rn = clampd(rn, kRhoMin, kRhoMax);
-            if (rn > s.rho * kAdaptTol || rn < s.rho / kAdaptTol) s.rho_new = rn;
-          }
-        }
-      }
-    });
-  }
-
-  // ================================ 5. polish (polish.c) ========================================
-  MPC_HD void polish() {
-    // active set (polish.c:36-52) and per-foot bases
-    ex.par([&](Th &t) {
-      for_rows(t, [&](int i) { s.act[i] = (cz()[i] - s.ls[i] < -cy()[i]) ? -1 : ((s.us[i] - cz()[i] < cy()[i]) ? 1 : 0); });
-    });
-    ex.par([&](Th &t) {
-      if (t.tid < NF) {
-        const int f = t.tid;
-        const double *a = s.As + 15 * f;
-        // (all register arrays are indexed statically: a runtime row index would push them to scratch memory.
-        //  Rows of Q beyond the current rank are zero, so projecting on all three rows equals projecting on the
-        //  first r of them.)
-        double Q[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Nn[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        int r = 0;
-#pragma unroll
-        for (int row = 0; row < 5; ++row) {
-          const bool cand = r < 3 && s.act[5 * f + row];
-          double v[3] = {a[3 * row], a[3 * row + 1], a[3 * row + 2]};
-          const double n0 = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-#pragma unroll
-          for (int pass = 0; pass < 2; ++pass)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-              const double d = v[0] * Q[3 * k] + v[1] * Q[3 * k + 1] + v[2] * Q[3 * k + 2];
-              v[0] -= d * Q[3 * k]; v[1] -= d * Q[3 * k + 1]; v[2] -= d * Q[3 * k + 2];
-            }
-          const double nr = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-          const bool take = cand && nr > 1e-6 * n0;
-          const double q0 = v[0] / nr, q1 = v[1] / nr, q2 = v[2] / nr;
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const bool here = take && r == k;
-            Q[3 * k] = here ? q0 : Q[3 * k]; Q[3 * k + 1] = here ? q1 : Q[3 * k + 1]; Q[3 * k + 2] = here ? q2 : Q[3 * k + 2];
-          }
-          r += take ? 1 : 0;
-        }
-        if (r == 0) { Nn[0] = 1; Nn[4] = 1; Nn[8] = 1; }
-        else if (r == 1) {
-          const int imin = fabs(Q[0]) <= fabs(Q[1]) ? (fabs(Q[0]) <= fabs(Q[2]) ? 0 : 2) : (fabs(Q[1]) <= fabs(Q[2]) ? 1 : 2);
-          const double e[3] = {imin == 0 ? 1.0 : 0.0, imin == 1 ? 1.0 : 0.0, imin == 2 ? 1.0 : 0.0};
-          const double d = imin == 0 ? Q[0] : imin == 1 ? Q[1] : Q[2];
-          double v[3] = {e[0] - d * Q[0], e[1] - d * Q[1], e[2] - d * Q[2]};
-          const double nr = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-          Nn[0] = v[0] / nr; Nn[1] = v[1] / nr; Nn[2] = v[2] / nr;
-          Nn[3] = Q[1] * Nn[2] - Q[2] * Nn[1]; Nn[4] = Q[2] * Nn[0] - Q[0] * Nn[2]; Nn[5] = Q[0] * Nn[1] - Q[1] * Nn[0];
-        } else if (r == 2) {
-          Nn[0] = Q[1] * Q[5] - Q[2] * Q[4]; Nn[1] = Q[2] * Q[3] - Q[0] * Q[5]; Nn[2] = Q[0] * Q[4] - Q[1] * Q[3];
-          const double nr = sqrt(Nn[0] * Nn[0] + Nn[1] * Nn[1] + Nn[2] * Nn[2]);
-          Nn[0] /= nr; Nn[1] /= nr; Nn[2] /= nr;
-        }
-        const int nn = 3 - r;
-        s.nnull[f] = nn;
-        for (int k = 0; k < 9; ++k) s.Nb[9 * f + k] = Nn[k];          // row k (< nn) = null vector k
-        for (int k = 0; k < 3; ++k) s.isnull[3 * f + k] = k < nn;     // null coordinate (f, k) sits at index 3f+k
-        // Gamma = Q (Q^T B Q)^{-1} Q^T with B = A_act^T A_act
-        double B[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, G[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Gi[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-        for (int row = 0; row < 5; ++row)
-          if (s.act[5 * f + row])
-            for (int c1 = 0; c1 < 3; ++c1) for (int c2 = 0; c2 < 3; ++c2) B[3 * c1 + c2] += a[3 * row + c1] * a[3 * row + c2];
-        for (int k1 = 0; k1 < 3; ++k1) for (int k2 = 0; k2 < 3; ++k2) {
-          if (k1 >= r || k2 >= r) continue;
-          double tt = 0;
-          for (int c1 = 0; c1 < 3; ++c1) for (int c2 = 0; c2 < 3; ++c2) tt += Q[3 * k1 + c1] * B[3 * c1 + c2] * Q[3 * k2 + c2];
-          G[3 * k1 + k2] = tt;
-        }
-        // Gauss-Jordan on the (identity padded) 3x3
-        for (int p = 0; p < 3; ++p) {
-          const double d = 1.0 / G[3 * p + p];
-          for (int j = 0; j < 3; ++j) { G[3 * p + j] *= d; Gi[3 * p + j] *= d; }
-          for (int i = 0; i < 3; ++i) {
-            if (i == p) continue;
-            const double fc = G[3 * i + p];
-            for (int j = 0; j < 3; ++j) { G[3 * i + j] -= fc * G[3 * p + j]; Gi[3 * i + j] -= fc * Gi[3 * p + j]; }
-          }
-        }
-        for (int c1 = 0; c1 < 3; ++c1) for (int c2 = 0; c2 < 3; ++c2) {
-          double tt = 0;
-          for (int k1 = 0; k1 < 3; ++k1) for (int k2 = 0; k2 < 3; ++k2) {
-            if (k1 >= r || k2 >= r) continue;
-            tt += Q[3 * k1 + c1] * Gi[3 * k1 + k2] * Q[3 * k2 + c2];
-          }
-          s.Gm[9 * f + 3 * c1 + c2] = tt;
-        }
-      }
-    });
-    MPC_SUBLAP(3, 9);
-    // u = Gamma A_act^T b  (the point satisfying the active rows), g = -q - P u
-    ex.par([&](Th &t) {
-      if (t.tid < N) {
-        const int j = t.tid, f = j / 3;
-        double v[3];
-        for (int c = 0; c < 3; ++c) {
-          double tt = 0;
-          for (int r = 0; r < 5; ++r) {
-            const int i = 5 * f + r;
-            if (s.act[i]) tt += s.As[15 * f + 3 * r + c] * (s.act[i] < 0 ? s.ls[i] : s.us[i]);
-          }
-          v[c] = tt;
-        }
-        const double *G = s.Gm + 9 * f + 3 * (j - 3 * f);
-        s.u0[j] = G[0] * v[0] + G[1] * v[1] + G[2] * v[2];
-        s.xN[j] = 0; s.PxN[j] = 0; wv()[j] = 0;
-        if (j % TS == 0) {
-          int m = 0;
-          for (int b = 0; b < TS; ++b) m |= (s.isnull[j + b] ? 1 : 0) << b;
-          s.rowmask[j / TS] = m;
-        }
-      }
-    });
-    MPC_SUBLAP(3, 10);
-    mul_P(s.u0, s.Pu);
-    MPC_SUBLAP(3, 11);
-    lap(11);
-    // H = N~^T P N~ + delta I on the null coordinates, identity elsewhere; N~ = blockdiag([N_f | 0]).
-    // Tile-local: 2 row feet x 2 column feet of 3 x 3 blocks, all register indices static.
-    ex.par([&](Th &t) {
-      if (t.tid < N) s.g[t.tid] = -s.qs[t.tid] - s.Pu[t.tid];
-      for_tiles(t, [&](Tv &tv, int) {
-        load_tile(tv, Pg);
-#pragma unroll
-        for (int fr = 0; fr < 2; ++fr)
-#pragma unroll
-          for (int fc = 0; fc < 2; ++fc) {
-            const int rf = 2 * tv.ti + fr, cf = 2 * tv.tj + fc;
-            const double *nr = s.Nb + 9 * rf, *nc = s.Nb + 9 * cf;   // row k = null vector k (zero rows beyond nnull)
-            const int nnr = s.nnull[rf], nnc = s.nnull[cf];
-            double T1[9];
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-              for (int k2 = 0; k2 < 3; ++k2)
-                T1[3 * r + k2] = tv.Mx[(3 * fr + r) * TS + 3 * fc] * nc[3 * k2] + tv.Mx[(3 * fr + r) * TS + 3 * fc + 1] * nc[3 * k2 + 1] +
-                                 tv.Mx[(3 * fr + r) * TS + 3 * fc + 2] * nc[3 * k2 + 2];
-#pragma unroll
-            for (int k1 = 0; k1 < 3; ++k1)
-#pragma unroll
-              for (int k2 = 0; k2 < 3; ++k2) {
-                double v = (k1 < nnr && k2 < nnc) ? nr[3 * k1] * T1[k2] + nr[3 * k1 + 1] * T1[3 + k2] + nr[3 * k1 + 2] * T1[6 + k2] : 0.0;
-                if (k1 == k2 && rf == cf) v = (k1 < nnr) ? v + kDelta : 1.0;
-                tv.Mx[(3 * fr + k1) * TS + 3 * fc + k2] = v;
-              }
-          }
-      });
-    });
-    MPC_SUBLAP(3, 12);
-    sweep_all(true);   // Mx <- -(H + delta I)^{-1} on the null coordinates
-    ex.par([&](Th &t) { if (t.tid == 0) s.nfact++; });
-    lap(12);
-    // delta-regularised solve + 3 refinement steps (polish.c:102-160) in the null space: with Hd = H + delta I,
-    // w_{k+1} = w_k + Hd^{-1} rho_k and rho_k = b - H w_k obey rho_{k+1} = delta Hd^{-1} rho_k (H Hd^{-1} = I - delta Hd^{-1}),
-    // so the refinement needs no further products with P.
-    ex.par([&](Th &t) {   // rho_0 = N~^T g
-      if (t.tid < N) {
-        const int j = t.tid, f = j / 3, k = j - 3 * f;
-        const double *nv = s.Nb + 9 * f + 3 * k;
-        rw()[j] = (k < s.nnull[f]) ? nv[0] * s.g[3 * f] + nv[1] * s.g[3 * f + 1] + nv[2] * s.g[3 * f + 2] : 0.0;
-      }
-    });
-    for (int it = 0; it <= kPolishRefine; ++it) {
-      ex.par([&](Th &t) { for_tiles(t, [&](Tv &v, int) { tile_matvec(v, rw()); }); });
-      ex.par([&](Th &t) {
-        if (t.tid < N && s.isnull[t.tid]) {
-          const double dw = inv_combine(s, t.tid, rw());
-          wv()[t.tid] += dw;
-          rw()[t.tid] = kDelta * dw;
-        }
-      });
-    }
-    ex.par([&](Th &t) {   // xN = N~ w
-      if (t.tid < N) {
-        const int j = t.tid, f = j / 3, c = j - 3 * f;
-        double v = 0;
-        for (int k = 0; k < 3; ++k) if (k < s.nnull[f]) v += s.Nb[9 * f + 3 * k + c] * wv()[3 * f + k];
-        s.xN[j] = v;
-      }
-    });
-    mul_P(s.xN, s.PxN);
-    lap(13);
-    // x = u + xN ; y = A Gamma (g - P xN) on active rows ; z = A x ; normal-cone projection (proj.c:17-31)
-    ex.par([&](Th &t) {
-      if (t.tid < N) {
-        const int j = t.tid, f = j / 3;
-        s.xt[j] = s.u0[j] + s.xN[j];                                   // polished x (scaled)
-        const double *G = s.Gm + 9 * f + 3 * (j - 3 * f);
-        rw()[j] = G[0] * (s.g[3 * f] - s.PxN[3 * f]) + G[1] * (s.g[3 * f + 1] - s.PxN[3 * f + 1]) + G[2] * (s.g[3 * f + 2] - s.PxN[3 * f + 2]);
-      }
-    });
-    ex.par([&](Th &t) {
-      for_rows(t, [&](int i) {
-        const double yv = s.act[i] ? a_row_dot(s, i, rw()) : 0.0;
-        const double tt = a_row_dot(s, i, s.xt) + yv;
-        const double zc = clampd(tt, s.ls[i], s.us[i]);
-        zpol()[i] = zc;
-        ypol()[i] = tt - zc;
-      });
-    });
-    // residuals at the polished point, acceptance (polish.c:306-345)
-    const double pri0 = s.pri_res, dua0 = s.dua_res;
-    ex.par([&](Th &t) { if (t.tid < N) s.Pu[t.tid] += s.PxN[t.tid]; });   // P_s x_pol
-    residuals(s.xt, zpol(), ypol(), s.Pu);
-    ex.par([&](Th &t) {
-      if (t.tid == 0) {
-        const double pri = bitsd(s.red[0]), dua = s.cinv * bitsd(s.red[6]);
-        const bool ok = !s.bad && ((pri < pri0 && dua < dua0) || (pri < pri0 && dua0 < 1e-10) || (dua < dua0 && pri0 < 1e-10));
-        s.status_polish = ok ? 1 : -1;
-        if (ok) { s.pri_res = pri; s.dua_res = dua; }
-      }
-    });
-    ex.par([&](Th &t) {
-      if (s.status_polish == 1) {
-        if (t.tid < N) s.x[t.tid] = s.xt[t.tid];
-        for_rows(t, [&](int i) { cz()[i] = zpol()[i]; cy()[i] = ypol()[i]; });
-      }
-    });
-  }
-
-  // ================================ driver ======================================================
   MPC_HD void run() {
-    const long long t0 = MPC_CLOCK();
-    tlast = t0;
     load();
     scale();
-    set_rho_vec();
-    factor(false);
-    if (!s.first) mul_P(s.x, s.Px);                       // warm start: P_s x_0 once, then carried by recursion
-    else ex.par([&](Th &t) { if (t.tid < N) s.Px[t.tid] = 0.0; });
-    lap(9);
-    admm_prepare();
-    lap(8);
-    // kCheck iterations between termination checks (osqp.c:417-517 checks when iter % 25 == 0): the iterations
-    // run in their own inner loop so that the register allocator keeps the tile resident across them and places
-    // its live-range splits around the check / refactor code, which runs 25x less often.
-    static_assert(kMaxIter % kCheck == 0, "the check falls on the last iteration");
-    int iter = 0;
-    while (!s.done && !s.bad && iter < kMaxIter) {
-      pin_tiles(2);
-      for (int k = 0; k < kCheck; ++k) admm_iter();
-      pin_tiles(3);
-      iter += kCheck;
-      lap(8);
-      residuals(s.x, cz(), cy(), s.Px);
-      check_and_adapt(iter);
-      lap(10);
-      if (!s.done && s.rho_new > 0) {          // osqp_update_rho: new rho_vec, refactor
-        ex.par([&](Th &t) { if (t.tid == 0) { s.rho = s.rho_new; s.rho_updates++; } });
-        set_rho_vec();
-        factor(true);
-        admm_prepare();
-        lap(8);
-      }
-    }
-    if (C::kLoopExitFence) lap(8);   // (the clock read of an instrumented build is a fence too)
-    // Register allocation of the whole kernel hinges on whether the scheduler may move code across the loop exit
-    // (measured, hipcc 7.2, and re-measured whenever the code around it changes): a fence here is worth 3.5 % at h = 10 and,
-    // with the current code, takes h = 16 from 0.38 to 0.54 M steps/s; h = 20 is faster without it.
-    if (C::kLoopExitFence) MPC_SCHED_FENCE();
-    if (!s.done && !s.bad) {   // max_iter reached (osqp.c:564-568): only SOLVED counts for the reference
-      ex.par([&](Th &t) { if (t.tid == 0) s.status = kStMaxIter; });
-    }
-    if (s.status == kStSolved && !s.bad) polish();
-    lap(14);
-    tc[15] = MPC_CLOCK() - t0;
-    // outputs + persistent state (store_solution, auxil.c:528-561; mpc_osqp.cc:788-790: forces = -x)
-    ex.par([&](Th &t) {
-      const bool solved = s.status == kStSolved && !s.bad;
-      if (t.tid < N) {
-        if (solved) forces[t.tid] = -(s.D[t.tid] * s.x[t.tid]);
-        state[t.tid] = s.x[t.tid];
-        state[N + 2 * M + t.tid] = q_at(t.tid);
-      }
-      for_rows(t, [&](int i) { state[N + i] = cz()[i]; state[N + M + i] = cy()[i]; });
-      if (t.tid == 0) {
-        state[2 * N + 2 * M] = s.rho;
-        state[2 * N + 2 * M + 1] = 1.0;
-        info[0] = s.iter; info[1] = s.bad ? kStNonCvx : s.status; info[2] = s.status_polish; info[3] = s.rho_updates;
-        info[4] = s.nfact; info[5] = s.first; info[6] = 0; info[7] = 0;
-        if (prof) for (int k = 0; k < kProfLen; ++k) if (k != 1 && k != 2) prof[k] = tc[k];   // (1, 2: the assembly kernel's)
-      }
-    });
   }
 };
 

@@ -1,0 +1,1110 @@
+// mpc_wrench.h -- the OSQP iteration of one robot's convex-MPC QP, carried out in the space of the net body wrenches.
+//
+// Reference semantics (unchanged): extern/osqp/src auxil.c:164-228 (ADMM iteration), :243-362, 684-793 (residuals,
+// termination), :13-77 (rho adaptation), polish.c (polish), osqp.c:354-519 (driver) on the QP that
+// mpc_osqp.cc:578-796 builds, with the reference's settings (:705-712).  What is new is the LINEAR ALGEBRA behind
+// OSQP's KKT solve  x~ = K^{-1} (sigma x - q + A^T (R z - y)),  K = P_s + sigma I + A_s^T R A_s  (n = 12 h).
+//
+// The single-rigid-body model only feels the NET WRENCH of the four foot forces of a step:
+//     A_exp^k B_exp = Gamma_k B6,   B6 = [I_w^-1 [r_i]x ; I / m]  (6 x 12, the same for every step),
+//     Gamma_k = [dt^2 (k + 1/2) That ; dt I6]
+// so the QP Hessian is  P = alpha I + BB^T Theta BB  with BB = blockdiag(B6) (6 h x 12 h) and the 6 h x 6 h matrix
+//     Theta_{jj'} = sum_{i >= max(j,j')} 2 Gamma_{i-j}^T Q Gamma_{i-j'} = s2(j,j') th1 + n(j,j') diag(th2)
+// (th1, th2: QP record of the assembly kernel; s2, n: numbers that depend on the step indices only).  In OSQP's scaled
+// variables  K = S + W^T (c Theta) W  with  W = BB D  and  S = c alpha D^2 + sigma I + A_s^T R A_s,  which is block diagonal
+// with one 3 x 3 block per (step, foot).  Woodbury, in the form that stays accurate for every rho in [1e-6, 1e6]:
+//     Z = W S^-1 W^T = blockdiag(Z_k) = L L^T  (6 x 6 per step),  T = L^-1,  G = T W  (per foot 6 x 3),
+//     M = I + L^T (c Theta) L,     K^-1 b = v - S^-1 G^T (I - M^-1) (G v),  v = S^-1 b.
+// M is well conditioned whatever rho is (the textbook form (c Theta + Z^-1)^-1 is not: Z is nearly singular along torques that
+// only swing feet can produce, and the error of K^-1 b grows like rho).  The only dense object is the 6 h x 6 h matrix M:
+// 60 x 60 at h = 10 instead of 120 x 120 -- an eighth of the factorisation work and a quarter of the matrix-vector work per
+// ADMM iteration, exact (no swing-leg elimination, any gait), and small enough that ONE WAVEFRONT holds it: I - M^-1 lives as
+// the lower triangle of an h x h grid of 6 x 6 register tiles, 55 tiles at h = 10 -> one tile per lane, no workgroup barrier
+// anywhere in the solve (136 tiles / 192 threads at h = 16, 210 / 256 at h = 20).  Everything that belongs to one (step, foot)
+// -- three force variables, five cone rows, their iterates x, z, y, the scaled cone block, bounds, S^-1, G_f -- lives in the
+// registers of one "foot lane"; the wrench space is the only communication between lanes: six numbers per foot out (G_f v_f),
+// six per step back.
+//
+// Polish (polish.c) is the same algebra on the reduced Hessian of the active set: H^-1 restricted to the null space of the
+// active rows is  Xi - Xi G^T (I - M^-1) G Xi  with Xi = N (delta I + c alpha N^T D^2 N)^-1 N^T per foot in place of S^-1.
+// There Z is only positive SEMI-definite (two point feet cannot produce a torque about the line through them): the L D L^T
+// of a step drops its zero pivots (zero columns of L, zero rows of T), which leaves identity rows in M.
+#pragma once
+
+#include "mpc_core.h"
+
+namespace mpc {
+
+template <int H>
+struct WThread {
+  using C = Cfg<H>;
+  int tid;
+  // ---- tile lane (tid < MTW): my tile of the wrench grid
+  int ti, tj;
+  bool mact, dia;
+  double s2, nn;              // Theta_{ti,tj} = s2 th1 + nn diag(th2)
+  double Mx[C::TE];
+  // ---- foot lane (tid < NF): step tid / 4, foot tid % 4
+  double x[3], px[3], z[5], y[5], b[3], xt[3];   // iterates, P_s x, the right-hand side, x~
+  double q[3], D[3], a[9], up[5], lo4, Si[6];    // scaled q, D, the 9 non-zeros of the scaled cone block, bounds, S^{-1}
+  double Gf[18];                                 // G_f = T_k W_f (6 x 3) of the current factorisation
+  int ty[5];                                     // row types: -1 loose, 0 inequality, 1 equality (auxil.c:79-96)
+  // polish (foot lane)
+  int act[5];
+  double pG[9], pXi[6], pu0[3], pg[3], pr[3], pt[3], pxN[3], pPu[3], pw[3];
+  double xp[3], zp[5], yp[5];
+  MPC_HD void init(int id) {
+    tid = id;
+    mact = id < C::MTW;
+    int r = 0;
+    while ((r + 1) * (r + 2) / 2 <= id) ++r;
+    ti = r; tj = id - r * (r + 1) / 2; dia = ti == tj;
+    double acc = 0;
+    for (int sidx = ti; sidx < H; ++sidx) acc += (sidx - ti + 0.5) * (sidx - tj + 0.5);
+    s2 = mact ? acc : 0.0;
+    nn = mact ? (double)(H - ti) : 0.0;
+  }
+};
+
+#define MPC_V alignas(16) double
+template <int H>
+struct Shared {
+  using C = Cfg<H>;
+  static constexpr int RW = ((C::NF + 1) & ~1);                         // row stride of the residual scratch
+  static constexpr int PARTLEN_A = C::GW * C::NPW, PARTLEN_B = 14 * RW, PARTLEN_C = C::NF * 22;
+  static constexpr int PARTLEN = PARTLEN_A > PARTLEN_B ? (PARTLEN_A > PARTLEN_C ? PARTLEN_A : PARTLEN_C) : (PARTLEN_B > PARTLEN_C ? PARTLEN_B : PARTLEN_C);
+  MPC_V B6[72]; MPC_V th1[36]; MPC_V th2[8];
+  double c, cinv, rho, calpha;
+  double rho3[4], rinv3[4];                             // rho and 1 / rho of a loose / inequality / equality row (index type + 1)
+  MPC_V gp[C::NF * 6];                                  // per foot: W_f v_f
+  MPC_V g[C::NW + 2]; MPC_V gh[C::NW + 2]; MPC_V yw[C::NW + 2]; MPC_V dl[C::NW + 2];   // dl = diag(M)^-1/2, gh = dl g
+  MPC_V Lk[H * 36]; MPC_V Tk[H * 36];                   // per step: Z_k = L L^T, T = L^-1 (zero columns / rows at dropped pivots)
+  MPC_V prow_raw[2][C::NW + 2];
+  MPC_HD double *prow(int b) { return prow_raw[b] + MPC_PROW_SKEW; }
+  MPC_V piv[2][2];
+  union {
+    MPC_V part[PARTLEN];                                // [slot][row] partial products of the tile mat-vec; residual scratch [14][RW]
+    MPC_V zf[C::NF * 22];                               // per foot: W_f S_f^{-1} W_f^T, packed lower triangle (factorisation only)
+  };
+  unsigned long long red[16];
+  int first, iter, status, status_polish, rho_updates, nfact, done, bad;
+  double pri_res, dua_res, rho_new;
+};
+#undef MPC_V
+
+template <int H, class Exec>
+struct Solver {
+  using C = Cfg<H>;
+  using Th = WThread<H>;
+  using Sh = Shared<H>;
+  static constexpr int N = C::N, M = C::M, NF = C::NF, NW = C::NW, T = C::TW, TS = C::TS, G = C::GW, TE = C::TE, NP = C::NPW;
+
+  Exec &ex;
+  Sh &s;
+  const RobotModel &mdl;
+  double *state;       // [state_len<H>()]
+  const double *qp;    // [QP_LEN]  q, l, u, cone, wrench description from the assembly kernel
+  const double *sc;    // [SC_LEN]  D, E, q_s, A_s, l_s, u_s, c from the scaling kernel
+  double *forces;      // [N]   out: -D x (all horizon steps), untouched on failure
+  int *info;           // [kInfoLen]
+  long long *prof;     // [kProfLen] shader-clock cycles per section (may be null)
+#ifdef MPC_EMU_DEBUG
+  double *dbg = nullptr;   // host emulation only: per foot 20 doubles of the first polish application (tests/emu)
+#endif
+  using Tv = TileView;
+  long long tc[kProfLen] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = 0;
+#ifndef MPC_SECTION_PROFILE
+  MPC_HD void lap(int) {}
+#else
+  MPC_HD void lap(int k) { const long long now = MPC_CLOCK(); tc[k] += now - tlast; tlast = now; }
+#endif
+
+  static MPC_HD double fast_recip(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(d);            // v_rcp_f64 + two Newton steps (full double accuracy, not IEEE-rounded)
+    r = r * (2.0 - d * r);
+    r = r * (2.0 - d * r);
+    return r;
+#else
+    return 1.0 / d;
+#endif
+  }
+  MPC_HD double rho_at(int ty) const {
+    double r0 = s.rho3[0], r1 = s.rho3[1], r2 = s.rho3[2];
+    MPC_LAUNDER(r0); MPC_LAUNDER(r1); MPC_LAUNDER(r2);
+    return ty == 1 ? r2 : (ty == 0 ? r1 : r0);
+  }
+  MPC_HD double rinv_at(int ty) const {
+    double r0 = s.rinv3[0], r1 = s.rinv3[1], r2 = s.rinv3[2];
+    MPC_LAUNDER(r0); MPC_LAUNDER(r1); MPC_LAUNDER(r2);
+    return ty == 1 ? r2 : (ty == 0 ? r1 : r0);
+  }
+  // ---- the scaled cone block of a foot: rows (a0, 0, a1) (a2, 0, a3) (0, a4, a5) (0, a6, a7) (0, 0, a8)  (mpc_osqp.cc:437-447) ----
+  static MPC_HD void a_mul(const double *a, const double *v, double *out) {      // out[5] = A_f v
+    out[0] = a[0] * v[0] + a[1] * v[2];
+    out[1] = a[2] * v[0] + a[3] * v[2];
+    out[2] = a[4] * v[1] + a[5] * v[2];
+    out[3] = a[6] * v[1] + a[7] * v[2];
+    out[4] = a[8] * v[2];
+  }
+  static MPC_HD void at_mul(const double *a, const double *w, double *out) {     // out[3] = A_f^T w
+    out[0] = a[0] * w[0] + a[2] * w[1];
+    out[1] = a[4] * w[2] + a[6] * w[3];
+    out[2] = (((a[1] * w[0] + a[3] * w[1]) + a[5] * w[2]) + a[7] * w[3]) + a[8] * w[4];
+  }
+  static MPC_HD void sym3_mul(const double *m, const double *v, double *out) {   // packed (00 01 02 11 12 22)
+    out[0] = m[0] * v[0] + m[1] * v[1] + m[2] * v[2];
+    out[1] = m[1] * v[0] + m[3] * v[1] + m[4] * v[2];
+    out[2] = m[2] * v[0] + m[4] * v[1] + m[5] * v[2];
+  }
+  // inverse of a symmetric positive definite 3 x 3 matrix (packed) by LDL^T
+  static MPC_HD void sym3_inv(const double *m, double *inv) {
+    const double i0 = fast_recip(m[0]);
+    const double l10 = m[1] * i0, l20 = m[2] * i0;
+    const double d1 = m[3] - l10 * m[1];
+    const double i1 = fast_recip(d1);
+    const double t21 = m[4] - l20 * m[1];
+    const double l21 = t21 * i1;
+    const double d2 = m[5] - l20 * m[2] - l21 * t21;
+    const double i2 = fast_recip(d2);
+    // L^-1 = [1 0 0; -l10 1 0; l10 l21 - l20, -l21, 1]
+    const double k20 = l10 * l21 - l20;
+    inv[5] = i2;
+    inv[4] = -l21 * i2;
+    inv[2] = k20 * i2;
+    inv[3] = i1 + l21 * l21 * i2;
+    inv[1] = -l10 * i1 - l21 * k20 * i2;
+    inv[0] = i0 + l10 * l10 * i1 + k20 * k20 * i2;
+  }
+  // my foot's wrench map W_f = B6[:, 3 j .. 3 j + 2] diag(D)  (6 x 3, row-major in w[18])
+  MPC_HD void foot_w(const Th &t, double *w) const {
+    const int j = t.tid & 3;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) w[3 * r + c] = s.B6[12 * r + 3 * j + c] * t.D[c];
+  }
+  // gp[f] = W_f v
+  MPC_HD void put_wrench(const Th &t, const double *v) {
+    double w[18];
+    foot_w(t, w);
+    double *o = s.gp + 6 * t.tid;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) o[r] = w[3 * r] * v[0] + w[3 * r + 1] * v[1] + w[3 * r + 2] * v[2];
+  }
+  // out[3] = W_f^T y_k   (y of my step)
+  MPC_HD void get_wrench(const Th &t, const double *yv, double *out) const {
+    double w[18], yk[6];
+    foot_w(t, w);
+    const double *yp = yv + 6 * (t.tid >> 2);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) yk[r] = yp[r];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double acc = 0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) acc += w[3 * r + c] * yk[r];
+      out[c] = acc;
+    }
+  }
+
+  // out = T_k w  (T lower triangular, w 6 x 3)
+  MPC_HD void mul_tk(const Th &t, const double *w, double *out) const {
+    const double *tk = s.Tk + 36 * (t.tid >> 2);
+    double o[18];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        double v = 0;
+#pragma unroll
+        for (int k = 0; k <= r; ++k) v += tk[6 * r + k] * w[3 * k + c];
+        o[3 * r + c] = v;
+      }
+#pragma unroll
+    for (int k = 0; k < 18; ++k) out[k] = o[k];
+  }
+  // the same with the factorisation's G_f = T_k W_f (registers): gp[f] = G_f v,  out = G_f^T y_k
+  MPC_HD void put_g(const Th &t, const double *v) {
+    double *o = s.gp + 6 * t.tid;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) o[r] = t.Gf[3 * r] * v[0] + t.Gf[3 * r + 1] * v[1] + t.Gf[3 * r + 2] * v[2];
+  }
+  MPC_HD void get_g(const Th &t, const double *yv, double *out) const {
+    double yk[6];
+    const double *yp = yv + 6 * (t.tid >> 2);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) yk[r] = yp[r];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double acc = 0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) acc += t.Gf[3 * r + c] * yk[r];
+      out[c] = acc;
+    }
+  }
+
+  // ---- wrench-space products: gp --(G)--> g --(tile product)--> part --(combine)--> out -----------------------------
+  MPC_HD void phase_G() {
+    ex.par([&](Th &t) {
+      if (t.tid < NW) {
+        const int k = t.tid / 6, r = t.tid - 6 * k;
+        const double *p = s.gp + 24 * k + r;
+        const double gv = ((p[0] + p[6]) + p[12]) + p[18];
+        s.g[t.tid] = gv;
+        s.gh[t.tid] = s.dl[t.tid] * gv;
+      }
+    });
+  }
+  enum { kHeld = 0, kTheta = 1 };
+  // part <- partial products of the tile with v, both orientations (tile (i, j), j < i, stands for itself and its transpose)
+  template <int KIND>
+  MPC_HD void tile_product(const double *v) {
+    ex.par([&](Th &t) {
+      if (t.mact) {
+        double vc[TS], vr[TS], ar[TS], ac[TS];
+#pragma unroll
+        for (int bb = 0; bb < TS; ++bb) { vc[bb] = v[TS * t.tj + bb]; vr[bb] = v[TS * t.ti + bb]; ar[bb] = 0; ac[bb] = 0; }
+#pragma unroll
+        for (int aa = 0; aa < TS; ++aa)
+#pragma unroll
+          for (int bb = 0; bb < TS; ++bb) {
+            double m;
+            if (KIND == kHeld) m = t.Mx[aa * TS + bb];
+            else m = s.c * (t.s2 * s.th1[aa * TS + bb] + (aa == bb ? t.nn * s.th2[aa] : 0.0));
+            ar[aa] += m * vc[bb];
+            ac[bb] += m * vr[aa];
+          }
+        double *pd = s.part + t.tj * NP + TS * t.ti, *pt = s.part + t.ti * NP + TS * t.tj;
+#pragma unroll
+        for (int aa = 0; aa < TS; ++aa) pd[aa] = ar[aa];
+        if (!t.dia) {
+#pragma unroll
+          for (int bb = 0; bb < TS; ++bb) pt[bb] = ac[bb];
+        }
+      }
+    });
+  }
+  static MPC_HD double sum_parts(const Sh &s, int row) {   // fixed pairwise order
+    double v[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) v[k] = MPC_LDS_LOAD64(s.part + k * NP + row);
+#pragma unroll
+    for (int w = 1; w < G; w *= 2)
+#pragma unroll
+      for (int k = 0; k + w < G; k += 2 * w) v[k] = v[k] + v[k + w];
+    return v[0];
+  }
+  MPC_HD void combine(double *out) {
+    ex.par([&](Th &t) { if (t.tid < NW) out[t.tid] = sum_parts(s, t.tid); });
+  }
+  // yw <- (I - M^-1) g,  g = sum of the foot partials gp.  The tiles hold -Mh^-1 (+2 on the diagonal, see sweep_all) of the
+  // unit-diagonal Mh = dl M dl, so (I - M^-1) g = g - dl Mh^-1 (dl g).
+  MPC_HD void product_held() {
+    phase_G();
+    tile_product<kHeld>(s.gh);
+    ex.par([&](Th &t) { if (t.tid < NW) s.yw[t.tid] = s.g[t.tid] - s.dl[t.tid] * (2.0 * s.gh[t.tid] - sum_parts(s, t.tid)); });
+  }
+  // yw <- c Theta * (sum of the foot partials gp)
+  MPC_HD void product_theta() {
+    phase_G();
+    tile_product<kTheta>(s.g);
+    combine(s.yw);
+  }
+
+  // ================================ 1. load ======================================================================
+  MPC_HD void load() {
+    ex.par([&](Th &t) {
+      for (int i = t.tid; i < 72; i += T) s.B6[i] = qp[C::QP_B6 + i];
+      for (int i = t.tid; i < 36; i += T) s.th1[i] = qp[C::QP_TH1 + i];
+      for (int i = t.tid; i < 6; i += T) s.th2[i] = qp[C::QP_TH2 + i];
+      if (t.tid < NF) {
+        const int f = t.tid;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { t.x[c] = state[3 * f + c]; t.q[c] = sc[C::SC_QS + 3 * f + c]; t.D[c] = sc[C::SC_D + 3 * f + c]; t.px[c] = 0; }
+        const double *as = sc + C::SC_AS + 15 * f;
+        t.a[0] = as[0]; t.a[1] = as[2]; t.a[2] = as[3]; t.a[3] = as[5]; t.a[4] = as[7]; t.a[5] = as[8]; t.a[6] = as[10]; t.a[7] = as[11]; t.a[8] = as[14];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+          t.z[r] = state[N + 5 * f + r]; t.y[r] = state[N + M + 5 * f + r];   // scaled iterates of the previous call; zeros on the first call
+          const double lo = sc[C::SC_LS + 5 * f + r], hi = sc[C::SC_US + 5 * f + r];
+          t.up[r] = hi;
+          if (r == 4) t.lo4 = lo;
+          // set_rho_vec / update_rho_vec (auxil.c:79-141): the row type is a function of the scaled bounds
+          t.ty[r] = (lo < -kInfty * kMinScaling && hi > kInfty * kMinScaling) ? -1 : (hi - lo < kRhoTol ? 1 : 0);
+        }
+      }
+      if (t.tid == 0) {
+        const bool first = state[2 * N + 2 * M + 1] == 0.0;
+        s.first = first;
+        s.rho = first ? kRho0 : state[2 * N + 2 * M];
+        s.c = sc[C::SC_C]; s.cinv = sc[C::SC_C + 1]; s.calpha = sc[C::SC_C] * mdl.alpha;
+        s.status = kStUnsolved; s.status_polish = 0; s.rho_updates = 0; s.nfact = 0; s.iter = 0; s.done = 0; s.bad = 0;
+      }
+    });
+    lap(0);
+  }
+  MPC_HD double lo_at(const Th &t, int r) const { return r == 4 ? t.lo4 : 0.0; }   // rows 0-3 have l = 0 (mpc_osqp.cc:449-477)
+
+  MPC_HD void set_rho_vec() {   // rho per row type (auxil.c:79-96, osqp.c:1267-1310)
+    ex.par([&](Th &t) {
+      if (t.tid < 3) {
+        const double rv = t.tid == 0 ? kRhoMin : (t.tid == 2 ? kRhoEqOverIneq * s.rho : s.rho);
+        s.rho3[t.tid] = rv;
+        s.rinv3[t.tid] = 1.0 / rv;
+      }
+    });
+  }
+
+  // ---- 6 x 6 helpers of the step lanes (packed lower triangle: index r (r + 1) / 2 + c, c <= r; all indices static) --------
+  static constexpr MPC_HD int pk(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; }
+  // L D L^T of a symmetric positive semi-definite 6 x 6 (unit lower L in l[], pivots in d[]).  A pivot that is <= tol times its
+  // own diagonal entry -- row j lies in the span of the rows before it (sin^2 of the angle <= tol) -- is dropped: d = 0, column
+  // of L = 0.  (The test must be relative to the row's OWN diagonal: a wrench component that is small for every foot is not
+  // dependent, and dropping it would discard off-diagonal entries of relative size sqrt(tol).)
+  static MPC_HD void ldl6(const double *zz, double *l, double *d, double tol) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      double dj = zz[pk(j, j)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) dj -= l[pk(j, k)] * l[pk(j, k)] * d[k];
+      const bool ok = dj > tol * zz[pk(j, j)];
+      d[j] = ok ? dj : 0.0;
+      const double inv = ok ? fast_recip(dj) : 0.0;
+      l[pk(j, j)] = 1.0;
+#pragma unroll
+      for (int i = j + 1; i < 6; ++i) {
+        double v = zz[pk(i, j)];
+#pragma unroll
+        for (int k = 0; k < j; ++k) v -= l[pk(i, k)] * l[pk(j, k)] * d[k];
+        l[pk(i, j)] = v * inv;
+      }
+    }
+  }
+
+  // per foot: zf <- w X w^T for a symmetric 3 x 3 X (packed) and a 6 x 3 map w (W_f, or G_f in the second orthogonalisation pass)
+  MPC_HD void put_zf(const Th &t, const double *X, const double *w) {
+    double v[18];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) sym3_mul(X, w + 3 * r, v + 3 * r);   // V = W X (X symmetric)
+    double *o = s.zf + 22 * t.tid;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c <= r; ++c) o[pk(r, c)] = v[3 * r] * w[3 * c] + v[3 * r + 1] * w[3 * c + 1] + v[3 * r + 2] * w[3 * c + 2];
+  }
+  MPC_HD void sum_zf(int k, double *zz) const {
+    const double *p = s.zf + 88 * k;
+#pragma unroll
+    for (int e = 0; e < 21; ++e) zz[e] = ((p[e] + p[22 + e]) + p[44 + e]) + p[66 + e];
+  }
+
+  // ================================ 2. factorisation: Mx <- -Mh^-1,  Mh = dl (I + L^T (c Theta) L) dl =================
+  // xs(t): the symmetric 3 x 3 matrix X_f of the foot (S_f^-1 for the ADMM system, Xi_f for polish); Z_k = sum_f W_f X_f W_f^T
+  static MPC_HD double fast_rsqrt(double d) {   // 1 / sqrt(d), d > 0 finite: v_rsq_f64 + two Newton steps
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rsq(d);
+    const double hh = 0.5 * d;
+    r = r * (1.5 - hh * r * r);
+    r = r * (1.5 - hh * r * r);
+    return r;
+#else
+    return 1.0 / sqrt(d);
+#endif
+  }
+  // One orthogonalisation pass on the step lanes: Z_k = sum of the foot contributions zf = L_u D L_u^T (dependent rows dropped);
+  // FIRST: L = L_u D^1/2, T = D^-1/2 L_u^-1 -> Lk, Tk.  Second pass (Z_k is then G Xi G^T = I up to the first pass's loss of
+  // orthogonality, eps cond(Z)): L <- L L2, and T2 -> Tk for the foot lanes to update G <- T2 G.
+  template <bool FIRST>
+  MPC_HD void step_factor() {
+    ex.par([&](Th &t) {
+      if (t.tid < H) {
+        double zz[21], l[21], d[6], li[21];
+        sum_zf(t.tid, zz);
+        if (FIRST) {
+          double mxd = 0;
+#pragma unroll
+          for (int j = 0; j < 6; ++j) mxd = dmax(mxd, zz[pk(j, j)]);
+          if (!(mxd < kInfty)) s.bad = 1;   // (NaN / inf inputs)
+        }
+        ldl6(zz, l, d, 1e-13);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {   // li = L_u^-1 (unit lower)
+          li[pk(j, j)] = 1.0;
+#pragma unroll
+          for (int i = j + 1; i < 6; ++i) {
+            double v = l[pk(i, j)];
+#pragma unroll
+            for (int k = j + 1; k < i; ++k) v += l[pk(i, k)] * li[pk(k, j)];
+            li[pk(i, j)] = -v;
+          }
+        }
+        double sd[6], si[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const bool ok = d[j] > 0;
+          si[j] = ok ? fast_rsqrt(ok ? d[j] : 1.0) : 0.0;
+          sd[j] = ok ? d[j] * si[j] : 0.0;
+        }
+        double *ol = s.Lk + 36 * t.tid, *ot = s.Tk + 36 * t.tid;
+        if (FIRST) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) ol[6 * i + j] = i >= j ? l[pk(i, j)] * sd[j] : 0.0;
+        } else {
+          double l1[21];
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) l1[pk(i, j)] = ol[6 * i + j];
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {   // (L1 L2)_{ij} = sum_{j <= k <= i} L1_{ik} L2_{kj}
+              double v = 0;
+#pragma unroll
+              for (int k = j; k <= i; ++k) v += l1[pk(i, k)] * (l[pk(k, j)] * sd[j]);
+              ol[6 * i + j] = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int j = 0; j < 6; ++j) ot[6 * i + j] = i >= j ? li[pk(i, j)] * si[i] : 0.0;
+      }
+    });
+  }
+  // TWO_PASS: Cholesky-QR twice.  G Xi G^T must be the identity to working accuracy for the projector I - V V^T inside
+  // K^-1 = X^1/2 (I - V V^T + V M^-1 V^T) X^1/2 to cancel; polish needs it (|Xi| ~ 1 / delta amplifies the loss of
+  // orthogonality of a single pass by 1e6), the ADMM system does not (measured: tests/test_emulated_kernel.py).
+  template <bool TWO_PASS, class XS>
+  MPC_HD void factor_core(XS &&xs) {
+    ex.par([&](Th &t) {
+      if (t.tid < NF) {
+        double w[18];
+        foot_w(t, w);
+        put_zf(t, xs(t), w);
+      }
+    });
+    step_factor<true>();
+    if (TWO_PASS) {
+      ex.par([&](Th &t) {
+        if (t.tid < NF) {   // G1 = T1 W;  zf <- G1 X G1^T
+          double w[18];
+          foot_w(t, w);
+          mul_tk(t, w, t.Gf);
+          put_zf(t, xs(t), t.Gf);
+        }
+      });
+      step_factor<false>();
+    }
+    ex.par([&](Th &t) {
+      if (t.tid < NF) {   // G_f = T_k W_f  (second pass: T2 G1)
+        double w[18];
+        if (TWO_PASS) {
+#pragma unroll
+          for (int k = 0; k < 18; ++k) w[k] = t.Gf[k];
+        } else foot_w(t, w);
+        mul_tk(t, w, t.Gf);
+      }
+      if (t.tid < NW) {   // dl = diag(M)^-1/2,  M_rr = 1 + l_r^T (c Theta_kk) l_r  (l_r: column r of L_k)
+        const int k = t.tid / 6, r = t.tid - 6 * k;
+        const double mm = (double)(H - k), s2kk = mm * (4.0 * mm * mm - 1.0) / 12.0;   // sum_{i < m} (i + 1/2)^2
+        const double *lk = s.Lk + 36 * k;
+        double lc[TS];
+#pragma unroll
+        for (int a = 0; a < TS; ++a) lc[a] = lk[6 * a + r];
+        double acc = 0;
+#pragma unroll
+        for (int a = 0; a < TS; ++a) {
+          double row = 0;
+#pragma unroll
+          for (int bb = 0; bb < TS; ++bb) row += (s2kk * s.th1[a * TS + bb] + (a == bb ? mm * s.th2[a] : 0.0)) * lc[bb];
+          acc += lc[a] * row;
+        }
+        s.dl[t.tid] = fast_rsqrt(1.0 + s.c * acc);
+      }
+    });
+    ex.par([&](Th &t) {
+      if (t.mact) {   // Mh tile = dl_i ([i == j] I + L_i^T (c Theta_ij) L_j) dl_j   (L lower triangular); unit diagonal
+        const double *li = s.Lk + 36 * t.ti, *lj = s.Lk + 36 * t.tj, *di = s.dl + 6 * t.ti, *dj = s.dl + 6 * t.tj;
+        double t1[TE];
+#pragma unroll
+        for (int aa = 0; aa < TS; ++aa)
+#pragma unroll
+          for (int bb = 0; bb < TS; ++bb) {
+            double v = 0;
+#pragma unroll
+            for (int k = bb; k < TS; ++k) v += (s.c * (t.s2 * s.th1[aa * TS + k] + (aa == k ? t.nn * s.th2[aa] : 0.0))) * lj[k * TS + bb];
+            t1[aa * TS + bb] = v;
+          }
+#pragma unroll
+        for (int aa = 0; aa < TS; ++aa)
+#pragma unroll
+          for (int bb = 0; bb < TS; ++bb) {
+            double v = (t.dia && aa == bb) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = aa; k < TS; ++k) v += li[k * TS + aa] * t1[k * TS + bb];
+            t.Mx[aa * TS + bb] = (di[aa] * v) * dj[bb];
+          }
+      }
+    });
+    lap(6);
+    sweep_all();
+    ex.par([&](Th &t) { if (t.tid == 0) s.nfact++; });
+    lap(7);
+  }
+  MPC_HD void factor() {
+    ex.par([&](Th &t) {
+      if (t.tid < NF) {   // S_f = c alpha D^2 + sigma I + A_f^T R A_f  ->  S_f^-1
+        double rv[5];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) rv[r] = rho_at(t.ty[r]);
+        const double *a = t.a;
+        double S[6];
+        S[0] = (s.calpha * t.D[0] * t.D[0] + kSigma) + (rv[0] * a[0] * a[0] + rv[1] * a[2] * a[2]);
+        S[1] = 0.0;
+        S[2] = rv[0] * a[0] * a[1] + rv[1] * a[2] * a[3];
+        S[3] = (s.calpha * t.D[1] * t.D[1] + kSigma) + (rv[2] * a[4] * a[4] + rv[3] * a[6] * a[6]);
+        S[4] = rv[2] * a[4] * a[5] + rv[3] * a[6] * a[7];
+        S[5] = (s.calpha * t.D[2] * t.D[2] + kSigma) + ((((rv[0] * a[1] * a[1] + rv[1] * a[3] * a[3]) + rv[2] * a[5] * a[5]) + rv[3] * a[7] * a[7]) + rv[4] * a[8] * a[8]);
+        sym3_inv(S, t.Si);
+      }
+    });
+    factor_core<false>([](Th &t) { return t.Si; });
+  }
+
+  // Symmetric sweep of every pivot: after all pivots the matrix equals -inverse.  Per step k:  p = a_kk;
+  // a_ij -= a_ik a_kj / p (i,j != k);  a_ik -> a_ik / p;  a_kk -> -1/p.  The matrix stays symmetric, so both a_ik and a_kj are
+  // read from the published pivot row, and only the lower-triangle tiles are updated.  That row carries (p - 1) in slot k, which
+  // makes the generic update  a_ij -= (row_k[i] / p) * row_k[j]  produce a_ik / p on column k and a_kj / p on row k with no
+  // per-element select; the diagonal element of a swept row takes the generic update too and ends up as (true value + 2).
+  // The pivot loop is unrolled by TS = 6 so that the pivot's position inside its tile is static.
+  MPC_HD void sweep_all() {
+    int buf = 0;
+    ex.par([&](Th &t) { if (t.mact) publish<0>(t, 0, 0); });
+    for (int kt = 0; kt < G; ++kt) sweep_steps<0>(kt, buf);
+  }
+  template <int A>
+  MPC_HD void sweep_steps(int kt, int &buf) {
+    if constexpr (A < TS) {
+      sweep_step<A>(kt, buf);
+      buf ^= 1;
+      sweep_steps<A + 1>(kt, buf);
+    }
+  }
+  template <int A>
+  MPC_HD void sweep_step(int kt, int buf) {
+    constexpr int AN = (A + 1) % TS;                 // next pivot's position inside its tile
+    const int ktn = (A + 1 < TS) ? kt : kt + 1;      // tile row (= column) of the next pivot
+    const bool pub = ktn < G;
+    ex.par([&](Th &t) {
+      if (t.mact) {
+        double g[TS], pc[TS];
+        const double p = s.piv[buf][0], pinv = s.piv[buf][1];
+        const double *pr = s.prow(buf);
+#pragma unroll
+        for (int a = 0; a < TS; ++a) { g[a] = pr[TS * t.ti + a] * pinv; pc[a] = pr[TS * t.tj + a]; }
+#pragma unroll
+        for (int b = 0; b < TS; ++b) t.Mx[AN * TS + b] -= g[AN] * pc[b];
+#pragma unroll
+        for (int a = 0; a < TS; ++a)
+          if (a != AN) t.Mx[a * TS + AN] -= g[a] * pc[AN];
+        if (t.tid == 0 && !(p > 0)) s.bad = 1;     // not positive definite
+        if (pub) publish<AN>(t, buf ^ 1, ktn);
+        MPC_SCHED_FENCE();
+#pragma unroll
+        for (int a = 0; a < TS; ++a)
+#pragma unroll
+          for (int b = 0; b < TS; ++b)
+            if (a != AN && b != AN) t.Mx[a * TS + b] -= g[a] * pc[b];
+      }
+    });
+  }
+  // Row k = 6 kt + A of the matrix -> prow[b]: the tiles of tile row kt hold its part left of (and on) the
+  // diagonal as their row A, the tiles of tile column kt hold the rest as their column A.  Slot k itself
+  // gets (pivot - 1), and piv[b] = {pivot, 1 / pivot}.
+  template <int A>
+  MPC_HD void publish(const Th &t, int b, int kt) {
+    if (t.ti == kt) {
+      double *pn = s.prow(b) + TS * t.tj;
+#pragma unroll
+      for (int bb = 0; bb < TS; ++bb)
+        if (bb != A) pn[bb] = t.Mx[A * TS + bb];
+      const double pivot = t.Mx[A * TS + A];
+      pn[A] = t.dia ? pivot - 1.0 : pivot;
+      if (t.dia) {
+        s.piv[b][0] = pivot;
+        s.piv[b][1] = fast_recip(pivot);
+      }
+    } else if (t.tj == kt) {
+      double *pn = s.prow(b) + TS * t.ti;
+#pragma unroll
+      for (int a = 0; a < TS; ++a) MPC_LDS_STORE64(pn + a, t.Mx[a * TS + A]);
+    }
+  }
+
+  // ================================ 3. ADMM (auxil.c:164-228) ====================================================
+  // b = sigma x - q + A^T (R z - y);  v = S^-1 b;  gp = G v
+  MPC_HD void foot_rhs(Th &t) {
+    double tm[5], acc[3], v[3];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) tm[r] = rho_at(t.ty[r]) * t.z[r] - t.y[r];
+    at_mul(t.a, tm, acc);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) t.b[c] = kSigma * t.x[c] - t.q[c] + acc[c];
+    sym3_mul(t.Si, t.b, v);
+    put_g(t, v);
+  }
+  MPC_HD void admm_prepare() {
+    ex.par([&](Th &t) { if (t.tid < NF) foot_rhs(t); });
+  }
+  // One ADMM iteration: the wrench product (three short phases) and the foot phase, which finishes the KKT solve
+  //   x~ = S^-1 (b - G^T y_w),  z~ = A x~,  updates x, z, y (relaxation 1.6), carries P_s x by recursion, and prepares the next
+  // right-hand side.
+  MPC_HD void admm_iter() {
+    product_held();
+    ex.par([&](Th &t) {
+      if (t.tid < NF) {
+        double wy[3], tt[3], zt[5], tm[5], rzt[5], acc[3], arz[3];
+        get_g(t, s.yw, wy);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tt[c] = t.b[c] - wy[c];
+        sym3_mul(t.Si, tt, t.xt);
+        a_mul(t.a, t.xt, zt);
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+          const double rv = rho_at(t.ty[r]), ri = rinv_at(t.ty[r]);
+          const double zr = kAlphaRelax * zt[r] + (1.0 - kAlphaRelax) * t.z[r];
+          const double zn = clampd(zr + ri * t.y[r], lo_at(t, r), t.up[r]);
+          const double yn = t.y[r] + rv * (zr - zn);
+          t.z[r] = zn;
+          t.y[r] = yn;
+          tm[r] = rv * zn - yn;
+          rzt[r] = rv * zt[r];
+        }
+        at_mul(t.a, tm, acc);
+        at_mul(t.a, rzt, arz);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          // P_s x without a matrix product: K x~ = b gives P_s x~ = b - sigma x~ - A^T R z~, and x is affine in x~
+          t.px[c] = kAlphaRelax * (t.b[c] - kSigma * t.xt[c] - arz[c]) + (1.0 - kAlphaRelax) * t.px[c];
+          const double xn = kAlphaRelax * t.xt[c] + (1.0 - kAlphaRelax) * t.x[c];
+          t.x[c] = xn;
+          t.b[c] = kSigma * xn - t.q[c] + acc[c];
+        }
+        double v[3];
+        sym3_mul(t.Si, t.b, v);
+        put_g(t, v);
+      }
+    });
+  }
+
+  // P_s v for a per-foot vector given by sel(t): out = c alpha D^2 v + W^T (c Theta (W v)).  `in` and `out` are members of Th.
+  template <class In, class Out>
+  MPC_HD void mul_P(In &&in, Out &&out) {
+    ex.par([&](Th &t) { if (t.tid < NF) put_wrench(t, in(t)); });
+    product_theta();
+    ex.par([&](Th &t) {
+      if (t.tid < NF) {
+        double wy[3];
+        get_wrench(t, s.yw, wy);
+        const double *v = in(t);
+        double *o = out(t);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = (s.calpha * t.D[c] * t.D[c]) * v[c] + wy[c];
+      }
+    });
+  }
+
+  // residuals of (x, z, y) (auxil.c:243-306, 563-629) + the norms termination and rho need.
+  // red[] slots: 0 pri_res 1 ||Einv z|| 2 ||Einv Ax|| 3 ||rp|| 4 ||z|| 5 ||Ax||
+  //              6 ||Dinv rd|| 7 ||Dinv q|| 8 ||Dinv Aty|| 9 ||Dinv Px|| 10 ||rd|| 11 ||q|| 12 ||Aty|| 13 ||Px||
+  // Every foot lane forms the maxima over its five rows and three variables; 14 lanes finish.
+  template <class X, class Z, class Y, class PX>
+  MPC_HD void residuals(X &&xs, Z &&zs, Y &&ys, PX &&pxs) {
+    constexpr int RW = Sh::RW;
+    ex.par([&](Th &t) {
+      if (t.tid < NF) {
+        const double *x = xs(t), *z = zs(t), *y = ys(t), *px = pxs(t);
+        double mx[14], ax[5], aty[3];
+#pragma unroll
+        for (int k = 0; k < 14; ++k) mx[k] = 0;
+        a_mul(t.a, x, ax);
+        at_mul(t.a, y, aty);
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+          const double rr = ax[r] - z[r], ei = 1.0 / sc[C::SC_E + 5 * t.tid + r];
+          mx[0] = dmax(mx[0], fabs(ei * rr)); mx[1] = dmax(mx[1], fabs(ei * z[r])); mx[2] = dmax(mx[2], fabs(ei * ax[r]));
+          mx[3] = dmax(mx[3], fabs(rr)); mx[4] = dmax(mx[4], fabs(z[r])); mx[5] = dmax(mx[5], fabs(ax[r]));
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const double qv = t.q[c], rr = qv + px[c] + aty[c], di = 1.0 / t.D[c];
+          mx[6] = dmax(mx[6], fabs(di * rr)); mx[7] = dmax(mx[7], fabs(di * qv)); mx[8] = dmax(mx[8], fabs(di * aty[c]));
+          mx[9] = dmax(mx[9], fabs(di * px[c])); mx[10] = dmax(mx[10], fabs(rr)); mx[11] = dmax(mx[11], fabs(qv));
+          mx[12] = dmax(mx[12], fabs(aty[c])); mx[13] = dmax(mx[13], fabs(px[c]));
+        }
+#pragma unroll
+        for (int k = 0; k < 14; ++k) s.part[k * RW + t.tid] = mx[k];
+      }
+    });
+    ex.par([&](Th &t) {
+      if (t.tid < 14) {
+        const double *p = s.part + t.tid * RW;
+        double m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+        static_assert(NF % 4 == 0, "four feet per step");
+        for (int k = 0; k < NF; k += 4) { m0 = dmax(m0, p[k]); m1 = dmax(m1, p[k + 1]); m2 = dmax(m2, p[k + 2]); m3 = dmax(m3, p[k + 3]); }
+        s.red[t.tid] = dbits(dmax(dmax(m0, m1), dmax(m2, m3)));
+      }
+    });
+  }
+
+  // check_termination (auxil.c:684-793; infeasibility certificates not evaluated: the QP is always
+  // feasible and strictly convex) + adapt_rho decision (auxil.c:13-77).  One thread decides.
+  MPC_HD void check_and_adapt(int iter) {
+    ex.par([&](Th &t) {
+      if (t.tid == 0) {
+        const double pri = bitsd(s.red[0]), dua = s.cinv * bitsd(s.red[6]);
+        s.pri_res = pri; s.dua_res = dua; s.iter = iter; s.rho_new = 0;
+        if (!(pri <= kInfty) || !(dua <= kInfty)) { s.status = kStNonCvx; s.done = 1; }
+        else {
+          const double eps_prim = kEpsAbs + kEpsRel * dmax(bitsd(s.red[1]), bitsd(s.red[2]));
+          const double eps_dual = kEpsAbs + kEpsRel * s.cinv * dmax(dmax(bitsd(s.red[7]), bitsd(s.red[8])), bitsd(s.red[9]));
+          if (pri < eps_prim && dua < eps_dual) { s.status = kStSolved; s.done = 1; }
+          else {
+            double pr = bitsd(s.red[3]) / (dmax(bitsd(s.red[4]), bitsd(s.red[5])) + 1e-10);
+            double dr = bitsd(s.red[10]) / (dmax(dmax(bitsd(s.red[11]), bitsd(s.red[12])), bitsd(s.red[13])) + 1e-10);
+            double rn = s.rho * sqrt(pr / (dr + 1e-10));
+            rn = clampd(rn, kRhoMin, kRhoMax);
+            if (rn > s.rho * kAdaptTol || rn < s.rho / kAdaptTol) s.rho_new = rn;
+          }
+        }
+      }
+    });
+  }
+
+  // ================================ 4. polish (polish.c) =========================================================
+  // Active set from (z, y) (polish.c:36-52); the delta-regularised KKT solve with three refinement steps (polish.c:102-160)
+  // is carried out in the null space of the active rows, foot by foot, in FORCE coordinates: with N_f the orthonormal null
+  // basis of a foot's active rows, Hd = N^T (P_s + delta I) N and Omega = N Hd^-1 N^T,
+  //     w_{k+1} = w_k + Omega r_k,   r_{k+1} = delta Omega r_k        (H Hd^-1 = I - delta Hd^-1: no further products with P),
+  //     Omega r = Xi r - Xi G^T (I - M^-1) (G Xi r),  Xi = N (delta I + c alpha N^T D^2 N)^-1 N^T  (3 x 3 per foot),
+  // with G, M of factor_core(Xi).
+  MPC_HD void omega_apply() {   // in: gp = G (Xi r) from the foot lanes, pt = Xi r;  out: pw = Omega r
+    product_held();
+    ex.par([&](Th &t) {
+      if (t.tid < NF) {
+        double wy[3], xw[3];
+        get_g(t, s.yw, wy);
+        sym3_mul(t.pXi, wy, xw);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) t.pw[c] = t.pt[c] - xw[c];
+      }
+    });
+  }
+
+  MPC_HD void polish() {
+    ex.par([&](Th &t) {
+      if (t.tid < NF) {
+        const double *a = t.a;
+        // rows of the scaled cone block (static indexing)
+        const double A[15] = {a[0], 0, a[1], a[2], 0, a[3], 0, a[4], a[5], 0, a[6], a[7], 0, 0, a[8]};
+#pragma unroll
+        for (int r = 0; r < 5; ++r) t.act[r] = (t.z[r] - lo_at(t, r) < -t.y[r]) ? -1 : ((t.up[r] - t.z[r] < t.y[r]) ? 1 : 0);
+        // orthonormal basis Q of the active rows (rank r), null basis Nn (rows, 3 - r of them); rows of Q beyond the
+        // current rank are zero, so projecting on all three rows equals projecting on the first r of them
+        double Q[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Nn[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        int r = 0;
+#pragma unroll
+        for (int row = 0; row < 5; ++row) {
+          const bool cand = r < 3 && t.act[row];
+          double v[3] = {A[3 * row], A[3 * row + 1], A[3 * row + 2]};
+          const double n0 = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+#pragma unroll
+          for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              const double d = v[0] * Q[3 * k] + v[1] * Q[3 * k + 1] + v[2] * Q[3 * k + 2];
+              v[0] -= d * Q[3 * k]; v[1] -= d * Q[3 * k + 1]; v[2] -= d * Q[3 * k + 2];
+            }
+          const double nr = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+          const bool take = cand && nr > 1e-6 * n0;
+          const double q0 = v[0] / nr, q1 = v[1] / nr, q2 = v[2] / nr;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const bool here = take && r == k;
+            Q[3 * k] = here ? q0 : Q[3 * k]; Q[3 * k + 1] = here ? q1 : Q[3 * k + 1]; Q[3 * k + 2] = here ? q2 : Q[3 * k + 2];
+          }
+          r += take ? 1 : 0;
+        }
+        if (r == 0) { Nn[0] = 1; Nn[4] = 1; Nn[8] = 1; }
+        else if (r == 1) {
+          const int imin = fabs(Q[0]) <= fabs(Q[1]) ? (fabs(Q[0]) <= fabs(Q[2]) ? 0 : 2) : (fabs(Q[1]) <= fabs(Q[2]) ? 1 : 2);
+          const double e[3] = {imin == 0 ? 1.0 : 0.0, imin == 1 ? 1.0 : 0.0, imin == 2 ? 1.0 : 0.0};
+          const double d = imin == 0 ? Q[0] : imin == 1 ? Q[1] : Q[2];
+          double v[3] = {e[0] - d * Q[0], e[1] - d * Q[1], e[2] - d * Q[2]};
+          const double nr = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+          Nn[0] = v[0] / nr; Nn[1] = v[1] / nr; Nn[2] = v[2] / nr;
+          Nn[3] = Q[1] * Nn[2] - Q[2] * Nn[1]; Nn[4] = Q[2] * Nn[0] - Q[0] * Nn[2]; Nn[5] = Q[0] * Nn[1] - Q[1] * Nn[0];
+        } else if (r == 2) {
+          Nn[0] = Q[1] * Q[5] - Q[2] * Q[4]; Nn[1] = Q[2] * Q[3] - Q[0] * Q[5]; Nn[2] = Q[0] * Q[4] - Q[1] * Q[3];
+          const double nr = sqrt(Nn[0] * Nn[0] + Nn[1] * Nn[1] + Nn[2] * Nn[2]);
+          Nn[0] /= nr; Nn[1] /= nr; Nn[2] /= nr;
+        }
+        const int nn = 3 - r;
+        // Gamma = Q (Q^T B Q)^{-1} Q^T with B = A_act^T A_act
+        double B[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Gq[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Gi[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+#pragma unroll
+        for (int row = 0; row < 5; ++row)
+          if (t.act[row])
+#pragma unroll
+            for (int c1 = 0; c1 < 3; ++c1)
+#pragma unroll
+              for (int c2 = 0; c2 < 3; ++c2) B[3 * c1 + c2] += A[3 * row + c1] * A[3 * row + c2];
+#pragma unroll
+        for (int k1 = 0; k1 < 3; ++k1)
+#pragma unroll
+          for (int k2 = 0; k2 < 3; ++k2) {
+            if (k1 >= r || k2 >= r) continue;
+            double tt = 0;
+#pragma unroll
+            for (int c1 = 0; c1 < 3; ++c1)
+#pragma unroll
+              for (int c2 = 0; c2 < 3; ++c2) tt += Q[3 * k1 + c1] * B[3 * c1 + c2] * Q[3 * k2 + c2];
+            Gq[3 * k1 + k2] = tt;
+          }
+        // Gauss-Jordan on the (identity padded) 3x3
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const double d = 1.0 / Gq[3 * p + p];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) { Gq[3 * p + j] *= d; Gi[3 * p + j] *= d; }
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            if (i == p) continue;
+            const double fc = Gq[3 * i + p];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { Gq[3 * i + j] -= fc * Gq[3 * p + j]; Gi[3 * i + j] -= fc * Gi[3 * p + j]; }
+          }
+        }
+#pragma unroll
+        for (int c1 = 0; c1 < 3; ++c1)
+#pragma unroll
+          for (int c2 = 0; c2 < 3; ++c2) {
+            double tt = 0;
+#pragma unroll
+            for (int k1 = 0; k1 < 3; ++k1)
+#pragma unroll
+              for (int k2 = 0; k2 < 3; ++k2) {
+                if (k1 >= r || k2 >= r) continue;
+                tt += Q[3 * k1 + c1] * Gi[3 * k1 + k2] * Q[3 * k2 + c2];
+              }
+            t.pG[3 * c1 + c2] = tt;
+          }
+        // u0 = Gamma A_act^T b_act  (the point satisfying the active rows)
+        double vb[3] = {0, 0, 0};
+#pragma unroll
+        for (int row = 0; row < 5; ++row)
+          if (t.act[row]) {
+            const double bd = t.act[row] < 0 ? lo_at(t, row) : t.up[row];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vb[c] += A[3 * row + c] * bd;
+          }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) t.pu0[c] = t.pG[3 * c] * vb[0] + t.pG[3 * c + 1] * vb[1] + t.pG[3 * c + 2] * vb[2];
+        // Xi = N (delta I + c alpha N^T D^2 N)^-1 N^T  on the nn null coordinates (identity padding keeps the inverse well defined)
+        double Sp[6];
+        {
+          double nd[9];
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) nd[3 * k + c] = Nn[3 * k + c] * t.D[c];
+          const double ca = s.calpha;
+          Sp[0] = 0 < nn ? ca * (nd[0] * nd[0] + nd[1] * nd[1] + nd[2] * nd[2]) + kDelta : 1.0;
+          Sp[3] = 1 < nn ? ca * (nd[3] * nd[3] + nd[4] * nd[4] + nd[5] * nd[5]) + kDelta : 1.0;
+          Sp[5] = 2 < nn ? ca * (nd[6] * nd[6] + nd[7] * nd[7] + nd[8] * nd[8]) + kDelta : 1.0;
+          Sp[1] = 1 < nn ? ca * (nd[0] * nd[3] + nd[1] * nd[4] + nd[2] * nd[5]) : 0.0;
+          Sp[2] = 2 < nn ? ca * (nd[0] * nd[6] + nd[1] * nd[7] + nd[2] * nd[8]) : 0.0;
+          Sp[4] = 2 < nn ? ca * (nd[3] * nd[6] + nd[4] * nd[7] + nd[5] * nd[8]) : 0.0;
+        }
+        double Spi[6];
+        sym3_inv(Sp, Spi);
+        // Xi[c1][c2] = sum_{k1,k2 < nn} Nn[k1][c1] Spi[k1][k2] Nn[k2][c2]   (rows of Nn beyond nn are zero)
+        double tmp[9];
+#pragma unroll
+        for (int k1 = 0; k1 < 3; ++k1)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const double s0 = Spi[pk3(k1, 0)], s1 = Spi[pk3(k1, 1)], s2 = Spi[pk3(k1, 2)];
+            tmp[3 * k1 + c] = s0 * Nn[c] + s1 * Nn[3 + c] + s2 * Nn[6 + c];
+          }
+        int e = 0;
+#pragma unroll
+        for (int c1 = 0; c1 < 3; ++c1)
+#pragma unroll
+          for (int c2 = c1; c2 < 3; ++c2) t.pXi[e++] = Nn[c1] * tmp[c2] + Nn[3 + c1] * tmp[3 + c2] + Nn[6 + c1] * tmp[6 + c2];
+        put_wrench(t, t.pu0);
+      }
+    });
+    product_theta();
+    ex.par([&](Th &t) {
+      if (t.tid < NF) {   // P_s u0;  g = -q - P_s u0;  t = Xi g
+        double wy[3];
+        get_wrench(t, s.yw, wy);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          t.pPu[c] = (s.calpha * t.D[c] * t.D[c]) * t.pu0[c] + wy[c];
+          t.pg[c] = -t.q[c] - t.pPu[c];
+          t.pxN[c] = 0;
+        }
+        sym3_mul(t.pXi, t.pg, t.pt);                      // (Xi contains the projector N N^T)
+      }
+    });
+    lap(11);
+    factor_core<true>([](Th &t) { return t.pXi; });
+    ex.par([&](Th &t) { if (t.tid < NF) put_g(t, t.pt); });
+    lap(12);
+    for (int it = 0; it <= kPolishRefine; ++it) {
+      omega_apply();
+#ifdef MPC_EMU_DEBUG
+      if (dbg && it == 0) ex.par([&](Th &t) {
+        if (t.tid < NF) {
+          double *o = dbg + 38 * t.tid;
+          for (int r = 0; r < 5; ++r) o[r] = t.act[r];
+          for (int k = 0; k < 6; ++k) o[5 + k] = t.pXi[k];
+          for (int c = 0; c < 3; ++c) { o[11 + c] = t.pg[c]; o[14 + c] = t.pt[c]; o[17 + c] = t.pw[c]; }
+          for (int k = 0; k < 18; ++k) o[20 + k] = t.Gf[k];
+        }
+      });
+#endif
+      ex.par([&](Th &t) {
+        if (t.tid < NF) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { t.pxN[c] += t.pw[c]; t.pr[c] = kDelta * t.pw[c]; }
+          sym3_mul(t.pXi, t.pr, t.pt);
+          put_g(t, t.pt);
+        }
+      });
+    }
+    // P_s xN
+    ex.par([&](Th &t) { if (t.tid < NF) put_wrench(t, t.pxN); });
+    product_theta();
+    lap(13);
+    // x = u + xN ; y = A Gamma (g - P xN) on active rows ; z = A x ; normal-cone projection (proj.c:17-31)
+    ex.par([&](Th &t) {
+      if (t.tid < NF) {
+        double wy[3], pxn[3], gg[3], rwv[3], ax[5], ay[5];
+        get_wrench(t, s.yw, wy);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          pxn[c] = (s.calpha * t.D[c] * t.D[c]) * t.pxN[c] + wy[c];
+          t.xp[c] = t.pu0[c] + t.pxN[c];
+          gg[c] = t.pg[c] - pxn[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rwv[c] = t.pG[3 * c] * gg[0] + t.pG[3 * c + 1] * gg[1] + t.pG[3 * c + 2] * gg[2];
+        a_mul(t.a, rwv, ay);
+        a_mul(t.a, t.xp, ax);
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+          const double yv = t.act[r] ? ay[r] : 0.0;
+          const double tt = ax[r] + yv;
+          const double zc = clampd(tt, lo_at(t, r), t.up[r]);
+          t.zp[r] = zc;
+          t.yp[r] = tt - zc;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) t.pPu[c] += pxn[c];   // P_s x_pol
+      }
+    });
+    // residuals at the polished point, acceptance (polish.c:306-345)
+    const double pri0 = s.pri_res, dua0 = s.dua_res;
+    residuals([](Th &t) { return t.xp; }, [](Th &t) { return t.zp; }, [](Th &t) { return t.yp; }, [](Th &t) { return t.pPu; });
+    ex.par([&](Th &t) {
+      if (t.tid == 0) {
+        const double pri = bitsd(s.red[0]), dua = s.cinv * bitsd(s.red[6]);
+        const bool ok = !s.bad && ((pri < pri0 && dua < dua0) || (pri < pri0 && dua0 < 1e-10) || (dua < dua0 && pri0 < 1e-10));
+        s.status_polish = ok ? 1 : -1;
+        if (ok) { s.pri_res = pri; s.dua_res = dua; }
+      }
+    });
+    ex.par([&](Th &t) {
+      if (s.status_polish == 1 && t.tid < NF) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) t.x[c] = t.xp[c];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) { t.z[r] = t.zp[r]; t.y[r] = t.yp[r]; }
+      }
+    });
+  }
+  static constexpr MPC_HD int pk3(int r, int c) {   // packed symmetric 3 x 3: 00 01 02 11 12 22
+    return r <= c ? (r == 0 ? c : (r == 1 ? 2 + c : 5)) : (c == 0 ? r : (c == 1 ? 2 + r : 5));
+  }
+
+  // ================================ driver ======================================================================
+  MPC_HD void run() {
+    const long long t0 = MPC_CLOCK();
+    tlast = t0;
+    load();
+    set_rho_vec();
+    factor();
+    if (!s.first) mul_P([](Th &t) { return t.x; }, [](Th &t) { return t.px; });   // warm start: P_s x_0 once, then carried by recursion
+    lap(9);
+    admm_prepare();
+    lap(8);
+    // kCheck iterations between termination checks (osqp.c:417-517 checks when iter % 25 == 0)
+    static_assert(kMaxIter % kCheck == 0, "the check falls on the last iteration");
+    int iter = 0;
+    while (!s.done && !s.bad && iter < kMaxIter) {
+      for (int k = 0; k < kCheck; ++k) admm_iter();
+      iter += kCheck;
+      lap(8);
+      residuals([](Th &t) { return t.x; }, [](Th &t) { return t.z; }, [](Th &t) { return t.y; }, [](Th &t) { return t.px; });
+      check_and_adapt(iter);
+      lap(10);
+      if (!s.done && s.rho_new > 0) {          // osqp_update_rho: new rho_vec, refactor
+        ex.par([&](Th &t) { if (t.tid == 0) { s.rho = s.rho_new; s.rho_updates++; } });
+        set_rho_vec();
+        factor();
+        admm_prepare();
+        lap(8);
+      }
+    }
+    if (!s.done && !s.bad) {   // max_iter reached (osqp.c:564-568): only SOLVED counts for the reference
+      ex.par([&](Th &t) { if (t.tid == 0) s.status = kStMaxIter; });
+    }
+    if (s.status == kStSolved && !s.bad) polish();
+    lap(14);
+    tc[15] = MPC_CLOCK() - t0;
+    // outputs + persistent state (store_solution, auxil.c:528-561; mpc_osqp.cc:788-790: forces = -x).  A non-convex / non-finite
+    // problem has no solution: OSQP cold-starts the iterates (auxil.c:539-563) and keeps rho and the problem data.
+    ex.par([&](Th &t) {
+      const bool failed = s.bad || s.status == kStNonCvx;
+      const bool solved = s.status == kStSolved && !failed;
+      if (t.tid < NF) {
+        const int f = t.tid;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          if (solved) forces[3 * f + c] = -(t.D[c] * t.x[c]);
+          state[3 * f + c] = failed ? 0.0 : t.x[c];
+          state[N + 2 * M + 3 * f + c] = qp[C::QP_Q + 3 * f + c];
+        }
+#pragma unroll
+        for (int r = 0; r < 5; ++r) { state[N + 5 * f + r] = failed ? 0.0 : t.z[r]; state[N + M + 5 * f + r] = failed ? 0.0 : t.y[r]; }
+      }
+      if (t.tid == 0) {
+        state[2 * N + 2 * M] = s.rho;
+        state[2 * N + 2 * M + 1] = 1.0;
+        info[0] = s.iter; info[1] = s.bad ? kStNonCvx : s.status; info[2] = s.status_polish; info[3] = s.rho_updates;
+        info[4] = s.nfact; info[5] = s.first; info[6] = 0; info[7] = 0;
+        if (prof) for (int k = 0; k < kProfLen; ++k) if (k != 1 && k != 2) prof[k] = tc[k];   // (1, 2: the assembly kernel's)
+      }
+    });
+  }
+};
+
+}  // namespace mpc

@@ -3,6 +3,7 @@
 // all emulated threads sequentially (forward or reverse order: identical results are required, which
 // exposes intra-phase races).  Lets the CPU test-suite check the kernel's algorithm against the
 // oracle without a GPU.
+#define MPC_EMU_DEBUG 1
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -11,18 +12,19 @@
 #include "controller.h"
 #include "mpc_core.h"
 #include "mpc_model.h"
+#include "mpc_wrench.h"
 
 using namespace mpc;
 
-template <int H, int NTHREADS = Cfg<H>::T>
+template <class TH, int NTHREADS>
 struct HostExec {
-  std::vector<Thread<H>> th;
+  std::vector<TH> th;
   bool reverse;
   long phases = 0;
   explicit HostExec(bool rev) : th(NTHREADS), reverse(rev) {
     for (int i = 0; i < NTHREADS; ++i) {
+      std::memset((void *)&th[i], 0, sizeof(TH));
       th[i].init(i);
-      for (int j = 0; j < Cfg<H>::NT * Cfg<H>::TE; ++j) th[i].Mx[j] = 0;
     }
   }
   template <class F> void par(F &&f) {
@@ -30,31 +32,123 @@ struct HostExec {
     if (!reverse) for (int i = 0; i < NTHREADS; ++i) f(th[i]);
     else for (int i = NTHREADS - 1; i >= 0; --i) f(th[i]);
   }
-  void amax(unsigned long long *slot, double v) {
-    const unsigned long long b = dbits(v);
-    if (b > *slot) *slot = b;
-  }
 };
 
+// assembly kernel -> scaling kernel -> solve kernel of one robot (Pg: the P scratch, reused between robots)
 template <int H>
-static void solve_one(const RobotModel &mdl, const float *in, double *state, double *Pg, double *forces, int *info, bool reverse, long *phases) {
-  HostExec<H> ex(reverse);
-  Shared<H> *sh = new Shared<H>();
-  std::memset(sh, 0, sizeof(Shared<H>));
-  std::vector<double> qp(Cfg<H>::QP_LEN, 0.0);
+static void solve_one(const RobotModel &mdl, const float *in, double *state, double *Pg, double *forces, int *info, bool reverse, long *phases, double *dbg = nullptr) {
+  using C = Cfg<H>;
+  std::vector<double> qp(C::QP_LEN, 0.0), sc(C::SC_LEN, 0.0);
+  long ph = 0;
   {
     AsmShared<H> *as = new AsmShared<H>();
-    std::memset(as, 0, sizeof(AsmShared<H>));
-    HostExec<H, Cfg<H>::TA> exa(reverse);   // (the assembly kernel has its own workgroup size)
-    Assembler<H, HostExec<H, Cfg<H>::TA>> am{exa, *as, mdl, in, Pg, qp.data(), nullptr};
+    std::memset((void *)as, 0, sizeof(AsmShared<H>));
+    using Ex = HostExec<Thread<H>, C::TA>;   // (the assembly kernel has its own workgroup size)
+    Ex exa(reverse);
+    Assembler<H, Ex> am{exa, *as, mdl, in, Pg, qp.data(), nullptr};
     am.run();
-    ex.phases += exa.phases;
+    ph += exa.phases;
     delete as;
   }
-  Solver<H, HostExec<H>> sv{ex, *sh, mdl, state, Pg, qp.data(), forces, info, nullptr};
-  sv.run();
-  if (phases) *phases = ex.phases;
+  {
+    ScaleShared<H> *ss = new ScaleShared<H>();
+    std::memset((void *)ss, 0, sizeof(ScaleShared<H>));
+    using Ex = HostExec<Thread<H>, C::T>;
+    Ex exs(reverse);
+    Scaler<H, Ex> sk{exs, *ss, state, Pg, qp.data(), sc.data()};
+    sk.run();
+    ph += exs.phases;
+    delete ss;
+  }
+  {
+    Shared<H> *sh = new Shared<H>();
+    std::memset((void *)sh, 0, sizeof(Shared<H>));
+    using Ex = HostExec<WThread<H>, C::TW>;
+    Ex ex(reverse);
+    Solver<H, Ex> sv{ex, *sh, mdl, state, qp.data(), sc.data(), forces, info, nullptr};
+    sv.dbg = dbg;
+    sv.run();
+    ph += ex.phases;
+    delete sh;
+  }
+  if (phases) *phases = ph;
+}
+
+// ---- K-solve probe: x~ = K^{-1} b of the cold problem for a given rho, through the solver's own phases (factor + one product) ----
+template <int H>
+static void ksolve_one(const RobotModel &mdl, const float *in, double rho, const double *b, double *xt, double *sc_out) {
+  using C = Cfg<H>;
+  std::vector<double> qp(C::QP_LEN, 0.0), sc(C::SC_LEN, 0.0), state(state_len<H>(), 0.0), Pg(C::PG_LEN, 0.0), forces(C::N, 0.0);
+  int info[kInfoLen];
+  {
+    AsmShared<H> *as = new AsmShared<H>();
+    std::memset((void *)as, 0, sizeof(AsmShared<H>));
+    using Ex = HostExec<Thread<H>, C::TA>;
+    Ex exa(false);
+    Assembler<H, Ex> am{exa, *as, mdl, in, Pg.data(), qp.data(), nullptr};
+    am.run();
+    delete as;
+  }
+  {
+    ScaleShared<H> *ss = new ScaleShared<H>();
+    std::memset((void *)ss, 0, sizeof(ScaleShared<H>));
+    using Ex = HostExec<Thread<H>, C::T>;
+    Ex exs(false);
+    Scaler<H, Ex> sk{exs, *ss, state.data(), Pg.data(), qp.data(), sc.data()};
+    sk.run();
+    delete ss;
+  }
+  Shared<H> *sh = new Shared<H>();
+  std::memset((void *)sh, 0, sizeof(Shared<H>));
+  using Ex = HostExec<WThread<H>, C::TW>;
+  Ex ex(false);
+  Solver<H, Ex> sv{ex, *sh, mdl, state.data(), qp.data(), sc.data(), forces.data(), info, nullptr};
+  sv.load();
+  sh->rho = rho;
+  sv.set_rho_vec();
+  sv.factor();
+  ex.par([&](WThread<H> &t) {
+    if (t.tid < C::NF) {
+      double v[3];
+      for (int c = 0; c < 3; ++c) t.b[c] = b[3 * t.tid + c];
+      Solver<H, Ex>::sym3_mul(t.Si, t.b, v);
+      sv.put_g(t, v);
+    }
+  });
+  sv.product_held();
+  ex.par([&](WThread<H> &t) {
+    if (t.tid < C::NF) {
+      double wy[3], tt[3], o[3];
+      sv.get_g(t, sh->yw, wy);
+      for (int c = 0; c < 3; ++c) tt[c] = t.b[c] - wy[c];
+      Solver<H, Ex>::sym3_mul(t.Si, tt, o);
+      for (int c = 0; c < 3; ++c) xt[3 * t.tid + c] = o[c];
+    }
+  });
+  for (int i = 0; i < C::SC_LEN; ++i) sc_out[i] = sc[i];
   delete sh;
+}
+extern "C" {
+int emu_ksolve(int h, const double *model, double dt, double alpha, const float *in, double rho, const double *b, double *xt, double *sc_out) {
+  RobotModel mdl = make_model(model[0], model + 1, dt, alpha);
+  switch (h) {
+    case 10: ksolve_one<10>(mdl, in, rho, b, xt, sc_out); return 0;
+    case 16: ksolve_one<16>(mdl, in, rho, b, xt, sc_out); return 0;
+    case 20: ksolve_one<20>(mdl, in, rho, b, xt, sc_out); return 0;
+  }
+  return -1;
+}
+int emu_solve_debug(int h, const double *model, double dt, double alpha, const float *in, double *state, double *forces, int *info, double *dbg) {
+  RobotModel mdl = make_model(model[0], model + 1, dt, alpha);
+  std::vector<double> Pg((size_t)144 * h * h);
+  switch (h) {
+    case 10: solve_one<10>(mdl, in, state, Pg.data(), forces, info, false, nullptr, dbg); return 0;
+    case 16: solve_one<16>(mdl, in, state, Pg.data(), forces, info, false, nullptr, dbg); return 0;
+    case 20: solve_one<20>(mdl, in, state, Pg.data(), forces, info, false, nullptr, dbg); return 0;
+  }
+  return -1;
+}
+int emu_sc_len(int h) { return h == 10 ? Cfg<10>::SC_LEN : h == 16 ? Cfg<16>::SC_LEN : h == 20 ? Cfg<20>::SC_LEN : -1; }
 }
 
 extern "C" {
