@@ -25,9 +25,10 @@ using namespace mpc;
 #ifndef MPC_MIN_WAVES_MAX_T
 #define MPC_MIN_WAVES_MAX_T 256   // larger workgroups (h = 16), and the four-tiles-per-thread layout (h = 20), run one per CU
 #endif
-// waves per SIMD of the solve kernel (h = 10: one wave per robot; 2 -> 256 registers per lane, eight robots per CU)
+// waves per SIMD of the solve kernel (h = 10: one wave per robot).  1 -> the full 512-register budget (AGPRs as spill space), four
+// robots per CU: measured faster than two waves per SIMD at 256 registers, which spills to scratch memory
 #ifndef MPC_SOLVE_MIN_WAVES
-#define MPC_SOLVE_MIN_WAVES 2
+#define MPC_SOLVE_MIN_WAVES 1
 #endif
 
 namespace {
@@ -40,6 +41,16 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
     if (e_ != hipSuccess) return fail(MPC_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
+// A double moved between the lanes of a quad (lanes 4 q .. 4 q + 3) with DPP quad permutes: two v_mov_b32_dpp, no LDS.
+template <int CTRL>
+__device__ __forceinline__ double quad_perm(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+constexpr int quad_ctrl(int a, int b, int c, int d) { return a | (b << 2) | (c << 4) | (d << 6); }
+
 template <class TH>
 struct DeviceExec {
   TH &th;
@@ -47,6 +58,31 @@ struct DeviceExec {
   __device__ __forceinline__ void par(F &&f) {
     f(th);
     __syncthreads();   // (a single-wave workgroup -- the h = 10 solve kernel -- needs no s_barrier: the compiler drops it)
+  }
+  // a phase that hands nothing over through LDS (its results stay in registers or go to the quad operations below)
+  template <class F>
+  __device__ __forceinline__ void seq(F &&f) { f(th); }
+  // acc(th)[0 .. N) <- the sum over the four lanes of the quad, the same bits in every lane: (l0 + l1) + (l2 + l3)
+  template <int N, class A>
+  __device__ __forceinline__ void quad_allsum(A &&acc) {
+    double *v = acc(th);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const double a = v[i] + quad_perm<quad_ctrl(1, 0, 3, 2)>(v[i]);
+      v[i] = a + quad_perm<quad_ctrl(2, 3, 0, 1)>(a);
+    }
+  }
+  // dst(th)[r] <- src(lane r & 3 of the quad)[r >> 2], r = 0 .. 5
+  template <class S, class D>
+  __device__ __forceinline__ void quad_gather6(S &&src, D &&dst) {
+    const double *sv = src(th);
+    double *dv = dst(th);
+    dv[0] = quad_perm<quad_ctrl(0, 0, 0, 0)>(sv[0]);
+    dv[1] = quad_perm<quad_ctrl(1, 1, 1, 1)>(sv[0]);
+    dv[2] = quad_perm<quad_ctrl(2, 2, 2, 2)>(sv[0]);
+    dv[3] = quad_perm<quad_ctrl(3, 3, 3, 3)>(sv[0]);
+    dv[4] = quad_perm<quad_ctrl(0, 0, 0, 0)>(sv[1]);
+    dv[5] = quad_perm<quad_ctrl(1, 1, 1, 1)>(sv[1]);
   }
 };
 

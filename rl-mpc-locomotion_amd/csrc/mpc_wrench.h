@@ -42,13 +42,14 @@ struct WThread {
   // ---- tile lane (tid < MTW): my tile of the wrench grid
   int ti, tj;
   bool mact, dia;
-  double s2, nn;              // Theta_{ti,tj} = s2 th1 + nn diag(th2)
   double Mx[C::TE];
   // ---- foot lane (tid < NF): step tid / 4, foot tid % 4
   double x[3], px[3], z[5], y[5], b[3], xt[3];   // iterates, P_s x, the right-hand side, x~
-  double q[3], D[3], a[9], up[5], lo4, Si[6];    // scaled q, D, the 9 non-zeros of the scaled cone block, bounds, S^{-1}
-  double Gf[18];                                 // G_f = T_k W_f (6 x 3) of the current factorisation
-  int ty[5];                                     // row types: -1 loose, 0 inequality, 1 equality (auxil.c:79-96)
+  double q[3], Si[6];                            // scaled q, S^{-1}   (cone block and bounds: Shared::fa)
+  double w6[6];                                  // wrench exchange: my contribution out, the step's six numbers back
+  double gq[2], yq[2], dlq[2];                   // rows j and j + 4 of my step (j = tid & 3): g, y, diag(M)^-1/2
+  double zq[21];                                 // factorisation: W_f X_f W_f^T (packed lower triangle), then the step's sum
+  int tyb;                                       // row types, two bits per row: 0 loose, 1 inequality, 2 equality (auxil.c:79-96)
   // polish (foot lane)
   int act[5];
   double pG[9], pXi[6], pu0[3], pg[3], pr[3], pt[3], pxN[3], pPu[3], pw[3];
@@ -59,10 +60,6 @@ struct WThread {
     int r = 0;
     while ((r + 1) * (r + 2) / 2 <= id) ++r;
     ti = r; tj = id - r * (r + 1) / 2; dia = ti == tj;
-    double acc = 0;
-    for (int sidx = ti; sidx < H; ++sidx) acc += (sidx - ti + 0.5) * (sidx - tj + 0.5);
-    s2 = mact ? acc : 0.0;
-    nn = mact ? (double)(H - ti) : 0.0;
   }
 };
 
@@ -71,20 +68,20 @@ template <int H>
 struct Shared {
   using C = Cfg<H>;
   static constexpr int RW = ((C::NF + 1) & ~1);                         // row stride of the residual scratch
-  static constexpr int PARTLEN_A = C::GW * C::NPW, PARTLEN_B = 14 * RW, PARTLEN_C = C::NF * 22;
-  static constexpr int PARTLEN = PARTLEN_A > PARTLEN_B ? (PARTLEN_A > PARTLEN_C ? PARTLEN_A : PARTLEN_C) : (PARTLEN_B > PARTLEN_C ? PARTLEN_B : PARTLEN_C);
+  static constexpr int PARTLEN_A = C::GW * C::NPW, PARTLEN_B = 14 * RW;
+  static constexpr int PARTLEN = PARTLEN_A > PARTLEN_B ? PARTLEN_A : PARTLEN_B;
   MPC_V B6[72]; MPC_V th1[36]; MPC_V th2[8];
   double c, cinv, rho, calpha;
   double rho3[4], rinv3[4];                             // rho and 1 / rho of a loose / inequality / equality row (index type + 1)
-  MPC_V gp[C::NF * 6];                                  // per foot: W_f v_f
-  MPC_V g[C::NW + 2]; MPC_V gh[C::NW + 2]; MPC_V yw[C::NW + 2]; MPC_V dl[C::NW + 2];   // dl = diag(M)^-1/2, gh = dl g
-  MPC_V Lk[H * 36]; MPC_V Tk[H * 36];                   // per step: Z_k = L L^T, T = L^-1 (zero columns / rows at dropped pivots)
+  MPC_V gh[C::NW + 2]; MPC_V dl[C::NW + 2];             // the tile product's input (dl g, or g for Theta products); dl = diag(M)^-1/2
+  MPC_V fa[C::NF * 15];                                 // per foot: the 9 non-zeros of the scaled cone block, l of row 4, u of the five rows
+  MPC_V Gf[C::NF * 18];                                 // per foot: G_f = T_k W_f (6 x 3) of the current factorisation
   MPC_V prow_raw[2][C::NW + 2];
   MPC_HD double *prow(int b) { return prow_raw[b] + MPC_PROW_SKEW; }
   MPC_V piv[2][2];
   union {
     MPC_V part[PARTLEN];                                // [slot][row] partial products of the tile mat-vec; residual scratch [14][RW]
-    MPC_V zf[C::NF * 22];                               // per foot: W_f S_f^{-1} W_f^T, packed lower triangle (factorisation only)
+    struct { MPC_V Lk[H * 36]; MPC_V Tk[H * 36]; };     // factorisation only: per step Z_k = L L^T, T = L^-1 (zero columns / rows at dropped pivots)
   };
   unsigned long long red[16];
   int first, iter, status, status_polish, rho_updates, nfact, done, bad;
@@ -130,15 +127,20 @@ struct Solver {
     return 1.0 / d;
 #endif
   }
-  MPC_HD double rho_at(int ty) const {
-    double r0 = s.rho3[0], r1 = s.rho3[1], r2 = s.rho3[2];
-    MPC_LAUNDER(r0); MPC_LAUNDER(r1); MPC_LAUNDER(r2);
-    return ty == 1 ? r2 : (ty == 0 ? r1 : r0);
+  // Theta_{ti,tj} = s2 th1 + nn diag(th2):  s2 = sum_{i < m} (i + 1/2)(i + d + 1/2) = m (4 m^2 - 1) / 12 + d m^2 / 2,  nn = m = H - ti,  d = ti - tj
+  static MPC_HD double th_nn(const Th &t) { return (double)(H - t.ti); }
+  static MPC_HD double th_s2(const Th &t) { const double m = (double)(H - t.ti), d = (double)(t.ti - t.tj); return m * (4.0 * m * m - 1.0) / 12.0 + d * (m * m) * 0.5; }
+  MPC_HD double Dat(const Th &t, int c) const { return sc[C::SC_D + 3 * t.tid + c]; }   // D of my variables (scale record; not worth registers)
+  // rho / 1 / rho of row r of my foot (three uniform values, selected by the row's type code)
+  MPC_HD double rho_at(const Th &t, int r) const {
+    const int ty = (t.tyb >> (2 * r)) & 3;
+    const double r0 = s.rho3[0], r1 = s.rho3[1], r2 = s.rho3[2];
+    return ty == 2 ? r2 : (ty == 1 ? r1 : r0);
   }
-  MPC_HD double rinv_at(int ty) const {
-    double r0 = s.rinv3[0], r1 = s.rinv3[1], r2 = s.rinv3[2];
-    MPC_LAUNDER(r0); MPC_LAUNDER(r1); MPC_LAUNDER(r2);
-    return ty == 1 ? r2 : (ty == 0 ? r1 : r0);
+  MPC_HD double rinv_at(const Th &t, int r) const {
+    const int ty = (t.tyb >> (2 * r)) & 3;
+    const double r0 = s.rinv3[0], r1 = s.rinv3[1], r2 = s.rinv3[2];
+    return ty == 2 ? r2 : (ty == 1 ? r1 : r0);
   }
   // ---- the scaled cone block of a foot: rows (a0, 0, a1) (a2, 0, a3) (0, a4, a5) (0, a6, a7) (0, 0, a8)  (mpc_osqp.cc:437-447) ----
   static MPC_HD void a_mul(const double *a, const double *v, double *out) {      // out[5] = A_f v
@@ -183,32 +185,27 @@ struct Solver {
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) w[3 * r + c] = s.B6[12 * r + 3 * j + c] * t.D[c];
+      for (int c = 0; c < 3; ++c) w[3 * r + c] = s.B6[12 * r + 3 * j + c] * Dat(t, c);
   }
-  // gp[f] = W_f v
-  MPC_HD void put_wrench(const Th &t, const double *v) {
+  // t.w6 = W_f v  (my contribution to the step's wrench)
+  MPC_HD void put_wrench(Th &t, const double *v) const {
     double w[18];
     foot_w(t, w);
-    double *o = s.gp + 6 * t.tid;
 #pragma unroll
-    for (int r = 0; r < 6; ++r) o[r] = w[3 * r] * v[0] + w[3 * r + 1] * v[1] + w[3 * r + 2] * v[2];
+    for (int r = 0; r < 6; ++r) t.w6[r] = w[3 * r] * v[0] + w[3 * r + 1] * v[1] + w[3 * r + 2] * v[2];
   }
-  // out[3] = W_f^T y_k   (y of my step)
-  MPC_HD void get_wrench(const Th &t, const double *yv, double *out) const {
-    double w[18], yk[6];
+  // out[3] = W_f^T y_k   (y of my step: t.w6 after recv)
+  MPC_HD void get_wrench(const Th &t, double *out) const {
+    double w[18];
     foot_w(t, w);
-    const double *yp = yv + 6 * (t.tid >> 2);
-#pragma unroll
-    for (int r = 0; r < 6; ++r) yk[r] = yp[r];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       double acc = 0;
 #pragma unroll
-      for (int r = 0; r < 6; ++r) acc += w[3 * r + c] * yk[r];
+      for (int r = 0; r < 6; ++r) acc += w[3 * r + c] * t.w6[r];
       out[c] = acc;
     }
   }
-
   // out = T_k w  (T lower triangular, w 6 x 3)
   MPC_HD void mul_tk(const Th &t, const double *w, double *out) const {
     const double *tk = s.Tk + 36 * (t.tid >> 2);
@@ -225,44 +222,44 @@ struct Solver {
 #pragma unroll
     for (int k = 0; k < 18; ++k) out[k] = o[k];
   }
-  // the same with the factorisation's G_f = T_k W_f (registers): gp[f] = G_f v,  out = G_f^T y_k
-  MPC_HD void put_g(const Th &t, const double *v) {
-    double *o = s.gp + 6 * t.tid;
+  // the same with the factorisation's G_f = T_k W_f: t.w6 = G_f v,  out = G_f^T y_k.  G_f sits in LDS and is fetched where it
+  // is used (volatile 64-bit loads, see foot_a: 36 VGPRs the iteration loop does not have)
+  MPC_HD void load_g(const Th &t, double *gf) const {
 #pragma unroll
-    for (int r = 0; r < 6; ++r) o[r] = t.Gf[3 * r] * v[0] + t.Gf[3 * r + 1] * v[1] + t.Gf[3 * r + 2] * v[2];
+    for (int k = 0; k < 18; ++k) gf[k] = MPC_LDS_LOAD64(s.Gf + NF * k + t.tid);
   }
-  MPC_HD void get_g(const Th &t, const double *yv, double *out) const {
-    double yk[6];
-    const double *yp = yv + 6 * (t.tid >> 2);
+  MPC_HD void put_g(Th &t, const double *v) const {
+    double gf[18];
+    load_g(t, gf);
 #pragma unroll
-    for (int r = 0; r < 6; ++r) yk[r] = yp[r];
+    for (int r = 0; r < 6; ++r) t.w6[r] = gf[3 * r] * v[0] + gf[3 * r + 1] * v[1] + gf[3 * r + 2] * v[2];
+  }
+  MPC_HD void get_g(const Th &t, double *out) const {
+    double gf[18];
+    load_g(t, gf);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       double acc = 0;
 #pragma unroll
-      for (int r = 0; r < 6; ++r) acc += t.Gf[3 * r + c] * yk[r];
+      for (int r = 0; r < 6; ++r) acc += gf[3 * r + c] * t.w6[r];
       out[c] = acc;
     }
   }
 
-  // ---- wrench-space products: gp --(G)--> g --(tile product)--> part --(combine)--> out -----------------------------
-  MPC_HD void phase_G() {
-    ex.par([&](Th &t) {
-      if (t.tid < NW) {
-        const int k = t.tid / 6, r = t.tid - 6 * k;
-        const double *p = s.gp + 24 * k + r;
-        const double gv = ((p[0] + p[6]) + p[12]) + p[18];
-        s.g[t.tid] = gv;
-        s.gh[t.tid] = s.dl[t.tid] * gv;
-      }
-    });
-  }
+  // ---- wrench-space products.  The four feet of a step are the four lanes of a quad, so the step's sums and broadcasts are
+  // register operations (DPP quad permutes, Exec::quad_allsum / quad_gather6): no LDS round trip.  Lane j of the quad owns rows
+  // j and j + 4 (< 6) of its step.
+  //   send:  t.w6 (per foot) -> g_k = sum over the quad; the row owners publish the tile product's input to LDS
+  //   tile_product: part <- tile partials                                   (the only phase with an LDS hand-over)
+  //   recv:  the row owners combine their rows, the quad gathers all six -> t.w6 = (result)_k
   enum { kHeld = 0, kTheta = 1 };
   // part <- partial products of the tile with v, both orientations (tile (i, j), j < i, stands for itself and its transpose)
   template <int KIND>
-  MPC_HD void tile_product(const double *v) {
+  MPC_HD void tile_product() {
+    const double *v = s.gh;
     ex.par([&](Th &t) {
       if (t.mact) {
+        const double s2v = th_s2(t), nnv = th_nn(t);
         double vc[TS], vr[TS], ar[TS], ac[TS];
 #pragma unroll
         for (int bb = 0; bb < TS; ++bb) { vc[bb] = v[TS * t.tj + bb]; vr[bb] = v[TS * t.ti + bb]; ar[bb] = 0; ac[bb] = 0; }
@@ -272,7 +269,7 @@ struct Solver {
           for (int bb = 0; bb < TS; ++bb) {
             double m;
             if (KIND == kHeld) m = t.Mx[aa * TS + bb];
-            else m = s.c * (t.s2 * s.th1[aa * TS + bb] + (aa == bb ? t.nn * s.th2[aa] : 0.0));
+            else m = s.c * (s2v * s.th1[aa * TS + bb] + (aa == bb ? nnv * s.th2[aa] : 0.0));
             ar[aa] += m * vc[bb];
             ac[bb] += m * vr[aa];
           }
@@ -296,21 +293,42 @@ struct Solver {
       for (int k = 0; k + w < G; k += 2 * w) v[k] = v[k] + v[k + w];
     return v[0];
   }
-  MPC_HD void combine(double *out) {
-    ex.par([&](Th &t) { if (t.tid < NW) out[t.tid] = sum_parts(s, t.tid); });
+  // KIND = kHeld: the tiles hold -Mh^-1 (+2 on the diagonal, see sweep_all) of the unit-diagonal Mh = dl M dl, and the result is
+  // (I - M^-1) g = g - dl Mh^-1 (dl g).  KIND = kTheta: c Theta g.
+  template <int KIND>
+  MPC_HD void send() {
+    ex.template quad_allsum<6>([](Th &t) { return t.w6; });
+    ex.par([&](Th &t) {
+      if (t.tid < NF) {
+        const int k = t.tid >> 2, j = t.tid & 3;
+        const double g0 = j == 0 ? t.w6[0] : (j == 1 ? t.w6[1] : (j == 2 ? t.w6[2] : t.w6[3]));
+        const double g1 = j == 0 ? t.w6[4] : t.w6[5];
+        t.gq[0] = g0; t.gq[1] = g1;
+        s.gh[6 * k + j] = KIND == kHeld ? t.dlq[0] * g0 : g0;
+        if (j < 2) s.gh[6 * k + 4 + j] = KIND == kHeld ? t.dlq[1] * g1 : g1;
+      }
+    });
   }
-  // yw <- (I - M^-1) g,  g = sum of the foot partials gp.  The tiles hold -Mh^-1 (+2 on the diagonal, see sweep_all) of the
-  // unit-diagonal Mh = dl M dl, so (I - M^-1) g = g - dl Mh^-1 (dl g).
-  MPC_HD void product_held() {
-    phase_G();
-    tile_product<kHeld>(s.gh);
-    ex.par([&](Th &t) { if (t.tid < NW) s.yw[t.tid] = s.g[t.tid] - s.dl[t.tid] * (2.0 * s.gh[t.tid] - sum_parts(s, t.tid)); });
+  template <int KIND>
+  MPC_HD void recv() {
+    ex.seq([&](Th &t) {
+      if (t.tid < NF) {
+        const int k = t.tid >> 2, j = t.tid & 3;
+        const double s0 = sum_parts(s, 6 * k + j), s1 = sum_parts(s, 6 * k + 4 + (j & 1));   // (lanes 2, 3 have no second row: ignored)
+        if (KIND == kHeld) {
+          t.yq[0] = t.gq[0] - t.dlq[0] * (2.0 * (t.dlq[0] * t.gq[0]) - s0);
+          t.yq[1] = t.gq[1] - t.dlq[1] * (2.0 * (t.dlq[1] * t.gq[1]) - s1);
+        } else { t.yq[0] = s0; t.yq[1] = s1; }
+      }
+    });
+    ex.quad_gather6([](Th &t) { return t.yq; }, [](Th &t) { return t.w6; });
   }
-  // yw <- c Theta * (sum of the foot partials gp)
-  MPC_HD void product_theta() {
-    phase_G();
-    tile_product<kTheta>(s.g);
-    combine(s.yw);
+  // t.w6 <- (I - M^-1) (sum of the foot contributions t.w6)   /   c Theta (...)
+  template <int KIND>
+  MPC_HD void product() {
+    send<KIND>();
+    tile_product<KIND>();
+    recv<KIND>();
   }
 
   // ================================ 1. load ======================================================================
@@ -322,18 +340,22 @@ struct Solver {
       if (t.tid < NF) {
         const int f = t.tid;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { t.x[c] = state[3 * f + c]; t.q[c] = sc[C::SC_QS + 3 * f + c]; t.D[c] = sc[C::SC_D + 3 * f + c]; t.px[c] = 0; }
+        for (int c = 0; c < 3; ++c) { t.x[c] = state[3 * f + c]; t.q[c] = sc[C::SC_QS + 3 * f + c]; }
         const double *as = sc + C::SC_AS + 15 * f;
-        t.a[0] = as[0]; t.a[1] = as[2]; t.a[2] = as[3]; t.a[3] = as[5]; t.a[4] = as[7]; t.a[5] = as[8]; t.a[6] = as[10]; t.a[7] = as[11]; t.a[8] = as[14];
+        double *fa = s.fa + f;   // element k of my foot: fa[NF * k]  (consecutive lanes, consecutive banks)
+        fa[0] = as[0]; fa[NF] = as[2]; fa[2 * NF] = as[3]; fa[3 * NF] = as[5]; fa[4 * NF] = as[7]; fa[5 * NF] = as[8]; fa[6 * NF] = as[10]; fa[7 * NF] = as[11]; fa[8 * NF] = as[14];
+        int tyb = 0;
 #pragma unroll
         for (int r = 0; r < 5; ++r) {
           t.z[r] = state[N + 5 * f + r]; t.y[r] = state[N + M + 5 * f + r];   // scaled iterates of the previous call; zeros on the first call
           const double lo = sc[C::SC_LS + 5 * f + r], hi = sc[C::SC_US + 5 * f + r];
-          t.up[r] = hi;
-          if (r == 4) t.lo4 = lo;
+          fa[NF * (10 + r)] = hi;
+          if (r == 4) fa[NF * 9] = lo;
           // set_rho_vec / update_rho_vec (auxil.c:79-141): the row type is a function of the scaled bounds
-          t.ty[r] = (lo < -kInfty * kMinScaling && hi > kInfty * kMinScaling) ? -1 : (hi - lo < kRhoTol ? 1 : 0);
+          const int ty = (lo < -kInfty * kMinScaling && hi > kInfty * kMinScaling) ? 0 : (hi - lo < kRhoTol ? 2 : 1);
+          tyb |= ty << (2 * r);
         }
+        t.tyb = tyb;
       }
       if (t.tid == 0) {
         const bool first = state[2 * N + 2 * M + 1] == 0.0;
@@ -345,7 +367,19 @@ struct Solver {
     });
     lap(0);
   }
-  MPC_HD double lo_at(const Th &t, int r) const { return r == 4 ? t.lo4 : 0.0; }   // rows 0-3 have l = 0 (mpc_osqp.cc:449-477)
+  // my foot's constants, fetched where they are used (volatile 64-bit LDS loads: the compiler neither hoists them out of the
+  // iteration loop nor keeps them in registers across it -- 30 VGPRs the loop does not have)
+  MPC_HD void foot_a(const Th &t, double *a) const {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a[k] = MPC_LDS_LOAD64(s.fa + NF * k + t.tid);
+  }
+  MPC_HD void foot_bounds(const Th &t, double *lo, double *up) const {   // rows 0-3 have l = 0 (mpc_osqp.cc:449-477)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lo[r] = 0.0;
+    lo[4] = MPC_LDS_LOAD64(s.fa + NF * 9 + t.tid);
+#pragma unroll
+    for (int r = 0; r < 5; ++r) up[r] = MPC_LDS_LOAD64(s.fa + NF * (10 + r) + t.tid);
+  }
 
   MPC_HD void set_rho_vec() {   // rho per row type (auxil.c:79-96, osqp.c:1267-1310)
     ex.par([&](Th &t) {
@@ -383,21 +417,15 @@ struct Solver {
     }
   }
 
-  // per foot: zf <- w X w^T for a symmetric 3 x 3 X (packed) and a 6 x 3 map w (W_f, or G_f in the second orthogonalisation pass)
-  MPC_HD void put_zf(const Th &t, const double *X, const double *w) {
+  // per foot: t.zq <- w X w^T for a symmetric 3 x 3 X (packed) and a 6 x 3 map w (W_f, or G_f in the second orthogonalisation pass)
+  MPC_HD void put_zf(Th &t, const double *X, const double *w) const {
     double v[18];
 #pragma unroll
     for (int r = 0; r < 6; ++r) sym3_mul(X, w + 3 * r, v + 3 * r);   // V = W X (X symmetric)
-    double *o = s.zf + 22 * t.tid;
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
-      for (int c = 0; c <= r; ++c) o[pk(r, c)] = v[3 * r] * w[3 * c] + v[3 * r + 1] * w[3 * c + 1] + v[3 * r + 2] * w[3 * c + 2];
-  }
-  MPC_HD void sum_zf(int k, double *zz) const {
-    const double *p = s.zf + 88 * k;
-#pragma unroll
-    for (int e = 0; e < 21; ++e) zz[e] = ((p[e] + p[22 + e]) + p[44 + e]) + p[66 + e];
+      for (int c = 0; c <= r; ++c) t.zq[pk(r, c)] = v[3 * r] * w[3 * c] + v[3 * r + 1] * w[3 * c + 1] + v[3 * r + 2] * w[3 * c + 2];
   }
 
   // ================================ 2. factorisation: Mx <- -Mh^-1,  Mh = dl (I + L^T (c Theta) L) dl =================
@@ -413,15 +441,17 @@ struct Solver {
     return 1.0 / sqrt(d);
 #endif
   }
-  // One orthogonalisation pass on the step lanes: Z_k = sum of the foot contributions zf = L_u D L_u^T (dependent rows dropped);
+  // One orthogonalisation pass (lane 0 of every quad): Z_k = sum of the feet's t.zq = L_u D L_u^T (dependent rows dropped);
   // FIRST: L = L_u D^1/2, T = D^-1/2 L_u^-1 -> Lk, Tk.  Second pass (Z_k is then G Xi G^T = I up to the first pass's loss of
   // orthogonality, eps cond(Z)): L <- L L2, and T2 -> Tk for the foot lanes to update G <- T2 G.
   template <bool FIRST>
   MPC_HD void step_factor() {
+    ex.template quad_allsum<21>([](Th &t) { return t.zq; });
     ex.par([&](Th &t) {
-      if (t.tid < H) {
-        double zz[21], l[21], d[6], li[21];
-        sum_zf(t.tid, zz);
+      if (t.tid < NF && (t.tid & 3) == 0) {
+        const int kk = t.tid >> 2;
+        const double *zz = t.zq;
+        double l[21], d[6], li[21];
         if (FIRST) {
           double mxd = 0;
 #pragma unroll
@@ -447,7 +477,7 @@ struct Solver {
           si[j] = ok ? fast_rsqrt(ok ? d[j] : 1.0) : 0.0;
           sd[j] = ok ? d[j] * si[j] : 0.0;
         }
-        double *ol = s.Lk + 36 * t.tid, *ot = s.Tk + 36 * t.tid;
+        double *ol = s.Lk + 36 * kk, *ot = s.Tk + 36 * kk;
         if (FIRST) {
 #pragma unroll
           for (int i = 0; i < 6; ++i)
@@ -481,7 +511,7 @@ struct Solver {
   // orthogonality of a single pass by 1e6), the ADMM system does not (measured: tests/test_emulated_kernel.py).
   template <bool TWO_PASS, class XS>
   MPC_HD void factor_core(XS &&xs) {
-    ex.par([&](Th &t) {
+    ex.seq([&](Th &t) {
       if (t.tid < NF) {
         double w[18];
         foot_w(t, w);
@@ -490,45 +520,53 @@ struct Solver {
     });
     step_factor<true>();
     if (TWO_PASS) {
-      ex.par([&](Th &t) {
-        if (t.tid < NF) {   // G1 = T1 W;  zf <- G1 X G1^T
-          double w[18];
+      ex.seq([&](Th &t) {
+        if (t.tid < NF) {   // G1 = T1 W;  zq <- G1 X G1^T
+          double w[18], g1[18];
           foot_w(t, w);
-          mul_tk(t, w, t.Gf);
-          put_zf(t, xs(t), t.Gf);
+          mul_tk(t, w, g1);
+          put_zf(t, xs(t), g1);
+#pragma unroll
+          for (int k = 0; k < 18; ++k) s.Gf[NF * k + t.tid] = g1[k];
         }
       });
       step_factor<false>();
     }
     ex.par([&](Th &t) {
       if (t.tid < NF) {   // G_f = T_k W_f  (second pass: T2 G1)
-        double w[18];
-        if (TWO_PASS) {
+        double w[18], gf[18];
+        if (TWO_PASS) load_g(t, w);
+        else foot_w(t, w);
+        mul_tk(t, w, gf);
 #pragma unroll
-          for (int k = 0; k < 18; ++k) w[k] = t.Gf[k];
-        } else foot_w(t, w);
-        mul_tk(t, w, t.Gf);
-      }
-      if (t.tid < NW) {   // dl = diag(M)^-1/2,  M_rr = 1 + l_r^T (c Theta_kk) l_r  (l_r: column r of L_k)
-        const int k = t.tid / 6, r = t.tid - 6 * k;
+        for (int k = 0; k < 18; ++k) s.Gf[NF * k + t.tid] = gf[k];
+        // dl = diag(M)^-1/2 of my rows,  M_rr = 1 + l_r^T (c Theta_kk) l_r  (l_r: column r of L_k)
+        const int k = t.tid >> 2, j = t.tid & 3;
         const double mm = (double)(H - k), s2kk = mm * (4.0 * mm * mm - 1.0) / 12.0;   // sum_{i < m} (i + 1/2)^2
         const double *lk = s.Lk + 36 * k;
-        double lc[TS];
 #pragma unroll
-        for (int a = 0; a < TS; ++a) lc[a] = lk[6 * a + r];
-        double acc = 0;
+        for (int slot = 0; slot < 2; ++slot) {
+          const int r = slot == 0 ? j : 4 + (j & 1);
+          double lc[TS];
 #pragma unroll
-        for (int a = 0; a < TS; ++a) {
-          double row = 0;
+          for (int a = 0; a < TS; ++a) lc[a] = lk[6 * a + r];
+          double acc = 0;
 #pragma unroll
-          for (int bb = 0; bb < TS; ++bb) row += (s2kk * s.th1[a * TS + bb] + (a == bb ? mm * s.th2[a] : 0.0)) * lc[bb];
-          acc += lc[a] * row;
+          for (int a = 0; a < TS; ++a) {
+            double row = 0;
+#pragma unroll
+            for (int bb = 0; bb < TS; ++bb) row += (s2kk * s.th1[a * TS + bb] + (a == bb ? mm * s.th2[a] : 0.0)) * lc[bb];
+            acc += lc[a] * row;
+          }
+          const double dv = fast_rsqrt(1.0 + s.c * acc);
+          t.dlq[slot] = dv;
+          if (slot == 0 || j < 2) s.dl[6 * k + r] = dv;
         }
-        s.dl[t.tid] = fast_rsqrt(1.0 + s.c * acc);
       }
     });
     ex.par([&](Th &t) {
       if (t.mact) {   // Mh tile = dl_i ([i == j] I + L_i^T (c Theta_ij) L_j) dl_j   (L lower triangular); unit diagonal
+        const double s2v = th_s2(t), nnv = th_nn(t);
         const double *li = s.Lk + 36 * t.ti, *lj = s.Lk + 36 * t.tj, *di = s.dl + 6 * t.ti, *dj = s.dl + 6 * t.tj;
         double t1[TE];
 #pragma unroll
@@ -537,7 +575,7 @@ struct Solver {
           for (int bb = 0; bb < TS; ++bb) {
             double v = 0;
 #pragma unroll
-            for (int k = bb; k < TS; ++k) v += (s.c * (t.s2 * s.th1[aa * TS + k] + (aa == k ? t.nn * s.th2[aa] : 0.0))) * lj[k * TS + bb];
+            for (int k = bb; k < TS; ++k) v += (s.c * (s2v * s.th1[aa * TS + k] + (aa == k ? nnv * s.th2[aa] : 0.0))) * lj[k * TS + bb];
             t1[aa * TS + bb] = v;
           }
 #pragma unroll
@@ -561,15 +599,16 @@ struct Solver {
       if (t.tid < NF) {   // S_f = c alpha D^2 + sigma I + A_f^T R A_f  ->  S_f^-1
         double rv[5];
 #pragma unroll
-        for (int r = 0; r < 5; ++r) rv[r] = rho_at(t.ty[r]);
-        const double *a = t.a;
+        for (int r = 0; r < 5; ++r) rv[r] = rho_at(t, r);
+        double a[9];
+        foot_a(t, a);
         double S[6];
-        S[0] = (s.calpha * t.D[0] * t.D[0] + kSigma) + (rv[0] * a[0] * a[0] + rv[1] * a[2] * a[2]);
+        S[0] = (s.calpha * Dat(t, 0) * Dat(t, 0) + kSigma) + (rv[0] * a[0] * a[0] + rv[1] * a[2] * a[2]);
         S[1] = 0.0;
         S[2] = rv[0] * a[0] * a[1] + rv[1] * a[2] * a[3];
-        S[3] = (s.calpha * t.D[1] * t.D[1] + kSigma) + (rv[2] * a[4] * a[4] + rv[3] * a[6] * a[6]);
+        S[3] = (s.calpha * Dat(t, 1) * Dat(t, 1) + kSigma) + (rv[2] * a[4] * a[4] + rv[3] * a[6] * a[6]);
         S[4] = rv[2] * a[4] * a[5] + rv[3] * a[6] * a[7];
-        S[5] = (s.calpha * t.D[2] * t.D[2] + kSigma) + ((((rv[0] * a[1] * a[1] + rv[1] * a[3] * a[3]) + rv[2] * a[5] * a[5]) + rv[3] * a[7] * a[7]) + rv[4] * a[8] * a[8]);
+        S[5] = (s.calpha * Dat(t, 2) * Dat(t, 2) + kSigma) + ((((rv[0] * a[1] * a[1] + rv[1] * a[3] * a[3]) + rv[2] * a[5] * a[5]) + rv[3] * a[7] * a[7]) + rv[4] * a[8] * a[8]);
         sym3_inv(S, t.Si);
       }
     });
@@ -649,48 +688,49 @@ struct Solver {
   // ================================ 3. ADMM (auxil.c:164-228) ====================================================
   // b = sigma x - q + A^T (R z - y);  v = S^-1 b;  gp = G v
   MPC_HD void foot_rhs(Th &t) {
-    double tm[5], acc[3], v[3];
+    double tm[5], acc[3], v[3], a[9];
+    foot_a(t, a);
 #pragma unroll
-    for (int r = 0; r < 5; ++r) tm[r] = rho_at(t.ty[r]) * t.z[r] - t.y[r];
-    at_mul(t.a, tm, acc);
+    for (int r = 0; r < 5; ++r) tm[r] = rho_at(t, r) * t.z[r] - t.y[r];
+    at_mul(a, tm, acc);
 #pragma unroll
     for (int c = 0; c < 3; ++c) t.b[c] = kSigma * t.x[c] - t.q[c] + acc[c];
     sym3_mul(t.Si, t.b, v);
     put_g(t, v);
   }
   MPC_HD void admm_prepare() {
-    ex.par([&](Th &t) { if (t.tid < NF) foot_rhs(t); });
+    ex.seq([&](Th &t) { if (t.tid < NF) foot_rhs(t); });
+    send<kHeld>();
   }
-  // One ADMM iteration: the wrench product (three short phases) and the foot phase, which finishes the KKT solve
-  //   x~ = S^-1 (b - G^T y_w),  z~ = A x~,  updates x, z, y (relaxation 1.6), carries P_s x by recursion, and prepares the next
-  // right-hand side.
+  // One ADMM iteration = two phases: the tile product, and the foot phase, which finishes the KKT solve
+  //   x~ = S^-1 (b - G^T y_w),  z~ = A x~,  updates x, z, y (relaxation 1.6), prepares the next
+  // right-hand side and hands its wrench contribution to the quad.
   MPC_HD void admm_iter() {
-    product_held();
-    ex.par([&](Th &t) {
+    tile_product<kHeld>();
+    recv<kHeld>();
+    ex.seq([&](Th &t) {
       if (t.tid < NF) {
-        double wy[3], tt[3], zt[5], tm[5], rzt[5], acc[3], arz[3];
-        get_g(t, s.yw, wy);
+        double wy[3], tt[3], zt[5], tm[5], acc[3], a[9], lo[5], up[5];
+        get_g(t, wy);
 #pragma unroll
         for (int c = 0; c < 3; ++c) tt[c] = t.b[c] - wy[c];
         sym3_mul(t.Si, tt, t.xt);
-        a_mul(t.a, t.xt, zt);
+        foot_a(t, a);
+        foot_bounds(t, lo, up);
+        a_mul(a, t.xt, zt);
 #pragma unroll
         for (int r = 0; r < 5; ++r) {
-          const double rv = rho_at(t.ty[r]), ri = rinv_at(t.ty[r]);
+          const double rv = rho_at(t, r), ri = rinv_at(t, r);
           const double zr = kAlphaRelax * zt[r] + (1.0 - kAlphaRelax) * t.z[r];
-          const double zn = clampd(zr + ri * t.y[r], lo_at(t, r), t.up[r]);
+          const double zn = clampd(zr + ri * t.y[r], lo[r], up[r]);
           const double yn = t.y[r] + rv * (zr - zn);
           t.z[r] = zn;
           t.y[r] = yn;
           tm[r] = rv * zn - yn;
-          rzt[r] = rv * zt[r];
         }
-        at_mul(t.a, tm, acc);
-        at_mul(t.a, rzt, arz);
+        at_mul(a, tm, acc);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          // P_s x without a matrix product: K x~ = b gives P_s x~ = b - sigma x~ - A^T R z~, and x is affine in x~
-          t.px[c] = kAlphaRelax * (t.b[c] - kSigma * t.xt[c] - arz[c]) + (1.0 - kAlphaRelax) * t.px[c];
           const double xn = kAlphaRelax * t.xt[c] + (1.0 - kAlphaRelax) * t.x[c];
           t.x[c] = xn;
           t.b[c] = kSigma * xn - t.q[c] + acc[c];
@@ -700,21 +740,22 @@ struct Solver {
         put_g(t, v);
       }
     });
+    send<kHeld>();
   }
 
   // P_s v for a per-foot vector given by sel(t): out = c alpha D^2 v + W^T (c Theta (W v)).  `in` and `out` are members of Th.
   template <class In, class Out>
   MPC_HD void mul_P(In &&in, Out &&out) {
-    ex.par([&](Th &t) { if (t.tid < NF) put_wrench(t, in(t)); });
-    product_theta();
-    ex.par([&](Th &t) {
+    ex.seq([&](Th &t) { if (t.tid < NF) put_wrench(t, in(t)); });
+    product<kTheta>();
+    ex.seq([&](Th &t) {
       if (t.tid < NF) {
         double wy[3];
-        get_wrench(t, s.yw, wy);
+        get_wrench(t, wy);
         const double *v = in(t);
         double *o = out(t);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) o[c] = (s.calpha * t.D[c] * t.D[c]) * v[c] + wy[c];
+        for (int c = 0; c < 3; ++c) o[c] = (s.calpha * Dat(t, c) * Dat(t, c)) * v[c] + wy[c];
       }
     });
   }
@@ -729,11 +770,12 @@ struct Solver {
     ex.par([&](Th &t) {
       if (t.tid < NF) {
         const double *x = xs(t), *z = zs(t), *y = ys(t), *px = pxs(t);
-        double mx[14], ax[5], aty[3];
+        double mx[14], ax[5], aty[3], a[9];
+        foot_a(t, a);
 #pragma unroll
         for (int k = 0; k < 14; ++k) mx[k] = 0;
-        a_mul(t.a, x, ax);
-        at_mul(t.a, y, aty);
+        a_mul(a, x, ax);
+        at_mul(a, y, aty);
 #pragma unroll
         for (int r = 0; r < 5; ++r) {
           const double rr = ax[r] - z[r], ei = 1.0 / sc[C::SC_E + 5 * t.tid + r];
@@ -742,7 +784,7 @@ struct Solver {
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          const double qv = t.q[c], rr = qv + px[c] + aty[c], di = 1.0 / t.D[c];
+          const double qv = t.q[c], rr = qv + px[c] + aty[c], di = 1.0 / Dat(t, c);
           mx[6] = dmax(mx[6], fabs(di * rr)); mx[7] = dmax(mx[7], fabs(di * qv)); mx[8] = dmax(mx[8], fabs(di * aty[c]));
           mx[9] = dmax(mx[9], fabs(di * px[c])); mx[10] = dmax(mx[10], fabs(rr)); mx[11] = dmax(mx[11], fabs(qv));
           mx[12] = dmax(mx[12], fabs(aty[c])); mx[13] = dmax(mx[13], fabs(px[c]));
@@ -793,12 +835,12 @@ struct Solver {
   //     w_{k+1} = w_k + Omega r_k,   r_{k+1} = delta Omega r_k        (H Hd^-1 = I - delta Hd^-1: no further products with P),
   //     Omega r = Xi r - Xi G^T (I - M^-1) (G Xi r),  Xi = N (delta I + c alpha N^T D^2 N)^-1 N^T  (3 x 3 per foot),
   // with G, M of factor_core(Xi).
-  MPC_HD void omega_apply() {   // in: gp = G (Xi r) from the foot lanes, pt = Xi r;  out: pw = Omega r
-    product_held();
-    ex.par([&](Th &t) {
+  MPC_HD void omega_apply() {   // in: t.w6 = G (Xi r) from the foot lanes, pt = Xi r;  out: pw = Omega r
+    product<kHeld>();
+    ex.seq([&](Th &t) {
       if (t.tid < NF) {
         double wy[3], xw[3];
-        get_g(t, s.yw, wy);
+        get_g(t, wy);
         sym3_mul(t.pXi, wy, xw);
 #pragma unroll
         for (int c = 0; c < 3; ++c) t.pw[c] = t.pt[c] - xw[c];
@@ -809,11 +851,13 @@ struct Solver {
   MPC_HD void polish() {
     ex.par([&](Th &t) {
       if (t.tid < NF) {
-        const double *a = t.a;
+        double a[9], lo[5], up[5];
+        foot_a(t, a);
+        foot_bounds(t, lo, up);
         // rows of the scaled cone block (static indexing)
         const double A[15] = {a[0], 0, a[1], a[2], 0, a[3], 0, a[4], a[5], 0, a[6], a[7], 0, 0, a[8]};
 #pragma unroll
-        for (int r = 0; r < 5; ++r) t.act[r] = (t.z[r] - lo_at(t, r) < -t.y[r]) ? -1 : ((t.up[r] - t.z[r] < t.y[r]) ? 1 : 0);
+        for (int r = 0; r < 5; ++r) t.act[r] = (t.z[r] - lo[r] < -t.y[r]) ? -1 : ((up[r] - t.z[r] < t.y[r]) ? 1 : 0);
         // orthonormal basis Q of the active rows (rank r), null basis Nn (rows, 3 - r of them); rows of Q beyond the
         // current rank are zero, so projecting on all three rows equals projecting on the first r of them
         double Q[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Nn[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -909,7 +953,7 @@ struct Solver {
 #pragma unroll
         for (int row = 0; row < 5; ++row)
           if (t.act[row]) {
-            const double bd = t.act[row] < 0 ? lo_at(t, row) : t.up[row];
+            const double bd = t.act[row] < 0 ? lo[row] : up[row];
 #pragma unroll
             for (int c = 0; c < 3; ++c) vb[c] += A[3 * row + c] * bd;
           }
@@ -922,7 +966,7 @@ struct Solver {
 #pragma unroll
           for (int k = 0; k < 3; ++k)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) nd[3 * k + c] = Nn[3 * k + c] * t.D[c];
+            for (int c = 0; c < 3; ++c) nd[3 * k + c] = Nn[3 * k + c] * Dat(t, c);
           const double ca = s.calpha;
           Sp[0] = 0 < nn ? ca * (nd[0] * nd[0] + nd[1] * nd[1] + nd[2] * nd[2]) + kDelta : 1.0;
           Sp[3] = 1 < nn ? ca * (nd[3] * nd[3] + nd[4] * nd[4] + nd[5] * nd[5]) + kDelta : 1.0;
@@ -950,14 +994,14 @@ struct Solver {
         put_wrench(t, t.pu0);
       }
     });
-    product_theta();
-    ex.par([&](Th &t) {
+    product<kTheta>();
+    ex.seq([&](Th &t) {
       if (t.tid < NF) {   // P_s u0;  g = -q - P_s u0;  t = Xi g
         double wy[3];
-        get_wrench(t, s.yw, wy);
+        get_wrench(t, wy);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          t.pPu[c] = (s.calpha * t.D[c] * t.D[c]) * t.pu0[c] + wy[c];
+          t.pPu[c] = (s.calpha * Dat(t, c) * Dat(t, c)) * t.pu0[c] + wy[c];
           t.pg[c] = -t.q[c] - t.pPu[c];
           t.pxN[c] = 0;
         }
@@ -965,8 +1009,8 @@ struct Solver {
       }
     });
     lap(11);
-    factor_core<true>([](Th &t) { return t.pXi; });
-    ex.par([&](Th &t) { if (t.tid < NF) put_g(t, t.pt); });
+    factor_core<false>([](Th &t) { return t.pXi; });
+    ex.seq([&](Th &t) { if (t.tid < NF) put_g(t, t.pt); });
     lap(12);
     for (int it = 0; it <= kPolishRefine; ++it) {
       omega_apply();
@@ -977,11 +1021,11 @@ struct Solver {
           for (int r = 0; r < 5; ++r) o[r] = t.act[r];
           for (int k = 0; k < 6; ++k) o[5 + k] = t.pXi[k];
           for (int c = 0; c < 3; ++c) { o[11 + c] = t.pg[c]; o[14 + c] = t.pt[c]; o[17 + c] = t.pw[c]; }
-          for (int k = 0; k < 18; ++k) o[20 + k] = t.Gf[k];
+          for (int k = 0; k < 18; ++k) o[20 + k] = s.Gf[NF * k + t.tid];
         }
       });
 #endif
-      ex.par([&](Th &t) {
+      ex.seq([&](Th &t) {
         if (t.tid < NF) {
 #pragma unroll
           for (int c = 0; c < 3; ++c) { t.pxN[c] += t.pw[c]; t.pr[c] = kDelta * t.pw[c]; }
@@ -991,29 +1035,31 @@ struct Solver {
       });
     }
     // P_s xN
-    ex.par([&](Th &t) { if (t.tid < NF) put_wrench(t, t.pxN); });
-    product_theta();
+    ex.seq([&](Th &t) { if (t.tid < NF) put_wrench(t, t.pxN); });
+    product<kTheta>();
     lap(13);
     // x = u + xN ; y = A Gamma (g - P xN) on active rows ; z = A x ; normal-cone projection (proj.c:17-31)
     ex.par([&](Th &t) {
       if (t.tid < NF) {
-        double wy[3], pxn[3], gg[3], rwv[3], ax[5], ay[5];
-        get_wrench(t, s.yw, wy);
+        double wy[3], pxn[3], gg[3], rwv[3], ax[5], ay[5], a[9], lo[5], up[5];
+        foot_a(t, a);
+        foot_bounds(t, lo, up);
+        get_wrench(t, wy);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          pxn[c] = (s.calpha * t.D[c] * t.D[c]) * t.pxN[c] + wy[c];
+          pxn[c] = (s.calpha * Dat(t, c) * Dat(t, c)) * t.pxN[c] + wy[c];
           t.xp[c] = t.pu0[c] + t.pxN[c];
           gg[c] = t.pg[c] - pxn[c];
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) rwv[c] = t.pG[3 * c] * gg[0] + t.pG[3 * c + 1] * gg[1] + t.pG[3 * c + 2] * gg[2];
-        a_mul(t.a, rwv, ay);
-        a_mul(t.a, t.xp, ax);
+        a_mul(a, rwv, ay);
+        a_mul(a, t.xp, ax);
 #pragma unroll
         for (int r = 0; r < 5; ++r) {
           const double yv = t.act[r] ? ay[r] : 0.0;
           const double tt = ax[r] + yv;
-          const double zc = clampd(tt, lo_at(t, r), t.up[r]);
+          const double zc = clampd(tt, lo[r], up[r]);
           t.zp[r] = zc;
           t.yp[r] = tt - zc;
         }
@@ -1052,24 +1098,29 @@ struct Solver {
     load();
     set_rho_vec();
     factor();
-    if (!s.first) mul_P([](Th &t) { return t.x; }, [](Th &t) { return t.px; });   // warm start: P_s x_0 once, then carried by recursion
     lap(9);
     admm_prepare();
     lap(8);
-    // kCheck iterations between termination checks (osqp.c:417-517 checks when iter % 25 == 0)
+    // kCheck iterations between termination checks (osqp.c:417-517 checks when iter % 25 == 0).  P_s x, which only the dual
+    // residual needs, is formed at the check (one Theta product) instead of being carried through every iteration; that product
+    // uses the exchange registers of the iteration, so the right-hand side is handed over again afterwards (admm_prepare
+    // recomputes exactly the values the last iteration left).
     static_assert(kMaxIter % kCheck == 0, "the check falls on the last iteration");
     int iter = 0;
     while (!s.done && !s.bad && iter < kMaxIter) {
       for (int k = 0; k < kCheck; ++k) admm_iter();
       iter += kCheck;
       lap(8);
+      mul_P([](Th &t) { return t.x; }, [](Th &t) { return t.px; });
       residuals([](Th &t) { return t.x; }, [](Th &t) { return t.z; }, [](Th &t) { return t.y; }, [](Th &t) { return t.px; });
       check_and_adapt(iter);
       lap(10);
-      if (!s.done && s.rho_new > 0) {          // osqp_update_rho: new rho_vec, refactor
-        ex.par([&](Th &t) { if (t.tid == 0) { s.rho = s.rho_new; s.rho_updates++; } });
-        set_rho_vec();
-        factor();
+      if (!s.done) {
+        if (s.rho_new > 0) {          // osqp_update_rho: new rho_vec, refactor
+          ex.par([&](Th &t) { if (t.tid == 0) { s.rho = s.rho_new; s.rho_updates++; } });
+          set_rho_vec();
+          factor();
+        }
         admm_prepare();
         lap(8);
       }
@@ -1089,7 +1140,7 @@ struct Solver {
         const int f = t.tid;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          if (solved) forces[3 * f + c] = -(t.D[c] * t.x[c]);
+          if (solved) forces[3 * f + c] = -(Dat(t, c) * t.x[c]);
           state[3 * f + c] = failed ? 0.0 : t.x[c];
           state[N + 2 * M + 3 * f + c] = qp[C::QP_Q + 3 * f + c];
         }

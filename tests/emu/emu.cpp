@@ -32,6 +32,22 @@ struct HostExec {
     if (!reverse) for (int i = 0; i < NTHREADS; ++i) f(th[i]);
     else for (int i = NTHREADS - 1; i >= 0; --i) f(th[i]);
   }
+  template <class F> void seq(F &&f) { par(f); --phases; }   // (not an LDS hand-over on the device: not counted)
+  // the device's DPP quad operations (mpc_batch.hip DeviceExec), lane by lane
+  template <int N, class A> void quad_allsum(A &&acc) {
+    for (int q = 0; q + 3 < NTHREADS; q += 4)
+      for (int i = 0; i < N; ++i) {
+        const double v = (acc(th[q])[i] + acc(th[q + 1])[i]) + (acc(th[q + 2])[i] + acc(th[q + 3])[i]);
+        for (int j = 0; j < 4; ++j) acc(th[q + j])[i] = v;
+      }
+  }
+  template <class S, class D> void quad_gather6(S &&src, D &&dst) {
+    for (int q = 0; q + 3 < NTHREADS; q += 4) {
+      double v[6];
+      for (int r = 0; r < 6; ++r) v[r] = src(th[q + (r & 3)])[r >> 2];
+      for (int j = 0; j < 4; ++j) for (int r = 0; r < 6; ++r) dst(th[q + j])[r] = v[r];
+    }
+  }
 };
 
 // assembly kernel -> scaling kernel -> solve kernel of one robot (Pg: the P scratch, reused between robots)
@@ -107,7 +123,7 @@ static void ksolve_one(const RobotModel &mdl, const float *in, double rho, const
   sh->rho = rho;
   sv.set_rho_vec();
   sv.factor();
-  ex.par([&](WThread<H> &t) {
+  ex.seq([&](WThread<H> &t) {
     if (t.tid < C::NF) {
       double v[3];
       for (int c = 0; c < 3; ++c) t.b[c] = b[3 * t.tid + c];
@@ -115,11 +131,11 @@ static void ksolve_one(const RobotModel &mdl, const float *in, double rho, const
       sv.put_g(t, v);
     }
   });
-  sv.product_held();
-  ex.par([&](WThread<H> &t) {
+  sv.template product<Solver<H, Ex>::kHeld>();
+  ex.seq([&](WThread<H> &t) {
     if (t.tid < C::NF) {
       double wy[3], tt[3], o[3];
-      sv.get_g(t, sh->yw, wy);
+      sv.get_g(t, wy);
       for (int c = 0; c < 3; ++c) tt[c] = t.b[c] - wy[c];
       Solver<H, Ex>::sym3_mul(t.Si, tt, o);
       for (int c = 0; c < 3; ++c) xt[3 * t.tid + c] = o[c];
