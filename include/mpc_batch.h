@@ -86,12 +86,10 @@ int mpc_batch_state_len(const mpc_batch *b);
 int mpc_batch_get_state(mpc_batch *b, double *h_state);
 int mpc_batch_set_state(mpc_batch *b, const double *h_state);
 /* Kernel timing (benchmarks): after mpc_batch_enable_timing every launch records HIP events on its stream around the
- * assembly kernel and the scaling + solve kernels; mpc_batch_kernel_times synchronises and returns the durations (ms) of the last
+ * prep kernel (QP assembly + Ruiz scaling) and the solve kernel; mpc_batch_kernel_times synchronises and returns the durations (ms) of the last
  * `last_k` launches (oldest first, at most 64). */
 int mpc_batch_enable_timing(mpc_batch *b);
-int mpc_batch_kernel_times(mpc_batch *b, int last_k, float *ms_assemble, float *ms_solve);
-/* The same with the Ruiz-scaling kernel and the solve kernel reported separately (mpc_batch_kernel_times adds them up). */
-int mpc_batch_kernel_times3(mpc_batch *b, int last_k, float *ms_assemble, float *ms_scale, float *ms_solve);
+int mpc_batch_kernel_times(mpc_batch *b, int last_k, float *ms_prep, float *ms_solve);
 /* Shader-clock cycles of the last solve, [n, 16] int64: slot 15 = the whole solve kernel (always; it also orders the next
  * launch longest-first); slots 0-14 = per section (csrc/mpc_core.h), filled only by a library built with
  * -DMPC_SECTION_PROFILE (tools/section_profile.py) and zero otherwise -- the counters cost registers. */

@@ -51,13 +51,19 @@ __device__ __forceinline__ double quad_perm(double v) {
 }
 constexpr int quad_ctrl(int a, int b, int c, int d) { return a | (b << 2) | (c << 4) | (d << 6); }
 
-template <class TH>
+// WAVE: the workgroup is a single wavefront (the h = 10 solve kernel).  Its LDS instructions execute in program order, so a
+// phase boundary needs neither s_barrier nor a wait for the stores to land (the loads of the next phase queue up behind them):
+// only the compiler has to keep the order (wavefront-scope fence).
+template <class TH, bool WAVE = false>
 struct DeviceExec {
   TH &th;
   template <class F>
   __device__ __forceinline__ void par(F &&f) {
     f(th);
-    __syncthreads();   // (a single-wave workgroup -- the h = 10 solve kernel -- needs no s_barrier: the compiler drops it)
+    if constexpr (WAVE) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    } else __syncthreads();
   }
   // a phase that hands nothing over through LDS (its results stay in registers or go to the quad operations below)
   template <class F>
@@ -102,9 +108,10 @@ __global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES
   th.init(threadIdx.x);
 #pragma unroll
   for (int j = 0; j < C::TE; ++j) th.Mx[j] = 0;
-  DeviceExec<WThread<H>> ex{th};
+  using Ex = DeviceExec<WThread<H>, (C::TW <= 64)>;
+  Ex ex{th};
   const RobotModel &mdl = models[robot];   // (uniform loads; a by-value copy indexed at run time would sit in scratch)
-  Solver<H, DeviceExec<WThread<H>>> sv{ex,
+  Solver<H, Ex> sv{ex,
                                        sh,
                                        mdl,
                                        state + (size_t)robot * state_len<H>(),
@@ -114,26 +121,6 @@ __global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES
                                        info + (size_t)robot * kInfoLen,
                                        prof ? prof + (size_t)robot * kProfLen : nullptr};
   sv.run();
-}
-
-// Scaling kernel (mpc_core.h Scaler): OSQP's Ruiz equilibration of every active robot -> the scale record
-template <int H>
-__global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= MPC_MIN_WAVES_MAX_T && Cfg<H>::NT == 1 ? MPC_SCALE_MIN_WAVES : 1)) void mpc_scale_kernel(
-    int n, const double *__restrict__ state, const double *__restrict__ scratch, const double *__restrict__ qp,
-    double *__restrict__ sc, const int *__restrict__ active) {
-  __shared__ __attribute__((aligned(16))) ScaleShared<H> sh;
-  using C = Cfg<H>;
-  const int robot = (int)blockIdx.x;
-  if (robot >= n) return;
-  if (active && !active[robot]) return;
-  Thread<H> th;
-  th.init(threadIdx.x);
-#pragma unroll
-  for (int j = 0; j < C::NT * C::TE; ++j) th.Mx[j] = 0;
-  DeviceExec<Thread<H>> ex{th};
-  Scaler<H, DeviceExec<Thread<H>>> sk{ex, sh, state + (size_t)robot * state_len<H>(), scratch + (size_t)robot * C::PG_LEN,
-                                      qp + (size_t)robot * C::QP_LEN, sc + (size_t)robot * C::SC_LEN};
-  sk.run();
 }
 
 // Workgroup -> robot order for the solve kernel of THIS launch: robots sorted by the shader cycles their previous solve took,
@@ -172,13 +159,13 @@ __device__ void order_block(int n, const long long *__restrict__ prof, int *__re
   }
 }
 
-// Assembly kernel (mpc_core.h Assembler): q, bounds, cone block and P of every active robot -> HBM
+// Prep kernel (mpc_core.h Assembler + Scaler): QP record (q, bounds, cone block, wrench form of P) and scale record (OSQP's Ruiz
+// equilibration) of every active robot.  The dense P lives only in this kernel's registers.
 template <int H>
-__global__ __launch_bounds__(Cfg<H>::TA) void mpc_assemble_kernel(int n, const RobotModel *__restrict__ models, const float *__restrict__ in,
-                                                                 double *__restrict__ scratch, double *__restrict__ qp,
-                                                                 long long *__restrict__ prof, const int *__restrict__ active,
-                                                                 int *__restrict__ order) {
-  __shared__ __attribute__((aligned(16))) AsmShared<H> sh;
+__global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= MPC_MIN_WAVES_MAX_T && Cfg<H>::NT == 1 ? MPC_SCALE_MIN_WAVES : 1)) void mpc_prep_kernel(
+    int n, const RobotModel *__restrict__ models, const float *__restrict__ in, const double *__restrict__ state,
+    double *__restrict__ qp, double *__restrict__ sc, long long *__restrict__ prof, const int *__restrict__ active, int *__restrict__ order) {
+  __shared__ __attribute__((aligned(16))) PrepShared<H> sh;
   using C = Cfg<H>;
   if (blockIdx.x == 0) {      // the extra workgroup (first, so that it starts at once): dispatch order of the solve kernel that follows
     if (order) order_block(n, prof, order);
@@ -189,11 +176,16 @@ __global__ __launch_bounds__(Cfg<H>::TA) void mpc_assemble_kernel(int n, const R
   if (active && !active[robot]) return;
   Thread<H> th;
   th.init(threadIdx.x);
-  DeviceExec<Thread<H>> ex{th};
+#pragma unroll
+  for (int j = 0; j < C::NT * C::TE; ++j) th.Mx[j] = 0;
+  using Ex = DeviceExec<Thread<H>>;
+  Ex ex{th};
   const RobotModel &mdl = models[robot];
-  Assembler<H, DeviceExec<Thread<H>>> am{ex, sh, mdl, in + (size_t)robot * C::IN_LEN, scratch + (size_t)robot * C::PG_LEN,
-                                 qp + (size_t)robot * C::QP_LEN, prof ? prof + (size_t)robot * kProfLen : nullptr};
+  double *qpr = qp + (size_t)robot * C::QP_LEN;
+  Assembler<H, Ex> am{ex, sh.as, mdl, in + (size_t)robot * C::IN_LEN, sh.u12, qpr, prof ? prof + (size_t)robot * kProfLen : nullptr};
   am.run();
+  Scaler<H, Ex> sk{ex, sh.sc, state + (size_t)robot * state_len<H>(), sh.u12, mdl.alpha, qpr, sc + (size_t)robot * C::SC_LEN};
+  sk.run();
 }
 
 __global__ void reset_kernel(double *state, int state_len, const int *ids, int k, int n) {
@@ -204,15 +196,13 @@ __global__ void reset_kernel(double *state, int state_len, const int *ids, int k
 }
 
 template <int H>
-int launch(int n, const RobotModel *models, const float *in, double *state, double *scratch, double *qp, double *sc, double *forces, int *info,
+int launch(int n, const RobotModel *models, const float *in, double *state, double *qp, double *sc, double *forces, int *info,
            long long *prof, const int *active, const int *order, hipEvent_t *ev, hipStream_t stream) {
   if (ev) (void)hipEventRecord(ev[0], stream);
-  hipLaunchKernelGGL(mpc_assemble_kernel<H>, dim3(n + 1), dim3(Cfg<H>::TA), 0, stream, n, models, in, scratch, qp, prof, active, const_cast<int *>(order));
+  hipLaunchKernelGGL(mpc_prep_kernel<H>, dim3(n + 1), dim3(Cfg<H>::T), 0, stream, n, models, in, state, qp, sc, prof, active, const_cast<int *>(order));
   if (ev) (void)hipEventRecord(ev[1], stream);
-  hipLaunchKernelGGL(mpc_scale_kernel<H>, dim3(n), dim3(Cfg<H>::T), 0, stream, n, state, scratch, qp, sc, active);
-  if (ev) (void)hipEventRecord(ev[2], stream);
   hipLaunchKernelGGL(mpc_solve_kernel<H>, dim3(n), dim3(Cfg<H>::TW), 0, stream, n, models, state, qp, sc, forces, info, prof, active, order);
-  if (ev) (void)hipEventRecord(ev[3], stream);
+  if (ev) (void)hipEventRecord(ev[2], stream);
   HIP_TRY(hipGetLastError());
   return MPC_OK;
 }
@@ -226,12 +216,12 @@ struct mpc_batch {
   int n = 0, h = 0;
   int state_len = 0;
   RobotModel *d_models = nullptr;
-  double *d_state = nullptr, *d_scratch = nullptr, *d_qp = nullptr, *d_sc = nullptr;   // warm start, P tiles, QP record (q, l, u, cone, wrench form), scale record
+  double *d_state = nullptr, *d_qp = nullptr, *d_sc = nullptr;   // warm start, QP record (q, l, u, cone, wrench form of P), scale record
   int *d_info = nullptr;   // used when the caller passes no info buffer
   long long *d_prof = nullptr;   // per-robot section cycle counts of the last solve
   int *d_order = nullptr;        // workgroup -> robot map of the solve kernel (order_block, written by the assembly launch)
   bool timing = false;           // mpc_batch_enable_timing: HIP events around the two kernels of each launch
-  hipEvent_t ev[kTimingRing][4];
+  hipEvent_t ev[kTimingRing][3];
   long long launches = 0;
   float *d_host_in = nullptr;    // staging for mpc_batch_solve_host
   double *d_host_f = nullptr;
@@ -246,9 +236,9 @@ static int launch_solver(mpc_batch *b, const float *d_in, double *d_forces, int 
   hipEvent_t *ev = b->timing ? b->ev[b->launches % kTimingRing] : nullptr;
   int rc = MPC_E_HORIZON;
   switch (b->h) {
-    case 10: rc = launch<10>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, b->d_qp, b->d_sc, d_forces, d_info, b->d_prof, d_active, order, ev, st); break;
-    case 16: rc = launch<16>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, b->d_qp, b->d_sc, d_forces, d_info, b->d_prof, d_active, order, ev, st); break;
-    case 20: rc = launch<20>(b->n, b->d_models, d_in, b->d_state, b->d_scratch, b->d_qp, b->d_sc, d_forces, d_info, b->d_prof, d_active, order, ev, st); break;
+    case 10: rc = launch<10>(b->n, b->d_models, d_in, b->d_state, b->d_qp, b->d_sc, d_forces, d_info, b->d_prof, d_active, order, ev, st); break;
+    case 16: rc = launch<16>(b->n, b->d_models, d_in, b->d_state, b->d_qp, b->d_sc, d_forces, d_info, b->d_prof, d_active, order, ev, st); break;
+    case 20: rc = launch<20>(b->n, b->d_models, d_in, b->d_state, b->d_qp, b->d_sc, d_forces, d_info, b->d_prof, d_active, order, ev, st); break;
   }
   if (rc == MPC_E_HORIZON) return fail(MPC_E_HORIZON, "solver launch: horizon not compiled in");
   if (rc != MPC_OK) return rc;
@@ -277,7 +267,6 @@ int mpc_batch_create(mpc_batch **out, int n, int horizon, double timestep, doubl
   mpc_batch *b = new mpc_batch();
   b->n = n;
   b->h = horizon;
-  const size_t pg_len = horizon == 10 ? Cfg<10>::PG_LEN : horizon == 16 ? Cfg<16>::PG_LEN : Cfg<20>::PG_LEN;   // P_s scratch, lower-triangle tiles
   const size_t qp_len = horizon == 10 ? Cfg<10>::QP_LEN : horizon == 16 ? Cfg<16>::QP_LEN : Cfg<20>::QP_LEN;
   const size_t sc_len = horizon == 10 ? Cfg<10>::SC_LEN : horizon == 16 ? Cfg<16>::SC_LEN : Cfg<20>::SC_LEN;
   b->state_len = (int)(64 * horizon + 2);
@@ -287,7 +276,6 @@ int mpc_batch_create(mpc_batch **out, int n, int horizon, double timestep, doubl
   hipError_t e;
   if ((e = hipMalloc(&b->d_models, sizeof(RobotModel) * n)) != hipSuccess ||
       (e = hipMalloc(&b->d_state, sizeof(double) * (size_t)n * b->state_len)) != hipSuccess ||
-      (e = hipMalloc(&b->d_scratch, sizeof(double) * (size_t)n * pg_len)) != hipSuccess ||
       (e = hipMalloc(&b->d_qp, sizeof(double) * (size_t)n * qp_len)) != hipSuccess ||
       (e = hipMalloc(&b->d_sc, sizeof(double) * (size_t)n * sc_len)) != hipSuccess ||
       (e = hipMalloc(&b->d_info, sizeof(int) * (size_t)n * kInfoLen)) != hipSuccess ||
@@ -298,7 +286,7 @@ int mpc_batch_create(mpc_batch **out, int n, int horizon, double timestep, doubl
     cleanup();
     return fail(MPC_E_HIP, std::string("mpc_batch_create: ") + hipGetErrorString(e));
   }
-  b->bytes = (long long)(sizeof(RobotModel) * n + sizeof(double) * (size_t)n * (b->state_len + pg_len + qp_len + sc_len) + sizeof(int) * (size_t)n * kInfoLen);
+  b->bytes = (long long)(sizeof(RobotModel) * n + sizeof(double) * (size_t)n * (b->state_len + qp_len + sc_len) + sizeof(int) * (size_t)n * kInfoLen);
   *out = b;
   return MPC_OK;
 }
@@ -307,7 +295,6 @@ void mpc_batch_destroy(mpc_batch *b) {
   if (!b) return;
   if (b->d_models) (void)hipFree(b->d_models);
   if (b->d_state) (void)hipFree(b->d_state);
-  if (b->d_scratch) (void)hipFree(b->d_scratch);
   if (b->d_qp) (void)hipFree(b->d_qp);
   if (b->d_sc) (void)hipFree(b->d_sc);
   if (b->d_info) (void)hipFree(b->d_info);
@@ -375,19 +362,7 @@ int mpc_batch_kernel_times(mpc_batch *b, int last_k, float *ms_assemble, float *
   for (int i = 0; i < last_k; ++i) {
     hipEvent_t *e = b->ev[(b->launches - last_k + i) % kTimingRing];
     HIP_TRY(hipEventElapsedTime(ms_assemble + i, e[0], e[1]));
-    HIP_TRY(hipEventElapsedTime(ms_solve + i, e[1], e[3]));   // scaling + solve
-  }
-  return MPC_OK;
-}
-int mpc_batch_kernel_times3(mpc_batch *b, int last_k, float *ms_assemble, float *ms_scale, float *ms_solve) {
-  if (!b || !b->timing || last_k <= 0 || last_k > kTimingRing || last_k > b->launches || !ms_assemble || !ms_scale || !ms_solve)
-    return fail(MPC_E_ARG, "mpc_batch_kernel_times3: bad argument (enable timing first; at most 64 launches back)");
-  HIP_TRY(hipDeviceSynchronize());
-  for (int i = 0; i < last_k; ++i) {
-    hipEvent_t *e = b->ev[(b->launches - last_k + i) % kTimingRing];
-    HIP_TRY(hipEventElapsedTime(ms_assemble + i, e[0], e[1]));
-    HIP_TRY(hipEventElapsedTime(ms_scale + i, e[1], e[2]));
-    HIP_TRY(hipEventElapsedTime(ms_solve + i, e[2], e[3]));
+    HIP_TRY(hipEventElapsedTime(ms_solve + i, e[1], e[2]));
   }
   return MPC_OK;
 }

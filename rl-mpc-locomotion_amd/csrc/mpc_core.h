@@ -111,12 +111,9 @@ struct Cfg {
   static constexpr int NT = H > 16 ? MPC_NT_H20 : (H > 12 ? MPC_NT_H16 : 1);
   static constexpr int MTH = (MT + NT - 1) / NT;         // threads that hold tiles
   static constexpr int TE = TS * TS;                     // tile elements per thread
-  static constexpr int PG_LEN = MT * TE;                 // doubles of P_s scratch per robot (tile-major)
   static constexpr int T = (((MTH > N ? MTH : N) + 63) / 64) * 64;   // solve-kernel workgroup: a thread per tile slot and per variable
   static constexpr int MR = (M + T - 1) / T;             // constraint rows per thread (Solver::for_rows): 1, or 2 at h = 20
-  static constexpr int TA = ((M > 256 ? M : 256) + 63) / 64 * 64;   // assembly-kernel workgroup (>= M threads)
   static constexpr int IN_LEN = 56 + 4 * H;
-  static constexpr int NTASK2 = 21 + (H - 1) * 36;       // P assembly tasks (d, 2 x 2 block of (a, b))
   static_assert(T <= 1024, "workgroup too large");
   static constexpr int NP = N + 2;                       // row stride of part[] (doubles)
   static constexpr int MEVEN = (M + 1) & ~1;
@@ -204,7 +201,17 @@ struct AsmShared {
   MPC_V in[C::IN_LEN];
   MPC_V x0[13]; MPC_V xref[13 * H]; MPC_V sdiff[13 * H]; MPC_V xk[13 * H];
   MPC_V a_dt[169]; MPC_V b_dt[156]; MPC_V a_exp[169]; MPC_V b_exp[156];
-  MPC_V anb[H * 156]; MPC_V wanb[H * 156];              // A^k B and diag(w) A^k B
+  MPC_V wanb[H * 156];                                  // diag(w) A^k B
+  MPC_V B6[72]; MPC_V th1[36]; MPC_V th2[8];            // wrench description of P (mpc_wrench.h), also written to the QP record
+};
+// LDS of the prep kernel (assembly, then Ruiz scaling, of one robot): the assembly arrays are dead when the scaling starts
+template <int H>
+struct PrepShared {
+  union {
+    AsmShared<H> as;
+    ScaleShared<H> sc;
+  };
+  MPC_V u12[288];                                       // U1, U2: what the scaling part needs of the assembly (see Assembler::run)
 };
 #undef MPC_V
 
@@ -279,7 +286,6 @@ MPC_HD double bitsd(unsigned long long u) {
 
 // ------------------------------------------------------------------------------------------------
 // The solver.  `Exec` provides: par(f), amax(&slot, value) (LDS atomic max on a double >= 0).
-// `Pg` is this robot's n*n fp64 scratch in HBM (holds P, then the scaled P_s).
 // ------------------------------------------------------------------------------------------------
 // Diagnostic builds (-DMPC_PROFILE_SUB=<section>) split one section into slots 9..13 of the profile record:
 // 1 = dynamics, 2 = one scaling pass, 3 = polish set-up, 4 = A dt / B dt set-up, 5 = the four phases of an ADMM iteration.
@@ -289,21 +295,20 @@ MPC_HD double bitsd(unsigned long long u) {
 #define MPC_SUBLAP(sec, k) do { if (MPC_PROFILE_SUB == (sec)) lap(k); } while (0)
 
 // ============================================================================================================
-// 1. Assembly (mpc_osqp.cc:606-688), a kernel of its own: one workgroup per robot builds q, the bounds, the cone block
-// and P (tile-major, unscaled) and leaves them in HBM for the solve kernel.  It needs 38 KB of LDS that the solver does
-// not (four robots per CU instead of two) and is bound by LDS latency / bandwidth, not by fp64 issue.
+// 1. Assembly (mpc_osqp.cc:606-688), first part of the prep kernel: one workgroup per robot builds q, the bounds, the cone
+// block and the wrench description of P (B6, th1, th2) -> QP record in HBM, and the two 12 x 12 tables U1, U2 -> LDS.
 // ============================================================================================================
 template <int H, class Exec>
 struct Assembler {
   using C = Cfg<H>;
   using Th = Thread<H>;
-  static constexpr int N = C::N, M = C::M, NF = C::NF, T = C::TA, TS = C::TS, TE = C::TE;
+  static constexpr int N = C::N, M = C::M, NF = C::NF, T = C::T, TS = C::TS, TE = C::TE;
 
   Exec &ex;
   AsmShared<H> &s;
   const RobotModel &mdl;
   const float *in;     // [IN_LEN]
-  double *Pg;          // [PG_LEN]   out: P, lower-triangle tiles
+  double *u12;         // [288] LDS  out: U1 = B6^T th1 B6, U2 = B6^T diag(th2) B6 (12 x 12 each): P = Sigma2 (x) U1 + N (x) U2 + alpha I
   double *qp;          // [QP_LEN]   out: q, l, u, cone
   long long *prof;     // [kProfLen] slots 1 (dynamics) and 2 (q + P) are written here (may be null)
   long long tc[3] = {0, 0, 0};
@@ -323,11 +328,6 @@ struct Assembler {
       for (int j = 0; j < 3; ++j) c[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
   }
 
-  static MPC_HD size_t pg_index(int r, int c) {   // offset of entry (r, c) in the tile-major store; needs r / 6 >= c / 6
-    const int I = r / TS, J = c / TS;
-    return (size_t)(I * (I + 1) / 2 + J) * TE + (r - TS * I) * TS + (c - TS * J);
-  }
-
   // ================================ 1. assembly =================================================
   MPC_HD void run() {
     tlast = MPC_CLOCK();
@@ -335,7 +335,7 @@ struct Assembler {
       for (int i = t.tid; i < C::IN_LEN; i += T) s.in[i] = (double)in[i];
       for (int i = t.tid; i < 169; i += T) s.a_dt[i] = 0;
       for (int i = t.tid; i < 156; i += T) s.b_dt[i] = 0;
-      for (int i = t.tid; i < 72; i += T) qp[C::QP_B6 + i] = 0;
+      for (int i = t.tid; i < 72; i += T) { qp[C::QP_B6 + i] = 0; s.B6[i] = 0; }
     });
     // ---- A dt, B dt (mpc_osqp.cc:299-336, 606-617, 661-673): every 3 x 3 product is one entry per thread, all
     // operands in LDS (a thread-local array indexed by a runtime entry number would live in scratch memory).
@@ -374,8 +374,8 @@ struct Assembler {
         s.x0[i] = i < 3 ? s.in[IN_RPY + i] : i < 6 ? s.in[IN_POS + i - 3] : i < 9 ? s.in[IN_ANG + i - 6] : i < 12 ? s.in[IN_VEL + i - 9] : -kGravity;
       }
       // bounds (:449-477, 685-688, 720-721)
-      if (t.tid < M) {
-        const int i = t.tid, f = i / 5, r = i - 5 * f;
+      for (int i = t.tid; i < M; i += T) {
+        const int f = i / 5, r = i - 5 * f;
         const double cst = s.in[IN_CONTACT + f];
         const double fzmax = mdl.mass * kGravity * kMaxScale, fzmin = mdl.mass * kGravity * kMinScale;
         const double mu0 = s.in[in_fric<H>()];
@@ -431,10 +431,12 @@ struct Assembler {
         }
         s.b_dt[(6 + r) * 12 + 3 * i + c] = acc * dt;
         qp[C::QP_B6 + r * 12 + 3 * i + c] = acc;          // wrench map B6 = [I_w^-1 [r_i]x ; I / m]  (mpc_wrench.h)
+        s.B6[r * 12 + 3 * i + c] = acc;
       } else if (t.tid < 48) {   // B rows 9-11: I / m
         const int k = t.tid - 36, i = k / 3, r = k - 3 * i;
         s.b_dt[(9 + r) * 12 + 3 * i + r] = mdl.inv_mass * dt;
         qp[C::QP_B6 + (3 + r) * 12 + 3 * i + r] = mdl.inv_mass;
+        s.B6[(3 + r) * 12 + 3 * i + r] = mdl.inv_mass;
       } else if (t.tid < 57) {   // A rows 0-2: omega -> rpy rates (:311-312): {cy/cp, sy/cp, 0; -sy, cy, 0; cy tp, sy tp, 1}
         const int e = t.tid - 48, r = e / 3, c = e - 3 * r;
         const double cp = rym[0], cy = rzm[0], sy = rzm[3], tp = tp_[0];
@@ -486,8 +488,11 @@ struct Assembler {
           v *= d2;
         } else if (a == b) v = (d2 * dt * dt) * s.in[IN_W + a];
         qp[C::QP_TH1 + t.tid] = v;
+        s.th1[t.tid] = v;
       } else if (t.tid < 42) {
-        qp[C::QP_TH2 + t.tid - 36] = (2.0 * mdl.dt * mdl.dt) * s.in[IN_W + 6 + t.tid - 36];
+        const double v = (2.0 * mdl.dt * mdl.dt) * s.in[IN_W + 6 + t.tid - 36];
+        qp[C::QP_TH2 + t.tid - 36] = v;
+        s.th2[t.tid - 36] = v;
       }
     });
     MPC_SUBLAP(1, 10);
@@ -516,7 +521,6 @@ struct Assembler {
       for (int e = t.tid; e < H * 156; e += T) {
         const int k = e / 156, rc = e - 156 * k, r = rc / 12;
         const double v = r < 6 ? s.b_exp[rc] + (double)k * s.b_dt[rc] : s.b_exp[rc];
-        s.anb[e] = v;
         s.wanb[e] = s.in[IN_W + r] * v;
       }
       for (int e = t.tid; e < 13 * (H - 1); e += T) {   // (this overwrites the set-up scratch, which is dead by now)
@@ -530,10 +534,12 @@ struct Assembler {
       for (int k = t.tid; k < 13 * H; k += T) s.sdiff[k] = (k < 13 * (H - 1) ? s.xk[k] : 0.0) - s.xref[k];
     });
     lap(1);
-    // q (:683) and P (:387-434) -> Pg (unscaled, lower-triangle tiles)
+    // q (:683); and the two 12 x 12 tables from which every thread of the scaling part builds its own tile of P
+    // (P = 2 B_qp^T Q B_qp + alpha I = Sigma2 (x) U1 + N (x) U2 + alpha I in the wrench form, mpc_wrench.h; the reference's block
+    // recursion :387-434 gives the same numbers to rounding, and only the Ruiz norms read them)
     ex.par([&](Th &t) {
-      if (t.tid < N) {
-        const int j = t.tid / 12, c = t.tid - 12 * j;
+      for (int jc = t.tid; jc < N; jc += T) {
+        const int j = jc / 12, c = jc - 12 * j;
         double acc = 0;
         for (int i = j; i < H; ++i) {
           const double *bk = s.wanb + (i - j) * 156 + c, *sd = s.sdiff + 13 * i;
@@ -545,54 +551,21 @@ struct Assembler {
           }
           acc += e + o;
         }
-        qp[C::QP_Q + t.tid] = 2 * acc;
+        qp[C::QP_Q + jc] = 2 * acc;
       }
-      // P: 2 x 2 register blocks of (a, b) -- four outputs share two 16-byte loads per term (one LDS byte per flop
-      // instead of two: with four robots per CU this phase is LDS-bandwidth bound).  Tasks: for d = 0 the block pairs
-      // a2 <= b2 (21), for d >= 1 all 36; d-major, so a thread's second task is a short one.
-      for (int task = t.tid; task < C::NTASK2; task += T) {
-        int d, a2, b2;
-        if (task < 21) {
-          d = 0;
-          int k = task; a2 = 0;
-          while (k >= 6 - a2) { k -= 6 - a2; ++a2; }
-          b2 = a2 + k;
+      for (int e = t.tid; e < 288; e += T) {
+        const int which = e / 144, ab = e - 144 * which, a = ab / 12, b = ab - 12 * a;
+        double acc = 0;
+        if (which == 0) {
+          for (int p = 0; p < 6; ++p) {
+            double row = 0;
+            for (int q = 0; q < 6; ++q) row += s.th1[6 * p + q] * s.B6[12 * q + b];
+            acc += s.B6[12 * p + a] * row;
+          }
         } else {
-          const int k = task - 21;
-          d = 1 + k / 36;
-          const int ab = k - (d - 1) * 36;
-          a2 = ab / 6; b2 = ab - 6 * a2;
+          for (int p = 0; p < 6; ++p) acc += s.B6[12 * p + a] * (s.th2[p] * s.B6[12 * p + b]);
         }
-        const int a0 = 2 * a2, b0 = 2 * b2, ah = a0 / TS, bh = b0 / TS, ar = a0 - TS * ah, br = b0 - TS * bh;
-        // entry (12 I + a, 12 J + b), I = J - d <= J, lives at row 12 J + b, column 12 I + a of the lower triangle:
-        // tile (2 J + b / 6, 2 I + a / 6), position (b % 6, a % 6); a diagonal tile also takes the mirrored entry
-        const bool dtile = d == 0 && ah == bh;
-        const double *xa = s.wanb + d * 156 + a0, *yb = s.anb + b0;
-        double acc[4] = {0, 0, 0, 0};
-        const int ns = H - d;
-        for (int sidx = 0; sidx < ns; ++sidx) {
-          const double *x = xa + sidx * 156, *y = yb + sidx * 156;
-          double e[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0};   // even / odd terms: eight independent FMA chains
-#pragma unroll
-          for (int r = 0; r < 13; ++r) {
-            const double x0 = x[r * 12], x1 = x[r * 12 + 1], y0 = y[r * 12], y1 = y[r * 12 + 1];
-            double *w = (r & 1) ? o : e;
-            w[0] += x0 * y0; w[1] += x1 * y0; w[2] += x0 * y1; w[3] += x1 * y1;      // index ia + 2 ib
-          }
-          const int J = H - 1 - sidx, I = J - d;
-          const int tr = 2 * J + bh;
-          double *tile = Pg + (size_t)(tr * (tr + 1) / 2 + 2 * I + ah) * TE;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int ia = q & 1, ib = q >> 1;
-            acc[q] += e[q] + o[q];
-            if (d == 0 && a0 + ia > b0 + ib) continue;       // below the diagonal of a diagonal block: its mirror is computed
-            double v = 2.0 * acc[q];
-            if (d == 0 && a0 + ia == b0 + ib) v += mdl.alpha;
-            tile[(br + ib) * TS + ar + ia] = v;
-            if (dtile && a0 + ia != b0 + ib) tile[(ar + ia) * TS + br + ib] = v;
-          }
-        }
+        u12[e] = acc;
       }
     });
     lap(2);
@@ -604,9 +577,9 @@ struct Assembler {
 
 
 // ============================================================================================================
-// 2. Ruiz equilibration + cost scaling (scaling.c:44-156), a kernel of its own: one workgroup per robot holds the dense
-// P as 6 x 6 register tiles (the only consumer of the dense matrix: the solve kernel works in the wrench space, mpc_wrench.h),
-// runs the ten passes and leaves the scaled problem vectors in the robot's scale record.
+// 2. Ruiz equilibration + cost scaling (scaling.c:44-156), second part of the prep kernel: the workgroup holds the dense
+// P as 6 x 6 register tiles built from U1, U2 (the only consumer of the dense matrix: the solve kernel works in the wrench
+// space, mpc_wrench.h; P never exists in memory), runs the ten passes and leaves the scaled problem vectors in the scale record.
 // ============================================================================================================
 template <int H, class Exec>
 struct Scaler {
@@ -618,7 +591,8 @@ struct Scaler {
   Exec &ex;
   Sh &s;
   const double *state; // [state_len<H>()]  warm-start record (read: q of the previous call, cold flag)
-  const double *Pg;    // [PG_LEN]  P (unscaled, lower-triangle tiles) from the assembly kernel
+  const double *u12;   // [288] LDS  U1, U2 of the assembly part
+  double alpha;
   const double *qp;    // [QP_LEN]  q, l, u, cone from the assembly kernel
   double *sc;          // [SC_LEN]  out: D, E, q_s, A_s, l_s, u_s, c, 1/c
   using Tv = TileView;
@@ -693,7 +667,24 @@ struct Scaler {
       for (int b = 0; b < TS; ++b) pt[b] = mc[b] * dc[b];
     }
   }
-  // P_s in HBM is tile-major: tile `index` is the 36 doubles at G[36 index]
+  // my tile of P from the two 12 x 12 tables: tile (ti, tj) = feet pair ti & 1 of step ti / 2 against feet pair tj & 1 of step tj / 2,
+  //   P[(s, a), (s', b)] = s2(s, s') U1[a][b] + (H - s) U2[a][b] + [same entry] alpha,   s >= s',
+  //   s2 = sum_{i < m} (i + 1/2)(i + d + 1/2) = m (4 m^2 - 1) / 12 + d m^2 / 2,  m = H - s,  d = s - s'
+  MPC_HD void build_tile(Tv &t) {
+    const int sr = t.ti >> 1, sc_ = t.tj >> 1, rh = t.ti & 1, ch = t.tj & 1;
+    const double m = (double)(H - sr), d = (double)(sr - sc_);
+    const double s2 = m * (4.0 * m * m - 1.0) / 12.0 + d * (m * m) * 0.5;
+    const double *u1 = u12 + (6 * rh) * 12 + 6 * ch, *u2 = u1 + 144;
+#pragma unroll
+    for (int a = 0; a < TS; ++a)
+#pragma unroll
+      for (int b = 0; b < TS; ++b) {
+        double v = s2 * u1[12 * a + b] + m * u2[12 * a + b];
+        if (t.dia && a == b) v += alpha;
+        t.Mx[a * TS + b] = v;
+      }
+  }
+  // (tile-major HBM layout of the round-1 kernels: tile `index` is the 36 doubles at G[36 index])
   MPC_HD void load_tile(Tv &t, const double *Gm) {
     const double *g = Gm + (size_t)t.index * TE;
 #pragma unroll
@@ -755,7 +746,7 @@ struct Scaler {
   MPC_HD void scale() {
     lap(2);
     ex.par([&](Th &t) {
-      for_tiles(t, [&](Tv &v, int) { load_tile(v, Pg); tile_rownorms(v, nullptr); });
+      for_tiles(t, [&](Tv &v, int) { build_tile(v); tile_rownorms(v, nullptr); });
       if (t.tid < N) {
         s.qs[t.tid] = s.first ? q_at(t.tid) : s.xt[t.tid];   // osqp_update_P_A equilibrates with the PREVIOUS q
         s.D[t.tid] = 1.0;

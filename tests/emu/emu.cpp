@@ -50,32 +50,28 @@ struct HostExec {
   }
 };
 
-// assembly kernel -> scaling kernel -> solve kernel of one robot (Pg: the P scratch, reused between robots)
+// prep kernel (assembly + Ruiz scaling) of one robot: QP record and scale record
 template <int H>
-static void solve_one(const RobotModel &mdl, const float *in, double *state, double *Pg, double *forces, int *info, bool reverse, long *phases, double *dbg = nullptr) {
+static long prep_one(const RobotModel &mdl, const float *in, const double *state, double *qp, double *sc, bool reverse) {
+  using C = Cfg<H>;
+  PrepShared<H> *ps = new PrepShared<H>();
+  std::memset((void *)ps, 0, sizeof(PrepShared<H>));
+  using Ex = HostExec<Thread<H>, C::T>;
+  Ex ex(reverse);
+  Assembler<H, Ex> am{ex, ps->as, mdl, in, ps->u12, qp, nullptr};
+  am.run();
+  Scaler<H, Ex> sk{ex, ps->sc, state, ps->u12, mdl.alpha, qp, sc};
+  sk.run();
+  const long ph = ex.phases;
+  delete ps;
+  return ph;
+}
+// prep kernel -> solve kernel of one robot
+template <int H>
+static void solve_one(const RobotModel &mdl, const float *in, double *state, double *forces, int *info, bool reverse, long *phases, double *dbg = nullptr) {
   using C = Cfg<H>;
   std::vector<double> qp(C::QP_LEN, 0.0), sc(C::SC_LEN, 0.0);
-  long ph = 0;
-  {
-    AsmShared<H> *as = new AsmShared<H>();
-    std::memset((void *)as, 0, sizeof(AsmShared<H>));
-    using Ex = HostExec<Thread<H>, C::TA>;   // (the assembly kernel has its own workgroup size)
-    Ex exa(reverse);
-    Assembler<H, Ex> am{exa, *as, mdl, in, Pg, qp.data(), nullptr};
-    am.run();
-    ph += exa.phases;
-    delete as;
-  }
-  {
-    ScaleShared<H> *ss = new ScaleShared<H>();
-    std::memset((void *)ss, 0, sizeof(ScaleShared<H>));
-    using Ex = HostExec<Thread<H>, C::T>;
-    Ex exs(reverse);
-    Scaler<H, Ex> sk{exs, *ss, state, Pg, qp.data(), sc.data()};
-    sk.run();
-    ph += exs.phases;
-    delete ss;
-  }
+  long ph = prep_one<H>(mdl, in, state, qp.data(), sc.data(), reverse);
   {
     Shared<H> *sh = new Shared<H>();
     std::memset((void *)sh, 0, sizeof(Shared<H>));
@@ -94,26 +90,9 @@ static void solve_one(const RobotModel &mdl, const float *in, double *state, dou
 template <int H>
 static void ksolve_one(const RobotModel &mdl, const float *in, double rho, const double *b, double *xt, double *sc_out) {
   using C = Cfg<H>;
-  std::vector<double> qp(C::QP_LEN, 0.0), sc(C::SC_LEN, 0.0), state(state_len<H>(), 0.0), Pg(C::PG_LEN, 0.0), forces(C::N, 0.0);
+  std::vector<double> qp(C::QP_LEN, 0.0), sc(C::SC_LEN, 0.0), state(state_len<H>(), 0.0), forces(C::N, 0.0);
   int info[kInfoLen];
-  {
-    AsmShared<H> *as = new AsmShared<H>();
-    std::memset((void *)as, 0, sizeof(AsmShared<H>));
-    using Ex = HostExec<Thread<H>, C::TA>;
-    Ex exa(false);
-    Assembler<H, Ex> am{exa, *as, mdl, in, Pg.data(), qp.data(), nullptr};
-    am.run();
-    delete as;
-  }
-  {
-    ScaleShared<H> *ss = new ScaleShared<H>();
-    std::memset((void *)ss, 0, sizeof(ScaleShared<H>));
-    using Ex = HostExec<Thread<H>, C::T>;
-    Ex exs(false);
-    Scaler<H, Ex> sk{exs, *ss, state.data(), Pg.data(), qp.data(), sc.data()};
-    sk.run();
-    delete ss;
-  }
+  prep_one<H>(mdl, in, state.data(), qp.data(), sc.data(), false);
   Shared<H> *sh = new Shared<H>();
   std::memset((void *)sh, 0, sizeof(Shared<H>));
   using Ex = HostExec<WThread<H>, C::TW>;
@@ -156,11 +135,10 @@ int emu_ksolve(int h, const double *model, double dt, double alpha, const float 
 }
 int emu_solve_debug(int h, const double *model, double dt, double alpha, const float *in, double *state, double *forces, int *info, double *dbg) {
   RobotModel mdl = make_model(model[0], model + 1, dt, alpha);
-  std::vector<double> Pg((size_t)144 * h * h);
   switch (h) {
-    case 10: solve_one<10>(mdl, in, state, Pg.data(), forces, info, false, nullptr, dbg); return 0;
-    case 16: solve_one<16>(mdl, in, state, Pg.data(), forces, info, false, nullptr, dbg); return 0;
-    case 20: solve_one<20>(mdl, in, state, Pg.data(), forces, info, false, nullptr, dbg); return 0;
+    case 10: solve_one<10>(mdl, in, state, forces, info, false, nullptr, dbg); return 0;
+    case 16: solve_one<16>(mdl, in, state, forces, info, false, nullptr, dbg); return 0;
+    case 20: solve_one<20>(mdl, in, state, forces, info, false, nullptr, dbg); return 0;
   }
   return -1;
 }
@@ -184,7 +162,7 @@ int emu_ctrl_replay(int n, int ticks, const double *robot_table, const int *robo
   std::vector<CtrlState> st(n);
   std::vector<RobotConst> rc(n);
   std::vector<RobotModel> mdl(n);
-  std::vector<double> state((size_t)n * (64 * H + 2), 0.0), Pg((size_t)12 * H * 12 * H), forces((size_t)n * 12 * H, 0.0);
+  std::vector<double> state((size_t)n * (64 * H + 2), 0.0), forces((size_t)n * 12 * H, 0.0);
   for (int r = 0; r < n; ++r) {
     const double *row = robot_table + 25 * robot_type[r];
     rc[r].abad = row[0]; rc[r].hip = row[1]; rc[r].knee = row[2];
@@ -202,7 +180,7 @@ int emu_ctrl_replay(int n, int ticks, const double *robot_table, const int *robo
       float *rec = rec_out + idx * inlen;
       ctrl_pre(st[r], rc[r], gt, cp, dof + idx * 24, est + idx * kEstLen, cmd + idx * 16, rec);
       int info[kInfoLen] = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (st[r].do_solve) solve_one<H>(mdl[r], rec, state.data() + (size_t)r * (64 * H + 2), Pg.data(), forces.data() + (size_t)r * 12 * H, info, false, nullptr);
+      if (st[r].do_solve) solve_one<H>(mdl[r], rec, state.data() + (size_t)r * (64 * H + 2), forces.data() + (size_t)r * 12 * H, info, false, nullptr);
       ctrl_post(st[r], rc[r], forces.data() + (size_t)r * 12 * H, info[1] == kStSolved, torques + idx * 12);
       for (int k = 0; k < 12; ++k) fff_out[idx * 12 + k] = st[r].f_ff[k];
     }
@@ -222,7 +200,6 @@ int emu_fsm_replay(int n, int ticks, const double *robot_table, const int *robot
   CtrlParams cp{dt, iters_between_mpc, dt * iters_between_mpc, H, flat_ground};
   const FsmParams P = fsm_params(dt, check_safety);
   const int inlen = 56 + 4 * H, sl = 64 * H + 2;
-  std::vector<double> Pg((size_t)12 * H * 12 * H);
   for (int r = 0; r < n; ++r) {
     const double *row = robot_table + 25 * robot_type[r];
     RobotConst rc;
@@ -247,7 +224,7 @@ int emu_fsm_replay(int n, int ticks, const double *robot_table, const int *robot
       if (f.run_loco) {
         ctrl_pre(st, rc, gt, cp, dof + idx * 24, est, cmd + idx * 16, rec.data());
         int info[kInfoLen] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (st.do_solve) solve_one<H>(mdl, rec.data(), state.data(), Pg.data(), forces.data(), info, false, nullptr);
+        if (st.do_solve) solve_one<H>(mdl, rec.data(), state.data(), forces.data(), info, false, nullptr);
         ctrl_post(st, rc, forces.data(), info[1] == kStSolved, torques + idx * 12);
       } else {
         fsm_joint_torques(f, st, torques + idx * 12);
@@ -276,7 +253,6 @@ int emu_batch_solve(int h, int n, const double *model, double dt, double alpha, 
   if (nthreads < 1) nthreads = 1;
   std::vector<std::thread> pool;
   auto work = [&](int lo, int hi) {
-    std::vector<double> Pg((size_t)N * N);
     for (int r = lo; r < hi; ++r) {
       RobotModel mdl = make_model(model[10 * r], model + 10 * r + 1, dt, alpha);
       long ph = 0;
@@ -284,10 +260,10 @@ int emu_batch_solve(int h, int n, const double *model, double dt, double alpha, 
       double *rs = state + (size_t)r * sl, *rf = forces + (size_t)r * N;
       int *rinfo = info + (size_t)r * kInfoLen;
       switch (h) {
-        case 6: solve_one<6>(mdl, ri, rs, Pg.data(), rf, rinfo, reverse, &ph); break;
-        case 10: solve_one<10>(mdl, ri, rs, Pg.data(), rf, rinfo, reverse, &ph); break;
-        case 16: solve_one<16>(mdl, ri, rs, Pg.data(), rf, rinfo, reverse, &ph); break;
-        case 20: solve_one<20>(mdl, ri, rs, Pg.data(), rf, rinfo, reverse, &ph); break;
+        case 6: solve_one<6>(mdl, ri, rs, rf, rinfo, reverse, &ph); break;
+        case 10: solve_one<10>(mdl, ri, rs, rf, rinfo, reverse, &ph); break;
+        case 16: solve_one<16>(mdl, ri, rs, rf, rinfo, reverse, &ph); break;
+        case 20: solve_one<20>(mdl, ri, rs, rf, rinfo, reverse, &ph); break;
       }
       if (phases_out) phases_out[r] = ph;
     }

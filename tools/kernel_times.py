@@ -19,8 +19,8 @@ solver = BatchedConvexMpc(wl.mass, inertia9, h, wl.dt_mpc, wl.alpha, device=dev)
 solver.enable_timing()
 for s in range(K + W): solver.solve(d_in[s])
 torch.cuda.synchronize()
-a = np.zeros(K, np.float32); b = np.zeros(K, np.float32); c = np.zeros(K, np.float32)
+a, c = solver.kernel_times(K)
 p = lambda x: x.ctypes.data_as(C.c_void_p)
-_lib.check(_lib.lib().mpc_batch_kernel_times3(solver._handle, K, p(a), p(b), p(c)), "times3")
-print(f"h={h} n={n} assemble {a.mean():.4f} ms  scale {b.mean():.4f} ms  solve {c.mean():.4f} ms  (min {a.min():.4f} {b.min():.4f} {c.min():.4f})")
+
+print(f"h={h} n={n} prep {a.mean():.4f} ms  solve {c.mean():.4f} ms  (min {a.min():.4f} {c.min():.4f})  -> {n / (a.mean() + c.mean()) / 1e3:.3f} M steps/s kernel-time")
 
