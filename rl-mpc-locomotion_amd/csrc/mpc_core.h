@@ -47,7 +47,11 @@
 // A 64-bit LDS load that is not paired into ds_read2_b64: the pairs' 8-bit offsets (2 KB reach) force one base register per
 // pair for the 20 slots of a partial-sum row, whereas single loads take 16-bit immediates off one base.
 #define MPC_LDS_LOAD64(p) (*(const volatile __attribute__((address_space(3))) double *)(p))
+// Two adjacent doubles (16-byte aligned) as one ds_read_b128 that is neither hoisted out of a loop nor split
+typedef double mpc_double2 __attribute__((ext_vector_type(2)));
+#define MPC_LDS_LOAD128(p, lo, hi) do { const mpc_double2 v2_ = *(const volatile __attribute__((address_space(3))) mpc_double2 *)(p); (lo) = v2_.x; (hi) = v2_.y; } while (0)
 #else
+#define MPC_LDS_LOAD128(p, lo, hi) do { (lo) = (p)[0]; (hi) = (p)[1]; } while (0)
 #define MPC_LDS_STORE64(p, v) (*(p) = (v))
 #define MPC_LDS_LOAD64(p) (*(p))
 #define MPC_LAUNDER(x) ((void)0)

@@ -74,7 +74,10 @@ struct Shared {
   double c, cinv, rho, calpha;
   double rho3[4], rinv3[4];                             // rho and 1 / rho of a loose / inequality / equality row (index type + 1)
   MPC_V gh[C::NW + 2]; MPC_V dl[C::NW + 2];             // the tile product's input (dl g, or g for Theta products); dl = diag(M)^-1/2
-  MPC_V fa[C::NF * 15];                                 // per foot: the 9 non-zeros of the scaled cone block, l of row 4, u of the five rows
+  // per-foot constants in LDS, element k of foot f at [((k >> 1) NF + f) 2 + (k & 1)]: consecutive lanes read consecutive 16-byte
+  // pairs (one conflict-free ds_read_b128 per pair)
+  MPC_V fa[C::NF * 16];                                 // 0-8: the non-zeros of the scaled cone block, 9: l of row 4, 10-14: u of the five rows
+  MPC_V fr[C::NF * 10];                                 // 0-8: the cone block times rho of its row (factorisation)
   MPC_V Gf[C::NF * 18];                                 // per foot: G_f = T_k W_f (6 x 3) of the current factorisation
   MPC_V prow_raw[2][C::NW + 2];
   MPC_HD double *prow(int b) { return prow_raw[b] + MPC_PROW_SKEW; }
@@ -224,9 +227,10 @@ struct Solver {
   }
   // the same with the factorisation's G_f = T_k W_f: t.w6 = G_f v,  out = G_f^T y_k.  G_f sits in LDS and is fetched where it
   // is used (volatile 64-bit loads, see foot_a: 36 VGPRs the iteration loop does not have)
+  static constexpr MPC_HD int pidx(int k, int f) { return ((k >> 1) * NF + f) * 2 + (k & 1); }   // pair layout (see Shared::fa)
   MPC_HD void load_g(const Th &t, double *gf) const {
 #pragma unroll
-    for (int k = 0; k < 18; ++k) gf[k] = MPC_LDS_LOAD64(s.Gf + NF * k + t.tid);
+    for (int k = 0; k < 18; k += 2) MPC_LDS_LOAD128(s.Gf + pidx(k, t.tid), gf[k], gf[k + 1]);
   }
   MPC_HD void put_g(Th &t, const double *v) const {
     double gf[18];
@@ -342,15 +346,15 @@ struct Solver {
 #pragma unroll
         for (int c = 0; c < 3; ++c) { t.x[c] = state[3 * f + c]; t.q[c] = sc[C::SC_QS + 3 * f + c]; }
         const double *as = sc + C::SC_AS + 15 * f;
-        double *fa = s.fa + f;   // element k of my foot: fa[NF * k]  (consecutive lanes, consecutive banks)
-        fa[0] = as[0]; fa[NF] = as[2]; fa[2 * NF] = as[3]; fa[3 * NF] = as[5]; fa[4 * NF] = as[7]; fa[5 * NF] = as[8]; fa[6 * NF] = as[10]; fa[7 * NF] = as[11]; fa[8 * NF] = as[14];
+        s.fa[pidx(0, f)] = as[0]; s.fa[pidx(1, f)] = as[2]; s.fa[pidx(2, f)] = as[3]; s.fa[pidx(3, f)] = as[5]; s.fa[pidx(4, f)] = as[7];
+        s.fa[pidx(5, f)] = as[8]; s.fa[pidx(6, f)] = as[10]; s.fa[pidx(7, f)] = as[11]; s.fa[pidx(8, f)] = as[14]; s.fa[pidx(15, f)] = 0.0;
         int tyb = 0;
 #pragma unroll
         for (int r = 0; r < 5; ++r) {
           t.z[r] = state[N + 5 * f + r]; t.y[r] = state[N + M + 5 * f + r];   // scaled iterates of the previous call; zeros on the first call
           const double lo = sc[C::SC_LS + 5 * f + r], hi = sc[C::SC_US + 5 * f + r];
-          fa[NF * (10 + r)] = hi;
-          if (r == 4) fa[NF * 9] = lo;
+          s.fa[pidx(10 + r, f)] = hi;
+          if (r == 4) s.fa[pidx(9, f)] = lo;
           // set_rho_vec / update_rho_vec (auxil.c:79-141): the row type is a function of the scaled bounds
           const int ty = (lo < -kInfty * kMinScaling && hi > kInfty * kMinScaling) ? 0 : (hi - lo < kRhoTol ? 2 : 1);
           tyb |= ty << (2 * r);
@@ -370,15 +374,25 @@ struct Solver {
   // my foot's constants, fetched where they are used (volatile 64-bit LDS loads: the compiler neither hoists them out of the
   // iteration loop nor keeps them in registers across it -- 30 VGPRs the loop does not have)
   MPC_HD void foot_a(const Th &t, double *a) const {
+    double dummy;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) a[k] = MPC_LDS_LOAD64(s.fa + NF * k + t.tid);
+    for (int k = 0; k < 8; k += 2) MPC_LDS_LOAD128(s.fa + pidx(k, t.tid), a[k], a[k + 1]);
+    MPC_LDS_LOAD128(s.fa + pidx(8, t.tid), a[8], dummy);
+  }
+  MPC_HD void foot_ar(const Th &t, double *a) const {   // the cone block times rho of its row
+    double dummy;
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) MPC_LDS_LOAD128(s.fr + pidx(k, t.tid), a[k], a[k + 1]);
+    MPC_LDS_LOAD128(s.fr + pidx(8, t.tid), a[8], dummy);
   }
   MPC_HD void foot_bounds(const Th &t, double *lo, double *up) const {   // rows 0-3 have l = 0 (mpc_osqp.cc:449-477)
+    double dummy;
 #pragma unroll
     for (int r = 0; r < 4; ++r) lo[r] = 0.0;
-    lo[4] = MPC_LDS_LOAD64(s.fa + NF * 9 + t.tid);
-#pragma unroll
-    for (int r = 0; r < 5; ++r) up[r] = MPC_LDS_LOAD64(s.fa + NF * (10 + r) + t.tid);
+    MPC_LDS_LOAD128(s.fa + pidx(8, t.tid), dummy, lo[4]);
+    MPC_LDS_LOAD128(s.fa + pidx(10, t.tid), up[0], up[1]);
+    MPC_LDS_LOAD128(s.fa + pidx(12, t.tid), up[2], up[3]);
+    MPC_LDS_LOAD128(s.fa + pidx(14, t.tid), up[4], dummy);
   }
 
   MPC_HD void set_rho_vec() {   // rho per row type (auxil.c:79-96, osqp.c:1267-1310)
@@ -527,7 +541,7 @@ struct Solver {
           mul_tk(t, w, g1);
           put_zf(t, xs(t), g1);
 #pragma unroll
-          for (int k = 0; k < 18; ++k) s.Gf[NF * k + t.tid] = g1[k];
+          for (int k = 0; k < 18; ++k) s.Gf[pidx(k, t.tid)] = g1[k];
         }
       });
       step_factor<false>();
@@ -539,7 +553,7 @@ struct Solver {
         else foot_w(t, w);
         mul_tk(t, w, gf);
 #pragma unroll
-        for (int k = 0; k < 18; ++k) s.Gf[NF * k + t.tid] = gf[k];
+        for (int k = 0; k < 18; ++k) s.Gf[pidx(k, t.tid)] = gf[k];
         // dl = diag(M)^-1/2 of my rows,  M_rr = 1 + l_r^T (c Theta_kk) l_r  (l_r: column r of L_k)
         const int k = t.tid >> 2, j = t.tid & 3;
         const double mm = (double)(H - k), s2kk = mm * (4.0 * mm * mm - 1.0) / 12.0;   // sum_{i < m} (i + 1/2)^2
@@ -610,6 +624,11 @@ struct Solver {
         S[4] = rv[2] * a[4] * a[5] + rv[3] * a[6] * a[7];
         S[5] = (s.calpha * Dat(t, 2) * Dat(t, 2) + kSigma) + ((((rv[0] * a[1] * a[1] + rv[1] * a[3] * a[3]) + rv[2] * a[5] * a[5]) + rv[3] * a[7] * a[7]) + rv[4] * a[8] * a[8]);
         sym3_inv(S, t.Si);
+        // the cone block times rho of its row, for the iteration's A^T R (.)
+        const double ar[9] = {a[0] * rv[0], a[1] * rv[0], a[2] * rv[1], a[3] * rv[1], a[4] * rv[2], a[5] * rv[2], a[6] * rv[3], a[7] * rv[3], a[8] * rv[4]};
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s.fr[pidx(k, t.tid)] = ar[k];
+        s.fr[pidx(9, t.tid)] = 0.0;
       }
     });
     factor_core<false>([](Th &t) { return t.Si; });
@@ -705,12 +724,22 @@ struct Solver {
   // One ADMM iteration = two phases: the tile product, and the foot phase, which finishes the KKT solve
   //   x~ = S^-1 (b - G^T y_w),  z~ = A x~,  updates x, z, y (relaxation 1.6), prepares the next
   // right-hand side and hands its wrench contribution to the quad.
+  // Inside a block of iterations t.y holds yh = y / rho (per row): OSQP's  z = clip(z_r + y / rho),  y <- y + rho (z_r - z)  becomes
+  // z = clip(z_r + yh),  yh <- (z_r + yh) - z,  and  rho z - y = rho (z - yh)  takes its rho from the pre-multiplied cone block (fr).
+  MPC_HD void y_scaled(bool to) {
+    ex.seq([&](Th &t) {
+      if (t.tid < NF) {
+#pragma unroll
+        for (int r = 0; r < 5; ++r) t.y[r] *= to ? rinv_at(t, r) : rho_at(t, r);
+      }
+    });
+  }
   MPC_HD void admm_iter() {
     tile_product<kHeld>();
     recv<kHeld>();
     ex.seq([&](Th &t) {
       if (t.tid < NF) {
-        double wy[3], tt[3], zt[5], tm[5], acc[3], a[9], lo[5], up[5];
+        double wy[3], tt[3], zt[5], dd[5], acc[3], a[9], lo[5], up[5];
         get_g(t, wy);
 #pragma unroll
         for (int c = 0; c < 3; ++c) tt[c] = t.b[c] - wy[c];
@@ -720,15 +749,16 @@ struct Solver {
         a_mul(a, t.xt, zt);
 #pragma unroll
         for (int r = 0; r < 5; ++r) {
-          const double rv = rho_at(t, r), ri = rinv_at(t, r);
           const double zr = kAlphaRelax * zt[r] + (1.0 - kAlphaRelax) * t.z[r];
-          const double zn = clampd(zr + ri * t.y[r], lo[r], up[r]);
-          const double yn = t.y[r] + rv * (zr - zn);
+          const double tq = zr + t.y[r];
+          const double zn = clampd(tq, lo[r], up[r]);
+          const double yn = tq - zn;
           t.z[r] = zn;
           t.y[r] = yn;
-          tm[r] = rv * zn - yn;
+          dd[r] = zn - yn;
         }
-        at_mul(a, tm, acc);
+        foot_ar(t, a);
+        at_mul(a, dd, acc);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const double xn = kAlphaRelax * t.xt[c] + (1.0 - kAlphaRelax) * t.x[c];
@@ -1021,7 +1051,7 @@ struct Solver {
           for (int r = 0; r < 5; ++r) o[r] = t.act[r];
           for (int k = 0; k < 6; ++k) o[5 + k] = t.pXi[k];
           for (int c = 0; c < 3; ++c) { o[11 + c] = t.pg[c]; o[14 + c] = t.pt[c]; o[17 + c] = t.pw[c]; }
-          for (int k = 0; k < 18; ++k) o[20 + k] = s.Gf[NF * k + t.tid];
+          for (int k = 0; k < 18; ++k) o[20 + k] = s.Gf[pidx(k, t.tid)];
         }
       });
 #endif
@@ -1108,7 +1138,9 @@ struct Solver {
     static_assert(kMaxIter % kCheck == 0, "the check falls on the last iteration");
     int iter = 0;
     while (!s.done && !s.bad && iter < kMaxIter) {
+      y_scaled(true);
       for (int k = 0; k < kCheck; ++k) admm_iter();
+      y_scaled(false);
       iter += kCheck;
       lap(8);
       mul_P([](Th &t) { return t.x; }, [](Th &t) { return t.px; });
