@@ -1,19 +1,31 @@
 #!/usr/bin/env python
 """bench.py -- MPC control steps/s of the batched convex-MPC contact-force solve on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5]
 
-A "step" = one pass of the hot path over one batch of synthetic input: every robot of the batch does
-one ``compute_contact_forces`` (QP build + OSQP-equivalent solve, mpc_osqp.cc:578-796) on the GPU.
-Workload at N=1: BASELINE.json configs[1] -- 4096 Aliengo, trot, horizon 10, flat terrain.  The K+W
-input batches are a seeded sequence: step 0 is the cold "osqp_setup" solve, the
-following ones advance the gait and perturb the state, so the timed steps are warm-started solves,
-as in the reference's control loop.  Inputs are resident in HBM before the timed region.
-Multi-GPU: robots shard across ranks (weak scaling, 4096 per GPU, no data-path collective).
+A "step" = one pass of the hot path over one batch of synthetic input: every robot of the batch does one
+``compute_contact_forces`` (QP build + OSQP-equivalent solve, mpc_osqp.cc:578-796) on the GPU.  The leg-torque map
+(LegController.updateCommand) is NOT inside `value`; the whole ``controller.run`` seam including it is the
+secondary ``control_loop`` leg.
+
+Workloads (BASELINE.json configs):
+  --config 2 (default, the configuration the metric is quoted on): 4096 Aliengo per GPU, trot, horizon 10, flat terrain; weak scaling.
+  --config 3: 4096 robots per GPU, {Go1, A1, Aliengo} mixed, trot / walk / bound, horizon 10; weak scaling.
+  --config 4: 32768 Aliengo in total, horizon 16, random terrain normals, sharded over the N ranks; strong scaling.
+  --config 5: 65536 Aliengo in total, horizon 20, sharded over the N ranks; strong scaling.
+The K+W input batches are a seeded sequence: step 0 is the cold "osqp_setup" solve, the following ones advance the gait and
+perturb the state, so the timed steps are warm-started solves, as in the reference's control loop.  Inputs are resident in HBM
+before the timed region.
+
+Multi-GPU: one process per GPU, robots shard across ranks, no data-path collective.  With N > 1 and no
+torch.distributed environment, this script launches itself under ``python -m torch.distributed.run`` (one node, 127.0.0.1).
+A separate, separately reported leg times the optional RCCL all-gather of the per-robot torques on a side stream.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,12 +36,23 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (vector)"; SURVEY.md 8(d) prices against it
-FP64_VECTOR_PEAK_TFLOPS = 78.6    # datasheet fp64 vector rate (half the fp32 rate); the kernel computes in fp64
+FP64_VECTOR_PEAK_TFLOPS = 78.6    # datasheet fp64 vector rate (half the fp32 rate); the kernels compute in fp64
+
+CONFIGS = {
+    2: dict(h=10, robots_total=None, robots_per_gpu=4096, scaling="weak",
+            what="Aliengo, trot, horizon=10, flat terrain (BASELINE configs[1])"),
+    3: dict(h=10, robots_total=None, robots_per_gpu=4096, scaling="weak",
+            what="{Go1, A1, Aliengo} mixed, trot / walk / bound, horizon=10 (BASELINE configs[2])"),
+    4: dict(h=16, robots_total=32768, robots_per_gpu=None, scaling="strong",
+            what="Aliengo, horizon=16, random terrain normals, 32768 robots sharded over the ranks (BASELINE configs[3])"),
+    5: dict(h=20, robots_total=65536, robots_per_gpu=None, scaling="strong",
+            what="Aliengo, horizon=20, 65536 robots sharded over the ranks (BASELINE configs[4]; fp64 arithmetic, see DESIGN.md)"),
+}
 
 
 def algorithmic_flops(h, contact, iters, nfact):
     """SURVEY.md 8(d) minimal-algorithm flop count per control step, summed over the batch, split by kernel:
-    (assembly kernel: A^k B, P recursion, q;  solve kernel: F factorisations + I ADMM iterations).
+    (prep kernel: A^k B, P recursion, q;  solve kernel: F factorisations + I ADMM iterations).
     n_r = 3 * (stance leg-steps in the horizon); I = ADMM iterations executed; F = factorisations."""
     n_r = 3.0 * contact.reshape(len(contact), -1).sum(1)
     fixed = 4056.0 * (h - 1) + 3900.0 * h * (h + 1) / 2 + 2.0 * 13 * h * (13 + 12 * h)
@@ -37,51 +60,49 @@ def algorithmic_flops(h, contact, iters, nfact):
     return float(fixed * len(n_r)), float(per.sum())
 
 
-def executed_flops(h, iters, nfact, polished):
-    """fp64 operations the kernel actually executes per batch: the OSQP-faithful algorithm keeps all
-    n = 12 h variables.  Per robot: nfact_K full symmetric sweeps (n pivots x MT tiles x (36 FMA + 6 mul)), the masked
-    polish sweep counted as half a sweep, `iters` ADMM iterations (tile mat-vec 2 x 36 FMA per tile + ~45 flops per
-    variable + ~15 per constraint row), 10 Ruiz passes (4 ops per tile entry) and three P_s products (the assembly kernel's
-    work is not counted here)."""
-    n, m, mt = 12 * h, 20 * h, h * (2 * h + 1)
-    sweep = n * mt * (72.0 + 6.0)
-    it = mt * 144.0 + 45.0 * n + 15.0 * m
-    fixed = 10 * mt * 144.0 + 3 * mt * 144.0
-    n_k = nfact - polished                       # factorisations of K (the polish one is counted in info[4])
-    return float((n_k * sweep + polished * 0.5 * sweep + iters * it + fixed).sum())
+def executed_flops(h, iters, nfact):
+    """fp64 operations the solve kernel executes per batch: the OSQP iteration on all 12 h variables, with the KKT
+    solve carried through the 6 h x 6 h wrench-space core.  Per robot: `nfact` factorisations (6 h pivots x MT tiles x (36 FMA + 6 mul)
+    + the tile build 2 x 216 FMA + 72 mul per tile + ~900 flops per foot), `iters` ADMM iterations (tile mat-vec 2 x 36 FMA per tile
+    + ~230 flops per foot), and ~4 products with Theta per termination check / polish.  (The prep kernel's work -- ten Ruiz passes
+    over the dense P, 4 ops per entry -- is not counted here.)"""
+    nw, nf, mt = 6 * h, 4 * h, h * (h + 1) // 2
+    sweep = nw * mt * 78.0
+    build = mt * (2 * 432.0 + 72.0) + nf * 900.0
+    it = mt * 144.0 + nf * 230.0
+    return float((nfact * (sweep + build) + iters * it + (iters / 25.0 + 3.0) * mt * 290.0).sum())
 
 
-def main():
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--robots", type=int, default=4096, help="robots per GPU")
-    ap.add_argument("--horizon", type=int, default=10)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--robots", type=int, default=None, help="robots per GPU (overrides the configuration's size)")
+    ap.add_argument("--horizon", type=int, default=None, help="(overrides the configuration's horizon)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-control-loop", action="store_true", help="skip the secondary controller.run leg (profiling runs)")
-    args = ap.parse_args()
+    ap.add_argument("--no-control-loop", action="store_true", help="skip the secondary legs (profiling runs)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary single-GPU lines of the other configurations")
+    return ap.parse_args()
 
+
+def run_leg(cfg_id, n, h, K, W, dev, rank, world, dist):
+    """Warm up, then time exactly K steps bracketed by barrier + synchronize; returns the raw measurements of this rank."""
     import torch
-    import rl_mpc_locomotion_amd  # noqa: F401
     from rl_mpc_locomotion_amd import layout as L
     from rl_mpc_locomotion_amd.batched import BatchedConvexMpc
     from rl_mpc_locomotion_amd.synthetic import make_solver_workload, perturb_workload
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    dev = torch.device(f"cuda:{local_rank}")
-    torch.cuda.set_device(dev)
-
-    n, h, K, W = args.robots, args.horizon, args.steps, args.warmup
-    # this rank's shard of the global batch: robots [rank*n, (rank+1)*n) of a world*n batch
-    wl = make_solver_workload(n, h=h, seed=1000 + rank, config=2)
+    wl = make_solver_workload(n, h=h, seed=1000 + rank, config=cfg_id)   # this rank's shard: its own seeded robots
     batches = []
     w = wl
     for s in range(K + W):
@@ -103,7 +124,7 @@ def main():
     t0 = time.perf_counter()
     first_out = torch.zeros((n, 12 * h), dtype=torch.float64, device=dev)
     for s in range(K):
-        ev[s][0].record()                      # HIP events on the stream the kernel is launched on
+        ev[s][0].record()                      # HIP events on the stream the kernels are launched on
         solver.solve(d_in[W + s], forces=first_out if s == 0 else None, info=infos[s])
         ev[s][1].record()
     torch.cuda.synchronize(dev)
@@ -114,38 +135,81 @@ def main():
         from rl_mpc_locomotion_amd.sharding import max_over_ranks
         elapsed = max_over_ranks(elapsed, dev)
 
-    step_ms = np.array([a.elapsed_time(b) for a, b in ev])        # assembly + solve + dispatch-order kernels of one step
+    step_ms = np.array([a.elapsed_time(b) for a, b in ev])        # both kernels of one step
     kt = min(K, 64)
-    assemble_ms, kernel_ms = (a.astype(np.float64) for a in solver.kernel_times(kt))   # the dominant kernel (mpc_solve_kernel) alone
-    first_forces = first_out.cpu().numpy()
+    prep_ms, solve_ms = (a.astype(np.float64) for a in solver.kernel_times(kt))
     info = torch.stack(infos).cpu().numpy()                         # [K, n, 8]
-    solved = int((info[..., 1] == 1).sum())
     flops = asm_flops = 0.0
     for s in range(K):
         contact = batches[W + s][:, L.IN_CONTACT:L.IN_CONTACT + 4 * h]
         fa, fs = algorithmic_flops(h, contact, info[s, :, 0].astype(np.float64), info[s, :, 4].astype(np.float64))
         flops += fs; asm_flops += fa
-    flops_per_launch = flops / K                                     # of the dominant kernel (mpc_solve_kernel)
-    exec_flops = sum(executed_flops(h, info[s, :, 0].astype(np.float64), info[s, :, 4].astype(np.float64),
-                                    (info[s, :, 2] != 0).astype(np.float64)) for s in range(K)) / K
-    achieved_tflops = flops_per_launch / (kernel_ms.mean() * 1e-3) / 1e12
+    exec_flops = sum(executed_flops(h, info[s, :, 0].astype(np.float64), info[s, :, 4].astype(np.float64)) for s in range(K)) / K
+    return dict(wl=wl, batches=batches, solver=solver, elapsed=elapsed, step_ms=step_ms, prep_ms=prep_ms, solve_ms=solve_ms, info=info,
+                first_forces=first_out.cpu().numpy(), flops_per_launch=flops / K, prep_flops_per_launch=asm_flops / K, exec_flops=exec_flops)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launch ourselves as one process per GPU (the driver's own launch line); rank 0 prints the JSON line
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(cmd, env=env))
+
+    import torch
+    import rl_mpc_locomotion_amd  # noqa: F401
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} has no GPU {local_rank} ({torch.cuda.device_count()} visible)")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        assert dist.get_world_size() == args.gpus, "RCCL saw a different number of ranks than --gpus"
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+
+    cfg = CONFIGS[args.config]
+    h = args.horizon or cfg["h"]
+    K, W = args.steps, args.warmup
+    if args.robots:
+        n = args.robots
+    elif cfg["robots_per_gpu"]:
+        n = cfg["robots_per_gpu"]
+    else:
+        from rl_mpc_locomotion_amd.sharding import shard_bounds
+        lo, hi = shard_bounds(cfg["robots_total"], rank, world)
+        n = hi - lo
+    n_total = n * world if (args.robots or cfg["robots_per_gpu"]) else cfg["robots_total"]
+
+    m = run_leg(args.config, n, h, K, W, dev, rank, world, dist)
+    gather = all_gather_leg(n, n_total, dev, dist) if dist is not None else None
 
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
+    info, solve_ms, prep_ms = m["info"], m["solve_ms"], m["prep_ms"]
+    achieved_tflops = m["flops_per_launch"] / (solve_ms.mean() * 1e-3) / 1e12
     # HBM traffic of the solve kernel is a rocprofv3 PMC measurement taken offline on this same command
     # (tools/pmc_passes.sh -> profiles/rNN_pmc_summary.json); bench.py cannot run the profiler on itself.
     traffic = None
     try:
         import glob
         pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
-        if pm and n == 4096 and h == 10:
+        if pm and n == 4096 and h == 10 and args.config == 2:
             traffic = float(json.load(open(pm[-1]))["hbm_traffic_bytes_per_launch"])
     except (OSError, ValueError, KeyError):
         traffic = None
-    value = world * n * K / elapsed
+    value = n_total * K / m["elapsed"]
     out = {
         "metric": "MPC control steps/sec (whole node) @ horizon=10, 4096 robots; max |GRF| err vs OSQP",
         "value": value,
@@ -153,41 +217,84 @@ def main():
         "n_gpus": world,
         "steps": K,
         "warmup": W,
-        "ms_per_step": elapsed / K * 1e3,
+        "ms_per_step": m["elapsed"] / K * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": cfg["scaling"],
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"{n} Aliengo/GPU, trot, horizon={h}, flat terrain, 1 compute_contact_forces per robot per step "
-                               "(BASELINE configs[1]); warm-started seeded sequence, SURVEY.md 8(d)",
-                   "robots_per_gpu": n, "horizon": h, "parallelism": f"robot-sharded x{world}"},
-        "solved_fraction": solved / float(K * n),
+        "config": {"workload": f"config {args.config}: {n} robots/GPU x {world} GPU(s), {cfg['what']}; one compute_contact_forces (QP build + solve) per robot "
+                               "per step, warm-started seeded sequence, SURVEY.md 8(d); the leg-torque map (a22) is outside `value` (see control_loop)",
+                   "robots_per_gpu": n, "robots_total": n_total, "horizon": h, "parallelism": f"robot-sharded x{world}"},
+        "solved_fraction": float((info[..., 1] == 1).mean()),
         "mean_admm_iters": float(info[..., 0].mean()),
         "mean_factorisations": float(info[..., 4].mean()),
-        "roofline": {"bound": "mfma", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "roofline": {"bound": "vector_fp64", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic,
-                     "traffic_note": "HBM-side bytes per launch from rocprofv3 PMC (profiles/*_pmc_summary.json, measured offline on this command)",
-                     "note": "vector-FP bound, no MFMA/HBM roofline applies (SURVEY 8d): algorithmic flops (n_r formula) / "
-                             "mean duration of mpc_solve_kernel from HIP events; kernel arithmetic is fp64 (peak 78.6 TF)",
-                     "kernel": "mpc_solve_kernel", "kernel_ms": float(kernel_ms.mean()), "assemble_kernel_ms": float(assemble_ms.mean()),
-                     "step_ms_all_kernels": float(step_ms.mean()), "flops_per_launch": flops_per_launch,
-                     "assemble_kernel_flops_per_launch": asm_flops / K,
+                     "traffic_note": "HBM-side bytes per launch of the solve kernel from rocprofv3 PMC (profiles/*_pmc_summary.json, measured offline on this command)",
+                     "note": "vector-FP bound, no MFMA / HBM roofline applies (SURVEY 8d): algorithmic flops (n_r formula, solve-kernel share) / "
+                             "mean duration of mpc_solve_kernel from HIP events on the launch stream; `peak` is the FP32 vector rate SURVEY 8(d) "
+                             "prescribes, the kernel's arithmetic is fp64 (frac_fp64_peak, peak 78.6 TF)",
+                     "kernel": "mpc_solve_kernel", "kernel_ms": float(solve_ms.mean()), "prep_kernel_ms": float(prep_ms.mean()),
+                     "step_ms_all_kernels": float(m["step_ms"].mean()), "flops_per_launch": m["flops_per_launch"],
+                     "prep_kernel_flops_per_launch": m["prep_flops_per_launch"],
                      "frac_fp64_peak": achieved_tflops / FP64_VECTOR_PEAK_TFLOPS,
-                     "executed": {"flops_per_launch": exec_flops, "tflops": exec_flops / (kernel_ms.mean() * 1e-3) / 1e12,
-                                  "frac_fp64_peak": exec_flops / (kernel_ms.mean() * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                                  "note": "operations the OSQP-faithful kernel executes (all 12h variables kept; bench.py executed_flops), "
-                                          "for orientation only -- `achieved` / `frac` above use the SURVEY 8(d) minimal-algorithm count"}},
+                     "executed": {"flops_per_launch": m["exec_flops"], "tflops": m["exec_flops"] / (solve_ms.mean() * 1e-3) / 1e12,
+                                  "frac_fp64_peak": m["exec_flops"] / (solve_ms.mean() * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                                  "note": "operations the solve kernel executes (bench.py executed_flops: OSQP on all 12 h variables through the 6 h x 6 h "
+                                          "wrench-space core), for orientation only -- `achieved` / `frac` use the SURVEY 8(d) minimal-algorithm count"}},
     }
+    if gather is not None:
+        out["all_gather_torques"] = gather
+    if world == 1 and not args.no_secondary and args.config == 2 and not args.robots:
+        out["secondary"] = secondary_lines(dev)          # the other BASELINE configurations at their per-GPU sizes (N = 1 only)
     if not args.no_control_loop and world == 1:      # secondary legs: single-GPU runs only
         out["control_loop"] = control_loop_leg(n, h, dev)
         out["policy"] = policy_leg(n, dev)
     if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
-        out["cpu_baseline"] = cpu_baseline(wl, batches, W, h, gpu_first_forces=first_forces)
+        out["cpu_baseline"] = cpu_baseline(m["wl"], m["batches"], W, h, gpu_first_forces=m["first_forces"])
         out["max_grf_err_vs_osqp"] = out["cpu_baseline"].pop("_gpu_err", None)
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def secondary_lines(dev, steps=5, warm=2):
+    """Single-GPU lines of the other BASELINE configurations at their per-GPU shard sizes (config 3: 4096; config 4: 32768 / 8;
+    config 5: 65536 / 8), so that the driver's N = 1 record carries them too.  Not `value`."""
+    out = {}
+    for cid, n in ((3, 4096), (4, 4096), (5, 8192)):
+        h = CONFIGS[cid]["h"]
+        m = run_leg(cid, n, h, steps, warm, dev, 0, 1, None)
+        out[f"config{cid}"] = {"robots": n, "horizon": h, "steps": steps, "control_steps_per_s": n * steps / m["elapsed"],
+                               "ms_per_step": m["elapsed"] / steps * 1e3, "prep_kernel_ms": float(m["prep_ms"].mean()),
+                               "solve_kernel_ms": float(m["solve_ms"].mean()), "solved_fraction": float((m["info"][..., 1] == 1).mean()),
+                               "mean_admm_iters": float(m["info"][..., 0].mean()), "what": CONFIGS[cid]["what"]}
+        del m
+    return out
+
+
+def all_gather_leg(n, n_total, dev, dist, reps=50, warm=5):
+    """The optional exchange of SURVEY 8(e): RCCL all-gather of the per-robot torques ([n_local, 12] float32 per rank) on a side
+    stream, timed with HIP events on that stream; reported separately, never part of `value`."""
+    import torch
+    from rl_mpc_locomotion_amd.sharding import all_gather_torques
+    side = torch.cuda.Stream(device=dev)
+    local = torch.randn((n, 12), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize(dev)
+    with torch.cuda.stream(side):
+        for _ in range(warm):
+            all_gather_torques(local, n_total)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(side)
+        for _ in range(reps):
+            out = all_gather_torques(local, n_total)
+        e1.record(side)
+    side.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    ok = bool(tuple(out.shape) == (n_total, 12))
+    return {"ms": ms, "bytes_per_rank": n * 48, "robots_total": n_total, "shape_ok": ok,
+            "note": "one all_gather_into_tensor of [n_local, 12] float32 per rank over RCCL / xGMI on a side stream; latency-bound"}
 
 
 def control_loop_leg(n, h, dev, ticks=40, warm=10):
@@ -210,8 +317,10 @@ def control_loop_leg(n, h, dev, ticks=40, warm=10):
     dt = time.perf_counter() - t0
     solved = float((ctl.solver_info()[:, 1] == 1).mean())
     return {"robot_ticks_per_s": n * ticks / dt, "ms_per_tick": dt / ticks * 1e3, "ticks": ticks, "mpc_every_n_ticks": 2,
+            "control_steps_per_s_incl_torque_map": n * ticks / dt / 2,
             "solved_fraction_last_mpc": solved,
-            "note": "controller.run for every robot per tick; the MPC solve runs on every 2nd tick, so this is ~2x the control-step rate by construction"}
+            "note": "controller.run for every robot per tick (estimator, gait, foot placement, MPC solve on every 2nd tick, swing / stance "
+                    "commands, leg-torque map a22); robot_ticks_per_s is ~2x the control-step rate by construction"}
 
 
 def policy_leg(n, dev, steps=50, warm=5):
@@ -256,7 +365,8 @@ def usable_cores():
 def cpu_baseline(wl, batches, W, h, sample=2048, steps=4, gpu_first_forces=None):
     """The reference path (oracle/_ref: restated mpc_osqp.cc assembly + the vendored OSQP) timed on the
     host cores on a bounded sample of the same workload: the first `sample` robots, cold solve +
-    `steps` timed warm solves (the same batches the GPU warmed up / timed on)."""
+    `steps` timed warm solves (the same batches the GPU warmed up / timed on); all granted cores, then one core
+    on a quarter of the sample."""
     from oracle.refmpc import RefBatch
     cores = usable_cores()
     sample = min(sample, len(wl.mass))
@@ -275,9 +385,36 @@ def cpu_baseline(wl, batches, W, h, sample=2048, steps=4, gpu_first_forces=None)
         ok = ~np.isnan(fr0[:, 0])
         g = gpu_first_forces[:sample]
         err = float((np.abs(g[ok, :12] - fr0[ok, :12]).max(1) / np.maximum(np.abs(fr0[ok, :12]).max(1), 1.0)).max())
-    return {"_gpu_err": err, "value": sample * steps / dt, "unit": "control steps/s", "cores": cores, "kind": "reference",
-            "sample": f"first {sample} robots of the workload, {W} warm-up + {steps} timed warm-started solves each, "
-                      f"one OSQP workspace per robot, static partition over {cores} threads"}
+    # one core: SURVEY 8(d)(i)
+    s1 = max(64, sample // 8)
+    ref1 = RefBatch(wl.mass[:s1], wl.inertia_diag[:s1], h, wl.dt_mpc, wl.alpha)
+    for s in range(W):
+        ref1.solve(batches[s][:s1], nthreads=1)
+    t1 = time.perf_counter()
+    for s in range(steps):
+        ref1.solve(batches[W + s][:s1], nthreads=1)
+    dt1 = time.perf_counter() - t1
+    out = {"_gpu_err": err, "value": sample * steps / dt, "unit": "control steps/s", "cores": cores, "kind": "reference",
+           "sample": f"first {sample} robots of the workload, {W} warm-up + {steps} timed warm-started solves each, "
+                     f"one OSQP workspace per robot, static partition over {cores} threads",
+           "one_core": {"value": s1 * steps / dt1, "cores": 1, "sample": f"first {s1} robots, same sequence, one thread"}}
+    tick = python_tick_baseline()
+    if tick is not None:
+        out["python_tick"] = tick
+    return out
+
+
+def python_tick_baseline(ticks=200):
+    """the real Python path of BASELINE configs[0] -- one Aliengo, RobotRunnerMin.run, trot, h = 10 -- timed per tick with
+    the oracle behind the reference's mpc_osqp seam.  Only where the reference tree is present (not on the GPU boxes)."""
+    if not os.path.isdir("/root/reference/MPC_Controller"):
+        return None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        import make_golden_controller as mg
+        return mg.time_reference_tick(ticks)
+    except Exception as e:      # the baseline is optional; never fail the bench line on it
+        return {"error": repr(e)}
 
 
 if __name__ == "__main__":

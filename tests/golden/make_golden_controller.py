@@ -96,6 +96,30 @@ def run_case(name, n, ticks, seed, flat_ground):
     print(name, "written: max |tau|", float(np.abs(out["torque"]).max()))
 
 
+def time_reference_tick(ticks=200, warm=20):
+    """SURVEY 8(d) CPU timing of BASELINE configs[0]: one Aliengo, trot, h = 10, the unmodified RobotRunnerMin.run per tick
+    (Python controller + the oracle's OSQP solve on every second tick), open-loop replay.  Used by bench.py's cpu_baseline."""
+    import time
+    rng = np.random.default_rng(7)
+    Parameters.flat_ground = False
+    Parameters.cmpc_gait = GaitType.TROT
+    st = dict(phase=rng.uniform(0, 2 * np.pi, 21), amp=rng.uniform(0.02, 0.15, 21), yaw0=rng.uniform(-3, 3),
+              H=float(rng.uniform(0.25, 0.36)), v0=rng.uniform(-0.5, 0.5, 3) * np.array([1, 0.4, 0.1]),
+              cmd=np.array([rng.uniform(-1.5, 1.5), rng.uniform(-0.5, 0.5), rng.uniform(-1.0, 1.0)]),
+              w=np.array([5, 5, 5, 50, 50, 50, 1, 1, 1, 1, 1, 1]) + rng.uniform(-1, 1, 12) * np.array([4, 4, 4, 20, 20, 20, 1, 1, 1, 1, 1, 1]))
+    runner = RobotRunnerMin()
+    runner.init(REF_TYPES[0])
+    ins = [inputs_for(0, k, st) for k in range(warm + ticks)]
+    for k in range(warm):
+        runner.run(*ins[k])
+    t0 = time.perf_counter()
+    for k in range(warm, warm + ticks):
+        runner.run(*ins[k])
+    dt = time.perf_counter() - t0
+    return {"ms_per_tick": dt / ticks * 1e3, "robot_ticks_per_s": ticks / dt, "control_steps_per_s": ticks / dt / 2, "ticks": ticks, "cores": 1,
+            "what": "unmodified RobotRunnerMin.run, one Aliengo, trot, h=10, oracle (vendored OSQP) behind the mpc_osqp seam; MPC solve on every 2nd tick"}
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for case in (("controller_h10_slope", 9, 48, 5, False), ("controller_h10_flat", 6, 48, 6, True),

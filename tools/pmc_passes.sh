@@ -6,7 +6,7 @@
 set -u
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
-CMD="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-control-loop"
+CMD="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-control-loop --no-secondary"
 cd /tmp
 for spec in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq1:SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU" "sq2:SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_ANY SQ_WAVES"; do
   name=${spec%%:*}; ctrs=${spec#*:}

@@ -18,15 +18,17 @@ for name, d in per.items():
     counters[name] = sum(vals) / len(vals)
 traffic = (2 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024
 N, M = 12 * h, 20 * h
-alg = n * ((56 + 4 * h) * 4 + (2 * N + 2 * M + 2) * 8 * 2 + N * 8 + 8 * 4)
+alg = n * ((56 + 4 * h) * 4 + (2 * N + 2 * M + 2) * 8 * 2 + N * 8 + 8 * 4)   # path level: input record, warm-start state r+w, forces, info
+rec = n * ((2 * N + 3 * M + 60 * h + 2) + (N + 2 * M + 16 + 116)) * 8 * 2            # scale + QP records handed from the prep kernel to the solve kernel (written once, read once)
 c = counters
 summary = {
-    "command": "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-control-loop (tools/pmc_passes.sh: one rocprofv3 --pmc pass per counter group, --kernel-trace only)",
+    "command": "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-control-loop --no-secondary (tools/pmc_passes.sh: one rocprofv3 --pmc pass per counter group, --kernel-trace only)",
     "kernel": f"mpc_solve_kernel<{h}>, {n} robots per launch, mean of the 5 timed (warm-started) dispatches",
     "counters_per_launch": counters,
     "hbm_traffic_bytes_per_launch": traffic,
     "traffic_rule": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM section) so it is doubled; other access widths and WRITE_SIZE are uncalibrated there, and the fabric counters include Infinity-Cache hits -- treat as an upper bound on HBM bytes",
     "algorithmic_bytes_per_launch": alg,
+    "inter_kernel_record_bytes_per_launch": rec,
     "derived": {
         "lds_bank_conflict_frac_of_lds_cycles": c.get("SQ_LDS_BANK_CONFLICT", 0) / max(c.get("SQ_LDS_IDX_ACTIVE", 1), 1),
         "wave_cycles_parked_frac (SQ_WAIT_ANY/SQ_WAVE_CYCLES)": c.get("SQ_WAIT_ANY", 0) / max(c.get("SQ_WAVE_CYCLES", 1), 1),
