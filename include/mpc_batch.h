@@ -74,6 +74,9 @@ int mpc_batch_solve(mpc_batch *b, const float *d_in, double *d_forces, int *d_in
 /* Cold-start the listed robots (HOST array of indices); ids == NULL resets all. */
 int mpc_batch_reset(mpc_batch *b, const int *ids, int k, void *stream);
 
+/* The same with a DEVICE array of indices (an Isaac-style env_ids tensor): no host round trip, stream-ordered. */
+int mpc_batch_reset_device(mpc_batch *b, const int *d_ids, int k, void *stream);
+
 /* Convenience for the per-robot plugin seam: host buffers, synchronous. */
 int mpc_batch_solve_host(mpc_batch *b, const float *h_in, double *h_forces, int *h_info);
 
@@ -129,6 +132,7 @@ int mpc_ctrl_step(mpc_ctrl *c, const float *d_dof, const float *d_est, const flo
  * d_body: [n, 13] float32 = pos3, quat xyzw, linear velocity (world), angular velocity (world). */
 int mpc_ctrl_run(mpc_ctrl *c, const float *d_dof, const float *d_body, const float *d_cmd, float *d_torques, void *stream);
 int mpc_ctrl_reset(mpc_ctrl *c, const int *ids, int k, void *stream);      /* HOST ids; NULL = all */
+int mpc_ctrl_reset_device(mpc_ctrl *c, const int *d_ids, int k, void *stream);   /* DEVICE ids (env_ids tensor), stream-ordered */
 int mpc_ctrl_set_gait(mpc_ctrl *c, const int *gait_id, void *stream);       /* HOST [n] */
 int mpc_ctrl_solver_info(mpc_ctrl *c, int *h_info);                          /* [n, 8] of the last solves */
 

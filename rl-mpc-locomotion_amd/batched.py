@@ -62,6 +62,10 @@ class BatchedConvexMpc:
         if env_ids is None:
             _lib.check(_lib.lib().mpc_batch_reset(self._handle, None, 0, stream), "mpc_batch_reset")
             return
+        if hasattr(env_ids, "is_cuda") and env_ids.is_cuda:      # an env_ids tensor on the device (VecTask.reset_idx): no host round trip
+            d_ids = env_ids.to(device=self.device, dtype=torch.int32).contiguous()
+            _lib.check(_lib.lib().mpc_batch_reset_device(self._handle, d_ids.data_ptr(), d_ids.numel(), stream), "mpc_batch_reset_device")
+            return
         ids = np.ascontiguousarray(env_ids.detach().cpu().numpy() if hasattr(env_ids, "detach") else env_ids, dtype=np.int32)
         _lib.check(_lib.lib().mpc_batch_reset(self._handle, ids.ctypes.data, len(ids), stream), "mpc_batch_reset")
 

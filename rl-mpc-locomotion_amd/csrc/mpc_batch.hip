@@ -330,6 +330,15 @@ int mpc_batch_reset(mpc_batch *b, const int *ids, int k, void *stream) {
   return MPC_OK;
 }
 
+int mpc_batch_reset_device(mpc_batch *b, const int *d_ids, int k, void *stream) {
+  if (!b || !d_ids || k < 0) return fail(MPC_E_ARG, "mpc_batch_reset_device: bad argument");
+  if (k == 0) return MPC_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(reset_kernel, dim3(k), dim3(256), 0, st, b->d_state, b->state_len, d_ids, k, b->n);
+  HIP_TRY(hipGetLastError());
+  return MPC_OK;
+}
+
 int mpc_batch_solve_host(mpc_batch *b, const float *h_in, double *h_forces, int *h_info) {
   if (!b || !h_in || !h_forces) return fail(MPC_E_ARG, "mpc_batch_solve_host: bad argument");
   const size_t inlen = 56 + 4 * (size_t)b->h, N = 12 * (size_t)b->h;
@@ -429,7 +438,8 @@ __global__ __launch_bounds__(kCtrlThreads) void estimator_kernel(int n, const Ct
   estimator_update(body + (size_t)r * 13, nrm, e);
   for (int k = 0; k < kEstLen; ++k) est[(size_t)r * kEstLen + k] = e[k];
 }
-__global__ __launch_bounds__(kCtrlThreads) void fsm_init_kernel(int n, CtrlState *st, FsmState *fs, const RobotConst *rc, const int *mode, int op_mode, const int *ids, int k, int fresh) {
+__global__ __launch_bounds__(kCtrlThreads) void fsm_init_kernel(int n, CtrlState *st, FsmState *fs, const RobotConst *rc, const int *mode, int op_mode, const int *ids, int k, int fresh,
+                                                                double *solver_state, int state_len) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= k) return;
   const int r = ids ? ids[i] : i;
@@ -438,6 +448,10 @@ __global__ __launch_bounds__(kCtrlThreads) void fsm_init_kernel(int n, CtrlState
   FsmState f = fs[r];
   if (fresh) fsm_init(f, mode[r], op_mode, s, rc[s.robot_type], 0.f);
   else fsm_reinit(f, mode[r], op_mode, s, rc[s.robot_type], f.last_rb22);
+  // entering LOCOMOTION runs cMPC.initialize (FSM_State_Locomotion.py:32-42 -> ConvexMPCLocomotion.py:102-108): a NEW ConvexMpc object,
+  // i.e. x = y = z = 0, rho = 0.1 and an "osqp_setup" first call.  (fsm_tick clears entered_loco at its top, so it is consumed here.)
+  if (f.entered_loco && solver_state)
+    for (int q = 0; q < state_len; ++q) solver_state[(size_t)r * state_len + q] = 0.0;
   st[r] = s; fs[r] = f;
 }
 // RobotRunnerFSM.run up to the solver launch: fsm_tick, then ctrl_pre for the robots whose state runs the locomotion controller
@@ -612,6 +626,18 @@ int mpc_ctrl_reset(mpc_ctrl *c, const int *ids, int k, void *stream) {
   return MPC_OK;
 }
 
+int mpc_ctrl_reset_device(mpc_ctrl *c, const int *d_ids, int k, void *stream) {
+  if (!c || !d_ids || k < 0) return fail(MPC_E_ARG, "mpc_ctrl_reset_device: bad argument");
+  if (k == 0) return MPC_OK;
+  c->mirror_valid = false;     // the host copy of the MPC counters cannot follow ids it never sees: launch the solver on every tick (active mask)
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int rc = mpc_batch_reset_device(c->solver, d_ids, k, stream);
+  if (rc != MPC_OK) return rc;
+  hipLaunchKernelGGL(ctrl_reset_kernel, dim3((k + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, st, c->n, c->d_state, c->d_rc, d_ids, k);
+  HIP_TRY(hipGetLastError());
+  return MPC_OK;
+}
+
 int mpc_ctrl_set_gait(mpc_ctrl *c, const int *gait_id, void *stream) {
   if (!c || !gait_id) return fail(MPC_E_ARG, "mpc_ctrl_set_gait: bad argument");
   for (int r = 0; r < c->n; ++r) if (gait_id[r] < 0 || gait_id[r] >= kNumGaitIds) return fail(MPC_E_ARG, "mpc_ctrl_set_gait: gait id out of range");
@@ -640,7 +666,7 @@ int mpc_ctrl_fsm_init(mpc_ctrl *c, const int *control_mode, int operating_mode, 
   if (rc != MPC_OK) return rc;
   hipLaunchKernelGGL(ctrl_init_kernel, dim3((c->n + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, st, c->n, c->d_state, c->d_rc, c->d_robot_type, c->d_gait);
   hipLaunchKernelGGL(fsm_init_kernel, dim3((c->n + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, st, c->n, c->d_state, c->d_fsm, c->d_rc, c->d_fsm_mode, operating_mode,
-                     (const int *)nullptr, c->n, 1);
+                     (const int *)nullptr, c->n, 1, (double *)nullptr, 0);   // (the whole solver was reset above)
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(st));                          // control_mode is a host buffer
   return MPC_OK;
@@ -649,7 +675,12 @@ int mpc_ctrl_fsm_init(mpc_ctrl *c, const int *control_mode, int operating_mode, 
 int mpc_ctrl_fsm_reset(mpc_ctrl *c, const int *ids, int k, const int *control_mode, void *stream) {
   if (!c || !c->d_fsm || (ids && k < 0)) return fail(MPC_E_ARG, "mpc_ctrl_fsm_reset: bad argument (mpc_ctrl_fsm_init first)");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (control_mode) HIP_TRY(hipMemcpyAsync(c->d_fsm_mode, control_mode, sizeof(int) * c->n, hipMemcpyHostToDevice, st));
+  if (control_mode) {   // [n] entries, like mpc_ctrl_fsm_init
+    for (int r = 0; r < c->n; ++r)
+      if (control_mode[r] != kFsmPassive && control_mode[r] != kFsmLocomotion && control_mode[r] != kFsmRecoveryStand)
+        return fail(MPC_E_ARG, "mpc_ctrl_fsm_reset: control mode must be 0 (PASSIVE), 4 (LOCOMOTION) or 6 (RECOVERY_STAND)");
+    HIP_TRY(hipMemcpyAsync(c->d_fsm_mode, control_mode, sizeof(int) * c->n, hipMemcpyHostToDevice, st));
+  }
   const int cnt = ids ? k : c->n;
   if (cnt == 0) return MPC_OK;
   int *d_ids = nullptr;
@@ -657,7 +688,8 @@ int mpc_ctrl_fsm_reset(mpc_ctrl *c, const int *ids, int k, const int *control_mo
     HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&d_ids), sizeof(int) * k, st));
     HIP_TRY(hipMemcpyAsync(d_ids, ids, sizeof(int) * k, hipMemcpyHostToDevice, st));
   }
-  hipLaunchKernelGGL(fsm_init_kernel, dim3((cnt + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, st, c->n, c->d_state, c->d_fsm, c->d_rc, c->d_fsm_mode, c->fsm_op_mode, d_ids, cnt, 0);
+  hipLaunchKernelGGL(fsm_init_kernel, dim3((cnt + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, st, c->n, c->d_state, c->d_fsm, c->d_rc, c->d_fsm_mode, c->fsm_op_mode, d_ids, cnt, 0,
+                     c->solver->d_state, c->solver->state_len);
   HIP_TRY(hipGetLastError());
   if (d_ids) HIP_TRY(hipFreeAsync(d_ids, st));
   HIP_TRY(hipStreamSynchronize(st));

@@ -52,7 +52,8 @@ struct WThread {
   int tyb;                                       // row types, two bits per row: 0 loose, 1 inequality, 2 equality (auxil.c:79-96)
   // polish (foot lane)
   int act[5];
-  double pG[9], pXi[6], pu0[3], pg[3], pr[3], pt[3], pxN[3], pPu[3], pw[3];
+  double pG[9], pC[9], pu0[3], pg[3], pr[3], pt[3], pxN[3], pPu[3], pw[3];
+  double pQ[18], pR[21], pv[3], pn[6];           // orthogonalisation of the step's wrench columns (polish)
   double xp[3], zp[5], yp[5];
   MPC_HD void init(int id) {
     tid = id;
@@ -431,7 +432,7 @@ struct Solver {
     }
   }
 
-  // per foot: t.zq <- w X w^T for a symmetric 3 x 3 X (packed) and a 6 x 3 map w (W_f, or G_f in the second orthogonalisation pass)
+  // per foot: t.zq <- w X w^T for a symmetric 3 x 3 X (packed) and the 6 x 3 map w = W_f
   MPC_HD void put_zf(Th &t, const double *X, const double *w) const {
     double v[18];
 #pragma unroll
@@ -455,10 +456,8 @@ struct Solver {
     return 1.0 / sqrt(d);
 #endif
   }
-  // One orthogonalisation pass (lane 0 of every quad): Z_k = sum of the feet's t.zq = L_u D L_u^T (dependent rows dropped);
-  // FIRST: L = L_u D^1/2, T = D^-1/2 L_u^-1 -> Lk, Tk.  Second pass (Z_k is then G Xi G^T = I up to the first pass's loss of
-  // orthogonality, eps cond(Z)): L <- L L2, and T2 -> Tk for the foot lanes to update G <- T2 G.
-  template <bool FIRST>
+  // Lane 0 of every quad: Z_k = sum of the feet's t.zq = L_u D L_u^T;  L = L_u D^1/2 -> Lk,  T = D^-1/2 L_u^-1 -> Tk.
+  // (Z_k of the ADMM system is positive definite; a row that is numerically dependent all the same is dropped.)
   MPC_HD void step_factor() {
     ex.template quad_allsum<21>([](Th &t) { return t.zq; });
     ex.par([&](Th &t) {
@@ -466,12 +465,10 @@ struct Solver {
         const int kk = t.tid >> 2;
         const double *zz = t.zq;
         double l[21], d[6], li[21];
-        if (FIRST) {
-          double mxd = 0;
+        double mxd = 0;
 #pragma unroll
-          for (int j = 0; j < 6; ++j) mxd = dmax(mxd, zz[pk(j, j)]);
-          if (!(mxd < kInfty)) s.bad = 1;   // (NaN / inf inputs)
-        }
+        for (int j = 0; j < 6; ++j) mxd = dmax(mxd, zz[pk(j, j)]);
+        if (!(mxd < kInfty)) s.bad = 1;   // (NaN / inf inputs)
         ldl6(zz, l, d, 1e-13);
 #pragma unroll
         for (int j = 0; j < 6; ++j) {   // li = L_u^-1 (unit lower)
@@ -492,38 +489,20 @@ struct Solver {
           sd[j] = ok ? d[j] * si[j] : 0.0;
         }
         double *ol = s.Lk + 36 * kk, *ot = s.Tk + 36 * kk;
-        if (FIRST) {
-#pragma unroll
-          for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) ol[6 * i + j] = i >= j ? l[pk(i, j)] * sd[j] : 0.0;
-        } else {
-          double l1[21];
-#pragma unroll
-          for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j <= i; ++j) l1[pk(i, j)] = ol[6 * i + j];
-#pragma unroll
-          for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j <= i; ++j) {   // (L1 L2)_{ij} = sum_{j <= k <= i} L1_{ik} L2_{kj}
-              double v = 0;
-#pragma unroll
-              for (int k = j; k <= i; ++k) v += l1[pk(i, k)] * (l[pk(k, j)] * sd[j]);
-              ol[6 * i + j] = v;
-            }
-        }
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
-          for (int j = 0; j < 6; ++j) ot[6 * i + j] = i >= j ? li[pk(i, j)] * si[i] : 0.0;
+          for (int j = 0; j < 6; ++j) {
+            ol[6 * i + j] = i >= j ? l[pk(i, j)] * sd[j] : 0.0;
+            ot[6 * i + j] = i >= j ? li[pk(i, j)] * si[i] : 0.0;
+          }
       }
     });
   }
-  // TWO_PASS: Cholesky-QR twice.  G Xi G^T must be the identity to working accuracy for the projector I - V V^T inside
-  // K^-1 = X^1/2 (I - V V^T + V M^-1 V^T) X^1/2 to cancel; polish needs it (|Xi| ~ 1 / delta amplifies the loss of
-  // orthogonality of a single pass by 1e6), the ADMM system does not (measured: tests/test_emulated_kernel.py).
-  template <bool TWO_PASS, class XS>
+  // The ADMM system: X_f = S_f^-1.  Gram-matrix orthogonalisation (L D L^T of Z_k = F^T F) loses eps cond(Z_k) in the range of
+  // F; with |S^-1| W^T Theta W of order 1e3 at most that is harmless here (tests/test_emulated_kernel.py: K^-1 b agrees with a
+  // dense solve to 1e-15 for rho from 1e-5 to 1e3).  Polish, where 1 / delta stands in for S^-1, orthogonalises F itself.
+  template <class XS>
   MPC_HD void factor_core(XS &&xs) {
     ex.seq([&](Th &t) {
       if (t.tid < NF) {
@@ -532,29 +511,22 @@ struct Solver {
         put_zf(t, xs(t), w);
       }
     });
-    step_factor<true>();
-    if (TWO_PASS) {
-      ex.seq([&](Th &t) {
-        if (t.tid < NF) {   // G1 = T1 W;  zq <- G1 X G1^T
-          double w[18], g1[18];
-          foot_w(t, w);
-          mul_tk(t, w, g1);
-          put_zf(t, xs(t), g1);
-#pragma unroll
-          for (int k = 0; k < 18; ++k) s.Gf[pidx(k, t.tid)] = g1[k];
-        }
-      });
-      step_factor<false>();
-    }
+    step_factor();
     ex.par([&](Th &t) {
-      if (t.tid < NF) {   // G_f = T_k W_f  (second pass: T2 G1)
+      if (t.tid < NF) {   // G_f = T_k W_f
         double w[18], gf[18];
-        if (TWO_PASS) load_g(t, w);
-        else foot_w(t, w);
+        foot_w(t, w);
         mul_tk(t, w, gf);
 #pragma unroll
         for (int k = 0; k < 18; ++k) s.Gf[pidx(k, t.tid)] = gf[k];
-        // dl = diag(M)^-1/2 of my rows,  M_rr = 1 + l_r^T (c Theta_kk) l_r  (l_r: column r of L_k)
+      }
+    });
+    factor_tail();
+  }
+  // from L_k (LDS) to the held tiles: dl = diag(M)^-1/2 of my rows, the unit-diagonal tile of Mh, the sweep
+  MPC_HD void factor_tail() {
+    ex.par([&](Th &t) {
+      if (t.tid < NF) {   // M_rr = 1 + l_r^T (c Theta_kk) l_r  (l_r: column r of L_k)
         const int k = t.tid >> 2, j = t.tid & 3;
         const double mm = (double)(H - k), s2kk = mm * (4.0 * mm * mm - 1.0) / 12.0;   // sum_{i < m} (i + 1/2)^2
         const double *lk = s.Lk + 36 * k;
@@ -631,7 +603,7 @@ struct Solver {
         s.fr[pidx(9, t.tid)] = 0.0;
       }
     });
-    factor_core<false>([](Th &t) { return t.Si; });
+    factor_core([](Th &t) { return t.Si; });
   }
 
   // Symmetric sweep of every pivot: after all pivots the matrix equals -inverse.  Per step k:  p = a_kk;
@@ -865,17 +837,117 @@ struct Solver {
   //     w_{k+1} = w_k + Omega r_k,   r_{k+1} = delta Omega r_k        (H Hd^-1 = I - delta Hd^-1: no further products with P),
   //     Omega r = Xi r - Xi G^T (I - M^-1) (G Xi r),  Xi = N (delta I + c alpha N^T D^2 N)^-1 N^T  (3 x 3 per foot),
   // with G, M of factor_core(Xi).
-  MPC_HD void omega_apply() {   // in: t.w6 = G (Xi r) from the foot lanes, pt = Xi r;  out: pw = Omega r
+  MPC_HD void omega_apply() {   // in: t.w6 = V_f^T u from the foot lanes, pt = u = C^T r;  out: pw = Omega r = C (u - V_f (I - M^-1) V^T u)
     product<kHeld>();
     ex.seq([&](Th &t) {
       if (t.tid < NF) {
-        double wy[3], xw[3];
-        get_g(t, wy);
-        sym3_mul(t.pXi, wy, xw);
+        double vy[3], d[3];
+        get_g(t, vy);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) t.pw[c] = t.pt[c] - xw[c];
+        for (int k = 0; k < 3; ++k) d[k] = t.pt[k] - vy[k];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) t.pw[c] = t.pC[3 * c] * d[0] + t.pC[3 * c + 1] * d[1] + t.pC[3 * c + 2] * d[2];
       }
     });
+  }
+  static MPC_HD void ct_mul(const double *C, const double *r, double *u) {   // u = C^T r
+#pragma unroll
+    for (int k = 0; k < 3; ++k) u[k] = C[k] * r[0] + C[3 + k] * r[1] + C[6 + k] * r[2];
+  }
+  // Polish factorisation.  H^-1 restricted to the null space of the active rows is  C (I - V V^T + V M^-1 V^T) C^T  with
+  // Xi = C C^T per foot and V an ORTHONORMAL basis of the range of F = C^T W^T (per step: the 12 x 6 stack of its feet).
+  // |Xi| ~ 1 / delta multiplies whatever I - V V^T fails to annihilate, so the range must be accurate to ~1e-11: Gram-matrix
+  // orthogonalisation (the L D L^T of Z = F^T F that the ADMM system uses) loses eps cond(Z) and is not enough; the columns
+  // are orthogonalised directly -- classical Gram-Schmidt, twice per column, the inner products summed over the quad -- which
+  // loses eps cond(F) only.  A column whose remainder is below 1e-12 of its length lies in the span of the earlier ones
+  // (two point feet give no torque about the line through them) and is dropped.  F = V R, so Z = R^T R: L = R^T.
+  template <int J>
+  MPC_HD void orth_col() {
+    if constexpr (J < 6) {
+      ex.seq([&](Th &t) {
+        if (t.tid < NF) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) t.pv[k] = t.zq[3 * J + k];
+#pragma unroll
+          for (int i = 0; i < J; ++i) t.pR[pk(J, i)] = 0.0;
+        }
+      });
+      for (int rep = 0; rep < 2; ++rep) {
+        ex.seq([&](Th &t) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) t.w6[i] = (i < J && t.tid < NF) ? t.pQ[3 * i] * t.pv[0] + t.pQ[3 * i + 1] * t.pv[1] + t.pQ[3 * i + 2] * t.pv[2] : 0.0;
+        });
+        ex.template quad_allsum<6>([](Th &t) { return t.w6; });
+        ex.seq([&](Th &t) {
+          if (t.tid < NF) {
+#pragma unroll
+            for (int i = 0; i < J; ++i) {
+#pragma unroll
+              for (int k = 0; k < 3; ++k) t.pv[k] -= t.w6[i] * t.pQ[3 * i + k];
+              t.pR[pk(J, i)] += t.w6[i];
+            }
+          }
+        });
+      }
+      ex.seq([&](Th &t) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) t.w6[i] = 0.0;
+        if (t.tid < NF) t.w6[0] = t.pv[0] * t.pv[0] + t.pv[1] * t.pv[1] + t.pv[2] * t.pv[2];
+      });
+      ex.template quad_allsum<6>([](Th &t) { return t.w6; });
+      ex.seq([&](Th &t) {
+        if (t.tid < NF) {
+          const double n2 = t.w6[0];
+          const bool keep = n2 > 1e-24 * t.pn[J];
+          const double inv = keep ? fast_rsqrt(keep ? n2 : 1.0) : 0.0;
+          t.pR[pk(J, J)] = keep ? n2 * inv : 0.0;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) t.pQ[3 * J + k] = t.pv[k] * inv;
+        }
+      });
+      orth_col<J + 1>();
+    }
+  }
+  MPC_HD void polish_factor() {
+    ex.seq([&](Th &t) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) t.w6[r] = 0.0;
+      if (t.tid < NF) {   // F_f[k][r] = sum_c C[c][k] W[r][c]  ->  zq[3 r + k]; squared column lengths
+        double w[18];
+        foot_w(t, w);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          double n2 = 0;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const double v = t.pC[k] * w[3 * r] + t.pC[3 + k] * w[3 * r + 1] + t.pC[6 + k] * w[3 * r + 2];
+            t.zq[3 * r + k] = v;
+            n2 += v * v;
+          }
+          t.w6[r] = n2;
+        }
+      }
+    });
+    ex.template quad_allsum<6>([](Th &t) { return t.w6; });
+    ex.seq([&](Th &t) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) t.pn[r] = t.w6[r];
+    });
+    orth_col<0>();
+    ex.par([&](Th &t) {
+      if (t.tid < NF) {
+#pragma unroll
+        for (int k = 0; k < 18; ++k) s.Gf[pidx(k, t.tid)] = t.pQ[k];          // "G_f" = V_f^T (6 x 3)
+        if ((t.tid & 3) == 0) {   // L = R^T (pR[pk(j, i)] = R[i][j], i <= j)
+          double *ol = s.Lk + 36 * (t.tid >> 2);
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) ol[6 * i + j] = i >= j ? t.pR[pk(i, j)] : 0.0;
+        }
+      }
+    });
+    factor_tail();
   }
 
   MPC_HD void polish() {
@@ -1005,22 +1077,28 @@ struct Solver {
           Sp[2] = 2 < nn ? ca * (nd[0] * nd[6] + nd[1] * nd[7] + nd[2] * nd[8]) : 0.0;
           Sp[4] = 2 < nn ? ca * (nd[3] * nd[6] + nd[4] * nd[7] + nd[5] * nd[8]) : 0.0;
         }
-        double Spi[6];
-        sym3_inv(Sp, Spi);
-        // Xi[c1][c2] = sum_{k1,k2 < nn} Nn[k1][c1] Spi[k1][k2] Nn[k2][c2]   (rows of Nn beyond nn are zero)
-        double tmp[9];
+        // Xi = C C^T with C = N^T Ls^-T (Sp = Ls Ls^T): the factor is what the orthogonalisation below works with
+        {
+          const double i00 = fast_rsqrt(Sp[0]), l00 = Sp[0] * i00;
+          const double l10 = Sp[1] * i00, l20 = Sp[2] * i00;
+          const double d1 = Sp[3] - l10 * l10;
+          const double i11 = fast_rsqrt(d1), l11 = d1 * i11;
+          const double l21 = (Sp[4] - l20 * l10) * i11;
+          const double d2 = Sp[5] - l20 * l20 - l21 * l21;
+          const double i22 = fast_rsqrt(d2);
+          (void)l00; (void)l11;
+          const double i10 = -l10 * i00 * i11, i21 = -l21 * i11 * i22, i20 = -(l20 * i00 + l21 * i10) * i22;
+          const double U[9] = {i00, i10, i20, 0, i11, i21, 0, 0, i22};   // Ls^-T, upper triangular
 #pragma unroll
-        for (int k1 = 0; k1 < 3; ++k1)
+          for (int c = 0; c < 3; ++c)
 #pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const double s0 = Spi[pk3(k1, 0)], s1 = Spi[pk3(k1, 1)], s2 = Spi[pk3(k1, 2)];
-            tmp[3 * k1 + c] = s0 * Nn[c] + s1 * Nn[3 + c] + s2 * Nn[6 + c];
-          }
-        int e = 0;
+            for (int k = 0; k < 3; ++k) {
+              double v = 0;
 #pragma unroll
-        for (int c1 = 0; c1 < 3; ++c1)
-#pragma unroll
-          for (int c2 = c1; c2 < 3; ++c2) t.pXi[e++] = Nn[c1] * tmp[c2] + Nn[3 + c1] * tmp[3 + c2] + Nn[6 + c1] * tmp[6 + c2];
+              for (int mm = 0; mm <= k; ++mm) v += Nn[3 * mm + c] * U[3 * mm + k];
+              t.pC[3 * c + k] = v;
+            }
+        }
         put_wrench(t, t.pu0);
       }
     });
@@ -1035,13 +1113,17 @@ struct Solver {
           t.pg[c] = -t.q[c] - t.pPu[c];
           t.pxN[c] = 0;
         }
-        sym3_mul(t.pXi, t.pg, t.pt);                      // (Xi contains the projector N N^T)
+        ct_mul(t.pC, t.pg, t.pt);                         // u = C^T g
       }
     });
     lap(11);
-    factor_core<false>([](Th &t) { return t.pXi; });
+    polish_factor();
     ex.seq([&](Th &t) { if (t.tid < NF) put_g(t, t.pt); });
     lap(12);
+    // w_0 = Omega g, then kPolishRefine steps of iterative refinement against the UN-regularised system (polish.c:102-160):
+    //   w <- w + Omega (g - P_s w).   With an exact Omega the residual obeys r_{k+1} = delta Omega r_k and needs no product with
+    // P; Omega is only accurate to ~1e-10 |Xi|, so the true residual is formed (one Theta product per step) -- which is also
+    // what OSQP does, and what keeps the refinement self-correcting.  The last product is the P_s xN the finish needs anyway.
     for (int it = 0; it <= kPolishRefine; ++it) {
       omega_apply();
 #ifdef MPC_EMU_DEBUG
@@ -1049,8 +1131,8 @@ struct Solver {
         if (t.tid < NF) {
           double *o = dbg + 38 * t.tid;
           for (int r = 0; r < 5; ++r) o[r] = t.act[r];
-          for (int k = 0; k < 6; ++k) o[5 + k] = t.pXi[k];
-          for (int c = 0; c < 3; ++c) { o[11 + c] = t.pg[c]; o[14 + c] = t.pt[c]; o[17 + c] = t.pw[c]; }
+          for (int c1 = 0, e = 0; c1 < 3; ++c1) for (int c2 = c1; c2 < 3; ++c2, ++e) o[5 + e] = t.pC[3 * c1] * t.pC[3 * c2] + t.pC[3 * c1 + 1] * t.pC[3 * c2 + 1] + t.pC[3 * c1 + 2] * t.pC[3 * c2 + 2];
+          for (int c = 0; c < 3; ++c) { o[11 + c] = t.pg[c]; o[14 + c] = t.pC[3 * c] * t.pt[0] + t.pC[3 * c + 1] * t.pt[1] + t.pC[3 * c + 2] * t.pt[2]; o[17 + c] = t.pw[c]; }
           for (int k = 0; k < 18; ++k) o[20 + k] = s.Gf[pidx(k, t.tid)];
         }
       });
@@ -1058,15 +1140,24 @@ struct Solver {
       ex.seq([&](Th &t) {
         if (t.tid < NF) {
 #pragma unroll
-          for (int c = 0; c < 3; ++c) { t.pxN[c] += t.pw[c]; t.pr[c] = kDelta * t.pw[c]; }
-          sym3_mul(t.pXi, t.pr, t.pt);
-          put_g(t, t.pt);
+          for (int c = 0; c < 3; ++c) t.pxN[c] += t.pw[c];
+          put_wrench(t, t.pxN);
         }
       });
+      product<kTheta>();                                  // c Theta W xN  (-> P_s xN)
+      if (it < kPolishRefine) {
+        ex.seq([&](Th &t) {
+          if (t.tid < NF) {
+            double wy[3];
+            get_wrench(t, wy);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) t.pr[c] = t.pg[c] - ((s.calpha * Dat(t, c) * Dat(t, c)) * t.pxN[c] + wy[c]);
+            ct_mul(t.pC, t.pr, t.pt);
+            put_g(t, t.pt);
+          }
+        });
+      }
     }
-    // P_s xN
-    ex.seq([&](Th &t) { if (t.tid < NF) put_wrench(t, t.pxN); });
-    product<kTheta>();
     lap(13);
     // x = u + xN ; y = A Gamma (g - P xN) on active rows ; z = A x ; normal-cone projection (proj.c:17-31)
     ex.par([&](Th &t) {
@@ -1104,6 +1195,9 @@ struct Solver {
       if (t.tid == 0) {
         const double pri = bitsd(s.red[0]), dua = s.cinv * bitsd(s.red[6]);
         const bool ok = !s.bad && ((pri < pri0 && dua < dua0) || (pri < pri0 && dua0 < 1e-10) || (dua < dua0 && pri0 < 1e-10));
+#ifdef MPC_EMU_DEBUG
+        if (dbg) { dbg[38 * NF] = pri0; dbg[38 * NF + 1] = dua0; dbg[38 * NF + 2] = pri; dbg[38 * NF + 3] = dua; }
+#endif
         s.status_polish = ok ? 1 : -1;
         if (ok) { s.pri_res = pri; s.dua_res = dua; }
       }

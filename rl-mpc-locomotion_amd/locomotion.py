@@ -74,6 +74,10 @@ class BatchedLocomotion:
         if env_ids is None:
             _lib.check(_lib.lib().mpc_ctrl_reset(self._handle, None, 0, stream), "mpc_ctrl_reset")
             return
+        if hasattr(env_ids, "is_cuda") and env_ids.is_cuda:      # an env_ids tensor on the device (VecTask.reset_idx): no host round trip
+            d_ids = env_ids.to(device=self.device, dtype=torch.int32).contiguous()
+            _lib.check(_lib.lib().mpc_ctrl_reset_device(self._handle, d_ids.data_ptr(), d_ids.numel(), stream), "mpc_ctrl_reset_device")
+            return
         ids = np.ascontiguousarray(env_ids.detach().cpu().numpy() if hasattr(env_ids, "detach") else env_ids, dtype=np.int32)
         _lib.check(_lib.lib().mpc_ctrl_reset(self._handle, ids.ctypes.data, len(ids), stream), "mpc_ctrl_reset")
 
@@ -119,6 +123,8 @@ class BatchedLocomotion:
         import torch
         stream = torch.cuda.current_stream(self.device).cuda_stream
         cm = None if control_mode is None else np.ascontiguousarray(control_mode, dtype=np.int32)
+        if cm is not None and cm.shape != (self.n,):
+            raise ValueError(f"fsm_reset: control_mode must have one entry per robot ({self.n}), got shape {cm.shape}")
         ids = None
         if env_ids is not None:
             ids = np.ascontiguousarray(env_ids.detach().cpu().numpy() if hasattr(env_ids, "detach") else env_ids, dtype=np.int32)

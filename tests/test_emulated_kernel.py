@@ -8,7 +8,7 @@ from tests.emu.emu import EmuBatch
 from tests.helpers import GRF_RTOL, grf_rtol, grf_relerr, load_golden
 
 
-@pytest.mark.parametrize("name", ["solver_h10_cfg2", "solver_h10_cfg3", "solver_h16_cfg4", "solver_h20_cfg5", "solver_h10_stress", "solver_h10_edge"])
+@pytest.mark.parametrize("name", ["solver_h10_cfg2", "solver_h10_cfg3", "solver_h16_cfg4", "solver_h20_cfg5", "solver_h10_stress", "solver_h10_edge", "solver_h16_polish"])
 def test_emulated_kernel_matches_golden(name):
     g = load_golden(name)
     h, n = int(g["h"]), len(g["mass"])

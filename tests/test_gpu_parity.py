@@ -22,7 +22,7 @@ def _solve(gpu, rec):
     return f.cpu().numpy().copy(), info.cpu().numpy().copy()
 
 
-@pytest.mark.parametrize("name", ["solver_h10_cfg2", "solver_h10_cfg3", "solver_h16_cfg4", "solver_h20_cfg5", "solver_h10_stress", "solver_h10_edge"])
+@pytest.mark.parametrize("name", ["solver_h10_cfg2", "solver_h10_cfg3", "solver_h16_cfg4", "solver_h20_cfg5", "solver_h10_stress", "solver_h10_edge", "solver_h16_polish"])
 def test_hip_matches_golden(name):
     g = load_golden(name)
     gpu = _gpu(g["mass"], g["inertia_diag"], int(g["h"]), float(g["dt_mpc"]), float(g["alpha"]))

@@ -85,7 +85,7 @@ def test_assembly_matches_dense_formulation():
     assert (l[np.arange(20 * h) % 5 != 4] == 0).all()
 
 
-@pytest.mark.parametrize("name", ["solver_h10_cfg2", "solver_h10_cfg3", "solver_h16_cfg4", "solver_h20_cfg5", "solver_h10_stress", "solver_h10_edge"])
+@pytest.mark.parametrize("name", ["solver_h10_cfg2", "solver_h10_cfg3", "solver_h16_cfg4", "solver_h20_cfg5", "solver_h10_stress", "solver_h10_edge", "solver_h16_polish"])
 def test_oracle_reproduces_golden(name):
     g = load_golden(name)
     h = int(g["h"])

@@ -8,15 +8,15 @@ of the code shape.  This tool reads the assembly and says where the scratch inst
   python tools/isa_census.py /tmp/all.s                 # per horizon: loops, weighted spill estimate
   python tools/isa_census.py /tmp/all.s --blocks 8      # also every block with >= 8 scratch instructions
 
-Loops are recognised by the assembler's "in Loop: Header=.. Depth=.." comments and classified by their barrier count:
-6 = a sweep loop (six pivot steps per trip), 4 = the ADMM iteration, 3 = a Ruiz pass, 15 = the check / refactor loop.
+Loops are recognised by the assembler's "in Loop: Header=.. Depth=.." comments and classified by what they contain: a sweep loop
+has six v_rcp_f64 (six pivot steps per trip); the ADMM iteration is the depth-2 loop with the quad exchanges (v_mov_b32_dpp);
+the depth-1 loop around both is the check / refactor loop.  (The h = 10 solve kernel is a single wave: it has no s_barrier.)
 (tests/test_isa_budget.py asserts the hot loops of the benchmark horizon stay free of scratch traffic.)"""
 import re
 import subprocess
 import sys
 
 KERNEL_RE = r'\n(_ZN[^\n]*mpc_solve_kernelILi%sE[^\n:]*):[^\n]*\n(.*?)\n\.Lfunc_end'
-ROLE = {6: "sweep", 4: "admm-iteration", 3: "ruiz-pass", 15: "check-loop"}
 
 
 def compile_to_asm(src, out, include_dir, extra=()):
@@ -80,8 +80,11 @@ def loop_stats(txt, H):
         a["lds"] += sum(1 for l in ins if l.startswith('\tds_'))
         a["scratch"] += sum(1 for l in ins if l.startswith('\tscratch'))
         a["barriers"] += sum(1 for l in ins if l.startswith('\ts_barrier'))
+        a["rcp"] = a.get("rcp", 0) + sum(1 for l in ins if l.startswith('\tv_rcp_f64'))
+        a["dpp"] = a.get("dpp", 0) + sum(1 for l in ins if l.startswith('\tv_mov_b32_dpp'))
     for a in agg.values():
-        a["role"] = ROLE.get(a["barriers"], "")
+        a["role"] = "sweep" if a.get("rcp", 0) == 6 and a["ins"] < 1000 else ("admm-iteration" if a["depth"] == 2 and a.get("dpp", 0) else
+                                                                               ("check-loop" if a["depth"] == 1 and a["ins"] > 2000 else ""))
     return agg
 
 
