@@ -186,9 +186,18 @@ MPC_HD void estimator_update(const float *body, const float *normal, float *est)
   Ml[6] = round_to_half(2.f * (e1 * e3 - e0 * e2)); Ml[7] = round_to_half(2.f * (e2 * e3 + e0 * e1)); Ml[8] = round_to_half(1.f - 2.f * (e1 * e1 + e2 * e2));
   float R[9];
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[3 * i + j] = Ml[3 * j + i];
-  for (int i = 0; i < 3; ++i) {   // float16 matrix @ float32 vector -> float32 (BLAS there; +-1 ulp)
-    est[i] = (R[3 * i] * body[7] + R[3 * i + 1] * body[8]) + R[3 * i + 2] * body[9];
-    est[3 + i] = (R[3 * i] * body[10] + R[3 * i + 1] * body[11]) + R[3 * i + 2] * body[12];
+  // float16 matrix @ float32 vector -> float32: numpy hands this to OpenBLAS (sgemv on the C-ordered float32 copy), whose
+  // kernel takes the rows in pairs -- rows 0 and 1 vectorised, products and sums rounded one by one -- and the odd last row in a
+  // scalar tail compiled with FMA contraction: fma(a2, b2, fma(a0, b0, a1 * b1)).  Probed with crafted inputs
+  // (tests/test_controller.py::test_estimator_matmul_rule_matches_numpy) and bit-exact on every recorded sample of the goldens.
+  for (int i = 0; i < 3; ++i) {
+    if (i < 2) {
+      est[i] = (R[3 * i] * body[7] + R[3 * i + 1] * body[8]) + R[3 * i + 2] * body[9];
+      est[3 + i] = (R[3 * i] * body[10] + R[3 * i + 1] * body[11]) + R[3 * i + 2] * body[12];
+    } else {
+      est[i] = fmaf(R[3 * i + 2], body[9], fmaf(R[3 * i], body[7], R[3 * i + 1] * body[8]));
+      est[3 + i] = fmaf(R[3 * i + 2], body[12], fmaf(R[3 * i], body[10], R[3 * i + 1] * body[11]));
+    }
   }
   // quat_to_rpy (:120-133) -- only the yaw of the world-frame rpy is used
   const float yaw = round_to_half(atan2f(2.f * (x * y + w * z), w * w + x * x - y * y - z * z));

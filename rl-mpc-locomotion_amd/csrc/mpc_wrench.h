@@ -1258,7 +1258,8 @@ struct Solver {
     lap(14);
     tc[15] = MPC_CLOCK() - t0;
     // outputs + persistent state (store_solution, auxil.c:528-561; mpc_osqp.cc:788-790: forces = -x).  A non-convex / non-finite
-    // problem has no solution: OSQP cold-starts the iterates (auxil.c:539-563) and keeps rho and the problem data.
+    // problem has no solution: OSQP cold-starts the iterates (auxil.c:539-563); here the whole record is cleared, so that the
+    // robot's next call is the cold "osqp_setup" call on clean data (with NaN inputs the vendored OSQP itself stays poisoned).
     ex.par([&](Th &t) {
       const bool failed = s.bad || s.status == kStNonCvx;
       const bool solved = s.status == kStSolved && !failed;
@@ -1268,14 +1269,15 @@ struct Solver {
         for (int c = 0; c < 3; ++c) {
           if (solved) forces[3 * f + c] = -(Dat(t, c) * t.x[c]);
           state[3 * f + c] = failed ? 0.0 : t.x[c];
-          state[N + 2 * M + 3 * f + c] = qp[C::QP_Q + 3 * f + c];
+          state[N + 2 * M + 3 * f + c] = failed ? 0.0 : qp[C::QP_Q + 3 * f + c];
         }
 #pragma unroll
         for (int r = 0; r < 5; ++r) { state[N + 5 * f + r] = failed ? 0.0 : t.z[r]; state[N + M + 5 * f + r] = failed ? 0.0 : t.y[r]; }
       }
       if (t.tid == 0) {
-        state[2 * N + 2 * M] = s.rho;
-        state[2 * N + 2 * M + 1] = 1.0;
+        const bool failed = s.bad || s.status == kStNonCvx;
+        state[2 * N + 2 * M] = failed ? 0.0 : s.rho;
+        state[2 * N + 2 * M + 1] = failed ? 0.0 : 1.0;
         info[0] = s.iter; info[1] = s.bad ? kStNonCvx : s.status; info[2] = s.status_polish; info[3] = s.rho_updates;
         info[4] = s.nfact; info[5] = s.first; info[6] = 0; info[7] = 0;
         if (prof) for (int k = 0; k < kProfLen; ++k) if (k != 1 && k != 2) prof[k] = tc[k];   // (1, 2: the assembly kernel's)

@@ -30,16 +30,15 @@ def test_emulated_controller_matches_reference_python(name):
 
 @pytest.mark.parametrize("name", ["controller_h10_flat", "controller_h10_slope", "controller_h10_config1"])
 def test_emulated_estimator_matches_reference_python(name):
-    """StateEstimator.update restated with explicit float16/float32 semantics: the float16 outputs (rpyBody,
-    ground_R_body_frame) must be bit-identical to the reference's, the float32 ones within an ulp or two
-    (numpy's float16 @ float32 product goes through BLAS there)."""
+    """StateEstimator.update restated with explicit float16/float32 semantics: every output -- the float16 ones (rpyBody,
+    ground_R_body_frame) and the float32 ones (vBody, omegaBody, numpy's float16 @ float32 product through OpenBLAS) -- must be
+    bit-identical to the reference's."""
     from tests.emu.emu import estimator_update
     g = load_golden(name)
     T, n = g["body"].shape[:2]
     normal_prev = np.concatenate([np.tile(np.array([0, 0, 1], np.float32), (1, n, 1)), g["normal"][:-1]], axis=0)   # estimate of the previous tick
     est = estimator_update(g["body"].reshape(T * n, 13), normal_prev.reshape(T * n, 3)).reshape(T, n, 18)
-    assert np.array_equal(est[..., 6:], g["est"][..., 6:])
-    np.testing.assert_allclose(est[..., :6], g["est"][..., :6], rtol=3e-7, atol=1e-7)
+    assert np.array_equal(est, g["est"])
 
 
 def test_gait_tables_match_reference_definition():
@@ -99,13 +98,30 @@ def test_hip_controller_matches_reference_python(name):
     assert worst < TAU_RTOL
 
 
+def test_estimator_matmul_rule_matches_numpy():
+    """The rule estimator_update uses for rBody @ vWorld (csrc/controller.h) against numpy itself on random data: rows 0 and 1
+    plain float32 products and sums, row 2 fma(a2, b2, fma(a0, b0, a1 * b1)) -- what OpenBLAS' sgemv does with a 3 x 3 matrix on
+    this class of CPU.  (If a numpy / OpenBLAS build ever rounds differently this test says so before the torque tests do.)"""
+    rng = np.random.default_rng(0)
+    f32 = np.float32
+    fma = lambda a, b, c: (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(f32)
+    for _ in range(200):
+        A16 = rng.uniform(-1, 1, (3, 3)).astype(np.float16)
+        x = rng.uniform(-2, 2, (3, 1)).astype(f32)
+        rB = np.array(A16.tolist(), dtype=np.float16).T            # like orientation_tools.quat_to_rot
+        got = (rB @ x).flatten()
+        a = rB.astype(f32); b = x[:, 0]
+        want = np.array([(a[0, 0] * b[0] + a[0, 1] * b[1]) + a[0, 2] * b[2], (a[1, 0] * b[0] + a[1, 1] * b[1]) + a[1, 2] * b[2],
+                         fma(a[2, 2], b[2], fma(a[2, 0], b[0], a[2, 1] * b[1]))], dtype=f32)
+        assert np.array_equal(got, want)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["controller_h10_flat", "controller_h10_slope"])
+@pytest.mark.parametrize("name", ["controller_h10_flat", "controller_h10_slope", "controller_h10_config1"])
 def test_hip_full_run_matches_reference_python(name):
-    """The complete controller.run seam (estimator + controller + solve) on the GPU against the reference's
-    torques.  vBody / omegaBody can differ from numpy's by a float32 ulp, which on rare ticks moves a solver
-    input across a float16 rounding or an OSQP decision: require 99 % of the (tick, robot) samples inside
-    TAU_RTOL and all of them inside 2 %."""
+    """The complete controller.run seam (estimator + controller + solve) on the GPU against the reference's torques: every
+    (tick, robot) sample inside TAU_RTOL (the estimator's outputs are bit-identical to the reference's, see
+    test_emulated_estimator_matches_reference_python)."""
     import torch
     from rl_mpc_locomotion_amd.locomotion import BatchedLocomotion
     g = load_golden(name)
@@ -114,10 +130,9 @@ def test_hip_full_run_matches_reference_python(name):
     errs = []
     for k in range(T):
         tau = ctl.run(torch.from_numpy(g["dof"][k]).cuda(), torch.from_numpy(g["body"][k]).cuda(), torch.from_numpy(g["cmd"][k]).cuda())
-        torch.cuda.synchronize()
         errs.append(_relerr(tau.cpu().numpy(), g["torque"][k]))
     errs = np.concatenate(errs)
-    assert (errs < TAU_RTOL).mean() >= 0.99 and errs.max() < 2e-2, (float((errs < TAU_RTOL).mean()), float(errs.max()))
+    assert errs.max() < TAU_RTOL, (float((errs < TAU_RTOL).mean()), float(errs.max()))
 
 
 @pytest.mark.gpu

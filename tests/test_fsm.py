@@ -75,3 +75,29 @@ def test_fsm_reset_and_bad_arguments():
     ctl.fsm_reset(env_ids=[1, 3], control_mode=np.full(n, BatchedLocomotion.PASSIVE))
     st = ctl.fsm_state()
     assert st[[1, 3], 0].tolist() == [0, 0] and (st[[0, 2, 4, 5], 0] == 4).all()
+
+
+@pytest.mark.gpu
+def test_fsm_reset_into_locomotion_cold_starts_the_solver():
+    """RobotRunnerFSM.reset -> ControlFSM.initialize -> FSM_State_Locomotion.onEnter -> cMPC.initialize builds a NEW ConvexMpc
+    (FSM_State_Locomotion.py:32-42, ConvexMPCLocomotion.py:102-108): the reset robots' next solve is the cold "osqp_setup" solve
+    (x = y = z = 0, rho = 0.1), the others stay warm."""
+    import torch
+    import rl_mpc_locomotion_amd  # noqa: F401
+    from rl_mpc_locomotion_amd.locomotion import BatchedLocomotion
+    g = np.load(GOLD)
+    n = g["dof"].shape[1]
+    ctl = BatchedLocomotion(g["robot_type"], np.zeros(n, np.int32), horizon=10)
+    ctl.fsm_init(np.full(n, BatchedLocomotion.LOCOMOTION))
+    req = torch.full((n,), BatchedLocomotion.LOCOMOTION, dtype=torch.int32, device="cuda")
+    run = lambda k: ctl.run_fsm(torch.from_numpy(g["dof"][k]).cuda(), torch.from_numpy(g["body"][k]).cuda(), torch.from_numpy(g["cmd"][k]).cuda(), req)
+    for k in range(6):
+        run(k)
+    assert (ctl.solver_info()[:, 5] == 0).all()                 # everybody is warm by now
+    ctl.fsm_reset(env_ids=[1, 4], control_mode=np.full(n, BatchedLocomotion.LOCOMOTION))
+    for k in range(6, 8):                                        # the next MPC update of every robot (every 2nd tick)
+        run(k)
+    first = ctl.solver_info()[:, 5]
+    assert first[[1, 4]].tolist() == [1, 1] and (first[[0, 2, 3, 5]] == 0).all()
+    with pytest.raises(ValueError):
+        ctl.fsm_reset(env_ids=[1], control_mode=[BatchedLocomotion.LOCOMOTION])       # one mode per ROBOT, not per id

@@ -128,6 +128,30 @@ def test_non_finite_input_fails_cleanly():
     assert info[2, 1] != 1 and (f[2] == 123.0).all()
     keep = np.arange(n) != 2
     assert (info[keep, 1] == 1).all() and np.array_equal(f[keep], good[keep])
+    # the NEXT call: a failed robot's record is cleared, so it solves again as a cold robot (the vendored OSQP itself reports SOLVED
+    # with NaN iterates on NaN data and stays poisoned until the object is rebuilt: tests/test_oracle.py::test_reference_is_poisoned_by_nan)
+    f2, info2 = gpu2.solve(torch.from_numpy(wl.inputs).cuda())
+    torch.cuda.synchronize()
+    f2 = f2.cpu().numpy(); info2 = info2.cpu().numpy()
+    assert info2[2, 1] == 1 and info2[2, 5] == 1                       # solved, as an "osqp_setup" call
+    assert np.array_equal(f2[2], good[2]) and np.array_equal(info2[2, :5], _solve(_gpu(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha), wl.inputs)[1][2, :5])
+
+
+def test_reset_with_device_ids_equals_host_ids():
+    """env_ids as a device tensor (VecTask.reset_idx) takes the stream-ordered device path; same result as host ids."""
+    import torch
+    n, h = 12, 10
+    wl = make_solver_workload(n, h=h, seed=9, config=3)
+    a = _gpu(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
+    b = _gpu(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
+    _solve(a, wl.inputs); _solve(b, wl.inputs)
+    ids = [1, 4, 7, 11]
+    a.reset(ids)
+    b.reset(torch.tensor(ids, dtype=torch.int64, device="cuda:0"))
+    wl2 = perturb_workload(wl, 3)
+    fa, ia = _solve(a, wl2.inputs); fb, ib = _solve(b, wl2.inputs)
+    assert np.array_equal(fa, fb) and np.array_equal(ia, ib)
+    assert ia[ids, 5].tolist() == [1, 1, 1, 1] and ia[[0, 2, 3], 5].tolist() == [0, 0, 0]
 
 
 def test_single_robot_batch_and_state_roundtrip():
