@@ -68,8 +68,22 @@ int mpc_batch_create(mpc_batch **out, int n_robots, int horizon, double timestep
                      const double *mass, const double *inertia9);
 void mpc_batch_destroy(mpc_batch *b);
 
+/* Which result a solve returns -- the reference's QPSolverName (mpc_osqp.cc:952-967, constructor argument of ConvexMpc):
+ *   MPC_SOLVER_OSQP  (default) the OSQP branch (mpc_osqp.cc:690-796): OSQP 0.6.0's iterates at eps 1e-3 with polish, warm-started
+ *                    from the previous call -- BASELINE.json's comparator;
+ *   MPC_SOLVER_EXACT the qpOASES branch (:797-947, what the shipped Python selects, ConvexMPCLocomotion.py:108): the QP's optimum
+ *                    (unique: the Hessian is 2 B^T Q B + alpha I), cold on every call like that branch.  qpOASES itself is an empty
+ *                    submodule in the reference; its RESULT is reproduced (the same ADMM run to 1e-9 and polished), swing-foot
+ *                    forces come out as ~1e-10 instead of qpOASES' exact zeros. */
+enum { MPC_SOLVER_OSQP = 0, MPC_SOLVER_EXACT = 1 };
+int mpc_batch_set_solver(mpc_batch *b, int solver);
+
 /* d_in: [n, 56+4h] float32; d_forces: [n, 12h] float64; d_info: [n, 8] int32 (may be NULL). */
 int mpc_batch_solve(mpc_batch *b, const float *d_in, double *d_forces, int *d_info, void *stream);
+
+/* The same with a float64 input record (the reference's pybind11 signature takes std::vector<double>, mpc_osqp.cc:578-591:
+ * nothing is narrowed on this entry). */
+int mpc_batch_solve_f64(mpc_batch *b, const double *d_in, double *d_forces, int *d_info, void *stream);
 
 /* Cold-start the listed robots (HOST array of indices); ids == NULL resets all. */
 int mpc_batch_reset(mpc_batch *b, const int *ids, int k, void *stream);
@@ -79,6 +93,8 @@ int mpc_batch_reset_device(mpc_batch *b, const int *d_ids, int k, void *stream);
 
 /* Convenience for the per-robot plugin seam: host buffers, synchronous. */
 int mpc_batch_solve_host(mpc_batch *b, const float *h_in, double *h_forces, int *h_info);
+
+int mpc_batch_solve_host_f64(mpc_batch *b, const double *h_in, double *h_forces, int *h_info);   /* float64 record */
 
 int mpc_batch_size(const mpc_batch *b);
 int mpc_batch_horizon(const mpc_batch *b);

@@ -154,6 +154,47 @@ int mpcref_solve(void *hd, const double *in, double *forces_out, int64_t *info, 
   return 1;
 }
 
+/*
+ * The EXACT optimum of the QP of one call: what the reference's qpOASES branch (mpc_osqp.cc:797-947, the solver the shipped
+ * Python selects, ConvexMPCLocomotion.py:108) returns.  qpOASES is an empty submodule in the reference, so its result -- not its
+ * iterations -- is pinned: the QP is strictly convex (alpha I), its optimum is unique, and the vendored OSQP reaches it when it is
+ * run to eps_abs = eps_rel = 1e-9 with polish from a cold start (no warm start in that branch, :906-919; swing feet, whose bounds
+ * are l = u = 0, come out as exact zeros there and to ~1e-10 here).  forces_out = -x.  Returns the OSQP status value.
+ * info[4] = {iter, status_val, status_polish, rho_updates}
+ */
+int mpcref_solve_exact(void *hd, const double *in, double *forces_out, int64_t *info) {
+  MpcRef *s = (MpcRef *)hd;
+  mpc_assemble(&s->mdl, in, &s->wk, s->P, s->q, s->cone, s->l, s->u);
+  c_int nnzP, nnzA;
+  to_csc(s, &nnzP, &nnzA);
+  for (int i = 0; i < s->m; ++i) {
+    if (s->l[i] < -OSQP_INFTY) s->l[i] = -OSQP_INFTY;
+    if (s->u[i] > OSQP_INFTY) s->u[i] = OSQP_INFTY;
+  }
+  OSQPSettings settings;
+  osqp_set_default_settings(&settings);
+  settings.verbose = 0;
+  settings.warm_start = 0;
+  settings.polish = 1;
+  settings.polish_refine_iter = 10;
+  settings.adaptive_rho_interval = 25;
+  settings.eps_abs = 1e-9;
+  settings.eps_rel = 1e-9;
+  settings.max_iter = 200000;
+  csc Pm = {nnzP, s->n, s->n, s->Pp, s->Pi, s->Px, -1};
+  csc Am = {nnzA, s->m, s->n, s->Ap, s->Ai, s->Ax, -1};
+  OSQPData data;
+  data.n = s->n; data.m = s->m; data.P = &Pm; data.A = &Am; data.q = s->q; data.l = s->l; data.u = s->u;
+  OSQPWorkspace *w = 0;
+  if (osqp_setup(&w, &data, &settings) != 0) return -100;
+  osqp_solve(w);
+  const int st = (int)w->info->status_val;
+  if (info) { info[0] = w->info->iter; info[1] = st; info[2] = w->info->status_polish; info[3] = w->info->rho_updates; }
+  for (int i = 0; i < s->n; ++i) forces_out[i] = -w->solution->x[i];
+  osqp_cleanup(w);
+  return st;
+}
+
 /* Test access: the assembled QP of the last call (dense P, q, l, u, the 5x3 cone block). */
 void mpcref_get_qp(void *hd, double *P, double *q, double *l, double *u, double *cone) {
   MpcRef *s = (MpcRef *)hd;

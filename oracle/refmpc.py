@@ -36,6 +36,8 @@ def lib():
         _LIB.mpcref_solve.restype = C.c_int
         _LIB.mpcref_solve.argtypes = [C.c_void_p] * 5
         _LIB.mpcref_get_qp.argtypes = [C.c_void_p] * 6
+        _LIB.mpcref_solve_exact.restype = C.c_int
+        _LIB.mpcref_solve_exact.argtypes = [C.c_void_p] * 4
         _LIB.mpcref_get_state.argtypes = [C.c_void_p] * 7
         _LIB.mpcref_assemble_only.argtypes = [C.c_void_p, C.c_void_p]
         _LIB.mpcref_get_dyn.argtypes = [C.c_void_p] * 5
@@ -77,6 +79,14 @@ class RefConvexMpc:
         pack_args(self.h, *args, out=rec)
         f = self.solve_flat(rec)
         return [] if f is None else list(f)
+
+    def solve_exact(self, rec):
+        """The QP's exact optimum (what the reference's qpOASES branch returns, mpc_osqp.cc:797-947): vendored OSQP, cold, eps 1e-9, polish."""
+        rec = np.ascontiguousarray(rec, dtype=np.float64)
+        out = np.zeros(self.n, dtype=np.float64)
+        self.exact_info = np.zeros(4, dtype=np.int64)
+        self.exact_status = lib().mpcref_solve_exact(self._h, _p(rec), _p(out), _p(self.exact_info))
+        return out
 
     def reset_solver(self):
         pass  # mpc_osqp.cc:576 only flips a flag nothing reads

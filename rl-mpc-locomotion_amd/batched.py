@@ -18,8 +18,9 @@ STATUS_SOLVED = 1
 
 
 class BatchedConvexMpc:
-    def __init__(self, mass, inertia9, planning_horizon, timestep, alpha=1e-5, device=None):
-        """mass: [N] floats; inertia9: [N, 9] row-major 3x3 body inertias (host arrays)."""
+    def __init__(self, mass, inertia9, planning_horizon, timestep, alpha=1e-5, device=None, solver="osqp"):
+        """mass: [N] floats; inertia9: [N, 9] row-major 3x3 body inertias (host arrays).
+        solver: "osqp" = the reference's OSQP branch (BASELINE's comparator), "exact" = its qpOASES branch (the QP's optimum, cold every call)."""
         import torch
         if not torch.cuda.is_available():
             raise _lib.MpcLibraryError("BatchedConvexMpc needs a GPU (torch.cuda.is_available() is False); no CPU fallback")
@@ -33,6 +34,9 @@ class BatchedConvexMpc:
         L = _lib.lib()
         _lib.check(L.mpc_batch_create(C.byref(self._handle), self.n, self.h, float(timestep), float(alpha),
                                       mass.ctypes.data, inertia9.ctypes.data), "mpc_batch_create")
+        if solver not in ("osqp", "exact"):
+            raise ValueError("solver must be 'osqp' or 'exact'")
+        _lib.check(L.mpc_batch_set_solver(self._handle, 1 if solver == "exact" else 0), "mpc_batch_set_solver")
         self.forces = torch.zeros((self.n, 12 * self.h), dtype=torch.float64, device=self.device)
         self.info = torch.zeros((self.n, 8), dtype=torch.int32, device=self.device)
 

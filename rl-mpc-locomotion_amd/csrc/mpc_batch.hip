@@ -97,7 +97,7 @@ template <int H>
 __global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES : 1)) void mpc_solve_kernel(
     int n, const RobotModel *__restrict__ models, double *__restrict__ state, const double *__restrict__ qp,
     const double *__restrict__ sc, double *__restrict__ forces, int *__restrict__ info, long long *__restrict__ prof,
-    const int *__restrict__ active, const int *__restrict__ order) {
+    const int *__restrict__ active, const int *__restrict__ order, int exact) {
   // static LDS: absolute addresses fold into the ds_* offset fields
   __shared__ __attribute__((aligned(16))) Shared<H> sh;
   using C = Cfg<H>;
@@ -120,6 +120,7 @@ __global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES
                                        forces + (size_t)robot * C::N,
                                        info + (size_t)robot * kInfoLen,
                                        prof ? prof + (size_t)robot * kProfLen : nullptr};
+  if (exact) sv.exact();
   sv.run();
 }
 
@@ -163,7 +164,7 @@ __device__ void order_block(int n, const long long *__restrict__ prof, int *__re
 // equilibration) of every active robot.  The dense P lives only in this kernel's registers.
 template <int H>
 __global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= MPC_MIN_WAVES_MAX_T && Cfg<H>::NT == 1 ? MPC_SCALE_MIN_WAVES : 1)) void mpc_prep_kernel(
-    int n, const RobotModel *__restrict__ models, const float *__restrict__ in, const double *__restrict__ state,
+    int n, const RobotModel *__restrict__ models, const float *__restrict__ in, const double *__restrict__ in64, const double *__restrict__ state,
     double *__restrict__ qp, double *__restrict__ sc, long long *__restrict__ prof, const int *__restrict__ active, int *__restrict__ order) {
   __shared__ __attribute__((aligned(16))) PrepShared<H> sh;
   using C = Cfg<H>;
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= MPC_MIN_WAVES_MAX_T && Cfg
   Ex ex{th};
   const RobotModel &mdl = models[robot];
   double *qpr = qp + (size_t)robot * C::QP_LEN;
-  Assembler<H, Ex> am{ex, sh.as, mdl, in + (size_t)robot * C::IN_LEN, sh.u12, qpr, prof ? prof + (size_t)robot * kProfLen : nullptr};
+  Assembler<H, Ex> am{ex, sh.as, mdl, in ? in + (size_t)robot * C::IN_LEN : nullptr, in64 ? in64 + (size_t)robot * C::IN_LEN : nullptr, sh.u12, qpr, prof ? prof + (size_t)robot * kProfLen : nullptr};
   am.run();
   Scaler<H, Ex> sk{ex, sh.sc, state + (size_t)robot * state_len<H>(), sh.u12, mdl.alpha, qpr, sc + (size_t)robot * C::SC_LEN};
   sk.run();
@@ -196,12 +197,12 @@ __global__ void reset_kernel(double *state, int state_len, const int *ids, int k
 }
 
 template <int H>
-int launch(int n, const RobotModel *models, const float *in, double *state, double *qp, double *sc, double *forces, int *info,
-           long long *prof, const int *active, const int *order, hipEvent_t *ev, hipStream_t stream) {
+int launch(int n, const RobotModel *models, const float *in, const double *in64, double *state, double *qp, double *sc, double *forces, int *info,
+           long long *prof, const int *active, const int *order, hipEvent_t *ev, hipStream_t stream, int exact) {
   if (ev) (void)hipEventRecord(ev[0], stream);
-  hipLaunchKernelGGL(mpc_prep_kernel<H>, dim3(n + 1), dim3(Cfg<H>::T), 0, stream, n, models, in, state, qp, sc, prof, active, const_cast<int *>(order));
+  hipLaunchKernelGGL(mpc_prep_kernel<H>, dim3(n + 1), dim3(Cfg<H>::T), 0, stream, n, models, in, in64, state, qp, sc, prof, active, const_cast<int *>(order));
   if (ev) (void)hipEventRecord(ev[1], stream);
-  hipLaunchKernelGGL(mpc_solve_kernel<H>, dim3(n), dim3(Cfg<H>::TW), 0, stream, n, models, state, qp, sc, forces, info, prof, active, order);
+  hipLaunchKernelGGL(mpc_solve_kernel<H>, dim3(n), dim3(Cfg<H>::TW), 0, stream, n, models, state, qp, sc, forces, info, prof, active, order, exact);
   if (ev) (void)hipEventRecord(ev[2], stream);
   HIP_TRY(hipGetLastError());
   return MPC_OK;
@@ -224,21 +225,24 @@ struct mpc_batch {
   hipEvent_t ev[kTimingRing][3];
   long long launches = 0;
   float *d_host_in = nullptr;    // staging for mpc_batch_solve_host
+  double *d_host_in64 = nullptr; // ... and mpc_batch_solve_host_f64
   double *d_host_f = nullptr;
   bool order_valid = false;
+  int exact = 0;                 // mpc_batch_set_solver: 1 = the QP's exact optimum (the reference's qpOASES branch), cold on every call
   long long bytes = 0;
 };
 
 
 // one solver launch on b's robots (+ the dispatch order for the next one)
-static int launch_solver(mpc_batch *b, const float *d_in, double *d_forces, int *d_info, const int *d_active, hipStream_t st) {
+static int launch_solver(mpc_batch *b, const float *d_in, double *d_forces, int *d_info, const int *d_active, hipStream_t st, const double *d_in64 = nullptr) {
   const int *order = b->order_valid ? b->d_order : nullptr;
+  if (b->exact) HIP_TRY(hipMemsetAsync(b->d_state, 0, sizeof(double) * (size_t)b->n * b->state_len, st));   // no warm start in that branch (mpc_osqp.cc:906-919)
   hipEvent_t *ev = b->timing ? b->ev[b->launches % kTimingRing] : nullptr;
   int rc = MPC_E_HORIZON;
   switch (b->h) {
-    case 10: rc = launch<10>(b->n, b->d_models, d_in, b->d_state, b->d_qp, b->d_sc, d_forces, d_info, b->d_prof, d_active, order, ev, st); break;
-    case 16: rc = launch<16>(b->n, b->d_models, d_in, b->d_state, b->d_qp, b->d_sc, d_forces, d_info, b->d_prof, d_active, order, ev, st); break;
-    case 20: rc = launch<20>(b->n, b->d_models, d_in, b->d_state, b->d_qp, b->d_sc, d_forces, d_info, b->d_prof, d_active, order, ev, st); break;
+    case 10: rc = launch<10>(b->n, b->d_models, d_in, d_in64, b->d_state, b->d_qp, b->d_sc, d_forces, d_info, b->d_prof, d_active, order, ev, st, b->exact); break;
+    case 16: rc = launch<16>(b->n, b->d_models, d_in, d_in64, b->d_state, b->d_qp, b->d_sc, d_forces, d_info, b->d_prof, d_active, order, ev, st, b->exact); break;
+    case 20: rc = launch<20>(b->n, b->d_models, d_in, d_in64, b->d_state, b->d_qp, b->d_sc, d_forces, d_info, b->d_prof, d_active, order, ev, st, b->exact); break;
   }
   if (rc == MPC_E_HORIZON) return fail(MPC_E_HORIZON, "solver launch: horizon not compiled in");
   if (rc != MPC_OK) return rc;
@@ -302,6 +306,7 @@ void mpc_batch_destroy(mpc_batch *b) {
   if (b->d_order) (void)hipFree(b->d_order);
   if (b->timing) for (auto &e3 : b->ev) for (auto &e : e3) (void)hipEventDestroy(e);
   if (b->d_host_in) (void)hipFree(b->d_host_in);
+  if (b->d_host_in64) (void)hipFree(b->d_host_in64);
   if (b->d_host_f) (void)hipFree(b->d_host_f);
   delete b;
 }
@@ -311,6 +316,17 @@ int mpc_batch_solve(mpc_batch *b, const float *d_in, double *d_forces, int *d_in
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int *info = d_info ? d_info : b->d_info;
   return launch_solver(b, d_in, d_forces, info, nullptr, st);
+}
+
+int mpc_batch_set_solver(mpc_batch *b, int solver) {
+  if (!b || (solver != MPC_SOLVER_OSQP && solver != MPC_SOLVER_EXACT)) return fail(MPC_E_ARG, "mpc_batch_set_solver: MPC_SOLVER_OSQP (0) or MPC_SOLVER_EXACT (1)");
+  b->exact = solver == MPC_SOLVER_EXACT;
+  return MPC_OK;
+}
+
+int mpc_batch_solve_f64(mpc_batch *b, const double *d_in, double *d_forces, int *d_info, void *stream) {
+  if (!b || !d_in || !d_forces) return fail(MPC_E_ARG, "mpc_batch_solve_f64: bad argument");
+  return launch_solver(b, nullptr, d_forces, d_info ? d_info : b->d_info, nullptr, reinterpret_cast<hipStream_t>(stream), d_in);
 }
 
 int mpc_batch_reset(mpc_batch *b, const int *ids, int k, void *stream) {
@@ -344,11 +360,27 @@ int mpc_batch_solve_host(mpc_batch *b, const float *h_in, double *h_forces, int 
   const size_t inlen = 56 + 4 * (size_t)b->h, N = 12 * (size_t)b->h;
   if (!b->d_host_in) {   // staging buffers of the host-pointer entry point, kept for the life of the handle
     HIP_TRY(hipMalloc(&b->d_host_in, sizeof(float) * b->n * inlen));
-    HIP_TRY(hipMalloc(&b->d_host_f, sizeof(double) * b->n * N));
+    if (!b->d_host_f) HIP_TRY(hipMalloc(&b->d_host_f, sizeof(double) * b->n * N));
   }
   HIP_TRY(hipMemcpy(b->d_host_in, h_in, sizeof(float) * b->n * inlen, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(b->d_host_f, h_forces, sizeof(double) * b->n * N, hipMemcpyHostToDevice));   // rows of unsolved robots stay as passed in
   const int rc = mpc_batch_solve(b, b->d_host_in, b->d_host_f, nullptr, nullptr);
+  if (rc != MPC_OK) return rc;
+  HIP_TRY(hipMemcpy(h_forces, b->d_host_f, sizeof(double) * b->n * N, hipMemcpyDeviceToHost));     // (synchronises with the null stream)
+  if (h_info) HIP_TRY(hipMemcpy(h_info, b->d_info, sizeof(int) * b->n * kInfoLen, hipMemcpyDeviceToHost));
+  return MPC_OK;
+}
+
+int mpc_batch_solve_host_f64(mpc_batch *b, const double *h_in, double *h_forces, int *h_info) {
+  if (!b || !h_in || !h_forces) return fail(MPC_E_ARG, "mpc_batch_solve_host_f64: bad argument");
+  const size_t inlen = 56 + 4 * (size_t)b->h, N = 12 * (size_t)b->h;
+  if (!b->d_host_in64) {
+    HIP_TRY(hipMalloc(&b->d_host_in64, sizeof(double) * b->n * inlen));
+    if (!b->d_host_f) HIP_TRY(hipMalloc(&b->d_host_f, sizeof(double) * b->n * N));
+  }
+  HIP_TRY(hipMemcpy(b->d_host_in64, h_in, sizeof(double) * b->n * inlen, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b->d_host_f, h_forces, sizeof(double) * b->n * N, hipMemcpyHostToDevice));   // rows of unsolved robots stay as passed in
+  const int rc = mpc_batch_solve_f64(b, b->d_host_in64, b->d_host_f, nullptr, nullptr);
   if (rc != MPC_OK) return rc;
   HIP_TRY(hipMemcpy(h_forces, b->d_host_f, sizeof(double) * b->n * N, hipMemcpyDeviceToHost));     // (synchronises with the null stream)
   if (h_info) HIP_TRY(hipMemcpy(h_info, b->d_info, sizeof(int) * b->n * kInfoLen, hipMemcpyDeviceToHost));

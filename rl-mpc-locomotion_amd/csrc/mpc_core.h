@@ -311,7 +311,8 @@ struct Assembler {
   Exec &ex;
   AsmShared<H> &s;
   const RobotModel &mdl;
-  const float *in;     // [IN_LEN]
+  const float *in;     // [IN_LEN]   the input record as float32 ...
+  const double *in64;  // [IN_LEN]   ... or as float64 (the reference's std::vector<double> arguments, mpc_osqp.cc:578-591); one of the two is null
   double *u12;         // [288] LDS  out: U1 = B6^T th1 B6, U2 = B6^T diag(th2) B6 (12 x 12 each): P = Sigma2 (x) U1 + N (x) U2 + alpha I
   double *qp;          // [QP_LEN]   out: q, l, u, cone
   long long *prof;     // [kProfLen] slots 1 (dynamics) and 2 (q + P) are written here (may be null)
@@ -336,7 +337,7 @@ struct Assembler {
   MPC_HD void run() {
     tlast = MPC_CLOCK();
     ex.par([&](Th &t) {
-      for (int i = t.tid; i < C::IN_LEN; i += T) s.in[i] = (double)in[i];
+      for (int i = t.tid; i < C::IN_LEN; i += T) s.in[i] = in64 ? in64[i] : (double)in[i];
       for (int i = t.tid; i < 169; i += T) s.a_dt[i] = 0;
       for (int i = t.tid; i < 156; i += T) s.b_dt[i] = 0;
       for (int i = t.tid; i < 72; i += T) { qp[C::QP_B6 + i] = 0; s.B6[i] = 0; }

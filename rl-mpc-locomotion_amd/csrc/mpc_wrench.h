@@ -109,6 +109,12 @@ struct Solver {
   double *forces;      // [N]   out: -D x (all horizon steps), untouched on failure
   int *info;           // [kInfoLen]
   long long *prof;     // [kProfLen] shader-clock cycles per section (may be null)
+  // Solver settings.  Defaults = the reference's OSQP call (mpc_osqp.cc:705-712).  exact(): the QP's optimum to working accuracy,
+  // i.e. what the reference's qpOASES branch returns (mpc_osqp.cc:797-947) -- the same algorithm run to 1e-9 and polished with ten
+  // refinement steps (the caller clears the warm-start record: that branch never warm-starts, :906-919).
+  double eps_abs = kEpsAbs, eps_rel = kEpsRel;
+  int max_iter = kMaxIter, polish_refine = kPolishRefine;
+  MPC_HD void exact() { eps_abs = 1e-9; eps_rel = 1e-9; max_iter = 50 * kMaxIter; polish_refine = 10; }
 #ifdef MPC_EMU_DEBUG
   double *dbg = nullptr;   // host emulation only: per foot 20 doubles of the first polish application (tests/emu)
 #endif
@@ -815,8 +821,8 @@ struct Solver {
         s.pri_res = pri; s.dua_res = dua; s.iter = iter; s.rho_new = 0;
         if (!(pri <= kInfty) || !(dua <= kInfty)) { s.status = kStNonCvx; s.done = 1; }
         else {
-          const double eps_prim = kEpsAbs + kEpsRel * dmax(bitsd(s.red[1]), bitsd(s.red[2]));
-          const double eps_dual = kEpsAbs + kEpsRel * s.cinv * dmax(dmax(bitsd(s.red[7]), bitsd(s.red[8])), bitsd(s.red[9]));
+          const double eps_prim = eps_abs + eps_rel * dmax(bitsd(s.red[1]), bitsd(s.red[2]));
+          const double eps_dual = eps_abs + eps_rel * s.cinv * dmax(dmax(bitsd(s.red[7]), bitsd(s.red[8])), bitsd(s.red[9]));
           if (pri < eps_prim && dua < eps_dual) { s.status = kStSolved; s.done = 1; }
           else {
             double pr = bitsd(s.red[3]) / (dmax(bitsd(s.red[4]), bitsd(s.red[5])) + 1e-10);
@@ -1124,7 +1130,7 @@ struct Solver {
     //   w <- w + Omega (g - P_s w).   With an exact Omega the residual obeys r_{k+1} = delta Omega r_k and needs no product with
     // P; Omega is only accurate to ~1e-10 |Xi|, so the true residual is formed (one Theta product per step) -- which is also
     // what OSQP does, and what keeps the refinement self-correcting.  The last product is the P_s xN the finish needs anyway.
-    for (int it = 0; it <= kPolishRefine; ++it) {
+    for (int it = 0; it <= polish_refine; ++it) {
       omega_apply();
 #ifdef MPC_EMU_DEBUG
       if (dbg && it == 0) ex.par([&](Th &t) {
@@ -1145,7 +1151,7 @@ struct Solver {
         }
       });
       product<kTheta>();                                  // c Theta W xN  (-> P_s xN)
-      if (it < kPolishRefine) {
+      if (it < polish_refine) {
         ex.seq([&](Th &t) {
           if (t.tid < NF) {
             double wy[3];
@@ -1231,7 +1237,7 @@ struct Solver {
     // recomputes exactly the values the last iteration left).
     static_assert(kMaxIter % kCheck == 0, "the check falls on the last iteration");
     int iter = 0;
-    while (!s.done && !s.bad && iter < kMaxIter) {
+    while (!s.done && !s.bad && iter < max_iter) {
       y_scaled(true);
       for (int k = 0; k < kCheck; ++k) admm_iter();
       y_scaled(false);

@@ -48,3 +48,13 @@ def pack_args(h, qp_weights, com_position, com_velocity, com_roll_pitch_yaw, gro
     put(in_des_rpy(h), desired_com_roll_pitch_yaw, 3)
     put(in_des_angvel(h), desired_com_angular_velocity, 3)
     return out
+
+
+def unpack_args(h, rec):
+    """Inverse of pack_args: the 13 positional arguments of compute_contact_forces as float64 arrays."""
+    import numpy as np
+    r = np.asarray(rec, dtype=np.float64).reshape(-1)
+    cut = lambda off, k: r[off:off + k].copy()
+    return (cut(IN_WEIGHTS, 13), cut(IN_COM_POS, 3), cut(IN_COM_VEL, 3), cut(IN_RPY, 3), cut(IN_NORMAL, 3), cut(IN_ANGVEL, 3),
+            cut(IN_CONTACT, 4 * h), cut(in_footpos(h), 12), cut(in_friction(h), 4), cut(in_des_pos(h), 3), cut(in_des_vel(h), 3),
+            cut(in_des_rpy(h), 3), cut(in_des_angvel(h), 3))

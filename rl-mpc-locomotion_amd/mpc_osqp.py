@@ -7,9 +7,10 @@ Same names, argument meaning and error behaviour as the reference module, served
     forces = cpp_mpc.compute_contact_forces(w, pos, vel, rpy, normal, omega, table, feet, mu, dpos, dvel, drpy, domega)
 
 ``forces`` is a list of 12*h floats ([step][leg][xyz], negated like mpc_osqp.cc:789-790) or ``[]`` when
-the solver does not report OSQP_SOLVED (mpc_osqp.cc:781-794).  The solver always runs the OSQP
-algorithm (BASELINE.json's comparator); ``qp_solver_name`` is accepted for signature compatibility
-(qpOASES is an empty submodule in the reference, its branch cannot be pinned).
+the solver does not report OSQP_SOLVED (mpc_osqp.cc:781-794).  ``qp_solver_name`` selects what the reference's
+two branches return: ``OSQP`` -> OSQP 0.6.0's warm-started iterates at eps 1e-3 with polish (mpc_osqp.cc:690-796, BASELINE.json's
+comparator); ``QPOASES`` -> the QP's optimum, cold on every call (mpc_osqp.cc:797-947 -- qpOASES is an empty submodule in
+the reference, so its result, the unique optimum of the strictly convex QP, is reproduced rather than its iterations).
 To serve the *unmodified* reference Python, put this module on ``sys.modules['mpc_osqp']`` before
 importing ``MPC_Controller.convex_MPC.ConvexMPCLocomotion``.
 """
@@ -45,7 +46,8 @@ class ConvexMpc:
         m = np.array([float(mass)])
         _lib.check(_lib.lib().mpc_batch_create(C.byref(self._handle), 1, self._h, float(timestep), float(alpha),
                                                m.ctypes.data, inertia.ctypes.data), "mpc_batch_create")
-        self._rec = np.zeros(in_len(self._h), dtype=np.float32)
+        _lib.check(_lib.lib().mpc_batch_set_solver(self._handle, 1 if int(qp_solver_name) == int(QPOASES) else 0), "mpc_batch_set_solver")
+        self._rec = np.zeros(in_len(self._h), dtype=np.float64)     # pybind11 widens every argument to double (mpc_osqp.cc:578-591)
         self._out = np.zeros(12 * self._h, dtype=np.float64)
         self.info = np.zeros(8, dtype=np.int32)
 
@@ -63,8 +65,8 @@ class ConvexMpc:
                   com_angular_velocity, foot_contact_states, foot_positions_body_frame, foot_friction_coeffs,
                   desired_com_position, desired_com_velocity, desired_com_roll_pitch_yaw,
                   desired_com_angular_velocity, out=self._rec)
-        _lib.check(_lib.lib().mpc_batch_solve_host(self._handle, self._rec.ctypes.data, self._out.ctypes.data,
-                                                   self.info.ctypes.data), "mpc_batch_solve_host")
+        _lib.check(_lib.lib().mpc_batch_solve_host_f64(self._handle, self._rec.ctypes.data, self._out.ctypes.data,
+                                                       self.info.ctypes.data), "mpc_batch_solve_host_f64")
         if self.info[1] != 1:      # not OSQP_SOLVED -> empty vector (mpc_osqp.cc:781-794)
             return []
         return self._out.tolist()

@@ -58,7 +58,7 @@ static long prep_one(const RobotModel &mdl, const float *in, const double *state
   std::memset((void *)ps, 0, sizeof(PrepShared<H>));
   using Ex = HostExec<Thread<H>, C::T>;
   Ex ex(reverse);
-  Assembler<H, Ex> am{ex, ps->as, mdl, in, ps->u12, qp, nullptr};
+  Assembler<H, Ex> am{ex, ps->as, mdl, in, nullptr, ps->u12, qp, nullptr};
   am.run();
   Scaler<H, Ex> sk{ex, ps->sc, state, ps->u12, mdl.alpha, qp, sc};
   sk.run();

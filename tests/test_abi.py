@@ -13,7 +13,7 @@ from tests.helpers import ROOT
 def _declared():
     src = open(os.path.join(ROOT, "include", "mpc_batch.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(mpc_[a-z_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(mpc_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_header_symbols_are_exported():
