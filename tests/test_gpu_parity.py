@@ -97,7 +97,7 @@ def test_mpc_osqp_shim_signature():
     h = 10
     d = g["inertia_diag"][0]
     obj = mpc.ConvexMpc(float(g["mass"][0]), [d[0], 0, 0, 0, d[1], 0, 0, 0, d[2]], 4, h, float(g["dt_mpc"]),
-                        float(g["alpha"]), mpc.QPOASES)
+                        float(g["alpha"]), mpc.OSQP)      # the OSQP branch: BASELINE's comparator (QPOASES = the exact optimum: tests/test_dropin.py)
     r = g["inputs_0"][0]
     out = obj.compute_contact_forces(
         list(r[0:13]), r[13:16], r[16:19], r[19:22], r[22:25], r[25:28], r[28:28 + 4 * h],
