@@ -17,10 +17,11 @@
 
 using namespace mpc;
 
-// minimum waves per SIMD the register allocator must leave room for in the scaling kernel: 4 -> a 256-thread workgroup
-// (h = 10) gets 128 VGPRs and four robots share a CU
+// minimum waves per SIMD the register allocator must leave room for in the prep kernel: 3 -> a 256-thread workgroup (h = 10)
+// gets 168 VGPRs and three robots share a CU.  (Four -- 128 VGPRs, 40 KB of LDS each -- were measured slower: 0.278 against
+// 0.235 ms per 4096 robots; the Ruiz passes then spill.)
 #ifndef MPC_SCALE_MIN_WAVES
-#define MPC_SCALE_MIN_WAVES 4
+#define MPC_SCALE_MIN_WAVES 3
 #endif
 #ifndef MPC_MIN_WAVES_MAX_T
 #define MPC_MIN_WAVES_MAX_T 256   // larger workgroups (h = 16), and the four-tiles-per-thread layout (h = 20), run one per CU
@@ -29,6 +30,9 @@ using namespace mpc;
 // robots per CU: measured faster than two waves per SIMD at 256 registers, which spills to scratch memory
 #ifndef MPC_SOLVE_MIN_WAVES
 #define MPC_SOLVE_MIN_WAVES 1
+#endif
+#ifndef MPC_SOLVE_MIN_WAVES_WIDE   // the multi-wave workgroups of the long horizons (192 threads at h = 16, 256 at h = 20): two waves per
+#define MPC_SOLVE_MIN_WAVES_WIDE 2  // SIMD hide their barriers (measured: h = 16 3.00 -> 2.35 ms, h = 20 3.55 -> 2.83 ms per 4096 robots)
 #endif
 
 namespace {
@@ -94,7 +98,7 @@ struct DeviceExec {
 
 // Solve kernel (mpc_wrench.h Solver): ADMM + polish of every active robot, from the QP and scale records
 template <int H>
-__global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES : 1)) void mpc_solve_kernel(
+__global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES : MPC_SOLVE_MIN_WAVES_WIDE)) void mpc_solve_kernel(
     int n, const RobotModel *__restrict__ models, double *__restrict__ state, const double *__restrict__ qp,
     const double *__restrict__ sc, double *__restrict__ forces, int *__restrict__ info, long long *__restrict__ prof,
     const int *__restrict__ active, const int *__restrict__ order, int exact) {

@@ -194,7 +194,6 @@ struct ScaleShared {
   int first;
   MPC_V xt[C::N];                                       // q of the previous call (osqp_update_P_A scales with it)
   MPC_V cone[16];
-  MPC_V l[C::M]; MPC_V u[C::M];                         // unscaled bounds
   MPC_V dt_[C::N]; MPC_V et_[C::M]; MPC_V cn_[C::N];    // Ruiz pass temporaries
   MPC_V part[C::NP * C::G];                             // [slot][row] partial maxima of the tile row norms
 };
@@ -828,8 +827,8 @@ struct Scaler {
       }
       for_rows(t, [&](int i) {
         sc[C::SC_E + i] = s.E[i];
-        sc[C::SC_LS + i] = s.E[i] * s.l[i];
-        sc[C::SC_US + i] = s.E[i] * s.u[i];
+        sc[C::SC_LS + i] = s.E[i] * qp[C::QP_L + i];      // (the unscaled bounds stay in the QP record: LDS is what limits the robots per CU)
+        sc[C::SC_US + i] = s.E[i] * qp[C::QP_U + i];
       });
       for (int k = t.tid; k < NF * 15; k += T) sc[C::SC_AS + k] = s.As[k];
     });
@@ -839,7 +838,6 @@ struct Scaler {
   MPC_HD void load() {
     ex.par([&](Th &t) {
       for (int i = t.tid; i < N; i += T) { if constexpr (C::kQInLds) s.q[i] = qp[C::QP_Q + i]; s.xt[i] = state[N + 2 * M + i]; /* q_old */ }
-      for (int i = t.tid; i < M; i += T) { s.l[i] = qp[C::QP_L + i]; s.u[i] = qp[C::QP_U + i]; }
       if (t.tid < 15) s.cone[t.tid] = qp[C::QP_CONE + t.tid];
       if (t.tid == 0) s.first = state[2 * N + 2 * M + 1] == 0.0;
     });
