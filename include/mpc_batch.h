@@ -104,6 +104,14 @@ long long mpc_batch_device_bytes(const mpc_batch *b);
 int mpc_batch_state_len(const mpc_batch *b);
 int mpc_batch_get_state(mpc_batch *b, double *h_state);
 int mpc_batch_set_state(mpc_batch *b, const double *h_state);
+/* What the prep kernel handed to the solve kernel in the last launch (parity tests of the assembly and of the Ruiz scaling):
+ *   QP record    [n, mpc_batch_qp_len]    q[12h] l[20h] u[20h] cone[15] pad | B6[6x12] th1[6x6] th2[6] pad -- the QP of
+ *                mpc_osqp.cc:606-688 with its Hessian in the wrench form P = BB^T Theta BB + alpha I (csrc/mpc_wrench.h);
+ *   scale record [n, mpc_batch_scale_len] D[12h] E[20h] q_s[12h] A_s[15*4h] l_s[20h] u_s[20h] c 1/c -- OSQP's scaling.c output. */
+int mpc_batch_qp_len(const mpc_batch *b);
+int mpc_batch_scale_len(const mpc_batch *b);
+int mpc_batch_get_qp(mpc_batch *b, double *h_qp);
+int mpc_batch_get_scale(mpc_batch *b, double *h_sc);
 /* Kernel timing (benchmarks): after mpc_batch_enable_timing every launch records HIP events on its stream around the
  * prep kernel (QP assembly + Ruiz scaling) and the solve kernel; mpc_batch_kernel_times synchronises and returns the durations (ms) of the last
  * `last_k` launches (oldest first, at most 64). */

@@ -81,6 +81,18 @@ class BatchedConvexMpc:
         _lib.check(_lib.lib().mpc_batch_get_state(self._handle, out.ctypes.data), "mpc_batch_get_state")
         return out
 
+    def get_qp(self):
+        """[N, qp_len] float64: the QP record of the last launch (see include/mpc_batch.h)."""
+        out = np.zeros((self.n, _lib.lib().mpc_batch_qp_len(self._handle)))
+        _lib.check(_lib.lib().mpc_batch_get_qp(self._handle, out.ctypes.data), "mpc_batch_get_qp")
+        return out
+
+    def get_scale(self):
+        """[N, scale_len] float64: the scale record (OSQP's Ruiz equilibration) of the last launch."""
+        out = np.zeros((self.n, _lib.lib().mpc_batch_scale_len(self._handle)))
+        _lib.check(_lib.lib().mpc_batch_get_scale(self._handle, out.ctypes.data), "mpc_batch_get_scale")
+        return out
+
     def enable_timing(self):
         _lib.check(_lib.lib().mpc_batch_enable_timing(self._handle), "mpc_batch_enable_timing")
 

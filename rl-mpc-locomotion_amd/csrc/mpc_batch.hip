@@ -232,6 +232,7 @@ struct mpc_batch {
   double *d_host_in64 = nullptr; // ... and mpc_batch_solve_host_f64
   double *d_host_f = nullptr;
   bool order_valid = false;
+  int device = 0;                // the HIP device the handle was created on: every entry point makes it current
   int exact = 0;                 // mpc_batch_set_solver: 1 = the QP's exact optimum (the reference's qpOASES branch), cold on every call
   long long bytes = 0;
 };
@@ -239,6 +240,7 @@ struct mpc_batch {
 
 // one solver launch on b's robots (+ the dispatch order for the next one)
 static int launch_solver(mpc_batch *b, const float *d_in, double *d_forces, int *d_info, const int *d_active, hipStream_t st, const double *d_in64 = nullptr) {
+  HIP_TRY(hipSetDevice(b->device));
   const int *order = b->order_valid ? b->d_order : nullptr;
   if (b->exact) HIP_TRY(hipMemsetAsync(b->d_state, 0, sizeof(double) * (size_t)b->n * b->state_len, st));   // no warm start in that branch (mpc_osqp.cc:906-919)
   hipEvent_t *ev = b->timing ? b->ev[b->launches % kTimingRing] : nullptr;
@@ -273,6 +275,7 @@ int mpc_batch_create(mpc_batch **out, int n, int horizon, double timestep, doubl
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MPC_E_NODEVICE, "mpc_batch_create: no HIP device");
   mpc_batch *b = new mpc_batch();
+  (void)hipGetDevice(&b->device);
   b->n = n;
   b->h = horizon;
   const size_t qp_len = horizon == 10 ? Cfg<10>::QP_LEN : horizon == 16 ? Cfg<16>::QP_LEN : Cfg<20>::QP_LEN;
@@ -335,6 +338,7 @@ int mpc_batch_solve_f64(mpc_batch *b, const double *d_in, double *d_forces, int 
 
 int mpc_batch_reset(mpc_batch *b, const int *ids, int k, void *stream) {
   if (!b) return fail(MPC_E_ARG, "mpc_batch_reset: bad argument");
+  HIP_TRY(hipSetDevice(b->device));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!ids) {
     HIP_TRY(hipMemsetAsync(b->d_state, 0, sizeof(double) * (size_t)b->n * b->state_len, st));
@@ -352,6 +356,7 @@ int mpc_batch_reset(mpc_batch *b, const int *ids, int k, void *stream) {
 
 int mpc_batch_reset_device(mpc_batch *b, const int *d_ids, int k, void *stream) {
   if (!b || !d_ids || k < 0) return fail(MPC_E_ARG, "mpc_batch_reset_device: bad argument");
+  HIP_TRY(hipSetDevice(b->device));
   if (k == 0) return MPC_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(reset_kernel, dim3(k), dim3(256), 0, st, b->d_state, b->state_len, d_ids, k, b->n);
@@ -417,8 +422,26 @@ long long mpc_batch_device_bytes(const mpc_batch *b) { return b ? b->bytes : 0; 
 int mpc_batch_state_len(const mpc_batch *b) { return b ? b->state_len : 0; }
 int mpc_batch_get_state(mpc_batch *b, double *h_state) {
   if (!b || !h_state) return fail(MPC_E_ARG, "mpc_batch_get_state: bad argument");
+  HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(h_state, b->d_state, sizeof(double) * (size_t)b->n * b->state_len, hipMemcpyDeviceToHost));
+  return MPC_OK;
+}
+// Test / debugging access to what the prep kernel handed to the solve kernel in the last launch
+static size_t qp_len_of(int h) { return h == 10 ? Cfg<10>::QP_LEN : h == 16 ? Cfg<16>::QP_LEN : Cfg<20>::QP_LEN; }
+static size_t sc_len_of(int h) { return h == 10 ? Cfg<10>::SC_LEN : h == 16 ? Cfg<16>::SC_LEN : Cfg<20>::SC_LEN; }
+int mpc_batch_qp_len(const mpc_batch *b) { return b ? (int)qp_len_of(b->h) : 0; }
+int mpc_batch_scale_len(const mpc_batch *b) { return b ? (int)sc_len_of(b->h) : 0; }
+int mpc_batch_get_qp(mpc_batch *b, double *h_qp) {
+  if (!b || !h_qp) return fail(MPC_E_ARG, "mpc_batch_get_qp: bad argument");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(h_qp, b->d_qp, sizeof(double) * (size_t)b->n * qp_len_of(b->h), hipMemcpyDeviceToHost));
+  return MPC_OK;
+}
+int mpc_batch_get_scale(mpc_batch *b, double *h_sc) {
+  if (!b || !h_sc) return fail(MPC_E_ARG, "mpc_batch_get_scale: bad argument");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(h_sc, b->d_sc, sizeof(double) * (size_t)b->n * sc_len_of(b->h), hipMemcpyDeviceToHost));
   return MPC_OK;
 }
 int mpc_batch_get_profile(mpc_batch *b, long long *h_prof) {
@@ -429,6 +452,7 @@ int mpc_batch_get_profile(mpc_batch *b, long long *h_prof) {
 }
 int mpc_batch_set_state(mpc_batch *b, const double *h_state) {
   if (!b || !h_state) return fail(MPC_E_ARG, "mpc_batch_set_state: bad argument");
+  HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipMemcpy(b->d_state, h_state, sizeof(double) * (size_t)b->n * b->state_len, hipMemcpyHostToDevice));
   return MPC_OK;
 }
@@ -612,6 +636,7 @@ int mpc_ctrl_create(mpc_ctrl **out, int n, int horizon, double controller_dt, in
 
 int mpc_ctrl_step(mpc_ctrl *c, const float *d_dof, const float *d_est, const float *d_cmd, float *d_torques, void *stream) {
   if (!c || !d_dof || !d_est || !d_cmd || !d_torques) return fail(MPC_E_ARG, "mpc_ctrl_step: bad argument");
+  HIP_TRY(hipSetDevice(c->solver->device));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int n = c->n, blocks = (n + kCtrlThreads - 1) / kCtrlThreads;
   bool any_due = true;
@@ -634,6 +659,7 @@ int mpc_ctrl_step(mpc_ctrl *c, const float *d_dof, const float *d_est, const flo
 
 int mpc_ctrl_run(mpc_ctrl *c, const float *d_dof, const float *d_body, const float *d_cmd, float *d_torques, void *stream) {
   if (!c || !d_dof || !d_body || !d_cmd || !d_torques) return fail(MPC_E_ARG, "mpc_ctrl_run: bad argument");
+  HIP_TRY(hipSetDevice(c->solver->device));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(estimator_kernel, dim3((c->n + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, st, c->n, c->d_state, d_body, c->d_est);
   HIP_TRY(hipGetLastError());
@@ -642,6 +668,7 @@ int mpc_ctrl_run(mpc_ctrl *c, const float *d_dof, const float *d_body, const flo
 
 int mpc_ctrl_reset(mpc_ctrl *c, const int *ids, int k, void *stream) {
   if (!c) return fail(MPC_E_ARG, "mpc_ctrl_reset: bad argument");
+  HIP_TRY(hipSetDevice(c->solver->device));
   if (!ids) c->h_iter.assign(c->n, 0);
   else for (int i = 0; i < k; ++i) if (ids[i] >= 0 && ids[i] < c->n && (int)c->h_iter.size() == c->n) c->h_iter[ids[i]] = 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -664,6 +691,7 @@ int mpc_ctrl_reset(mpc_ctrl *c, const int *ids, int k, void *stream) {
 
 int mpc_ctrl_reset_device(mpc_ctrl *c, const int *d_ids, int k, void *stream) {
   if (!c || !d_ids || k < 0) return fail(MPC_E_ARG, "mpc_ctrl_reset_device: bad argument");
+  HIP_TRY(hipSetDevice(c->solver->device));
   if (k == 0) return MPC_OK;
   c->mirror_valid = false;     // the host copy of the MPC counters cannot follow ids it never sees: launch the solver on every tick (active mask)
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -676,6 +704,7 @@ int mpc_ctrl_reset_device(mpc_ctrl *c, const int *d_ids, int k, void *stream) {
 
 int mpc_ctrl_set_gait(mpc_ctrl *c, const int *gait_id, void *stream) {
   if (!c || !gait_id) return fail(MPC_E_ARG, "mpc_ctrl_set_gait: bad argument");
+  HIP_TRY(hipSetDevice(c->solver->device));
   for (int r = 0; r < c->n; ++r) if (gait_id[r] < 0 || gait_id[r] >= kNumGaitIds) return fail(MPC_E_ARG, "mpc_ctrl_set_gait: gait id out of range");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   HIP_TRY(hipMemcpyAsync(c->d_gait, gait_id, sizeof(int) * c->n, hipMemcpyHostToDevice, st));
@@ -686,6 +715,7 @@ int mpc_ctrl_set_gait(mpc_ctrl *c, const int *gait_id, void *stream) {
 
 int mpc_ctrl_fsm_init(mpc_ctrl *c, const int *control_mode, int operating_mode, int check_safety, void *stream) {
   if (!c || !control_mode || (operating_mode != kOpTest && operating_mode != kOpNormal)) return fail(MPC_E_ARG, "mpc_ctrl_fsm_init: bad argument");
+  HIP_TRY(hipSetDevice(c->solver->device));
   for (int r = 0; r < c->n; ++r)
     if (control_mode[r] != kFsmPassive && control_mode[r] != kFsmLocomotion && control_mode[r] != kFsmRecoveryStand)
       return fail(MPC_E_ARG, "mpc_ctrl_fsm_init: control mode must be 0 (PASSIVE), 4 (LOCOMOTION) or 6 (RECOVERY_STAND)");
@@ -710,6 +740,7 @@ int mpc_ctrl_fsm_init(mpc_ctrl *c, const int *control_mode, int operating_mode, 
 
 int mpc_ctrl_fsm_reset(mpc_ctrl *c, const int *ids, int k, const int *control_mode, void *stream) {
   if (!c || !c->d_fsm || (ids && k < 0)) return fail(MPC_E_ARG, "mpc_ctrl_fsm_reset: bad argument (mpc_ctrl_fsm_init first)");
+  HIP_TRY(hipSetDevice(c->solver->device));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (control_mode) {   // [n] entries, like mpc_ctrl_fsm_init
     for (int r = 0; r < c->n; ++r)
@@ -734,6 +765,7 @@ int mpc_ctrl_fsm_reset(mpc_ctrl *c, const int *ids, int k, const int *control_mo
 
 int mpc_ctrl_run_fsm(mpc_ctrl *c, const float *d_dof, const float *d_body, const float *d_cmd, const int *d_request, float *d_torques, void *stream) {
   if (!c || !d_dof || !d_body || !d_cmd || !d_request || !d_torques) return fail(MPC_E_ARG, "mpc_ctrl_run_fsm: bad argument");
+  HIP_TRY(hipSetDevice(c->solver->device));
   if (!c->d_fsm) return fail(MPC_E_ARG, "mpc_ctrl_run_fsm: call mpc_ctrl_fsm_init first");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int n = c->n, blocks = (n + kCtrlThreads - 1) / kCtrlThreads;

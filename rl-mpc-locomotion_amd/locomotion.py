@@ -59,6 +59,7 @@ class BatchedLocomotion:
         (RL_Environment/tasks/aliengo.py:252-256): dof_states [N,12,2], body_states [N,13] (pos3, quat xyzw,
         lin vel3, ang vel3, world frame), commands [N,16]; returns torques [N,12]."""
         import torch
+        commands = self._full_commands(commands)
         for name, t, numel in (("dof_states", dof_states, self.n * 24), ("body_states", body_states, self.n * 13), ("commands", commands, self.n * 16)):
             if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or t.numel() != numel:
                 raise ValueError(f"{name} must be a contiguous cuda float32 tensor with {numel} elements")
@@ -67,6 +68,16 @@ class BatchedLocomotion:
         _lib.check(_lib.lib().mpc_ctrl_run(self._handle, dof_states.data_ptr(), body_states.data_ptr(), commands.data_ptr(),
                                            torques.data_ptr(), stream), "mpc_ctrl_run")
         return torques
+
+    def _full_commands(self, commands):
+        """[N, 3] commands (vx, vy, yaw rate: the interactive runners, mpc_weights None) -> [N, 16] with NaN weights, which the
+        controller replaces by the robot type's Quadruped._mpc_weights (ConvexMPCLocomotion.py:132-135)."""
+        import torch
+        if commands.dim() == 2 and commands.shape[1] == 3:
+            full = torch.full((self.n, 16), float("nan"), dtype=torch.float32, device=commands.device)
+            full[:, :3] = commands
+            return full
+        return commands
 
     def reset(self, env_ids=None):
         import torch
@@ -107,6 +118,7 @@ class BatchedLocomotion:
         """The batched ``RobotRunnerFSM.run(dof_states, body_states, commands)`` (robot_runner/RobotRunnerFSM.py:44-71);
         ``request`` [N] cuda int32 is the control mode requested for each robot this tick."""
         import torch
+        commands = self._full_commands(commands)
         for name, t, numel in (("dof_states", dof_states, self.n * 24), ("body_states", body_states, self.n * 13), ("commands", commands, self.n * 16)):
             if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or t.numel() != numel:
                 raise ValueError(f"{name} must be a contiguous cuda float32 tensor with {numel} elements")

@@ -54,7 +54,10 @@ class ConvexMpc:
     def __del__(self):
         h = getattr(self, "_handle", None)
         if h:
-            _lib.lib().mpc_batch_destroy(h)
+            try:
+                _lib.lib().mpc_batch_destroy(h)
+            except Exception:      # interpreter shutdown: the loader module may be gone already
+                pass
             self._handle = None
 
     def compute_contact_forces(self, qp_weights, com_position, com_velocity, com_roll_pitch_yaw, ground_normal_vec,

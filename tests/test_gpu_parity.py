@@ -227,3 +227,43 @@ def test_full_size_properties_long_horizons(config, h, n):
     fr = ref.solve(wl.inputs[pick], nthreads=8)
     assert np.array_equal(ref.info[:, :4], ia[pick][:, :4])
     assert grf_relerr(fa[pick], fr, first_step_only=False).max() < GRF_RTOL
+
+
+@pytest.mark.parametrize("name", ["solver_h10_cfg3", "solver_h10_edge", "solver_h16_cfg4"])
+def test_assembly_and_scaling_records_match_the_oracle(name):
+    """the QP the prep kernel builds -- q, l, u, the cone block, and P through its wrench form
+    P = BB^T Theta BB + alpha I (B6, th1, th2 of the QP record) -- against the oracle's restated mpc_osqp.cc assembly, element by
+    element; and its Ruiz scaling (D, E, c, cold call) against the vendored OSQP's own scaling vectors."""
+    import torch
+    from oracle.refmpc import RefConvexMpc
+    g = load_golden(name)
+    h, n = int(g["h"]), min(len(g["mass"]), 10)
+    N, M = 12 * h, 20 * h
+    gpu = _gpu(g["mass"][:n], g["inertia_diag"][:n], h, float(g["dt_mpc"]), float(g["alpha"]))
+    gpu.solve(torch.from_numpy(g["inputs_0"][:n]).cuda())
+    qp, sc = gpu.get_qp(), gpu.get_scale()
+    dt = float(g["dt_mpc"])
+    for r in range(n):
+        d = g["inertia_diag"][r]
+        ref = RefConvexMpc(g["mass"][r], [d[0], 0, 0, 0, d[1], 0, 0, 0, d[2]], 4, h, dt, float(g["alpha"]))
+        ref.solve_flat(g["inputs_0"][r])
+        P, q, l, u, cone = ref.qp()
+        st = ref.state()
+        rec = qp[r]
+        np.testing.assert_allclose(rec[:N], q, rtol=1e-12, atol=1e-12 * np.abs(q).max())
+        np.testing.assert_array_equal(rec[N:N + M], l)
+        np.testing.assert_array_equal(rec[N + M:N + 2 * M], u)
+        np.testing.assert_array_equal(rec[N + 2 * M:N + 2 * M + 15].reshape(5, 3), cone)
+        o = N + 2 * M + 16
+        B6, th1, th2 = rec[o:o + 72].reshape(6, 12), rec[o + 72:o + 108].reshape(6, 6), rec[o + 108:o + 114]
+        Th = np.zeros((6 * h, 6 * h))
+        for i in range(h):
+            for j in range(h):
+                mm, dd = h - max(i, j), abs(i - j)
+                Th[6 * i:6 * i + 6, 6 * j:6 * j + 6] = (mm * (4 * mm * mm - 1) / 12.0 + dd * mm * mm / 2.0) * th1 + mm * np.diag(th2)
+        BB = np.kron(np.eye(h), B6)
+        P2 = BB.T @ Th @ BB + float(g["alpha"]) * np.eye(N)
+        assert np.abs(P2 - P).max() <= 1e-13 * np.abs(P).max()
+        np.testing.assert_allclose(sc[r, :N], st["D"], rtol=1e-11)
+        np.testing.assert_allclose(sc[r, N:N + M], st["E"], rtol=1e-11)
+        assert abs(sc[r, -2] / st["c"] - 1) < 1e-11
