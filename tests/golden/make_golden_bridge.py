@@ -1,0 +1,102 @@
+"""Golden fixture for the batched caller glue: the reference's OWN `pre_physics_step` and `reset_idx`
+(RL_Environment/tasks/aliengo.py:227-263, :321-349), taken from the source file by AST and executed unmodified on a stand-in task
+object -- Isaac Gym is not installed, so `gym` / `gymtorch` / `torch_rand_float` are stubs, while `self.controllers` are real
+RobotRunnerMin objects (their `mpc_osqp` module served by the oracle), exactly what aliengo.py:213-216 builds.
+
+    python tests/golden/make_golden_bridge.py        (build container only: needs /root/reference)
+
+Recorded per tick: actions, dof_state, root_states, commands -> the torques the reference hands to the simulator; env ids 1 and 3
+go through reset_idx before tick 20.  tests/test_controller.py::test_env_bridge_matches_reference_glue replays it through
+rl_mpc_locomotion_amd.env_bridge.MpcEnvBridge on the GPU."""
+import ast
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+import rl_mpc_locomotion_amd  # noqa: E402,F401
+from oracle.refmpc import RefConvexMpc  # noqa: E402
+
+m = types.ModuleType("mpc_osqp")
+m.ConvexMpc = RefConvexMpc
+m.OSQP, m.QPOASES = 0, 1
+sys.modules["mpc_osqp"] = m
+from MPC_Controller.Parameters import Parameters  # noqa: E402
+from MPC_Controller.utils import DTYPE, GaitType  # noqa: E402
+Parameters.bridge_MPC_to_RL = True
+from MPC_Controller.robot_runner.RobotRunnerMin import RobotRunnerMin  # noqa: E402
+from MPC_Controller.common.Quadruped import RobotType  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from make_golden_controller import inputs_for  # noqa: E402  (the same smooth seeded signals)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = "/root/reference/RL_Environment/tasks/aliengo.py"
+
+
+def reference_methods():
+    """`pre_physics_step` and `reset_idx` of class Aliengo, compiled from the reference's source text (the module itself cannot be
+    imported without Isaac Gym)."""
+    tree = ast.parse(open(SRC).read())
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "Aliengo"][0]
+    fns = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in ("pre_physics_step", "reset_idx")]
+    mod = ast.Module(body=fns, type_ignores=[])
+    gymtorch = types.SimpleNamespace(unwrap_tensor=lambda t: t)
+    ns = dict(np=np, torch=torch, Parameters=Parameters, DTYPE=DTYPE, gymtorch=gymtorch,
+              torch_rand_float=lambda lo, hi, shape, device=None: lo + (hi - lo) * torch.rand(*shape, generator=torch.Generator().manual_seed(0)))
+    exec(compile(mod, SRC, "exec"), ns)
+    return ns["pre_physics_step"], ns["reset_idx"]
+
+
+class StubGym:
+    def set_dof_actuation_force_tensor(self, sim, t): pass
+    def set_actor_root_state_tensor_indexed(self, *a): pass
+    def set_dof_state_tensor_indexed(self, *a): pass
+
+
+def main(n=4, ticks=40, reset_at=20, reset_ids=(1, 3), seed=11):
+    pre_physics_step, reset_idx = reference_methods()
+    rng = np.random.default_rng(seed)
+    Parameters.flat_ground = False
+    Parameters.cmpc_gait = GaitType.TROT
+    task = types.SimpleNamespace()
+    task.device, task.num_envs, task.num_dof = "cpu", n, 12
+    task.gym, task.sim = StubGym(), None
+    task.controllers = []
+    for _ in range(n):                       # aliengo.py:213-216
+        r = RobotRunnerMin()
+        r.init(RobotType.ALIENGO)
+        task.controllers.append(r)
+    task.default_dof_pos = torch.zeros((n, 12)); task.dof_pos = torch.zeros((n, 12)); task.dof_vel = torch.zeros((n, 12))
+    task.initial_root_states = torch.zeros((n, 13)); task.commands_x = torch.zeros(n); task.commands_y = torch.zeros(n); task.commands_yaw = torch.zeros(n)
+    task.command_x_range = task.command_y_range = task.command_yaw_range = (-1.0, 1.0)
+    task.progress_buf = torch.zeros(n, dtype=torch.long); task.reset_buf = torch.zeros(n, dtype=torch.long)
+    st = [dict(phase=rng.uniform(0, 2 * np.pi, 21), amp=rng.uniform(0.02, 0.15, 21), yaw0=rng.uniform(-3, 3), H=float(rng.uniform(0.28, 0.36)),
+               v0=rng.uniform(-0.5, 0.5, 3) * np.array([1, 0.4, 0.1]), cmd=np.zeros(3), w=np.zeros(12)) for _ in range(n)]
+    out = dict(actions=np.zeros((ticks, n, 12), np.float32), dof_state=np.zeros((ticks, n * 12, 2), np.float32), root_states=np.zeros((ticks, n, 13), np.float32),
+               commands=np.zeros((ticks, n, 3), np.float32), torques=np.zeros((ticks, n, 12), np.float32), reset_at=reset_at, reset_ids=np.array(reset_ids))
+    for k in range(ticks):
+        if k == reset_at:
+            task.dof_state = torch.zeros((n * 12, 2))
+            reset_idx(task, torch.tensor(reset_ids, dtype=torch.long))        # aliengo.py:321-349, unmodified
+        dofs, roots = [], []
+        for r in range(n):
+            dof, body, _ = inputs_for(r, k, st[r])
+            dofs.append(dof); roots.append(body)
+        actions = torch.from_numpy(rng.uniform(-1, 1, (n, 12)).astype(np.float32))
+        task.dof_state = torch.from_numpy(np.concatenate(dofs, 0))             # (num_envs * num_dofs, 2)
+        task.root_states = torch.from_numpy(np.stack(roots))
+        task.commands = torch.from_numpy(rng.uniform(-1, 1, (n, 3)).astype(np.float32) * np.array([1.5, 0.5, 1.0], np.float32))
+        pre_physics_step(task, actions)                                         # aliengo.py:227-263, unmodified
+        out["actions"][k], out["dof_state"][k], out["root_states"][k] = actions.numpy(), task.dof_state.numpy(), task.root_states.numpy()
+        out["commands"][k], out["torques"][k] = task.commands.numpy(), task.torques.numpy()
+    np.savez_compressed(os.path.join(HERE, "bridge_h10_aliengo.npz"), **out)
+    print("bridge_h10_aliengo written: max |tau|", float(np.abs(out["torques"]).max()))
+
+
+if __name__ == "__main__":
+    main()

@@ -160,6 +160,27 @@ def test_hip_controller_reset_and_gait_switch():
 
 
 @pytest.mark.gpu
+def test_env_bridge_matches_reference_glue():
+    """MpcEnvBridge against the reference's own pre_physics_step / reset_idx (RL_Environment/tasks/aliengo.py:227-263, :321-349),
+    executed unmodified by tests/golden/make_golden_bridge.py: rescaled actions, command record, controller.run for every env,
+    device env_ids in reset_idx."""
+    import torch
+    import rl_mpc_locomotion_amd  # noqa: F401
+    from rl_mpc_locomotion_amd.env_bridge import MpcEnvBridge
+    g = load_golden("bridge_h10_aliengo")
+    T, n = g["actions"].shape[:2]
+    br = MpcEnvBridge(np.zeros(n, np.int32), np.zeros(n, np.int32), horizon=10, flat_ground=False)        # four Aliengo, trot
+    worst = 0.0
+    for k in range(T):
+        if k == int(g["reset_at"]):
+            br.reset_idx(torch.tensor(g["reset_ids"], dtype=torch.long, device="cuda"))                 # env_ids stay on the device
+        tau = br.pre_physics_step(torch.from_numpy(g["actions"][k]).cuda(), torch.from_numpy(g["dof_state"][k]).cuda(),
+                                  torch.from_numpy(g["root_states"][k]).cuda(), torch.from_numpy(g["commands"][k]).cuda())
+        worst = max(worst, float(_relerr(tau.cpu().numpy(), g["torque" if "torque" in g else "torques"][k]).max()))
+    assert worst < TAU_RTOL, worst
+
+
+@pytest.mark.gpu
 def test_env_bridge_equals_manual_composition():
     """MpcEnvBridge.pre_physics_step = rescale + command record + controller.run (aliengo.py:237-258), reset_idx = per-robot reset."""
     import torch
