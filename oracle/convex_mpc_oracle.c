@@ -195,6 +195,69 @@ int mpcref_solve_exact(void *hd, const double *in, double *forces_out, int64_t *
   return st;
 }
 
+/*
+ * Experiment: the same QP with its swing-leg variables ELIMINATED -- the rows / columns whose bounds are
+ * l = u = 0, exactly the reduction of the reference's qpOASES branch (mpc_osqp.cc:838-856) -- solved by the vendored OSQP with the
+ * reference's OSQP settings from a cold start.  Answers "does OSQP on the reduced problem return the forces OSQP returns on the
+ * full one?" (tools/swing_elimination.py).  forces_out: the full vector (zeros at swing legs), negated.  Returns the status.
+ */
+int mpcref_solve_reduced(void *hd, const double *in, double *forces_out, int64_t *info) {
+  MpcRef *s = (MpcRef *)hd;
+  const int n = s->n, m = s->m, h = s->mdl.h;
+  mpc_assemble(&s->mdl, in, &s->wk, s->P, s->q, s->cone, s->l, s->u);
+  int *vmap = (int *)malloc(sizeof(int) * n), nr = 0, mr = 0;
+  int *feet = (int *)malloc(sizeof(int) * 4 * h), nfeet = 0;
+  for (int f = 0; f < 4 * h; ++f) {
+    int swing = 1;
+    for (int r = 0; r < 5; ++r) if (s->l[5 * f + r] != 0.0 || s->u[5 * f + r] != 0.0) swing = 0;
+    if (!swing) { feet[nfeet++] = f; for (int c = 0; c < 3; ++c) vmap[nr++] = 3 * f + c; }
+  }
+  mr = 5 * nfeet;
+  for (int i = 0; i < n; ++i) forces_out[i] = 0.0;
+  if (nr == 0) { if (info) { info[0] = 0; info[1] = OSQP_SOLVED; info[2] = 0; info[3] = 0; } free(vmap); free(feet); return OSQP_SOLVED; }
+  c_int *Pp = (c_int *)malloc(sizeof(c_int) * (nr + 1)), *Pi = (c_int *)malloc(sizeof(c_int) * (size_t)nr * (nr + 1) / 2);
+  c_float *Px = (c_float *)malloc(sizeof(c_float) * (size_t)nr * (nr + 1) / 2);
+  c_int *Ap = (c_int *)malloc(sizeof(c_int) * (nr + 1)), *Ai = (c_int *)malloc(sizeof(c_int) * 15 * nfeet);
+  c_float *Ax = (c_float *)malloc(sizeof(c_float) * 15 * nfeet);
+  c_float *q = (c_float *)malloc(sizeof(c_float) * nr), *l = (c_float *)malloc(sizeof(c_float) * mr), *u = (c_float *)malloc(sizeof(c_float) * mr);
+  c_int k = 0;
+  for (int c = 0; c < nr; ++c) {
+    Pp[c] = k;
+    for (int r = 0; r <= c; ++r) { double v = s->P[(size_t)vmap[r] * n + vmap[c]]; if (v != 0.0) { Pi[k] = r; Px[k] = v; ++k; } }
+    q[c] = s->q[vmap[c]];
+  }
+  Pp[nr] = k;
+  const c_int nnzP = k;
+  k = 0;
+  for (int c = 0; c < nr; ++c) {
+    Ap[c] = k;
+    const int foot = c / 3, cc = c % 3;
+    for (int r = 0; r < 5; ++r) { double v = s->cone[r * 3 + cc]; if (v != 0.0) { Ai[k] = foot * 5 + r; Ax[k] = v; ++k; } }
+  }
+  Ap[nr] = k;
+  for (int f = 0; f < nfeet; ++f) for (int r = 0; r < 5; ++r) { l[5 * f + r] = s->l[5 * feet[f] + r]; u[5 * f + r] = s->u[5 * feet[f] + r]; }
+  OSQPSettings settings;
+  osqp_set_default_settings(&settings);
+  settings.verbose = 0; settings.warm_start = 1; settings.polish = 1; settings.adaptive_rho_interval = 25;
+  settings.eps_abs = 1e-3; settings.eps_rel = 1e-3;
+  csc Pm = {nnzP, nr, nr, Pp, Pi, Px, -1};
+  csc Am = {k, mr, nr, Ap, Ai, Ax, -1};
+  OSQPData data;
+  data.n = nr; data.m = mr; data.P = &Pm; data.A = &Am; data.q = q; data.l = l; data.u = u;
+  OSQPWorkspace *w = 0;
+  int st = -100;
+  if (osqp_setup(&w, &data, &settings) == 0) {
+    osqp_solve(w);
+    st = (int)w->info->status_val;
+    if (info) { info[0] = w->info->iter; info[1] = st; info[2] = w->info->status_polish; info[3] = w->info->rho_updates; }
+    if (st == OSQP_SOLVED) for (int c = 0; c < nr; ++c) forces_out[vmap[c]] = -w->solution->x[c];
+    osqp_cleanup(w);
+  }
+  free(vmap); free(feet); free(Pp); free(Pi); free(Px); free(Ap); free(Ai); free(Ax); free(q); free(l); free(u);
+  (void)m;
+  return st;
+}
+
 /* Test access: the assembled QP of the last call (dense P, q, l, u, the 5x3 cone block). */
 void mpcref_get_qp(void *hd, double *P, double *q, double *l, double *u, double *cone) {
   MpcRef *s = (MpcRef *)hd;

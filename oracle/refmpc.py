@@ -36,6 +36,8 @@ def lib():
         _LIB.mpcref_solve.restype = C.c_int
         _LIB.mpcref_solve.argtypes = [C.c_void_p] * 5
         _LIB.mpcref_get_qp.argtypes = [C.c_void_p] * 6
+        _LIB.mpcref_solve_reduced.restype = C.c_int
+        _LIB.mpcref_solve_reduced.argtypes = [C.c_void_p] * 4
         _LIB.mpcref_solve_exact.restype = C.c_int
         _LIB.mpcref_solve_exact.argtypes = [C.c_void_p] * 4
         _LIB.mpcref_get_state.argtypes = [C.c_void_p] * 7
@@ -86,6 +88,14 @@ class RefConvexMpc:
         out = np.zeros(self.n, dtype=np.float64)
         self.exact_info = np.zeros(4, dtype=np.int64)
         self.exact_status = lib().mpcref_solve_exact(self._h, _p(rec), _p(out), _p(self.exact_info))
+        return out
+
+    def solve_reduced(self, rec):
+        """Experiment: OSQP (reference settings, cold) on the QP with the swing-leg variables eliminated (tools/swing_elimination.py)."""
+        rec = np.ascontiguousarray(rec, dtype=np.float64)
+        out = np.zeros(self.n, dtype=np.float64)
+        self.reduced_info = np.zeros(4, dtype=np.int64)
+        self.reduced_status = lib().mpcref_solve_reduced(self._h, _p(rec), _p(out), _p(self.reduced_info))
         return out
 
     def reset_solver(self):
