@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 
+#define MPC_LOCKSTEP 1   // a single-wavefront workgroup executes its LDS instructions in program order (mpc_wrench.h: Shared::NBUF)
 #include "../../include/mpc_batch.h"
 #include "controller.h"
 #include "mpc_core.h"

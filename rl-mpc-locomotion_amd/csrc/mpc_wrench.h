@@ -64,6 +64,15 @@ struct WThread {
   }
 };
 
+#ifndef MPC_PAIR_SWEEP          // which workgroup sizes sweep two pivots per phase (see sweep_all)
+#define MPC_PAIR_SWEEP(T) ((T) <= 64)
+#endif
+#ifndef MPC_LOCKSTEP
+#define MPC_LOCKSTEP 0
+#endif
+#ifndef MPC_ADMM_BATCH_LOADS   // which workgroup sizes request every LDS constant of the foot phase in one batch up front (~90 more registers)
+#define MPC_ADMM_BATCH_LOADS(T) ((T) <= 64)
+#endif
 #define MPC_V alignas(16) double
 template <int H>
 struct Shared {
@@ -80,9 +89,14 @@ struct Shared {
   MPC_V fa[C::NF * 16];                                 // 0-8: the non-zeros of the scaled cone block, 9: l of row 4, 10-14: u of the five rows
   MPC_V fr[C::NF * 10];                                 // 0-8: the cone block times rho of its row (factorisation)
   MPC_V Gf[C::NF * 18];                                 // per foot: G_f = T_k W_f (6 x 3) of the current factorisation
-  MPC_V prow_raw[2][C::NW + 2];
-  MPC_HD double *prow(int b) { return prow_raw[b] + MPC_PROW_SKEW; }
-  MPC_V piv[2][2];
+  // the published pivot rows are double buffered -- except where the workgroup is a single wavefront in lock step (MPC_LOCKSTEP:
+  // the device build at h = 10), whose LDS instructions execute in program order: every lane has read the pair before any lane
+  // publishes the next one
+  static constexpr int NBUF = (MPC_LOCKSTEP && C::TW <= 64) ? 1 : 2;
+  MPC_V prow_raw[NBUF][2][C::NW + 2];                   // [buffer][pivot of the pair][column]
+  MPC_HD double *prow(int b, int r) { return prow_raw[b & (NBUF - 1)][r] + MPC_PROW_SKEW; }
+  MPC_V piv_raw[NBUF][4];                               // [buffer]: the inverse of the pair's 2 x 2 pivot block (B00, B01, B11)
+  MPC_HD double *piv(int b) { return piv_raw[b & (NBUF - 1)]; }
   union {
     MPC_V part[PARTLEN];                                // [slot][row] partial products of the tile mat-vec; residual scratch [14][RW]
     struct { MPC_V Lk[H * 36]; MPC_V Tk[H * 36]; };     // factorisation only: per step Z_k = L L^T, T = L^-1 (zero columns / rows at dropped pivots)
@@ -612,35 +626,135 @@ struct Solver {
     factor_core([](Th &t) { return t.Si; });
   }
 
-  // Symmetric sweep of every pivot: after all pivots the matrix equals -inverse.  Per step k:  p = a_kk;
-  // a_ij -= a_ik a_kj / p (i,j != k);  a_ik -> a_ik / p;  a_kk -> -1/p.  The matrix stays symmetric, so both a_ik and a_kj are
-  // read from the published pivot row, and only the lower-triangle tiles are updated.  That row carries (p - 1) in slot k, which
-  // makes the generic update  a_ij -= (row_k[i] / p) * row_k[j]  produce a_ik / p on column k and a_kj / p on row k with no
-  // per-element select; the diagonal element of a swept row takes the generic update too and ends up as (true value + 2).
-  // The pivot loop is unrolled by TS = 6 so that the pivot's position inside its tile is static.
+  // Symmetric sweep of every pivot, two pivots at a time: after all pivots the matrix equals -inverse.  Per pair K = {k, k+1} with
+  // B = A_KK^-1:  A_ij -= A_iK B A_Kj (i, j outside K);  A_iK -> A_iK B;  A_KK -> -B.  The matrix stays symmetric, so both A_iK
+  // and A_Kj are read from the two published pivot rows, and only the lower-triangle tiles are updated.  The published rows carry
+  // A_KK - I in the slots of K, which makes the generic update  a_ij -= [u_i v_i] B [u_j v_j]^T  produce A_iK B on the pair's
+  // columns and B A_Kj on its rows with no per-element select ((A_KK - I) B = I - B); the diagonal elements of a swept pair take
+  // the generic update too and end up as (true value + 2), the off-diagonal one as -B01 exactly.
+  // One LDS round trip and one reciprocal (of the block's determinant) per pair: a wave that runs alone on its SIMD has nobody
+  // to hide that latency behind, and it was most of the 540 cycles per pivot of the one-pivot form.
+  // The loop over the pairs of a tile row is unrolled so that the pair's position inside its tile is static.
+  static constexpr bool kPairSweep = MPC_PAIR_SWEEP(T);
   MPC_HD void sweep_all() {
+    static_assert(TS % 2 == 0, "pairs must not straddle tiles");
+    if constexpr (!kPairSweep) { sweep_all_single(); return; }
     int buf = 0;
     ex.par([&](Th &t) { if (t.mact) publish<0>(t, 0, 0); });
-    for (int kt = 0; kt < G; ++kt) sweep_steps<0>(kt, buf);
+    for (int kt = 0; kt < G; ++kt) sweep_pairs<0>(kt, buf);
   }
   template <int A>
-  MPC_HD void sweep_steps(int kt, int &buf) {
+  MPC_HD void sweep_pairs(int kt, int &buf) {
     if constexpr (A < TS) {
-      sweep_step<A>(kt, buf);
+      sweep_pair<A>(kt, buf);
       buf ^= 1;
-      sweep_steps<A + 1>(kt, buf);
+      sweep_pairs<A + 2>(kt, buf);
     }
   }
   template <int A>
-  MPC_HD void sweep_step(int kt, int buf) {
+  MPC_HD void sweep_pair(int kt, int buf) {
+    constexpr int AN = (A + 2) % TS;                 // next pair's position inside its tile
+    const int ktn = (A + 2 < TS) ? kt : kt + 1;      // tile row (= column) of the next pair
+    const bool pub = ktn < G;
+    ex.par([&](Th &t) {
+      if (t.mact) {
+        double u[TS], v[TS], x[TS], y[TS];
+        const double *bi = s.piv(buf);
+        const double b00 = bi[0], b01 = bi[1], b11 = bi[2];
+        const double *r0 = s.prow(buf, 0), *r1 = s.prow(buf, 1);
+#pragma unroll
+        for (int a = 0; a < TS; ++a) {
+          u[a] = r0[TS * t.ti + a];
+          v[a] = r1[TS * t.ti + a];
+          const double uj = r0[TS * t.tj + a], vj = r1[TS * t.tj + a];
+          x[a] = b00 * uj + b01 * vj;
+          y[a] = b01 * uj + b11 * vj;
+        }
+        auto upd = [&](int a, int b) {   // two fused multiply-adds
+          double m = t.Mx[a * TS + b];
+          m -= u[a] * x[b];
+          m -= v[a] * y[b];
+          t.Mx[a * TS + b] = m;
+        };
+        // the cross through the next pair first: it is what the next phase waits for
+#pragma unroll
+        for (int a = AN; a < AN + 2; ++a)
+#pragma unroll
+          for (int b = 0; b < TS; ++b) upd(a, b);
+#pragma unroll
+        for (int a = 0; a < TS; ++a)
+#pragma unroll
+          for (int b = AN; b < AN + 2; ++b)
+            if (a != AN && a != AN + 1) upd(a, b);
+        if (pub) publish<AN>(t, buf ^ 1, ktn);
+        MPC_SCHED_FENCE();
+#pragma unroll
+        for (int a = 0; a < TS; ++a)
+#pragma unroll
+          for (int b = 0; b < TS; ++b)
+            if (a != AN && a != AN + 1 && b != AN && b != AN + 1) upd(a, b);
+      }
+    });
+  }
+  // Rows k = 6 kt + A and k + 1 of the matrix -> prow[b][0 / 1]: the tiles of tile row kt hold their part left of (and on) the
+  // diagonal as their rows A, A + 1, the tiles of tile column kt hold the rest as their columns A, A + 1.  The 2 x 2 pivot block
+  // goes out minus the identity, and piv[b] = its inverse.
+  template <int A>
+  MPC_HD void publish(const Th &t, int b, int kt) {
+    if (t.ti == kt) {
+      double *p0 = s.prow(b, 0) + TS * t.tj, *p1 = s.prow(b, 1) + TS * t.tj;
+      const double one = t.dia ? 1.0 : 0.0;
+#pragma unroll
+      for (int bb = 0; bb < TS; ++bb) {
+        p0[bb] = bb == A ? t.Mx[A * TS + bb] - one : t.Mx[A * TS + bb];
+        p1[bb] = bb == A + 1 ? t.Mx[(A + 1) * TS + bb] - one : t.Mx[(A + 1) * TS + bb];
+      }
+      if (t.dia) {
+        const double pp = t.Mx[A * TS + A], qq = t.Mx[(A + 1) * TS + A], ss = t.Mx[(A + 1) * TS + A + 1];
+        const double det = pp * ss - qq * qq, rd = fast_recip(det);
+        double *bo = s.piv(b);
+        bo[0] = ss * rd;
+        bo[1] = -(qq * rd);
+        bo[2] = pp * rd;
+        if (!(pp > 0) || !(det > 0)) s.bad = 1;      // not positive definite
+      }
+    } else if (t.tj == kt) {
+      double *p0 = s.prow(b, 0) + TS * t.ti, *p1 = s.prow(b, 1) + TS * t.ti;
+#pragma unroll
+      for (int a = 0; a < TS; ++a) {
+        MPC_LDS_STORE64(p0 + a, t.Mx[a * TS + A]);
+        MPC_LDS_STORE64(p1 + a, t.Mx[a * TS + A + 1]);
+      }
+    }
+  }
+
+  // ---- the one-pivot form of the same sweep (the multi-wave kernels of the long horizons: at their 256-register cap the pair form's
+  // two extra 6-vectors go to scratch inside the loop -- measured h = 16 2.35 -> 2.72 ms, h = 20 2.83 -> 3.11 ms per 4096 robots).
+  // Per step k:  p = a_kk;  a_ij -= a_ik a_kj / p;  a_ik -> a_ik / p;  a_kk -> -1/p (+2, as above).  The published row carries
+  // (p - 1) in slot k; piv = {p, 1 / p}.
+  MPC_HD void sweep_all_single() {
+    int buf = 0;
+    ex.par([&](Th &t) { if (t.mact) publish1<0>(t, 0, 0); });
+    for (int kt = 0; kt < G; ++kt) sweep_steps1<0>(kt, buf);
+  }
+  template <int A>
+  MPC_HD void sweep_steps1(int kt, int &buf) {
+    if constexpr (A < TS) {
+      sweep_step1<A>(kt, buf);
+      buf ^= 1;
+      sweep_steps1<A + 1>(kt, buf);
+    }
+  }
+  template <int A>
+  MPC_HD void sweep_step1(int kt, int buf) {
     constexpr int AN = (A + 1) % TS;                 // next pivot's position inside its tile
     const int ktn = (A + 1 < TS) ? kt : kt + 1;      // tile row (= column) of the next pivot
     const bool pub = ktn < G;
     ex.par([&](Th &t) {
       if (t.mact) {
         double g[TS], pc[TS];
-        const double p = s.piv[buf][0], pinv = s.piv[buf][1];
-        const double *pr = s.prow(buf);
+        const double p = s.piv(buf)[0], pinv = s.piv(buf)[1];
+        const double *pr = s.prow(buf, 0);
 #pragma unroll
         for (int a = 0; a < TS; ++a) { g[a] = pr[TS * t.ti + a] * pinv; pc[a] = pr[TS * t.tj + a]; }
 #pragma unroll
@@ -649,7 +763,7 @@ struct Solver {
         for (int a = 0; a < TS; ++a)
           if (a != AN) t.Mx[a * TS + AN] -= g[a] * pc[AN];
         if (t.tid == 0 && !(p > 0)) s.bad = 1;     // not positive definite
-        if (pub) publish<AN>(t, buf ^ 1, ktn);
+        if (pub) publish1<AN>(t, buf ^ 1, ktn);
         MPC_SCHED_FENCE();
 #pragma unroll
         for (int a = 0; a < TS; ++a)
@@ -663,20 +777,20 @@ struct Solver {
   // diagonal as their row A, the tiles of tile column kt hold the rest as their column A.  Slot k itself
   // gets (pivot - 1), and piv[b] = {pivot, 1 / pivot}.
   template <int A>
-  MPC_HD void publish(const Th &t, int b, int kt) {
+  MPC_HD void publish1(const Th &t, int b, int kt) {
     if (t.ti == kt) {
-      double *pn = s.prow(b) + TS * t.tj;
+      double *pn = s.prow(b, 0) + TS * t.tj;
 #pragma unroll
       for (int bb = 0; bb < TS; ++bb)
         if (bb != A) pn[bb] = t.Mx[A * TS + bb];
       const double pivot = t.Mx[A * TS + A];
       pn[A] = t.dia ? pivot - 1.0 : pivot;
       if (t.dia) {
-        s.piv[b][0] = pivot;
-        s.piv[b][1] = fast_recip(pivot);
+        s.piv(b)[0] = pivot;
+        s.piv(b)[1] = fast_recip(pivot);
       }
     } else if (t.tj == kt) {
-      double *pn = s.prow(b) + TS * t.ti;
+      double *pn = s.prow(b, 0) + TS * t.ti;
 #pragma unroll
       for (int a = 0; a < TS; ++a) MPC_LDS_STORE64(pn + a, t.Mx[a * TS + A]);
     }
@@ -712,19 +826,32 @@ struct Solver {
       }
     });
   }
+  static constexpr bool kBatchLoads = MPC_ADMM_BATCH_LOADS(T);
   MPC_HD void admm_iter() {
     tile_product<kHeld>();
     recv<kHeld>();
     ex.seq([&](Th &t) {
       if (t.tid < NF) {
-        double wy[3], tt[3], zt[5], dd[5], acc[3], a[9], lo[5], up[5];
-        get_g(t, wy);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) tt[c] = t.b[c] - wy[c];
-        sym3_mul(t.Si, tt, t.xt);
+        // every LDS constant of the phase is requested up front, as one batch behind a single wait (a wave that runs alone on its
+        // SIMD has nobody to hide five separate round trips behind; the registers are there: 512 per lane)
+        double gf[18], a[9], ar[9], lo[5], up[5];
+        load_g(t, gf);
         foot_a(t, a);
-        foot_bounds(t, lo, up);
+        if constexpr (kBatchLoads) {
+          foot_bounds(t, lo, up);
+          foot_ar(t, ar);
+        }
+        double tt[3], zt[5], dd[5], acc[3], v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          double wy = 0;
+#pragma unroll
+          for (int r = 0; r < 6; ++r) wy += gf[3 * r + c] * t.w6[r];
+          tt[c] = t.b[c] - wy;
+        }
+        sym3_mul(t.Si, tt, t.xt);
         a_mul(a, t.xt, zt);
+        if constexpr (!kBatchLoads) foot_bounds(t, lo, up);
 #pragma unroll
         for (int r = 0; r < 5; ++r) {
           const double zr = kAlphaRelax * zt[r] + (1.0 - kAlphaRelax) * t.z[r];
@@ -735,17 +862,17 @@ struct Solver {
           t.y[r] = yn;
           dd[r] = zn - yn;
         }
-        foot_ar(t, a);
-        at_mul(a, dd, acc);
+        if constexpr (!kBatchLoads) foot_ar(t, ar);
+        at_mul(ar, dd, acc);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const double xn = kAlphaRelax * t.xt[c] + (1.0 - kAlphaRelax) * t.x[c];
           t.x[c] = xn;
           t.b[c] = kSigma * xn - t.q[c] + acc[c];
         }
-        double v[3];
         sym3_mul(t.Si, t.b, v);
-        put_g(t, v);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) t.w6[r] = gf[3 * r] * v[0] + gf[3 * r + 1] * v[1] + gf[3 * r + 2] * v[2];
       }
     });
     send<kHeld>();

@@ -83,16 +83,24 @@ def loop_stats(txt, H):
         a["rcp"] = a.get("rcp", 0) + sum(1 for l in ins if l.startswith('\tv_rcp_f64'))
         a["dpp"] = a.get("dpp", 0) + sum(1 for l in ins if l.startswith('\tv_mov_b32_dpp'))
     for a in agg.values():
-        a["role"] = "sweep" if a.get("rcp", 0) == 6 and a["ins"] < 1000 else ("admm-iteration" if a["depth"] == 2 and a.get("dpp", 0) else
-                                                                               ("check-loop" if a["depth"] == 1 and a["ins"] > 2000 else ""))
+        # a sweep trip is six pivot steps with a reciprocal each (long horizons), or three pivot pairs with one reciprocal (of the
+        # pair's 2 x 2 determinant) each (h = 10)
+        if a.get("rcp", 0) in (3, 6) and a["ins"] < 1000:
+            a["role"] = "sweep"
+        elif a["depth"] == 2 and a.get("dpp", 0):
+            a["role"] = "admm-iteration"
+        elif a["depth"] == 1 and a["ins"] > 2000:
+            a["role"] = "check-loop"
+        else:
+            a["role"] = ""
     return agg
 
 
 def spill_cost(txt, H):
     """Estimated scratch instructions executed per wave and solve: static counts weighted by rough trip counts (a sweep loop
-    runs 2H trips, the Ruiz loop 10, the ADMM iteration ~50, the check loop ~2, anything else 4; straight-line code once)."""
+    runs H trips, the Ruiz loop 10, the ADMM iteration ~50, the check loop ~2, anything else 4; straight-line code once)."""
     loops = loop_stats(txt, H)
-    trips = {"sweep": 2 * H, "admm-iteration": 50, "check-loop": 2, "ruiz-pass": 10}
+    trips = {"sweep": H, "admm-iteration": 50, "check-loop": 2, "ruiz-pass": 10}
     total, detail = 0, {}
     for b in _blocks(txt, H):
         sc = sum(1 for l in _instructions(b) if l.startswith('\tscratch'))
