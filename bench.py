@@ -62,12 +62,13 @@ def algorithmic_flops(h, contact, iters, nfact):
 
 def executed_flops(h, iters, nfact):
     """fp64 operations the solve kernel executes per batch: the OSQP iteration on all 12 h variables, with the KKT
-    solve carried through the 6 h x 6 h wrench-space core.  Per robot: `nfact` factorisations (6 h pivots x MT tiles x (36 FMA + 6 mul)
+    solve carried through the 6 h x 6 h wrench-space core.  Per robot: `nfact` factorisations (6 h pivots x MT tiles x (36 FMA + 6 mul), or at h = 10, where two pivots are swept per phase,
+    3 h pairs x MT tiles x (84 FMA + 12 mul);
     + the tile build 2 x 216 FMA + 72 mul per tile + ~900 flops per foot), `iters` ADMM iterations (tile mat-vec 2 x 36 FMA per tile
     + ~230 flops per foot), and ~4 products with Theta per termination check / polish.  (The prep kernel's work -- ten Ruiz passes
     over the dense P, 4 ops per entry -- is not counted here.)"""
     nw, nf, mt = 6 * h, 4 * h, h * (h + 1) // 2
-    sweep = nw * mt * 78.0
+    sweep = nw * mt * (90.0 if h == 10 else 78.0)
     build = mt * (2 * 432.0 + 72.0) + nf * 900.0
     it = mt * 144.0 + nf * 230.0
     return float((nfact * (sweep + build) + iters * it + (iters / 25.0 + 3.0) * mt * 290.0).sum())

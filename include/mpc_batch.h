@@ -33,7 +33,12 @@
  * (mpc_osqp.cc:781-794).  Here the robot's force row is left untouched and info[1] (status) != 1.
  *
  * info record (int32, 8 per robot): {iterations, osqp status_val, status_polish, rho_updates,
- * factorisations, first_run, 0, 0}.
+ * factorisations, first_run, 0, 0}.  status_val takes OSQP's values for SOLVED (1), MAX_ITER_REACHED (-2) and NON_CVX (-7;
+ * also NaN / inf input -- the robot's warm-start record is then cleared, its next call starts cold).  OSQP's primal / dual
+ * INFEASIBLE statuses (-3, -4, and their INACCURATE forms) are never reported: the infeasibility certificates of
+ * auxil.c:364-515 are not evaluated, because this QP is always feasible (f = 0 satisfies every swing row, the cone and
+ * box rows admit f_z in [f_min, f_max]) and strictly convex (alpha > 0); a caller-made infeasible problem (e.g. l > u from a
+ * negative friction coefficient) ends as MAX_ITER_REACHED instead, which the reference treats the same way: empty result.
  *
  * All pointers named d_* are DEVICE pointers (HBM); `stream` is a hipStream_t (0 = default stream).
  * Functions return 0 on success, a negative MPC_E_* code otherwise; mpc_last_error() gives the text.
