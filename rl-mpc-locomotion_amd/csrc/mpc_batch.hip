@@ -55,6 +55,10 @@ __device__ __forceinline__ double quad_perm(double v) {
   return __hiloint2double(hi, lo);
 }
 constexpr int quad_ctrl(int a, int b, int c, int d) { return a | (b << 2) | (c << 4) | (d << 6); }
+__device__ __forceinline__ double read_lane(double v, int lane) {   // a lane's value as a wavefront-uniform scalar
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
 
 // WAVE: the workgroup is a single wavefront (the h = 10 solve kernel).  Its LDS instructions execute in program order, so a
 // phase boundary needs neither s_barrier nor a wait for the stores to land (the loads of the next phase queue up behind them):
@@ -82,6 +86,19 @@ struct DeviceExec {
       const double a = v[i] + quad_perm<quad_ctrl(1, 0, 3, 2)>(v[i]);
       v[i] = a + quad_perm<quad_ctrl(2, 3, 0, 1)>(a);
     }
+  }
+  // acc(th)[0] <- the sum, acc(th)[1] <- the maximum (of non-negative values) over the 64 lanes of the wavefront, the same bits in
+  // every lane: four DPP steps leave every lane with its row's (16 lanes) result, v_readlane fetches the four rows
+  template <class A>
+  __device__ __forceinline__ void wave_sum_max(A &&acc) {
+    double *v = acc(th);
+    double a = v[0], m = v[1];
+    a += quad_perm<quad_ctrl(1, 0, 3, 2)>(a);  m = fmax(m, quad_perm<quad_ctrl(1, 0, 3, 2)>(m));
+    a += quad_perm<quad_ctrl(2, 3, 0, 1)>(a);  m = fmax(m, quad_perm<quad_ctrl(2, 3, 0, 1)>(m));
+    a += quad_perm<0x141>(a);                  m = fmax(m, quad_perm<0x141>(m));     // row_half_mirror
+    a += quad_perm<0x140>(a);                  m = fmax(m, quad_perm<0x140>(m));     // row_mirror
+    v[0] = (read_lane(a, 0) + read_lane(a, 16)) + (read_lane(a, 32) + read_lane(a, 48));
+    v[1] = fmax(fmax(read_lane(m, 0), read_lane(m, 16)), fmax(read_lane(m, 32), read_lane(m, 48)));
   }
   // dst(th)[r] <- src(lane r & 3 of the quad)[r >> 2], r = 0 .. 5
   template <class S, class D>
@@ -190,7 +207,7 @@ __global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= MPC_MIN_WAVES_MAX_T && Cfg
   double *qpr = qp + (size_t)robot * C::QP_LEN;
   Assembler<H, Ex> am{ex, sh.as, mdl, in ? in + (size_t)robot * C::IN_LEN : nullptr, in64 ? in64 + (size_t)robot * C::IN_LEN : nullptr, sh.u12, qpr, prof ? prof + (size_t)robot * kProfLen : nullptr};
   am.run();
-  Scaler<H, Ex> sk{ex, sh.sc, state + (size_t)robot * state_len<H>(), sh.u12, mdl.alpha, qpr, sc + (size_t)robot * C::SC_LEN};
+  Scaler<H, Ex> sk{ex, sh.sc, state + (size_t)robot * state_len<H>(), sh.u12, mdl.alpha, qpr, sc + (size_t)robot * C::SC_LEN, prof ? prof + (size_t)robot * kProfLen : nullptr};
   sk.run();
 }
 

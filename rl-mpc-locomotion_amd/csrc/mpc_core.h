@@ -194,7 +194,7 @@ struct ScaleShared {
   int first;
   MPC_V xt[C::N];                                       // q of the previous call (osqp_update_P_A scales with it)
   MPC_V cone[16];
-  MPC_V dt_[C::N]; MPC_V et_[C::M]; MPC_V cn_[C::N];    // Ruiz pass temporaries
+  MPC_V dt_[C::N]; MPC_V et_[C::M];                     // Ruiz pass temporaries
   MPC_V part[C::NP * C::G];                             // [slot][row] partial maxima of the tile row norms
 };
 // LDS of the assembly kernel (one workgroup per robot, its own launch: see Assembler)
@@ -224,7 +224,10 @@ struct Thread {
   int tid;                        // thread id
   int ti[C::NT], tj[C::NT];       // my tiles: tile row / tile column (tj <= ti); tile u has index tid + u * MTH
   bool mact[C::NT], dia[C::NT];   // tile u exists; it sits on the diagonal
-  double Mx[C::NT * C::TE];       // my tiles of the current symmetric n x n matrix (P_s, K, -Kinv, H, -Hinv), row-major 6 x 6 each
+  double Mx[C::NT * C::TE];       // my tiles of the dense P, row-major 6 x 6 each
+  static constexpr int VPL = (C::N + 63) / 64;   // variables per lane of the first wavefront (Scaler::fold_phase): j = tid + 64 v
+  double rm[VPL];                 // their column maxima
+  double red[2];                  // wavefront reduction operands: a sum and a maximum
   MPC_HD void init(int id) {
     tid = id;
     for (int u = 0; u < C::NT; ++u) {
@@ -599,6 +602,9 @@ struct Scaler {
   double alpha;
   const double *qp;    // [QP_LEN]  q, l, u, cone from the assembly kernel
   double *sc;          // [SC_LEN]  out: D, E, q_s, A_s, l_s, u_s, c, 1/c
+  long long *prof = nullptr;   // [kProfLen] slots 3 (tile build + first norms), 4 (the ten passes), 5 (record store) under MPC_SECTION_PROFILE
+  long long tc[6] = {0, 0, 0, 0, 0, 0};
+  long long tlast = 0;
   using Tv = TileView;
   template <class F>
   MPC_HD void for_tiles(Th &t, F &&f) {
@@ -633,7 +639,11 @@ struct Scaler {
     if constexpr (C::kQInLds) return s.q[i];
     else return qp[C::QP_Q + i];
   }
+#ifndef MPC_SECTION_PROFILE
   MPC_HD void lap(int) {}
+#else
+  MPC_HD void lap(int k) { const long long now = MPC_CLOCK(); tc[k] += now - tlast; tlast = now; }
+#endif
   template <bool MAX>
   static MPC_HD double fold_parts(const Sh &s, int row) {   // fixed pairwise order (short dependency chains)
     double v[G];
@@ -725,30 +735,65 @@ struct Scaler {
   // needs the row norms of c D P D, which are c D_i max_j(|P_ij| D_j) with the cumulative D and c (tile_rownorms); D, c, q, A, E are updated incrementally as in
   // scaling.c, and c D P D is formed once after the last pass.  The cost scale c_temp of pass k is folded in
   // lazily at pass k + 1.
-  template <bool MAX>
-  MPC_HD double fold_half(const double *p) const {   // tree-reduce NF / 2 values whose loads are issued as one batch
-    constexpr int L = NF / 2;
-    double v[L];
+  // The reduction half of a Ruiz pass, on the first wavefront alone (lane l owns the variables l, l + 64, ...): the column maxima
+  // of D P D are folded from the tiles' partials once and serve both uses --
+  //   COST: the pass's cost scaling (scaling.c:108-139): c_temp = 1 / max(mean_j |c D P D column j|_inf, |q|_inf), a sum and a
+  //         maximum over all variables, reduced inside the wavefront (DPP row operations + four readlanes: no LDS, no barrier);
+  //   DUPD: the next pass's column scales from |column|_inf of [c c_temp D P D ; A] (scaling.c:65-84), D <- D_temp D;
+  //         without DUPD (after the last pass) q and c take the pending cost scale here.
+  // One barrier phase; the other wavefronts wait.  (It replaces two phases in which every thread of the first two wavefronts
+  // re-folded 80 per-foot partials for the same scalar.)
+  template <bool COST, bool DUPD>
+  MPC_HD void fold_phase() {
+    ex.seq([&](Th &t) {
+      if (t.tid < 64) {
+        double sum = 0, qm = 0;
 #pragma unroll
-    for (int f = 0; f < L; ++f) v[f] = p[f];
-    MPC_SCHED_FENCE();
+        for (int v = 0; v < Th::VPL; ++v) {
+          const int j = t.tid + 64 * v;
+          if (j < N) {
+            const double m = max_parts(s, j);
+            t.rm[v] = m;
+            if constexpr (COST) { sum += m; qm = raw_max(qm, fabs(s.qs[j])); }
+          }
+        }
+        t.red[0] = sum; t.red[1] = qm;
+      }
+    });
+    if constexpr (COST) ex.wave_sum_max([](Th &t) { return t.red; });
+    ex.par([&](Th &t) {
+      if (t.tid < 64) {
+        double ct = 1.0;
+        if constexpr (COST) {
+          const double mean = (s.c * t.red[0]) * (1.0 / N);
+          ct = fast_recip(limit_scaling(fmax(mean, limit_scaling(t.red[1]))));
+        }
 #pragma unroll
-    for (int w = 1; w < L; w *= 2)
+        for (int v = 0; v < Th::VPL; ++v) {
+          const int j = t.tid + 64 * v;
+          if (j < N) {
+            if constexpr (DUPD) {
+              const int f = j / 3, c = j - 3 * f;
+              double mx = (s.c * ct) * t.rm[v];
 #pragma unroll
-      for (int k = 0; k + w < L; k += 2 * w) v[k] = MAX ? raw_max(v[k], v[k + w]) : v[k] + v[k + w];
-    MPC_SCHED_FENCE();
-    return v[0];
-  }
-  MPC_HD double pending_cost_scale() const {   // scaling.c:108-139, from the per-foot partials in cn_
-    const double mean = (fold_half<false>(s.cn_) + fold_half<false>(s.cn_ + NF / 2)) * (1.0 / N);
-    const double nq = limit_scaling(fmax(fold_half<true>(s.cn_ + NF), fold_half<true>(s.cn_ + NF + NF / 2)));
-    return fast_recip(limit_scaling(fmax(mean, nq)));
+              for (int r = 0; r < 5; ++r) mx = fmax(mx, fabs(s.As[15 * f + 3 * r + c]));
+              const double d = fast_rsqrt(limit_scaling(mx));
+              s.dt_[j] = d;
+              s.D[j] *= d;
+            } else {
+              s.qs[j] *= ct;
+            }
+          }
+        }
+        if (t.tid == 0) s.ctmp = DUPD ? ct : s.c * ct;   // the pending cost scale; after the last pass the final c
+      }
+    });
   }
   static MPC_HD double row_scale3(double a0, double a1, double a2) {   // 1 / sqrt(|row|_inf) of a 3-entry row of A
     return fast_rsqrt(limit_scaling(fmax(fmax(fabs(a0), fabs(a1)), fabs(a2))));
   }
   MPC_HD void scale() {
-    lap(2);
+    tlast = MPC_CLOCK();
     ex.par([&](Th &t) {
       for_tiles(t, [&](Tv &v, int) { build_tile(v); tile_rownorms(v, nullptr); });
       if (t.tid < N) {
@@ -765,25 +810,9 @@ struct Scaler {
     });
     lap(3);
     pin_tiles(5);
+    fold_phase<false, true>();
     for (int it = 0; it < kScalingIters; ++it) {
       pin_tiles(7);
-      ex.par([&](Th &t) {   // column scales from |column|_inf of [c P ; A]; D <- D_temp D
-        if (t.tid < N) {
-          const int j = t.tid, f = j / 3, c = j - 3 * f;
-          const double ct = it > 0 ? pending_cost_scale() : 1.0;
-          double av[5];
-#pragma unroll
-          for (int r = 0; r < 5; ++r) av[r] = s.As[15 * f + 3 * r + c];
-          double mx = (s.c * ct) * max_parts(s, j);
-#pragma unroll
-          for (int r = 0; r < 5; ++r) mx = fmax(mx, fabs(av[r]));
-          const double d = fast_rsqrt(limit_scaling(mx));
-          s.dt_[j] = d;
-          s.D[j] *= d;
-          if (j == 0) s.ctmp = ct;
-        }
-      });
-      MPC_SUBLAP(2, 9);
       ex.par([&](Th &t) {   // A <- E A D, q <- D (c_temp q), c <- c_temp c; new row norms of D P D and A
         const double ct = s.ctmp;
         for_tiles(t, [&](Tv &v, int) { tile_rownorms(v, s.D); });
@@ -800,22 +829,10 @@ struct Scaler {
         if (t.tid < N) s.qs[t.tid] = (s.qs[t.tid] * ct) * s.dt_[t.tid];
         if (t.tid == T - 1) s.c *= ct;
       });
-      MPC_SUBLAP(2, 10);
-      ex.par([&](Th &t) {   // cost scaling (scaling.c:108-139): per-foot partial sums of the column norms, |q|_inf
-        if (t.tid < NF) {
-          const int f = t.tid;
-          const double q0 = s.qs[3 * f], q1 = s.qs[3 * f + 1], q2 = s.qs[3 * f + 2];
-          s.cn_[f] = s.c * ((max_parts(s, 3 * f) + max_parts(s, 3 * f + 1)) + max_parts(s, 3 * f + 2));
-          s.cn_[NF + f] = dmax(dmax(fabs(q0), fabs(q1)), fabs(q2));
-        }
-      });
-      MPC_SUBLAP(2, 11);
+      if (it + 1 < kScalingIters) fold_phase<true, true>();
+      else fold_phase<true, false>();
     }
-    ex.par([&](Th &t) {   // the last pass's cost scale (c D P D itself is never formed: the solve kernel works from D, c and the wrench form of P)
-      const double ct = pending_cost_scale(), cf = s.c * ct;
-      if (t.tid < N) s.qs[t.tid] *= ct;
-      if (t.tid == T - 1) s.ctmp = cf;   // (s.c is still being read in this phase)
-    });
+    lap(4);
     pin_tiles(6);
     ex.par([&](Th &t) {   // the scale record
       const double cf = s.ctmp;
@@ -832,6 +849,10 @@ struct Scaler {
       });
       for (int k = t.tid; k < NF * 15; k += T) sc[C::SC_AS + k] = s.As[k];
     });
+    lap(5);
+    if (prof) {
+      ex.par([&](Th &t) { if (t.tid == 0) { prof[3] = tc[3]; prof[4] = tc[4]; prof[5] = tc[5]; } });
+    }
   }
 
   // the QP record of the assembly kernel + what the warm-start record says about the previous call

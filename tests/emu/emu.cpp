@@ -41,6 +41,27 @@ struct HostExec {
         for (int j = 0; j < 4; ++j) acc(th[q + j])[i] = v;
       }
   }
+  // the device's wavefront reduction (same association order: quad, half row, row, then the four rows)
+  template <class A> void wave_sum_max(A &&acc) {
+    for (int w = 0; w + 63 < NTHREADS; w += 64) {
+      double rs[4], rmx[4];
+      for (int r = 0; r < 4; ++r) {
+        double hs[2], hm[2];
+        for (int hh = 0; hh < 2; ++hh) {
+          double qs[2], qm[2];
+          for (int q = 0; q < 2; ++q) {
+            const int b = w + 16 * r + 8 * hh + 4 * q;
+            qs[q] = (acc(th[b])[0] + acc(th[b + 1])[0]) + (acc(th[b + 2])[0] + acc(th[b + 3])[0]);
+            qm[q] = std::fmax(std::fmax(acc(th[b])[1], acc(th[b + 1])[1]), std::fmax(acc(th[b + 2])[1], acc(th[b + 3])[1]));
+          }
+          hs[hh] = qs[0] + qs[1]; hm[hh] = std::fmax(qm[0], qm[1]);
+        }
+        rs[r] = hs[0] + hs[1]; rmx[r] = std::fmax(hm[0], hm[1]);
+      }
+      const double sum = (rs[0] + rs[1]) + (rs[2] + rs[3]), mx = std::fmax(std::fmax(rmx[0], rmx[1]), std::fmax(rmx[2], rmx[3]));
+      for (int i = 0; i < 64; ++i) { acc(th[w + i])[0] = sum; acc(th[w + i])[1] = mx; }
+    }
+  }
   template <class S, class D> void quad_gather6(S &&src, D &&dst) {
     for (int q = 0; q + 3 < NTHREADS; q += 4) {
       double v[6];
