@@ -318,7 +318,7 @@ struct Assembler {
   double *u12;         // [288] LDS  out: U1 = B6^T th1 B6, U2 = B6^T diag(th2) B6 (12 x 12 each): P = Sigma2 (x) U1 + N (x) U2 + alpha I
   double *qp;          // [QP_LEN]   out: q, l, u, cone
   long long *prof;     // [kProfLen] slots 1 (dynamics) and 2 (q + P) are written here (may be null)
-  long long tc[3] = {0, 0, 0};
+  long long tc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = 0;
 #ifndef MPC_SECTION_PROFILE   // per-section counters cost ~30 SGPRs (and push uniform values into VGPRs): opt-in, tools/section_profile.py
   MPC_HD void lap(int) {}
@@ -577,7 +577,12 @@ struct Assembler {
     });
     lap(2);
     if (prof) {
-      ex.par([&](Th &t) { if (t.tid == 0) { prof[1] = tc[1]; prof[2] = tc[2]; } });
+      ex.par([&](Th &t) {
+        if (t.tid == 0) {
+          prof[1] = tc[1]; prof[2] = tc[2];
+          if (MPC_PROFILE_SUB == 1 || MPC_PROFILE_SUB == 4) for (int k = 9; k <= 13; ++k) prof[k] = tc[k];
+        }
+      });
     }
   }
 };

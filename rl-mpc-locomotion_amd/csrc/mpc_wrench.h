@@ -1413,7 +1413,7 @@ struct Solver {
         state[2 * N + 2 * M + 1] = failed ? 0.0 : 1.0;
         info[0] = s.iter; info[1] = s.bad ? kStNonCvx : s.status; info[2] = s.status_polish; info[3] = s.rho_updates;
         info[4] = s.nfact; info[5] = s.first; info[6] = 0; info[7] = 0;
-        if (prof) for (int k = 0; k < kProfLen; ++k) if (k < 1 || k > 5) prof[k] = tc[k];   // (1 .. 5: the prep kernel's)
+        if (prof) for (int k = 0; k < kProfLen; ++k) if ((k < 1 || k > 5) && !(MPC_PROFILE_SUB && MPC_PROFILE_SUB <= 4 && k >= 9 && k <= 13)) prof[k] = tc[k];   // (1 .. 5, and 9 .. 13 of a prep sub-profile: the prep kernel's)
       }
     });
   }
