@@ -151,8 +151,12 @@ __global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES
 // Warm-started robots repeat their iteration counts from step to step, and solve times differ 3x between a 25-iteration
 // and a 75-iteration robot; dispatching the long ones first keeps the tail of the launch short (a counting sort over
 // cycles / 16384 in one workgroup; the order inside a bucket is arbitrary, results do not depend on it).
-constexpr int kOrderBuckets = 256;
-__device__ void order_block(int n, const long long *__restrict__ prof, int *__restrict__ order) {
+// The sort key is the LONGEST of the robot's last kOrderHistory solves (one byte each, cycles / 16384): the reference's gaits
+// have ten segments, so a robot's hard phases (touch-down, lift-off) recur every ten solves, and a solve that is queued as
+// short but runs long is what stretches the tail (tools/tail_model.py: ordering by the previous solve alone 0.717 ms per
+// launch on average, by this key 0.692, clairvoyant 0.650).
+constexpr int kOrderBuckets = 256, kOrderHistory = 10;
+__device__ void order_block(int n, const long long *__restrict__ prof, unsigned char *__restrict__ hist, int slot, int *__restrict__ order) {
   __shared__ int cnt[kOrderBuckets], base[kOrderBuckets];
   for (int b = threadIdx.x; b < kOrderBuckets; b += blockDim.x) cnt[b] = 0;
   __syncthreads();
@@ -165,7 +169,12 @@ __device__ void order_block(int n, const long long *__restrict__ prof, int *__re
       bk[i] = -1;
       if (r < n) {
         const long long c = prof[(size_t)r * kProfLen + kProfLen - 1] >> 14;
-        bk[i] = (int)(c < 0 ? 0 : (c >= kOrderBuckets ? kOrderBuckets - 1 : c));
+        unsigned char *hr = hist + (size_t)r * kOrderHistory;
+        hr[slot] = (unsigned char)(c < 0 ? 0 : (c >= kOrderBuckets ? kOrderBuckets - 1 : c));
+        int mx = 0;
+#pragma unroll
+        for (int k = 0; k < kOrderHistory; ++k) mx = max(mx, (int)hr[k]);
+        bk[i] = mx;
         rank[i] = atomicAdd(&cnt[bk[i]], 1);      // rank inside the bucket (within this pass)
       }
     }
@@ -187,11 +196,12 @@ __device__ void order_block(int n, const long long *__restrict__ prof, int *__re
 template <int H>
 __global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= MPC_MIN_WAVES_MAX_T && Cfg<H>::NT == 1 ? MPC_SCALE_MIN_WAVES : 1)) void mpc_prep_kernel(
     int n, const RobotModel *__restrict__ models, const float *__restrict__ in, const double *__restrict__ in64, const double *__restrict__ state,
-    double *__restrict__ qp, double *__restrict__ sc, long long *__restrict__ prof, const int *__restrict__ active, int *__restrict__ order) {
+    double *__restrict__ qp, double *__restrict__ sc, long long *__restrict__ prof, const int *__restrict__ active, int *__restrict__ order,
+    unsigned char *__restrict__ hist, int hist_slot) {
   __shared__ __attribute__((aligned(16))) PrepShared<H> sh;
   using C = Cfg<H>;
   if (blockIdx.x == 0) {      // the extra workgroup (first, so that it starts at once): dispatch order of the solve kernel that follows
-    if (order) order_block(n, prof, order);
+    if (order) order_block(n, prof, hist, hist_slot, order);
     return;
   }
   const int robot = (int)blockIdx.x - 1;
@@ -220,9 +230,9 @@ __global__ void reset_kernel(double *state, int state_len, const int *ids, int k
 
 template <int H>
 int launch(int n, const RobotModel *models, const float *in, const double *in64, double *state, double *qp, double *sc, double *forces, int *info,
-           long long *prof, const int *active, const int *order, hipEvent_t *ev, hipStream_t stream, int exact) {
+           long long *prof, const int *active, const int *order, unsigned char *hist, int hist_slot, hipEvent_t *ev, hipStream_t stream, int exact) {
   if (ev) (void)hipEventRecord(ev[0], stream);
-  hipLaunchKernelGGL(mpc_prep_kernel<H>, dim3(n + 1), dim3(Cfg<H>::T), 0, stream, n, models, in, in64, state, qp, sc, prof, active, const_cast<int *>(order));
+  hipLaunchKernelGGL(mpc_prep_kernel<H>, dim3(n + 1), dim3(Cfg<H>::T), 0, stream, n, models, in, in64, state, qp, sc, prof, active, const_cast<int *>(order), hist, hist_slot);
   if (ev) (void)hipEventRecord(ev[1], stream);
   hipLaunchKernelGGL(mpc_solve_kernel<H>, dim3(n), dim3(Cfg<H>::TW), 0, stream, n, models, state, qp, sc, forces, info, prof, active, order, exact);
   if (ev) (void)hipEventRecord(ev[2], stream);
@@ -250,6 +260,8 @@ struct mpc_batch {
   double *d_host_in64 = nullptr; // ... and mpc_batch_solve_host_f64
   double *d_host_f = nullptr;
   bool order_valid = false;
+  unsigned char *d_hist = nullptr;   // [n][kOrderHistory] cycles / 16384 of the last solves (order_block's sort key is their maximum)
+  unsigned long long order_launches = 0;
   int device = 0;                // the HIP device the handle was created on: every entry point makes it current
   int exact = 0;                 // mpc_batch_set_solver: 1 = the QP's exact optimum (the reference's qpOASES branch), cold on every call
   long long bytes = 0;
@@ -260,13 +272,14 @@ struct mpc_batch {
 static int launch_solver(mpc_batch *b, const float *d_in, double *d_forces, int *d_info, const int *d_active, hipStream_t st, const double *d_in64 = nullptr) {
   HIP_TRY(hipSetDevice(b->device));
   const int *order = b->order_valid ? b->d_order : nullptr;
+  const int slot = (int)(b->order_launches++ % kOrderHistory);
   if (b->exact) HIP_TRY(hipMemsetAsync(b->d_state, 0, sizeof(double) * (size_t)b->n * b->state_len, st));   // no warm start in that branch (mpc_osqp.cc:906-919)
   hipEvent_t *ev = b->timing ? b->ev[b->launches % kTimingRing] : nullptr;
   int rc = MPC_E_HORIZON;
   switch (b->h) {
-    case 10: rc = launch<10>(b->n, b->d_models, d_in, d_in64, b->d_state, b->d_qp, b->d_sc, d_forces, d_info, b->d_prof, d_active, order, ev, st, b->exact); break;
-    case 16: rc = launch<16>(b->n, b->d_models, d_in, d_in64, b->d_state, b->d_qp, b->d_sc, d_forces, d_info, b->d_prof, d_active, order, ev, st, b->exact); break;
-    case 20: rc = launch<20>(b->n, b->d_models, d_in, d_in64, b->d_state, b->d_qp, b->d_sc, d_forces, d_info, b->d_prof, d_active, order, ev, st, b->exact); break;
+    case 10: rc = launch<10>(b->n, b->d_models, d_in, d_in64, b->d_state, b->d_qp, b->d_sc, d_forces, d_info, b->d_prof, d_active, order, b->d_hist, slot, ev, st, b->exact); break;
+    case 16: rc = launch<16>(b->n, b->d_models, d_in, d_in64, b->d_state, b->d_qp, b->d_sc, d_forces, d_info, b->d_prof, d_active, order, b->d_hist, slot, ev, st, b->exact); break;
+    case 20: rc = launch<20>(b->n, b->d_models, d_in, d_in64, b->d_state, b->d_qp, b->d_sc, d_forces, d_info, b->d_prof, d_active, order, b->d_hist, slot, ev, st, b->exact); break;
   }
   if (rc == MPC_E_HORIZON) return fail(MPC_E_HORIZON, "solver launch: horizon not compiled in");
   if (rc != MPC_OK) return rc;
@@ -310,7 +323,9 @@ int mpc_batch_create(mpc_batch **out, int n, int horizon, double timestep, doubl
       (e = hipMalloc(&b->d_info, sizeof(int) * (size_t)n * kInfoLen)) != hipSuccess ||
       (e = hipMalloc(&b->d_prof, sizeof(long long) * (size_t)n * kProfLen)) != hipSuccess ||
       (e = hipMalloc(&b->d_order, sizeof(int) * (size_t)n)) != hipSuccess ||
+      (e = hipMalloc(&b->d_hist, (size_t)n * kOrderHistory)) != hipSuccess ||
       (e = hipMemcpy(b->d_models, models.data(), sizeof(RobotModel) * n, hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemset(b->d_hist, 0, (size_t)n * kOrderHistory)) != hipSuccess ||
       (e = hipMemset(b->d_state, 0, sizeof(double) * (size_t)n * b->state_len)) != hipSuccess) {
     cleanup();
     return fail(MPC_E_HIP, std::string("mpc_batch_create: ") + hipGetErrorString(e));
@@ -329,6 +344,7 @@ void mpc_batch_destroy(mpc_batch *b) {
   if (b->d_info) (void)hipFree(b->d_info);
   if (b->d_prof) (void)hipFree(b->d_prof);
   if (b->d_order) (void)hipFree(b->d_order);
+  if (b->d_hist) (void)hipFree(b->d_hist);
   if (b->timing) for (auto &e3 : b->ev) for (auto &e : e3) (void)hipEventDestroy(e);
   if (b->d_host_in) (void)hipFree(b->d_host_in);
   if (b->d_host_in64) (void)hipFree(b->d_host_in64);

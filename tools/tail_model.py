@@ -68,3 +68,23 @@ if "--predict" in sys.argv:
                   f"iters prev->now of the 5 largest: {[(int(prev_it[i]), int(it[i])) for i in np.argsort(-cyc)[:5]]}")
         prev_c, prev_tab, prev_it = cyc, tab, it
         w = perturb_workload(w, 7000 + 131 * s)
+
+# ---- alternative predictors for the dispatch order, replayed through the list scheduler ----
+if "--orders" in sys.argv:
+    w = wl
+    hist = []
+    res = {}
+    for s in range(34):
+        solver.solve(torch.from_numpy(w.inputs).to(dev))
+        torch.cuda.synchronize()
+        cyc = solver.get_profile()[:, 15].astype(np.float64)
+        if len(hist) >= 10:
+            preds = {"previous": hist[-1], "max of last 2": np.maximum(hist[-1], hist[-2]), "max of last 3": np.maximum.reduce(hist[-3:]),
+                     "one gait period ago (10)": hist[-10], "max(previous, 10 ago)": np.maximum(hist[-1], hist[-10]),
+                     "mean of last 4": np.mean(hist[-4:], axis=0), "max of last 10": np.maximum.reduce(hist[-10:]), "clairvoyant": cyc}
+            for k, p in preds.items():
+                res.setdefault(k, []).append(schedule(np.argsort(-p, kind="stable"), cyc) / ghz / 1e6)
+        hist.append(cyc)
+        w = perturb_workload(w, 7000 + 131 * s)
+    for k, v in res.items():
+        print(f"order by {k:28s}: mean {np.mean(v):.4f} ms  max {np.max(v):.4f}  (over {len(v)} steps)")
