@@ -1,30 +1,30 @@
-// mpc_core.h -- one robot's convex-MPC contact-force solve, written once as sequences of
-// barrier-separated phases over the threads of one workgroup: Assembler (QP assembly, its own kernel),
-// Scaler (OSQP's Ruiz equilibration on the dense P, its own kernel) and -- in mpc_wrench.h -- Solver (the OSQP
-// iteration, re-expressed in the 6 h-dimensional space of the net body wrenches).
+// mpc_core.h -- the prep kernel of one robot's convex-MPC contact-force solve, written as sequences of barrier-separated
+// phases over the threads of one workgroup: Assembler (QP assembly) and Scaler (OSQP's Ruiz equilibration on the dense P), plus
+// what the solve kernel shares with them (constants, Cfg, the record layouts).  The OSQP iteration itself -- re-expressed in
+// the 6 h-dimensional space of the net body wrenches -- is Solver in mpc_wrench.h.
 //
 //   Device build (mpc_batch.hip): Exec::par(f) = { f(thread); __syncthreads(); } -- the per-thread
-//   state lives in VGPRs, Shared<H> in LDS.
+//   state lives in VGPRs, the shared structs in LDS.
 //   Host emulation (tests/emu): Exec::par(f) runs f for every emulated thread (in forward or reverse
 //   order, to expose intra-phase races); used only by the CPU tests.
 //
 // What is computed (reference boundary: MPC_Controller/convex_MPC/mpc_osqp.cc:578-796,
 // ConvexMpc::ComputeContactForces, OSQP branch):
-//   1. single-rigid-body QP assembly (mpc_osqp.cc:606-688): x0, x_ref, A/B, exact exp, A^k B, q, P
-//      (P by cumulative diagonal sums = the reference's block recursion :387-434 in the same order)
-//   2. the OSQP 0.6.0 algorithm the reference calls on it (extern/osqp/src): Ruiz scaling
-//      (scaling.c:44-156) here; ADMM, residuals / termination, rho adaptation and polish in mpc_wrench.h.
+//   1. single-rigid-body QP assembly (mpc_osqp.cc:606-688): x0, x_ref, A dt / B dt, the exact exponential, q, bounds, cone
+//      block, and P in its wrench form  P = alpha I + BB^T Theta BB  (B6, th1, th2; the reference's block recursion :387-434
+//      summed in closed form) -> QP record; the two 12 x 12 tables U1, U2 from which any entry of the dense P follows;
+//   2. Ruiz scaling + cost scaling of the OSQP 0.6.0 algorithm the reference calls on it (extern/osqp/src/scaling.c:44-156)
+//      -> scale record.  ADMM, residuals / termination, rho adaptation and polish: mpc_wrench.h.
 //   All arithmetic is fp64: an fp32 ADMM does not reproduce OSQP's iterates (oracle/README).
 //
-// Thread layout of the dense P (n = 12 H, assembly and scaling kernels): P is SYMMETRIC and is
-// held as the lower triangle of a G x G grid (G = 2 H) of 6 x 6 register tiles (2 feet x 2 feet), one tile
-// per thread (four at h = 20): tile index ti (ti + 1) / 2 + tj holds tile (ti, tj), tj <= ti; thread tid owns tiles
-// tid, tid + MTH, ...; a diagonal tile is stored in full.  An off-diagonal tile stands for itself and for its transpose.
+// Thread layout of the dense P (n = 12 H; only the Ruiz norms need it): P is SYMMETRIC and is held as the lower triangle of a
+// G x G grid (G = 2 H) of 6 x 6 register tiles (2 feet x 2 feet), one tile per thread (four at h = 20), built in registers from
+// U1 / U2 and never stored: tile index ti (ti + 1) / 2 + tj holds tile (ti, tj), tj <= ti; thread tid owns tiles tid,
+// tid + MTH, ...; a diagonal tile is held in full.  An off-diagonal tile stands for itself and for its transpose.
 // Vector phases use tid < n and the constraint rows tid, tid + T, ... < m (Scaler::for_rows).
 //
-// Per-horizon tuning knobs (Cfg: NT, kPinMask, kQInLds) exist because the scaling kernel
-// lives at the edge of the register file: they do not change any arithmetic, only how the compiler allocates registers, and
-// are set from measurements (tools/isa_census.py).
+// Per-horizon tuning knobs (Cfg: NT, kPinMask, kQInLds) do not change any arithmetic, only how the compiler allocates
+// registers, and are set from measurements (tools/isa_census.py).
 #pragma once
 
 #include <math.h>
@@ -58,12 +58,9 @@ typedef double mpc_double2 __attribute__((ext_vector_type(2)));
 #define MPC_SCHED_FENCE() ((void)0)
 #endif
 // Tuning hooks for tools/build_variant.sh experiments (the product build uses the defaults; see Cfg for what they mean):
-//   MPC_NT_H16 / MPC_NT_H20   tiles per thread at h = 16 / 20          MPC_EXIT_FENCE_UPTO  largest h with the loop-exit fence
-//   MPC_PIN_MASK              live-range split points (all horizons)   MPC_COLUMN_STORE64   0 / 1 for all horizons
-//   MPC_PROW_SKEW             1: pivot rows 8 bytes off the 16-byte grid (ds_write2_b64 instead of ds_write_b128)
-#ifndef MPC_EXIT_FENCE_UPTO
-#define MPC_EXIT_FENCE_UPTO 16
-#endif
+//   MPC_NT_H16 / MPC_NT_H20   dense-P tiles per thread of the prep kernel at h = 16 / 20
+//   MPC_PIN_MASK              live-range split points of the prep kernel's tile registers
+//   MPC_PROW_SKEW             1: pivot rows of the solve kernel 8 bytes off the 16-byte grid
 #ifndef MPC_PROW_SKEW
 #define MPC_PROW_SKEW 0
 #endif
@@ -72,13 +69,6 @@ typedef double mpc_double2 __attribute__((ext_vector_type(2)));
 #endif
 #ifndef MPC_NT_H16
 #define MPC_NT_H16 1
-#endif
-#define MPC_CHUNK 10   // columns between scheduling fences
-// A value that is the same in every lane, moved to a scalar register (so that branches on it are scalar branches)
-#if defined(__HIP_DEVICE_COMPILE__)
-#define MPC_UNIFORM_INT(x) __builtin_amdgcn_readfirstlane(x)
-#else
-#define MPC_UNIFORM_INT(x) (x)
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MPC_CLOCK() ((long long)__builtin_readcyclecounter())
@@ -108,37 +98,21 @@ struct Cfg {
   static constexpr int TS = 6;                           // register tile side (2 feet)
   static constexpr int G = N / TS;                       // tile grid G x G, lower triangle stored
   static constexpr int MT = G * (G + 1) / 2;             // lower-triangle tiles
-  // Tiles per thread.  Up to h = 16 every thread holds one tile.  The longest horizon has 820 tiles: with one or two per
-  // thread the workgroup runs 2-4 waves per SIMD, i.e. at most 256 / 128 registers per lane, and the tile spills to scratch
-  // in every hot loop (measured: spill traffic, not arithmetic, bounded the kernel).  Four tiles per thread make it a
-  // 256-thread workgroup, one wave per SIMD, with the full 512-register budget (256 VGPRs + 256 AGPRs as spill space).
+  // Dense-P tiles per thread of the prep kernel (the only user of the dense 2H x 2H tile grid: the Ruiz norms).  Up to h = 16
+  // every thread holds one tile.  The longest horizon has 820 tiles: four per thread make it a 256-thread workgroup with one
+  // wave per SIMD and the full 512-register budget (one or two per thread spill the tiles in the pass loop).
   static constexpr int NT = H > 16 ? MPC_NT_H20 : (H > 12 ? MPC_NT_H16 : 1);
   static constexpr int MTH = (MT + NT - 1) / NT;         // threads that hold tiles
   static constexpr int TE = TS * TS;                     // tile elements per thread
-  static constexpr int T = (((MTH > N ? MTH : N) + 63) / 64) * 64;   // solve-kernel workgroup: a thread per tile slot and per variable
-  static constexpr int MR = (M + T - 1) / T;             // constraint rows per thread (Solver::for_rows): 1, or 2 at h = 20
+  static constexpr int T = (((MTH > N ? MTH : N) + 63) / 64) * 64;   // prep-kernel workgroup: a thread per tile slot and per variable
+  static constexpr int MR = (M + T - 1) / T;             // constraint rows per thread (Scaler::for_rows): 1, or 2 at h = 20
   static constexpr int IN_LEN = 56 + 4 * H;
   static_assert(T <= 1024, "workgroup too large");
-  static constexpr int NP = N + 2;                       // row stride of part[] (doubles)
-  static constexpr int MEVEN = (M + 1) & ~1;
-  // LDS diet of the short horizon (three robots per CU need <= 54.6 KB each): q stays in the HBM record and rho per row
-  // is a three-way select on the row type.  h = 16 keeps both in LDS -- it runs one robot per CU whatever its LDS size,
-  // and the leaner forms cost it 9 % each (measured; they lengthen live ranges in a kernel that is at its register cap).
-  // h = 20 needs the per-type rho to fit 160 KB.
+  static constexpr int NP = N + 2;                       // row stride of the prep kernel's part[] (doubles)
+  // LDS diet of the short horizon (q is re-read from the QP record instead of a copy in LDS); the long horizons run one or two
+  // robots per CU whatever their LDS size and keep the copy.
   static constexpr bool kQInLds = H > 12;
-  static constexpr bool kRhoPerType = H <= 12 || H > 16;
-  static constexpr bool kLoopExitFence = H <= MPC_EXIT_FENCE_UPTO;   // scheduling fence after the ADMM loop (see Solver::run)
-  // publish() stores a tile column as six 64-bit LDS stores instead of three 128-bit ones (no v_mov packing: -9 % VALU
-  // instructions per sweep step; +2..3 %).
-#ifdef MPC_COLUMN_STORE64
-  static constexpr bool kColumnStore64 = MPC_COLUMN_STORE64;
-#else
-  static constexpr bool kColumnStore64 = true;
-#endif
-  // Live-range split points of the tile registers (Solver::pin_tiles): bit 0 / 1 before / after a sweep, 2 / 3 around the
-  // 25 ADMM iterations, 4 inside the sweep loop, 5 / 6 before / after the Ruiz passes, 7 inside them.  They mattered by
-  // factors while the kernel carried ~20 hoisted LDS base registers (see MPC_LDS_LOAD64); since those are gone h = 10 / 16 are
-  // within 2 % for every mask tried, and h = 20 still prefers 3 (246 k steps/s against 220-235 k).
+  // Live-range split points of the tile registers (Scaler::pin_tiles): bits 5 / 6 before / after the Ruiz passes, 7 inside them.
 #ifdef MPC_PIN_MASK
   static constexpr int kPinMask = MPC_PIN_MASK;
 #else
@@ -329,10 +303,6 @@ struct Assembler {
   static MPC_HD double mat3e(const double *a, const double *b, int e) {   // entry e = 3 i + j of the 3 x 3 product a b
     const int i = e / 3, j = e - 3 * i;
     return a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
-  }
-  static MPC_HD void mat3(const double *a, const double *b, double *c) {
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) c[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
   }
 
   // ================================ 1. assembly =================================================
@@ -660,9 +630,6 @@ struct Scaler {
       for (int k = 0; k + w < G; k += 2 * w) v[k] = MAX ? raw_max(v[k], v[k + w]) : v[k] + v[k + w];
     return v[0];
   }
-  static MPC_HD double sum_parts(const Sh &s, int row) { return fold_parts<false>(s, row); }
-  // combine the partial products of (-Minv) v for a swept row: see sweep_all()
-  static MPC_HD double inv_combine(const Sh &s, int row, const double *v) { return 2.0 * v[row] - sum_parts(s, row); }
   // (entries are norms: >= 0, never NaN since fmax drops NaNs)
   static MPC_HD double max_parts(const Sh &s, int row) { return fold_parts<true>(s, row); }
   // part <- D_i max_j (|m_ij| D_j) over the tile, for its rows and (transposed) for its columns; D = 1 if null
@@ -702,17 +669,6 @@ struct Scaler {
         if (t.dia && a == b) v += alpha;
         t.Mx[a * TS + b] = v;
       }
-  }
-  // (tile-major HBM layout of the round-1 kernels: tile `index` is the 36 doubles at G[36 index])
-  MPC_HD void load_tile(Tv &t, const double *Gm) {
-    const double *g = Gm + (size_t)t.index * TE;
-#pragma unroll
-    for (int e = 0; e < TE; ++e) t.Mx[e] = g[e];
-  }
-  MPC_HD void store_tile(const Tv &t, double *Gm) {
-    double *g = Gm + (size_t)t.index * TE;
-#pragma unroll
-    for (int e = 0; e < TE; ++e) g[e] = t.Mx[e];
   }
   static MPC_HD double fast_rsqrt(double d) {   // 1 / sqrt(d), d > 0 finite: v_rsq_f64 + two Newton steps (to the last ulp or two)
 #if defined(__HIP_DEVICE_COMPILE__)
