@@ -114,12 +114,14 @@ struct DeviceExec {
   }
 };
 
-// Solve kernel (mpc_wrench.h Solver): ADMM + polish of every active robot, from the QP and scale records
-template <int H>
+// Solve kernel (mpc_wrench.h Solver): ADMM + polish of every active robot, from the QP and scale records.  EXACT: the
+// exact-optimum mode (the reference's qpOASES branch) -- a separate instantiation, so that its outer loop does not touch the
+// register allocation of the OSQP mode.
+template <int H, bool EXACT>
 __global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES : MPC_SOLVE_MIN_WAVES_WIDE)) void mpc_solve_kernel(
     int n, const RobotModel *__restrict__ models, double *__restrict__ state, const double *__restrict__ qp,
     const double *__restrict__ sc, double *__restrict__ forces, int *__restrict__ info, long long *__restrict__ prof,
-    const int *__restrict__ active, const int *__restrict__ order, int exact) {
+    const int *__restrict__ active, const int *__restrict__ order) {
   // static LDS: absolute addresses fold into the ds_* offset fields
   __shared__ __attribute__((aligned(16))) Shared<H> sh;
   using C = Cfg<H>;
@@ -142,8 +144,8 @@ __global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES
                                        forces + (size_t)robot * C::N,
                                        info + (size_t)robot * kInfoLen,
                                        prof ? prof + (size_t)robot * kProfLen : nullptr};
-  if (exact) sv.exact();
-  sv.run();
+  if constexpr (EXACT) sv.exact();
+  sv.template run<EXACT>();
 }
 
 // Workgroup -> robot order for the solve kernel of THIS launch: robots sorted by the shader cycles their previous solve took,
@@ -234,7 +236,8 @@ int launch(int n, const RobotModel *models, const float *in, const double *in64,
   if (ev) (void)hipEventRecord(ev[0], stream);
   hipLaunchKernelGGL(mpc_prep_kernel<H>, dim3(n + 1), dim3(Cfg<H>::T), 0, stream, n, models, in, in64, state, qp, sc, prof, active, const_cast<int *>(order), hist, hist_slot);
   if (ev) (void)hipEventRecord(ev[1], stream);
-  hipLaunchKernelGGL(mpc_solve_kernel<H>, dim3(n), dim3(Cfg<H>::TW), 0, stream, n, models, state, qp, sc, forces, info, prof, active, order, exact);
+  if (exact) hipLaunchKernelGGL((mpc_solve_kernel<H, true>), dim3(n), dim3(Cfg<H>::TW), 0, stream, n, models, state, qp, sc, forces, info, prof, active, order);
+  else hipLaunchKernelGGL((mpc_solve_kernel<H, false>), dim3(n), dim3(Cfg<H>::TW), 0, stream, n, models, state, qp, sc, forces, info, prof, active, order);
   if (ev) (void)hipEventRecord(ev[2], stream);
   HIP_TRY(hipGetLastError());
   return MPC_OK;

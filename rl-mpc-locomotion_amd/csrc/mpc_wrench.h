@@ -35,6 +35,8 @@
 
 namespace mpc {
 
+constexpr double kEpsAdmmFloor = 1e-9;   // exact mode: the tightest ADMM stage (what its first version ran from the start)
+
 template <int H>
 struct WThread {
   using C = Cfg<H>;
@@ -64,6 +66,12 @@ struct WThread {
   }
 };
 
+#ifndef MPC_EXACT_RHO_UPDATES
+#define MPC_EXACT_RHO_UPDATES 10
+#endif
+#ifndef MPC_EPS_EXACT            // exact mode: optimality tolerance of an accepted active-set step (relative, OSQP's termination test)
+#define MPC_EPS_EXACT 1e-11
+#endif
 #ifndef MPC_PAIR_SWEEP          // which workgroup sizes sweep two pivots per phase (see sweep_all)
 #define MPC_PAIR_SWEEP(T) ((T) <= 64)
 #endif
@@ -102,7 +110,7 @@ struct Shared {
     struct { MPC_V Lk[H * 36]; MPC_V Tk[H * 36]; };     // factorisation only: per step Z_k = L L^T, T = L^-1 (zero columns / rows at dropped pivots)
   };
   unsigned long long red[16];
-  int first, iter, status, status_polish, rho_updates, nfact, done, bad;
+  int first, iter, status, status_polish, rho_updates, nfact, done, bad, pol_ok;
   double pri_res, dua_res, rho_new;
 };
 #undef MPC_V
@@ -124,11 +132,16 @@ struct Solver {
   int *info;           // [kInfoLen]
   long long *prof;     // [kProfLen] shader-clock cycles per section (may be null)
   // Solver settings.  Defaults = the reference's OSQP call (mpc_osqp.cc:705-712).  exact(): the QP's optimum to working accuracy,
-  // i.e. what the reference's qpOASES branch returns (mpc_osqp.cc:797-947) -- the same algorithm run to 1e-9 and polished with ten
-  // refinement steps (the caller clears the warm-start record: that branch never warm-starts, :906-919).
-  double eps_abs = kEpsAbs, eps_rel = kEpsRel;
-  int max_iter = kMaxIter, polish_refine = kPolishRefine;
-  MPC_HD void exact() { eps_abs = 1e-9; eps_rel = 1e-9; max_iter = 50 * kMaxIter; polish_refine = 10; }
+  // i.e. what the reference's qpOASES branch returns (mpc_osqp.cc:797-947; the caller clears the warm-start record: that branch
+  // never warm-starts, :906-919).  The optimum of this strictly convex QP is unique, so the route to it is free: ADMM to a loose
+  // tolerance, then the polish as an ACTIVE-SET step -- the equality-constrained solve on the guessed active set, ten refinement
+  // steps -- which is accepted only if the polished point satisfies the optimality conditions to eps_exact (its z / y are built by
+  // projection, so a wrong-signed multiplier or a violated inactive row shows up as a residual); otherwise the tolerance is
+  // tightened by 1e-2 and ADMM continues.  ADMM alone at 1e-9 (the first version) needed ~600 iterations per robot and let rho
+  // oscillate for ever on an occasional robot; rho updates are capped in this mode.
+  double eps_abs = kEpsAbs, eps_rel = kEpsRel, eps_exact = 0.0;
+  int max_iter = kMaxIter, polish_refine = kPolishRefine, max_rho_updates = 1 << 30;
+  MPC_HD void exact() { eps_exact = MPC_EPS_EXACT; max_iter = 5 * kMaxIter; polish_refine = 10; max_rho_updates = MPC_EXACT_RHO_UPDATES; }   // then run<true>()
 #ifdef MPC_EMU_DEBUG
   double *dbg = nullptr;   // host emulation only: per foot 20 doubles of the first polish application (tests/emu)
 #endif
@@ -387,7 +400,7 @@ struct Solver {
         s.first = first;
         s.rho = first ? kRho0 : state[2 * N + 2 * M];
         s.c = sc[C::SC_C]; s.cinv = sc[C::SC_C + 1]; s.calpha = sc[C::SC_C] * mdl.alpha;
-        s.status = kStUnsolved; s.status_polish = 0; s.rho_updates = 0; s.nfact = 0; s.iter = 0; s.done = 0; s.bad = 0;
+        s.status = kStUnsolved; s.status_polish = 0; s.rho_updates = 0; s.nfact = 0; s.iter = 0; s.done = 0; s.bad = 0; s.pol_ok = 0;
       }
     });
     lap(0);
@@ -956,7 +969,7 @@ struct Solver {
             double dr = bitsd(s.red[10]) / (dmax(dmax(bitsd(s.red[11]), bitsd(s.red[12])), bitsd(s.red[13])) + 1e-10);
             double rn = s.rho * sqrt(pr / (dr + 1e-10));
             rn = clampd(rn, kRhoMin, kRhoMax);
-            if (rn > s.rho * kAdaptTol || rn < s.rho / kAdaptTol) s.rho_new = rn;
+            if ((rn > s.rho * kAdaptTol || rn < s.rho / kAdaptTol) && s.rho_updates < max_rho_updates) s.rho_new = rn;
           }
         }
       }
@@ -1331,8 +1344,17 @@ struct Solver {
 #ifdef MPC_EMU_DEBUG
         if (dbg) { dbg[38 * NF] = pri0; dbg[38 * NF + 1] = dua0; dbg[38 * NF + 2] = pri; dbg[38 * NF + 3] = dua; }
 #endif
-        s.status_polish = ok ? 1 : -1;
-        if (ok) { s.pri_res = pri; s.dua_res = dua; }
+        // exact mode: is the polished point the optimum?  (the termination test of auxil.c:684-793 at eps_exact)
+        const double ep = eps_exact + eps_exact * dmax(bitsd(s.red[1]), bitsd(s.red[2]));
+        const double ed = eps_exact + eps_exact * s.cinv * dmax(dmax(bitsd(s.red[7]), bitsd(s.red[8])), bitsd(s.red[9]));
+        const bool verified = !s.bad && pri < ep && dua < ed;
+        // an early stage of the exact mode takes the polished point only when it is verified (an unverified one would bend the
+        // ADMM trajectory that the last stage relies on); everything else follows OSQP: take it when it improves the residuals
+        const bool early = eps_exact > 0 && eps_abs > kEpsAdmmFloor;
+        const bool take = early ? verified : ok;
+        s.pol_ok = verified ? 1 : 0;
+        s.status_polish = take ? 1 : -1;
+        if (take) { s.pri_res = pri; s.dua_res = dua; }
       }
     });
     ex.par([&](Th &t) {
@@ -1349,21 +1371,11 @@ struct Solver {
   }
 
   // ================================ driver ======================================================================
-  MPC_HD void run() {
-    const long long t0 = MPC_CLOCK();
-    tlast = t0;
-    load();
-    set_rho_vec();
-    factor();
-    lap(9);
-    admm_prepare();
-    lap(8);
-    // kCheck iterations between termination checks (osqp.c:417-517 checks when iter % 25 == 0).  P_s x, which only the dual
-    // residual needs, is formed at the check (one Theta product) instead of being carried through every iteration; that product
-    // uses the exchange registers of the iteration, so the right-hand side is handed over again afterwards (admm_prepare
-    // recomputes exactly the values the last iteration left).
-    static_assert(kMaxIter % kCheck == 0, "the check falls on the last iteration");
-    int iter = 0;
+  // kCheck iterations between termination checks (osqp.c:417-517 checks when iter % 25 == 0).  P_s x, which only the dual
+  // residual needs, is formed at the check (one Theta product) instead of being carried through every iteration; that product
+  // uses the exchange registers of the iteration, so the right-hand side is handed over again afterwards (admm_prepare
+  // recomputes exactly the values the last iteration left).
+  MPC_HD void admm_until_done(int &iter) {
     while (!s.done && !s.bad && iter < max_iter) {
       y_scaled(true);
       for (int k = 0; k < kCheck; ++k) admm_iter();
@@ -1384,10 +1396,36 @@ struct Solver {
         lap(8);
       }
     }
-    if (!s.done && !s.bad) {   // max_iter reached (osqp.c:564-568): only SOLVED counts for the reference
-      ex.par([&](Th &t) { if (t.tid == 0) s.status = kStMaxIter; });
+  }
+  template <bool EXACT = false>
+  MPC_HD void run() {
+    const long long t0 = MPC_CLOCK();
+    tlast = t0;
+    load();
+    set_rho_vec();
+    factor();
+    lap(9);
+    admm_prepare();
+    lap(8);
+    static_assert(kMaxIter % kCheck == 0, "the check falls on the last iteration");
+    int iter = 0;
+    for (;;) {
+      admm_until_done(iter);
+      if (!s.done && !s.bad) {   // max_iter reached (osqp.c:564-568): only SOLVED counts for the reference
+        ex.par([&](Th &t) { if (t.tid == 0) s.status = kStMaxIter; });
+      }
+      if (s.status == kStSolved && !s.bad) polish();
+      if constexpr (!EXACT) break;   // (a compile-time branch: the loop back edge would keep the ADMM state live through the polish)
+      // Exact mode.  (Repeating the polish from the polished point -- OSQP's active-set rule applied to z = clip(A x + y) is the
+      // primal-dual active-set update -- was tried here: it rarely converges within four steps on these QPs and costs a
+      // factorisation per step.)
+      if (s.status != kStSolved || s.bad || s.pol_ok || eps_abs <= kEpsAdmmFloor) break;
+      // not yet: tighter ADMM tolerance from the last polished point, K factorised again (the tiles hold the polish's)
+      eps_abs = eps_rel = dmax(eps_abs * 1e-2, kEpsAdmmFloor);
+      ex.par([&](Th &t) { if (t.tid == 0) { s.done = 0; s.status = kStUnsolved; } });
+      factor();
+      admm_prepare();
     }
-    if (s.status == kStSolved && !s.bad) polish();
     lap(14);
     tc[15] = MPC_CLOCK() - t0;
     // outputs + persistent state (store_solution, auxil.c:528-561; mpc_osqp.cc:788-790: forces = -x).  A non-convex / non-finite

@@ -89,7 +89,7 @@ static long prep_one(const RobotModel &mdl, const float *in, const double *state
 }
 // prep kernel -> solve kernel of one robot
 template <int H>
-static void solve_one(const RobotModel &mdl, const float *in, double *state, double *forces, int *info, bool reverse, long *phases, double *dbg = nullptr) {
+static void solve_one(const RobotModel &mdl, const float *in, double *state, double *forces, int *info, bool reverse, long *phases, double *dbg = nullptr, bool exact = false) {
   using C = Cfg<H>;
   std::vector<double> qp(C::QP_LEN, 0.0), sc(C::SC_LEN, 0.0);
   long ph = prep_one<H>(mdl, in, state, qp.data(), sc.data(), reverse);
@@ -100,7 +100,8 @@ static void solve_one(const RobotModel &mdl, const float *in, double *state, dou
     Ex ex(reverse);
     Solver<H, Ex> sv{ex, *sh, mdl, state, qp.data(), sc.data(), forces, info, nullptr};
     sv.dbg = dbg;
-    sv.run();
+    if (exact) { sv.exact(); sv.template run<true>(); }   // the exact-optimum mode (mpc_batch_set_solver); the caller clears the state record
+    else sv.run();
     ph += ex.phases;
     delete sh;
   }
@@ -268,8 +269,9 @@ int emu_shared_bytes(int h) { return h == 10 ? (int)sizeof(Shared<10>) : h == 16
 // model: per robot {mass, inertia9[9]} (10 doubles); in: [n][56+4h] floats; state: [n][state_len];
 // forces: [n][12h]; info: [n][8].  Returns -1 for an unsupported horizon.
 int emu_batch_solve(int h, int n, const double *model, double dt, double alpha, const float *in, double *state,
-                    double *forces, int *info, int reverse, int nthreads, long *phases_out) {
+                    double *forces, int *info, int reverse_and_mode, int nthreads, long *phases_out) {
   if (h != 10 && h != 16 && h != 20 && h != 6) return -1;
+  const bool reverse = reverse_and_mode & 1, exact = reverse_and_mode & 2;   // bit 1: exact-optimum mode
   const int N = 12 * h, inlen = 56 + 4 * h, sl = emu_state_len(h);
   if (nthreads < 1) nthreads = 1;
   std::vector<std::thread> pool;
@@ -281,10 +283,10 @@ int emu_batch_solve(int h, int n, const double *model, double dt, double alpha, 
       double *rs = state + (size_t)r * sl, *rf = forces + (size_t)r * N;
       int *rinfo = info + (size_t)r * kInfoLen;
       switch (h) {
-        case 6: solve_one<6>(mdl, ri, rs, rf, rinfo, reverse, &ph); break;
-        case 10: solve_one<10>(mdl, ri, rs, rf, rinfo, reverse, &ph); break;
-        case 16: solve_one<16>(mdl, ri, rs, rf, rinfo, reverse, &ph); break;
-        case 20: solve_one<20>(mdl, ri, rs, rf, rinfo, reverse, &ph); break;
+        case 6: solve_one<6>(mdl, ri, rs, rf, rinfo, reverse, &ph, nullptr, exact); break;
+        case 10: solve_one<10>(mdl, ri, rs, rf, rinfo, reverse, &ph, nullptr, exact); break;
+        case 16: solve_one<16>(mdl, ri, rs, rf, rinfo, reverse, &ph, nullptr, exact); break;
+        case 20: solve_one<20>(mdl, ri, rs, rf, rinfo, reverse, &ph, nullptr, exact); break;
       }
       if (phases_out) phases_out[r] = ph;
     }

@@ -32,12 +32,15 @@ class EmuBatch:
         self.info = np.zeros((n, 8), dtype=np.int32)
         self.phases = np.zeros(n, dtype=np.int64)
 
-    def solve(self, records, reverse=False, nthreads=8):
+    def solve(self, records, reverse=False, nthreads=8, exact=False):
+        """exact: the exact-optimum mode (mpc_batch_set_solver(MPC_SOLVER_EXACT)): cold on every call."""
+        if exact:
+            self.state[:] = 0.0
         rec = np.ascontiguousarray(records, dtype=np.float32)
         out = np.full((self.n, 12 * self.h), np.nan)
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         rc = lib().emu_batch_solve(self.h, self.n, p(self.model), self.dt, self.alpha, p(rec), p(self.state), p(out),
-                                   p(self.info), int(reverse), nthreads, p(self.phases))
+                                   p(self.info), int(reverse) | (2 if exact else 0), nthreads, p(self.phases))
         assert rc == 0
         return out
 

@@ -102,3 +102,23 @@ def test_exact_solver_batch_matches_the_unique_optimum():
                 assert np.abs(f[r] - fx).max() < 1e-6 * max(np.abs(fx).max(), 1.0), (name, s, r, np.abs(f[r] - fx).max())
                 swing = np.repeat(g[f"inputs_{s}"][r, 28:28 + 4 * h] == 0, 3)
                 assert np.abs(f[r][swing]).max(initial=0.0) < 1e-6
+
+
+def test_exact_solver_on_the_host_emulation_matches_the_unique_optimum():
+    """The exact-optimum mode of the kernel code (staged ADMM + verified active-set polish, mpc_wrench.h run<true>) on the host
+    emulation against the oracle's exact optimum; the second call of a pair must start cold."""
+    from oracle.refmpc import RefConvexMpc
+    from tests.emu.emu import EmuBatch
+    from tests.helpers import load_golden
+    for name, n in (("solver_h10_cfg3", 8), ("solver_h10_edge", 10), ("solver_h16_cfg4", 3)):
+        g = load_golden(name)
+        h = int(g["h"])
+        emu = EmuBatch(g["mass"][:n], g["inertia_diag"][:n], h, float(g["dt_mpc"]), float(g["alpha"]))
+        for s in range(2):
+            f = emu.solve(g[f"inputs_{s}"][:n], exact=True)
+            assert (emu.info[:, 1] == 1).all() and (emu.info[:, 5] == 1).all()
+            for r in range(n):
+                d = g["inertia_diag"][r]
+                ref = RefConvexMpc(g["mass"][r], [d[0], 0, 0, 0, d[1], 0, 0, 0, d[2]], 4, h, float(g["dt_mpc"]), float(g["alpha"]))
+                fx = ref.solve_exact(g[f"inputs_{s}"][r])
+                assert np.abs(f[r] - fx).max() < 1e-6 * max(np.abs(fx).max(), 1.0), (name, s, r)

@@ -16,7 +16,8 @@ import re
 import subprocess
 import sys
 
-KERNEL_RE = r'\n(_ZN[^\n]*mpc_solve_kernelILi%sE[^\n:]*):[^\n]*\n(.*?)\n\.Lfunc_end'
+# (the OSQP-mode instantiation mpc_solve_kernel<H, false>; the exact-mode one, <H, true>, is not performance critical)
+KERNEL_RE = r'\n(_ZN[^\n]*mpc_solve_kernelILi%sELb0E[^\n:]*):[^\n]*\n(.*?)\n\.Lfunc_end'
 
 
 def compile_to_asm(src, out, include_dir, extra=()):

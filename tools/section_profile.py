@@ -16,7 +16,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 h = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 wl = make_solver_workload(n, h=h, seed=1000, config={10: 2, 16: 4, 20: 5}[h])
 inertia9 = np.zeros((n, 9)); inertia9[:, 0], inertia9[:, 4], inertia9[:, 8] = wl.inertia_diag.T
-sv = BatchedConvexMpc(wl.mass, inertia9, h, wl.dt_mpc, wl.alpha)
+solver = sys.argv[3] if len(sys.argv) > 3 else "osqp"      # or "exact"
+sv = BatchedConvexMpc(wl.mass, inertia9, h, wl.dt_mpc, wl.alpha, solver=solver)
 names = ["load", "dyn", "qP", "sc-load", "sc-loop", "sc-store", "Kform", "sweep", "admm", "r-mulP", "r-rest", "p-setup", "p-H", "p-refine", "p-fin", "total"]
 w = wl
 for step in range(4):
