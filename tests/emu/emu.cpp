@@ -16,6 +16,12 @@
 
 using namespace mpc;
 
+// What a freshly launched workgroup finds in its registers and its LDS is undefined.  emu_set_poison(1) fills the emulated thread
+// state and shared memory with 0xFF bytes (NaN doubles, -1 integers) instead of zeros before a run -- only the tile registers are
+// zeroed, as the kernels do -- so that a read of anything the kernel has not written shows up as a changed (NaN) result.
+static int g_poison = 0;
+static inline int fill_byte() { return g_poison ? 0xFF : 0; }
+
 template <class TH, int NTHREADS>
 struct HostExec {
   std::vector<TH> th;
@@ -23,8 +29,9 @@ struct HostExec {
   long phases = 0;
   explicit HostExec(bool rev) : th(NTHREADS), reverse(rev) {
     for (int i = 0; i < NTHREADS; ++i) {
-      std::memset((void *)&th[i], 0, sizeof(TH));
+      std::memset((void *)&th[i], fill_byte(), sizeof(TH));
       th[i].init(i);
+      for (size_t e = 0; e < sizeof(th[i].Mx) / sizeof(double); ++e) th[i].Mx[e] = 0;   // (the kernels zero their tile registers)
     }
   }
   template <class F> void par(F &&f) {
@@ -76,7 +83,7 @@ template <int H>
 static long prep_one(const RobotModel &mdl, const float *in, const double *state, double *qp, double *sc, bool reverse) {
   using C = Cfg<H>;
   PrepShared<H> *ps = new PrepShared<H>();
-  std::memset((void *)ps, 0, sizeof(PrepShared<H>));
+  std::memset((void *)ps, fill_byte(), sizeof(PrepShared<H>));
   using Ex = HostExec<Thread<H>, C::T>;
   Ex ex(reverse);
   Assembler<H, Ex> am{ex, ps->as, mdl, in, nullptr, ps->u12, qp, nullptr};
@@ -95,7 +102,7 @@ static void solve_one(const RobotModel &mdl, const float *in, double *state, dou
   long ph = prep_one<H>(mdl, in, state, qp.data(), sc.data(), reverse);
   {
     Shared<H> *sh = new Shared<H>();
-    std::memset((void *)sh, 0, sizeof(Shared<H>));
+    std::memset((void *)sh, fill_byte(), sizeof(Shared<H>));
     using Ex = HostExec<WThread<H>, C::TW>;
     Ex ex(reverse);
     Solver<H, Ex> sv{ex, *sh, mdl, state, qp.data(), sc.data(), forces, info, nullptr};
@@ -116,7 +123,7 @@ static void ksolve_one(const RobotModel &mdl, const float *in, double rho, const
   int info[kInfoLen];
   prep_one<H>(mdl, in, state.data(), qp.data(), sc.data(), false);
   Shared<H> *sh = new Shared<H>();
-  std::memset((void *)sh, 0, sizeof(Shared<H>));
+  std::memset((void *)sh, fill_byte(), sizeof(Shared<H>));
   using Ex = HostExec<WThread<H>, C::TW>;
   Ex ex(false);
   Solver<H, Ex> sv{ex, *sh, mdl, state.data(), qp.data(), sc.data(), forces.data(), info, nullptr};
@@ -263,6 +270,7 @@ int emu_estimator_update(int n, const float *body, const float *normal, float *e
   return 0;
 }
 
+void emu_set_poison(int on) { g_poison = on; }
 int emu_state_len(int h) { return 24 * h + 40 * h + 2; }
 int emu_shared_bytes(int h) { return h == 10 ? (int)sizeof(Shared<10>) : h == 16 ? (int)sizeof(Shared<16>) : h == 20 ? (int)sizeof(Shared<20>) : h == 6 ? (int)sizeof(Shared<6>) : -1; }
 

@@ -45,3 +45,27 @@ def test_reset_semantics_cold_equals_fresh():
     a.state[:] = 0
     f2 = a.solve(g["inputs_0"][sel])
     assert np.array_equal(f0, f2)
+
+
+def test_no_read_of_unwritten_registers_or_lds():
+    """A workgroup's registers and LDS start undefined on the device, while the emulation starts from zeros.  With everything but
+    the tile registers (which the kernels zero) poisoned with NaN / -1 patterns the results must not move by a bit -- in both solver
+    modes, all horizons, and on the edge cases."""
+    from tests.emu.emu import lib
+    for name, n in (("solver_h10_cfg3", 8), ("solver_h10_edge", 10), ("solver_h16_cfg4", 2), ("solver_h20_cfg5", 1)):
+        g = load_golden(name)
+        h = int(g["h"])
+        runs = []
+        try:
+            for poison in (0, 1):
+                lib().emu_set_poison(poison)
+                emu = EmuBatch(g["mass"][:n], g["inertia_diag"][:n], h, float(g["dt_mpc"]), float(g["alpha"]))
+                out = [emu.solve(g[f"inputs_{s}"][:n]).copy() for s in range(2)]
+                ex = EmuBatch(g["mass"][:n], g["inertia_diag"][:n], h, float(g["dt_mpc"]), float(g["alpha"]))
+                out.append(ex.solve(g["inputs_0"][:n], exact=True).copy())
+                runs.append((out, emu.info.copy(), ex.info.copy()))
+        finally:
+            lib().emu_set_poison(0)
+        for a, b in zip(runs[0][0], runs[1][0]):
+            assert np.array_equal(a, b, equal_nan=True), name
+        assert np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2]), name
