@@ -52,6 +52,7 @@ struct WThread {
   double gq[2], yq[2], dlq[2];                   // rows j and j + 4 of my step (j = tid & 3): g, y, diag(M)^-1/2
   double zq[21];                                 // factorisation: W_f X_f W_f^T (packed lower triangle), then the step's sum
   int tyb;                                       // row types, two bits per row: 0 loose, 1 inequality, 2 equality (auxil.c:79-96)
+  int sig;                                       // exact mode: my rows' active-set guess at the last check (base-3 code)
   // polish (foot lane)
   int act[5];
   double pG[9], pC[9], pu0[3], pg[3], pr[3], pt[3], pxN[3], pPu[3], pw[3];
@@ -66,6 +67,9 @@ struct WThread {
   }
 };
 
+#ifndef MPC_STABLE_CHECKS         // exact mode: consecutive checks with an unchanged active-set guess before the polish is tried
+#define MPC_STABLE_CHECKS 2
+#endif
 #ifndef MPC_EXACT_RHO_UPDATES
 #define MPC_EXACT_RHO_UPDATES 10
 #endif
@@ -110,7 +114,7 @@ struct Shared {
     struct { MPC_V Lk[H * 36]; MPC_V Tk[H * 36]; };     // factorisation only: per step Z_k = L L^T, T = L^-1 (zero columns / rows at dropped pivots)
   };
   unsigned long long red[16];
-  int first, iter, status, status_polish, rho_updates, nfact, done, bad, pol_ok;
+  int first, iter, status, status_polish, rho_updates, nfact, done, bad, pol_ok, sig_changed, loose_ok;
   double pri_res, dua_res, rho_new;
 };
 #undef MPC_V
@@ -133,15 +137,18 @@ struct Solver {
   long long *prof;     // [kProfLen] shader-clock cycles per section (may be null)
   // Solver settings.  Defaults = the reference's OSQP call (mpc_osqp.cc:705-712).  exact(): the QP's optimum to working accuracy,
   // i.e. what the reference's qpOASES branch returns (mpc_osqp.cc:797-947; the caller clears the warm-start record: that branch
-  // never warm-starts, :906-919).  The optimum of this strictly convex QP is unique, so the route to it is free: ADMM to a loose
-  // tolerance, then the polish as an ACTIVE-SET step -- the equality-constrained solve on the guessed active set, ten refinement
-  // steps -- which is accepted only if the polished point satisfies the optimality conditions to eps_exact (its z / y are built by
-  // projection, so a wrong-signed multiplier or a violated inactive row shows up as a residual); otherwise the tolerance is
-  // tightened by 1e-2 and ADMM continues.  ADMM alone at 1e-9 (the first version) needed ~600 iterations per robot and let rho
-  // oscillate for ever on an occasional robot; rho updates are capped in this mode.
+  // never warm-starts, :906-919).  The optimum of this strictly convex QP is unique, so the route to it is free (run<true>): ADMM
+  // towards 1e-9, and as soon as OSQP's active-set guess (polish.c:36-52) has not changed over kStableChecks consecutive checks
+  // (and the iterate passes the 1e-3 test) the polish is tried as an ACTIVE-SET step -- the equality-constrained solve on the guessed
+  // set, ten refinement steps -- and accepted only if the polished point satisfies the optimality conditions to eps_exact (its z / y
+  // are built by projection, so a wrong-signed multiplier or a violated inactive row shows up as a residual).  A rejected step costs a
+  // polish and a re-factorisation of K and is not repeated until the guess has changed.  Rho updates are capped: ADMM run straight
+  // to 1e-9 (the first version: ~600 iterations per robot) let rho oscillate for ever on an occasional robot.
   double eps_abs = kEpsAbs, eps_rel = kEpsRel, eps_exact = 0.0;
   int max_iter = kMaxIter, polish_refine = kPolishRefine, max_rho_updates = 1 << 30;
-  MPC_HD void exact() { eps_exact = MPC_EPS_EXACT; max_iter = 5 * kMaxIter; polish_refine = 10; max_rho_updates = MPC_EXACT_RHO_UPDATES; }   // then run<true>()
+  bool polish_must_verify = false;   // (set around an early polish of the exact mode)
+  static constexpr int kStableChecks = MPC_STABLE_CHECKS;
+  MPC_HD void exact() { eps_exact = MPC_EPS_EXACT; eps_abs = eps_rel = kEpsAdmmFloor; max_iter = 5 * kMaxIter; polish_refine = 10; max_rho_updates = MPC_EXACT_RHO_UPDATES; }   // then run<true>()
 #ifdef MPC_EMU_DEBUG
   double *dbg = nullptr;   // host emulation only: per foot 20 doubles of the first polish application (tests/emu)
 #endif
@@ -400,7 +407,7 @@ struct Solver {
         s.first = first;
         s.rho = first ? kRho0 : state[2 * N + 2 * M];
         s.c = sc[C::SC_C]; s.cinv = sc[C::SC_C + 1]; s.calpha = sc[C::SC_C] * mdl.alpha;
-        s.status = kStUnsolved; s.status_polish = 0; s.rho_updates = 0; s.nfact = 0; s.iter = 0; s.done = 0; s.bad = 0; s.pol_ok = 0;
+        s.status = kStUnsolved; s.status_polish = 0; s.rho_updates = 0; s.nfact = 0; s.iter = 0; s.done = 0; s.bad = 0; s.pol_ok = 0; s.sig_changed = 0; s.loose_ok = 0;
       }
     });
     lap(0);
@@ -963,6 +970,8 @@ struct Solver {
         else {
           const double eps_prim = eps_abs + eps_rel * dmax(bitsd(s.red[1]), bitsd(s.red[2]));
           const double eps_dual = eps_abs + eps_rel * s.cinv * dmax(dmax(bitsd(s.red[7]), bitsd(s.red[8])), bitsd(s.red[9]));
+          s.sig_changed = 0;
+          s.loose_ok = pri < kEpsAbs + (eps_prim - eps_abs) * (kEpsRel / eps_rel) && dua < kEpsAbs + (eps_dual - eps_abs) * (kEpsRel / eps_rel);   // the 1e-3 test
           if (pri < eps_prim && dua < eps_dual) { s.status = kStSolved; s.done = 1; }
           else {
             double pr = bitsd(s.red[3]) / (dmax(bitsd(s.red[4]), bitsd(s.red[5])) + 1e-10);
@@ -1348,10 +1357,9 @@ struct Solver {
         const double ep = eps_exact + eps_exact * dmax(bitsd(s.red[1]), bitsd(s.red[2]));
         const double ed = eps_exact + eps_exact * s.cinv * dmax(dmax(bitsd(s.red[7]), bitsd(s.red[8])), bitsd(s.red[9]));
         const bool verified = !s.bad && pri < ep && dua < ed;
-        // an early stage of the exact mode takes the polished point only when it is verified (an unverified one would bend the
-        // ADMM trajectory that the last stage relies on); everything else follows OSQP: take it when it improves the residuals
-        const bool early = eps_exact > 0 && eps_abs > kEpsAdmmFloor;
-        const bool take = early ? verified : ok;
+        // an early polish of the exact mode is taken only when it is verified (an unverified one would bend the ADMM trajectory
+        // that the final polish relies on); everything else follows OSQP: take it when it improves the residuals
+        const bool take = polish_must_verify ? verified : ok;
         s.pol_ok = verified ? 1 : 0;
         s.status_polish = take ? 1 : -1;
         if (take) { s.pri_res = pri; s.dua_res = dua; }
@@ -1375,7 +1383,9 @@ struct Solver {
   // residual needs, is formed at the check (one Theta product) instead of being carried through every iteration; that product
   // uses the exchange registers of the iteration, so the right-hand side is handed over again afterwards (admm_prepare
   // recomputes exactly the values the last iteration left).
-  MPC_HD void admm_until_done(int &iter) {
+  // Returns true when the exact mode wants an early polish (the loop is left with the iterate unfinished).
+  template <bool EXACT>
+  MPC_HD bool admm_until_done(int &iter, int &stable) {
     while (!s.done && !s.bad && iter < max_iter) {
       y_scaled(true);
       for (int k = 0; k < kCheck; ++k) admm_iter();
@@ -1387,6 +1397,21 @@ struct Solver {
       check_and_adapt(iter);
       lap(10);
       if (!s.done) {
+        if constexpr (EXACT) {
+          ex.par([&](Th &t) {   // the active-set guess of my rows (polish.c:36-52), as a base-3 code; did it change since the last check?
+            if (t.tid < NF) {
+              double lo[5], up[5];
+              foot_bounds(t, lo, up);
+              int sig = 0;
+#pragma unroll
+              for (int r = 4; r >= 0; --r) sig = 3 * sig + ((t.z[r] - lo[r] < -t.y[r]) ? 0 : ((up[r] - t.z[r] < t.y[r]) ? 2 : 1));
+              if (sig != t.sig) s.sig_changed = 1;
+              t.sig = sig;
+            }
+          });
+          stable = s.sig_changed ? 0 : stable + 1;
+          if (stable >= kStableChecks && s.loose_ok) return true;
+        }
         if (s.rho_new > 0) {          // osqp_update_rho: new rho_vec, refactor
           ex.par([&](Th &t) { if (t.tid == 0) { s.rho = s.rho_new; s.rho_updates++; } });
           set_rho_vec();
@@ -1396,6 +1421,7 @@ struct Solver {
         lap(8);
       }
     }
+    return false;
   }
   template <bool EXACT = false>
   MPC_HD void run() {
@@ -1408,23 +1434,41 @@ struct Solver {
     admm_prepare();
     lap(8);
     static_assert(kMaxIter % kCheck == 0, "the check falls on the last iteration");
-    int iter = 0;
-    for (;;) {
-      admm_until_done(iter);
+    int iter = 0, stable = 0;
+    if constexpr (!EXACT) {
+      admm_until_done<false>(iter, stable);
       if (!s.done && !s.bad) {   // max_iter reached (osqp.c:564-568): only SOLVED counts for the reference
         ex.par([&](Th &t) { if (t.tid == 0) s.status = kStMaxIter; });
       }
       if (s.status == kStSolved && !s.bad) polish();
-      if constexpr (!EXACT) break;   // (a compile-time branch: the loop back edge would keep the ADMM state live through the polish)
-      // Exact mode.  (Repeating the polish from the polished point -- OSQP's active-set rule applied to z = clip(A x + y) is the
-      // primal-dual active-set update -- was tried here: it rarely converges within four steps on these QPs and costs a
-      // factorisation per step.)
-      if (s.status != kStSolved || s.bad || s.pol_ok || eps_abs <= kEpsAdmmFloor) break;
-      // not yet: tighter ADMM tolerance from the last polished point, K factorised again (the tiles hold the polish's)
-      eps_abs = eps_rel = dmax(eps_abs * 1e-2, kEpsAdmmFloor);
-      ex.par([&](Th &t) { if (t.tid == 0) { s.done = 0; s.status = kStUnsolved; } });
-      factor();
-      admm_prepare();
+    } else {
+      ex.seq([&](Th &t) { t.sig = -1; });
+      for (;;) {
+        const bool early = admm_until_done<true>(iter, stable);
+        if (s.bad) break;
+        if (!early) {                 // converged at the ADMM floor (then OSQP's own polish rule), or out of iterations
+          if (!s.done) ex.par([&](Th &t) { if (t.tid == 0) s.status = kStMaxIter; });
+          else if (s.status == kStSolved) polish();
+          break;
+        }
+        polish_must_verify = true;
+        polish();
+        polish_must_verify = false;
+        if (s.bad) break;
+        if (s.pol_ok) {
+          ex.par([&](Th &t) { if (t.tid == 0) s.status = kStSolved; });
+          break;
+        }
+        // rejected: on with ADMM from the untouched iterate (the tiles hold the polish's factorisation: K again, with the pending rho
+        // if there is one); no further attempt until the guess has changed and settled again
+        stable = -(1 << 20);
+        if (s.rho_new > 0) {
+          ex.par([&](Th &t) { if (t.tid == 0) { s.rho = s.rho_new; s.rho_updates++; } });
+          set_rho_vec();
+        }
+        factor();
+        admm_prepare();
+      }
     }
     lap(14);
     tc[15] = MPC_CLOCK() - t0;
