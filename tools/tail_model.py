@@ -88,3 +88,20 @@ if "--orders" in sys.argv:
         w = perturb_workload(w, 7000 + 131 * s)
     for k, v in res.items():
         print(f"order by {k:28s}: mean {np.mean(v):.4f} ms  max {np.max(v):.4f}  (over {len(v)} steps)")
+
+# ---- what would a separate polish launch buy?  (ADMM part: measured cycles minus a constant polish; polish: uniform jobs) ----
+if "--split" in sys.argv:
+    w = wl
+    polish, reload = 80e3, 8e3
+    prev = None
+    for s in range(10):
+        solver.solve(torch.from_numpy(w.inputs).to(dev))
+        torch.cuda.synchronize()
+        cyc = solver.get_profile()[:, 15].astype(np.float64)
+        if prev is not None and s >= 4:
+            one = schedule(np.argsort(-prev, kind="stable"), cyc)
+            a = schedule(np.argsort(-prev, kind="stable"), cyc - polish)
+            b = int(np.ceil(n / slots)) * (polish + reload)
+            print(f"step {s}: one launch {one / ghz / 1e6:.4f} ms | ADMM launch {a / ghz / 1e6:.4f} + polish launch {b / ghz / 1e6:.4f} + ~0.008 gap = {(a + b) / ghz / 1e6 + 0.008:.4f} ms")
+        prev = cyc
+        w = perturb_workload(w, 7000 + 131 * s)

@@ -21,7 +21,7 @@ def one():
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for s in range(K): sv.solve(d[W + s])
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / K * 1e3
-def split(parts):
+def split(parts, join=False):
     m = n // parts
     svs = [BatchedConvexMpc(wl.mass[i*m:(i+1)*m], inertia9[i*m:(i+1)*m], h, wl.dt_mpc, wl.alpha) for i in range(parts)]
     streams = [torch.cuda.Stream() for _ in range(parts)]
@@ -31,9 +31,13 @@ def split(parts):
         for i in range(parts):
             with torch.cuda.stream(streams[i]):
                 outs[i][s] = svs[i].solve(d[i][s])
+        if join:   # a closed-loop step: nothing of step s + 1 may start before all of step s is done (GPU-side join, no host sync)
+            evs = [st.record_event() for st in streams]
+            for st in streams:
+                for e in evs: st.wait_event(e)
     torch.cuda.synchronize()
     for s in range(W): step(s)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for s in range(K): step(W + s)
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / K * 1e3
-print("one launch: %.3f ms/step; two halves on two streams: %.3f; four quarters: %.3f" % (one(), split(2), split(4)))
+print("one launch: %.3f ms/step; two halves on two streams: %.3f; four quarters: %.3f; two halves joined after every step: %.3f; four joined: %.3f" % (one(), split(2), split(4), split(2, True), split(4, True)))
