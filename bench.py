@@ -86,7 +86,7 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=10, help="untimed steps (default: one gait period, which also fills the dispatch-order history)")
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--robots", type=int, default=None, help="robots per GPU (overrides the configuration's size)")
     ap.add_argument("--horizon", type=int, default=None, help="(overrides the configuration's horizon)")
