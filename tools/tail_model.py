@@ -105,3 +105,45 @@ if "--split" in sys.argv:
             print(f"step {s}: one launch {one / ghz / 1e6:.4f} ms | ADMM launch {a / ghz / 1e6:.4f} + polish launch {b / ghz / 1e6:.4f} + ~0.008 gap = {(a + b) / ghz / 1e6 + 0.008:.4f} ms")
         prev = cyc
         w = perturb_workload(w, 7000 + 131 * s)
+
+# ---- would a better static packing of the PREDICTED lengths, replayed greedily with the ACTUAL ones, beat longest-first? ----
+if "--packing" in sys.argv:
+    def multifit_order(pred):
+        """FFD inside a binary search on the bin capacity (multifit); returns the dispatch order = jobs sorted by planned start time."""
+        idx = np.argsort(-pred, kind="stable")
+        lo, hi = max(pred.sum() / slots, pred.max()), 2 * max(pred.sum() / slots, pred.max())
+        best = None
+        for _ in range(12):
+            cap = 0.5 * (lo + hi)
+            load = np.zeros(slots); assign = [[] for _ in range(slots)]
+            ok = True
+            for j in idx:
+                fits = np.nonzero(load + pred[j] <= cap)[0]
+                if len(fits) == 0: ok = False; break
+                b = fits[0]; assign[b].append(j); load[b] += pred[j]
+            if ok: hi, best = cap, assign
+            else: lo = cap
+        starts = []
+        for b in best:
+            t = 0.0
+            for j in b: starts.append((t, -pred[j], j)); t += pred[j]
+        starts.sort()
+        return np.array([j for _, _, j in starts]), hi
+    w = wl
+    hist = []
+    res = {"longest-first by max of last 10": [], "multifit on max of last 10": [], "longest-first clairvoyant": [], "multifit clairvoyant": [], "lower bound": []}
+    for s in range(22):
+        solver.solve(torch.from_numpy(w.inputs).to(dev))
+        torch.cuda.synchronize()
+        cyc = solver.get_profile()[:, 15].astype(np.float64)
+        if len(hist) >= 10 and s % 3 == 0:
+            pred = np.maximum.reduce(hist[-10:])
+            res["longest-first by max of last 10"].append(schedule(np.argsort(-pred, kind="stable"), cyc))
+            res["multifit on max of last 10"].append(schedule(multifit_order(pred)[0], cyc))
+            res["longest-first clairvoyant"].append(schedule(np.argsort(-cyc, kind="stable"), cyc))
+            res["multifit clairvoyant"].append(schedule(multifit_order(cyc)[0], cyc))
+            res["lower bound"].append(max(cyc.sum() / slots, cyc.max()))
+        hist.append(cyc)
+        w = perturb_workload(w, 7000 + 131 * s)
+    for k, v in res.items():
+        print(f"{k:34s}: mean {np.mean(v) / ghz / 1e6:.4f} ms over {len(v)} steps")
