@@ -1,15 +1,16 @@
 """Condense the rocprofv3 --pmc CSVs written by tools/pmc_passes.sh into profiles/rNN_pmc_summary.json.
-usage: python tools/pmc_summary.py <dir with pmc_*.csv> <out.json> [n_robots] [horizon]"""
+usage: python tools/pmc_summary.py <dir with pmc_*.csv> <out.json> [n_robots] [horizon] [kernel name substring, default mpc_solve_kernel]"""
 import csv, glob, json, os, sys
 from collections import defaultdict
 
 src, out = sys.argv[1], sys.argv[2]
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 h = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+kname = sys.argv[5] if len(sys.argv) > 5 else "mpc_solve_kernel"
 per = defaultdict(lambda: defaultdict(float))   # counter -> dispatch -> value
 for f in sorted(glob.glob(os.path.join(src, "*pmc_*.csv"))):
     for row in csv.DictReader(open(f)):
-        if "mpc_solve_kernel" not in row["Kernel_Name"]:   # the dominant kernel
+        if kname not in row["Kernel_Name"]:   # (default: the dominant kernel)
             continue
         per[row["Counter_Name"]][int(row["Dispatch_Id"])] += float(row["Counter_Value"])
 counters = {}
@@ -23,7 +24,7 @@ rec = n * ((2 * N + 3 * M + 60 * h + 2) + (N + 2 * M + 16 + 116)) * 8 * 2       
 c = counters
 summary = {
     "command": "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-control-loop --no-secondary (tools/pmc_passes.sh: one rocprofv3 --pmc pass per counter group, --kernel-trace only)",
-    "kernel": f"mpc_solve_kernel<{h}>, {n} robots per launch, mean of the 5 timed (warm-started) dispatches",
+    "kernel": f"{kname}<{h}>, {n} robots per launch, mean of the 5 timed (warm-started) dispatches",
     "counters_per_launch": counters,
     "hbm_traffic_bytes_per_launch": traffic,
     "traffic_rule": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM section) so it is doubled; other access widths and WRITE_SIZE are uncalibrated there, and the fabric counters include Infinity-Cache hits -- treat as an upper bound on HBM bytes",
