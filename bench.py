@@ -371,6 +371,7 @@ def cpu_baseline(wl, batches, W, h, sample=2048, steps=4, gpu_first_forces=None)
     from oracle.refmpc import RefBatch
     cores = usable_cores()
     sample = min(sample, len(wl.mass))
+    steps = max(1, min(steps, len(batches) - W))      # (--steps smaller than the default sample length)
     ref = RefBatch(wl.mass[:sample], wl.inertia_diag[:sample], h, wl.dt_mpc, wl.alpha)
     for s in range(W):
         ref.solve(batches[s][:sample], nthreads=cores)

@@ -267,3 +267,25 @@ def test_assembly_and_scaling_records_match_the_oracle(name):
         np.testing.assert_allclose(sc[r, :N], st["D"], rtol=1e-11)
         np.testing.assert_allclose(sc[r, N:N + M], st["E"], rtol=1e-11)
         assert abs(sc[r, -2] / st["c"] - 1) < 1e-11
+
+
+@pytest.mark.gpu
+def test_bench_contract_line():
+    """`python bench.py` prints ONE JSON line with the keys the driver reads (small sizes; the CPU baseline leg uses the oracle)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--robots", "256", "--steps", "3", "--warmup", "2", "--no-secondary", "--no-control-loop"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    b = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in b, key
+    assert b["n_gpus"] == 1 and b["steps"] == 3 and b["warmup"] == 2 and b["dtype"] == "f64" and b["scaling"] == "weak" and b["vs_baseline"] is None
+    assert b["value"] > 0 and abs(b["value"] - 256 * 3 / (b["ms_per_step"] * 3e-3)) < 1e-6 * b["value"]
+    r = b["roofline"]
+    assert r["bound"] == "vector_fp64" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    c = b["cpu_baseline"]
+    assert c["kind"] == "reference" and c["cores"] >= 1 and c["value"] > 0 and c["one_core"]["cores"] == 1
+    assert b["solved_fraction"] == 1.0 and b["max_grf_err_vs_osqp"] < 1e-5
