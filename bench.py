@@ -212,7 +212,7 @@ def main():
         traffic = None
     value = n_total * K / m["elapsed"]
     out = {
-        "metric": "MPC control steps/sec (whole node) @ horizon=10, 4096 robots; max |GRF| err vs OSQP",
+        "metric": f"MPC control steps/sec (whole node) @ horizon={h}, {n} robots; max |GRF| err vs OSQP",   # BASELINE.json's metric at the default configuration
         "value": value,
         "unit": "control steps/s",
         "n_gpus": world,

@@ -282,7 +282,7 @@ def test_bench_contract_line():
     b = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in b, key
-    assert b["n_gpus"] == 1 and b["steps"] == 3 and b["warmup"] == 2 and b["dtype"] == "f64" and b["scaling"] == "weak" and b["vs_baseline"] is None
+    assert b["metric"].startswith("MPC control steps/sec (whole node) @ horizon=10, 256 robots") and b["n_gpus"] == 1 and b["steps"] == 3 and b["warmup"] == 2 and b["dtype"] == "f64" and b["scaling"] == "weak" and b["vs_baseline"] is None
     assert b["value"] > 0 and abs(b["value"] - 256 * 3 / (b["ms_per_step"] * 3e-3)) < 1e-6 * b["value"]
     r = b["roofline"]
     assert r["bound"] == "vector_fp64" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
