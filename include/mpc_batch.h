@@ -33,12 +33,12 @@
  * (mpc_osqp.cc:781-794).  Here the robot's force row is left untouched and info[1] (status) != 1.
  *
  * info record (int32, 8 per robot): {iterations, osqp status_val, status_polish, rho_updates,
- * factorisations, first_run, 0, 0}.  status_val takes OSQP's values for SOLVED (1), MAX_ITER_REACHED (-2) and NON_CVX (-7;
- * also NaN / inf input -- the robot's warm-start record is then cleared, its next call starts cold).  OSQP's primal / dual
- * INFEASIBLE statuses (-3, -4, and their INACCURATE forms) are never reported: the infeasibility certificates of
- * auxil.c:364-515 are not evaluated, because this QP is always feasible (f = 0 satisfies every swing row, the cone and
- * box rows admit f_z in [f_min, f_max]) and strictly convex (alpha > 0); a caller-made infeasible problem (e.g. l > u from a
- * negative friction coefficient) ends as MAX_ITER_REACHED instead, which the reference treats the same way: empty result.
+ * factorisations, first_run, 0, 0}.  status_val takes OSQP's values (extern/osqp/include/constants.h:17-31): SOLVED (1),
+ * MAX_ITER_REACHED (-2), PRIMAL_INFEASIBLE (-3) / DUAL_INFEASIBLE (-4) when the certificates of auxil.c:364-515 hold at a
+ * termination check (evaluated exactly where check_termination does, auxil.c:732,744 -- a caller-made infeasible problem, e.g.
+ * negative friction coefficients, ends after 25-50 iterations like in OSQP, not after max_iter), their *_INACCURATE forms
+ * (2, 3, 4) from the second look at max_iter (osqp.c:563-568), and NON_CVX (-7; also NaN / inf input -- the robot's
+ * warm-start record is then cleared, its next call starts cold).  Only SOLVED returns forces, as in the reference.
  *
  * All pointers named d_* are DEVICE pointers (HBM); `stream` is a hipStream_t (0 = default stream).
  * Functions return 0 on success, a negative MPC_E_* code otherwise; mpc_last_error() gives the text.
@@ -62,7 +62,12 @@ enum {
 
 #define MPC_INFO_LEN 8
 #define MPC_STATUS_SOLVED 1           /* OSQP_SOLVED */
+#define MPC_STATUS_SOLVED_INACCURATE 2            /* at max_iter, the last check passes at 10 x the tolerances (osqp.c:563-568) */
+#define MPC_STATUS_PRIMAL_INFEASIBLE_INACCURATE 3
+#define MPC_STATUS_DUAL_INFEASIBLE_INACCURATE 4
 #define MPC_STATUS_MAX_ITER (-2)      /* OSQP_MAX_ITER_REACHED */
+#define MPC_STATUS_PRIMAL_INFEASIBLE (-3)         /* OSQP's certificate of auxil.c:364-424 holds */
+#define MPC_STATUS_DUAL_INFEASIBLE (-4)           /* ... of auxil.c:426-505 */
 #define MPC_STATUS_NON_CVX (-7)       /* OSQP_NON_CVX (also: KKT matrix not positive definite) */
 
 int mpc_input_len(int horizon);                       /* 56 + 4 h */
@@ -82,6 +87,12 @@ void mpc_batch_destroy(mpc_batch *b);
  *                    forces come out as ~1e-10 instead of qpOASES' exact zeros. */
 enum { MPC_SOLVER_OSQP = 0, MPC_SOLVER_EXACT = 1 };
 int mpc_batch_set_solver(mpc_batch *b, int solver);
+
+/* OSQP's max_iter setting (osqp_update_max_iter; the reference keeps the default 4000, extern/osqp/include/constants.h:60) for
+ * the OSQP mode: a positive multiple of 25, OSQP's check_termination interval.  A robot that reaches it reports what
+ * osqp.c:563-568 would: MAX_ITER_REACHED, or one of the *_INACCURATE statuses when the last check passes at ten times the
+ * tolerances. */
+int mpc_batch_set_max_iter(mpc_batch *b, int max_iter);
 
 /* d_in: [n, 56+4h] float32; d_forces: [n, 12h] float64; d_info: [n, 8] int32 (may be NULL). */
 int mpc_batch_solve(mpc_batch *b, const float *d_in, double *d_forces, int *d_info, void *stream);
@@ -112,7 +123,8 @@ int mpc_batch_set_state(mpc_batch *b, const double *h_state);
 /* What the prep kernel handed to the solve kernel in the last launch (parity tests of the assembly and of the Ruiz scaling):
  *   QP record    [n, mpc_batch_qp_len]    q[12h] l[20h] u[20h] cone[15] pad | B6[6x12] th1[6x6] th2[6] pad -- the QP of
  *                mpc_osqp.cc:606-688 with its Hessian in the wrench form P = BB^T Theta BB + alpha I (csrc/mpc_wrench.h);
- *   scale record [n, mpc_batch_scale_len] D[12h] E[20h] q_s[12h] A_s[15*4h] l_s[20h] u_s[20h] c 1/c -- OSQP's scaling.c output. */
+ *   scale record [n, mpc_batch_scale_len] D[12h] E[20h] q_s[12h] A_s[15*4h] l_s[20h] u_s[20h] c 1/c -- OSQP's scaling.c output -- and two
+ *                doubles of job hand-over (the ADMM part's residuals, read by the solve's polish job). */
 int mpc_batch_qp_len(const mpc_batch *b);
 int mpc_batch_scale_len(const mpc_batch *b);
 int mpc_batch_get_qp(mpc_batch *b, double *h_qp);

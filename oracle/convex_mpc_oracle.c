@@ -30,6 +30,7 @@ typedef struct {
   double *Px, *Ax;
   OSQPWorkspace *work; /* workspace_ (mpc_osqp.cc:276,550) */
   int structure_mismatch;
+  int max_iter; /* 0 = OSQP's default (what the reference runs); tests of the MAX_ITER_REACHED path lower it */
 } MpcRef;
 
 void *mpcref_create(double mass, const double *inertia9, int h, double dt, double alpha) {
@@ -117,6 +118,7 @@ int mpcref_solve(void *hd, const double *in, double *forces_out, int64_t *info, 
     settings.adaptive_rho_interval = 25;
     settings.eps_abs = 1e-3;
     settings.eps_rel = 1e-3;
+    if (s->max_iter > 0) settings.max_iter = s->max_iter;
     csc Pm = {nnzP, s->n, s->n, s->Pp, s->Pi, s->Px, -1};
     csc Am = {nnzA, s->m, s->n, s->Ap, s->Ai, s->Ax, -1};
     OSQPData data;
@@ -152,6 +154,14 @@ int mpcref_solve(void *hd, const double *in, double *forces_out, int64_t *info, 
   if (oi->status_val != OSQP_SOLVED) return 0; /* :788-794 */
   for (int i = 0; i < s->n; ++i) forces_out[i] = -s->work->solution->x[i];
   return 1;
+}
+
+/* OSQP's max_iter setting (the reference leaves the default, 4000): lets the tests reach MAX_ITER_REACHED and the *_INACCURATE
+ * statuses of osqp.c:563-568 on ordinary problems. */
+void mpcref_set_max_iter(void *hd, int max_iter) {
+  MpcRef *s = (MpcRef *)hd;
+  s->max_iter = max_iter;
+  if (s->work && max_iter > 0) osqp_update_max_iter(s->work, max_iter);
 }
 
 /*

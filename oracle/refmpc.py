@@ -44,6 +44,7 @@ def lib():
         _LIB.mpcref_assemble_only.argtypes = [C.c_void_p, C.c_void_p]
         _LIB.mpcref_get_dyn.argtypes = [C.c_void_p] * 5
         _LIB.mpcref_batch_solve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        _LIB.mpcref_set_max_iter.argtypes = [C.c_void_p, C.c_int]
     return _LIB
 
 
@@ -101,6 +102,10 @@ class RefConvexMpc:
     def reset_solver(self):
         pass  # mpc_osqp.cc:576 only flips a flag nothing reads
 
+    def set_max_iter(self, max_iter):
+        """OSQP's max_iter setting (reference: the default 4000); tests lower it to reach the MAX_ITER_REACHED path."""
+        lib().mpcref_set_max_iter(self._h, int(max_iter))
+
     # --- test access -------------------------------------------------------------------------
     def qp(self):
         P = np.zeros((self.n, self.n)); q = np.zeros(self.n); l = np.zeros(self.m); u = np.zeros(self.m)
@@ -137,6 +142,10 @@ class RefBatch:
             self.objs.append(RefConvexMpc(mass[i], [d[0], 0, 0, 0, d[1], 0, 0, 0, d[2]], 4, h, dt, alpha))
         self._handles = (C.c_void_p * n)(*[o._h for o in self.objs])
         self.info = np.zeros((n, 8), dtype=np.int64)
+
+    def set_max_iter(self, max_iter):
+        for o in self.objs:
+            o.set_max_iter(max_iter)
 
     def solve(self, records, nthreads=1):
         n = len(self.objs)

@@ -11,7 +11,7 @@ _LIB = None
 MPC_OK = 0
 SYMBOLS = [
     "mpc_input_len", "mpc_supported_horizons", "mpc_batch_create", "mpc_batch_destroy", "mpc_batch_solve",
-    "mpc_batch_set_solver", "mpc_batch_solve_f64", "mpc_batch_reset", "mpc_batch_reset_device", "mpc_batch_solve_host", "mpc_batch_solve_host_f64", "mpc_batch_size", "mpc_batch_horizon", "mpc_batch_device_bytes",
+    "mpc_batch_set_solver", "mpc_batch_set_max_iter", "mpc_batch_solve_f64", "mpc_batch_reset", "mpc_batch_reset_device", "mpc_batch_solve_host", "mpc_batch_solve_host_f64", "mpc_batch_size", "mpc_batch_horizon", "mpc_batch_device_bytes",
     "mpc_batch_state_len", "mpc_batch_get_state", "mpc_batch_set_state", "mpc_batch_qp_len", "mpc_batch_scale_len", "mpc_batch_get_qp", "mpc_batch_get_scale", "mpc_batch_get_profile", "mpc_batch_enable_timing",
     "mpc_batch_kernel_times", "mpc_last_error",
     "mpc_ctrl_create", "mpc_ctrl_destroy", "mpc_ctrl_step", "mpc_ctrl_run", "mpc_ctrl_reset", "mpc_ctrl_reset_device", "mpc_ctrl_set_gait", "mpc_ctrl_solver_info",
@@ -48,6 +48,7 @@ def lib():
         L.mpc_batch_solve_host_f64.argtypes = [vp, vp, vp, vp]; L.mpc_batch_solve_host_f64.restype = ci
         L.mpc_batch_solve_f64.argtypes = [vp, vp, vp, vp, vp]; L.mpc_batch_solve_f64.restype = ci
         L.mpc_batch_set_solver.argtypes = [vp, ci]; L.mpc_batch_set_solver.restype = ci
+        L.mpc_batch_set_max_iter.argtypes = [vp, ci]; L.mpc_batch_set_max_iter.restype = ci
         L.mpc_batch_size.argtypes = [vp]; L.mpc_batch_size.restype = ci
         L.mpc_batch_horizon.argtypes = [vp]; L.mpc_batch_horizon.restype = ci
         L.mpc_batch_device_bytes.argtypes = [vp]; L.mpc_batch_device_bytes.restype = C.c_longlong

@@ -60,6 +60,10 @@ class BatchedConvexMpc:
                    "mpc_batch_solve")
         return forces, info
 
+    def set_max_iter(self, max_iter):
+        """OSQP's max_iter setting (the reference keeps the default 4000): a positive multiple of 25."""
+        _lib.check(_lib.lib().mpc_batch_set_max_iter(self._handle, int(max_iter)), "mpc_batch_set_max_iter")
+
     def reset(self, env_ids=None):
         import torch
         stream = torch.cuda.current_stream(self.device).cuda_stream

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -114,6 +115,8 @@ struct DeviceExec {
   }
 };
 
+constexpr int kSchedNext = 0, kSchedHead = 1, kSchedTail = 2, kSchedJobs = 3, kSchedLen = 4;   // job bookkeeping of a launch (mpc_solve_jobs_kernel)
+
 // Solve kernel (mpc_wrench.h Solver): ADMM + polish of every active robot, from the QP and scale records.  EXACT: the
 // exact-optimum mode (the reference's qpOASES branch) -- a separate instantiation, so that its outer loop does not touch the
 // register allocation of the OSQP mode.
@@ -121,13 +124,12 @@ template <int H, bool EXACT>
 __global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES : MPC_SOLVE_MIN_WAVES_WIDE)) void mpc_solve_kernel(
     int n, const RobotModel *__restrict__ models, double *__restrict__ state, const double *__restrict__ qp,
     const double *__restrict__ sc, double *__restrict__ forces, int *__restrict__ info, long long *__restrict__ prof,
-    const int *__restrict__ active, const int *__restrict__ order) {
+    const int *__restrict__ order, const int *__restrict__ sched, int max_iter) {
   // static LDS: absolute addresses fold into the ds_* offset fields
   __shared__ __attribute__((aligned(16))) Shared<H> sh;
   using C = Cfg<H>;
-  if ((int)blockIdx.x >= n) return;
-  const int robot = order ? order[blockIdx.x] : (int)blockIdx.x;   // longest-expected solves first (order_block)
-  if (active && !active[robot]) return;   // robots whose controller is between two MPC updates
+  if ((int)blockIdx.x >= sched[kSchedJobs]) return;   // (the job list holds the active robots only: robots whose controller is between two MPC updates have no job)
+  const int robot = order[blockIdx.x];                // longest-expected solves first (order_block)
   WThread<H> th;
   th.init(threadIdx.x);
 #pragma unroll
@@ -145,7 +147,86 @@ __global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES
                                        info + (size_t)robot * kInfoLen,
                                        prof ? prof + (size_t)robot * kProfLen : nullptr};
   if constexpr (EXACT) sv.exact();
+  else sv.max_iter = max_iter;
   sv.template run<EXACT>();
+}
+
+// The OSQP-mode solve as a PERSISTENT kernel: one workgroup per wave slot of the chip, each pulling jobs until none is left.  A solve
+// is two jobs (mpc_wrench.h admm_job / polish_job): the ADMM part, 25 to 250+ iterations long, and the polish, the same ~100 k cycles for
+// every robot and dependent on the ADMM part's result only (x, z, y in the state record, two residuals).  With one job per robot a
+// 4096-robot launch is four jobs of very different length per wave slot, and the launch ends when the unluckiest slot does
+// (measured 0.69 ms against 0.55 ms of work per slot, tools/sched_model.py); with the polishes as uniform filler jobs -- taken only
+// once no ADMM job is left to start -- the tail shrinks to a fraction of one polish.
+//   sched[kSchedNext]  next ADMM job (index into `order`)          sched[kSchedTail]  polish entries published
+//   sched[kSchedHead]  next polish entry to take                   sched[kSchedJobs]  number of jobs (active robots; order_block)
+//   ready[i]           -1 not yet published; robot: polish it; -2: that solve needs no polish (not SOLVED)
+// An ADMM job publishes exactly one entry, in completion order, after a device-scope release of its results; a wave that takes entry
+// i spins until it is there (every job of the launch is then running or done, so the wait is bounded by the longest ADMM part)
+// and acquires before it loads the record.
+template <int H>
+__global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES : MPC_SOLVE_MIN_WAVES_WIDE)) void mpc_solve_jobs_kernel(
+    const RobotModel *__restrict__ models, double *__restrict__ state, const double *__restrict__ qp, double *__restrict__ sc,
+    double *__restrict__ forces, int *__restrict__ info, long long *__restrict__ prof, const int *__restrict__ order, int *__restrict__ sched,
+    int *__restrict__ ready, int max_iter) {
+  __shared__ __attribute__((aligned(16))) Shared<H> sh;
+  __shared__ int job;
+  using C = Cfg<H>;
+  using Ex = DeviceExec<WThread<H>, (C::TW <= 64)>;
+  WThread<H> th;
+  th.init(threadIdx.x);
+  Ex ex{th};
+  const int njobs = sched[kSchedJobs];
+  auto solver = [&](int robot) {
+    return Solver<H, Ex>{ex, sh, models[robot], state + (size_t)robot * state_len<H>(), qp + (size_t)robot * C::QP_LEN, sc + (size_t)robot * C::SC_LEN,
+                         forces + (size_t)robot * C::N, info + (size_t)robot * kInfoLen, prof ? prof + (size_t)robot * kProfLen : nullptr};
+  };
+  for (;;) {     // ---- ADMM jobs, in the dispatch order of order_block
+    ex.par([&](WThread<H> &t) { if (t.tid == 0) job = atomicAdd(&sched[kSchedNext], 1); });
+    const int idx = job;
+    ex.par([](WThread<H> &) {});     // (everybody has read `job` before thread 0 overwrites it)
+    if (idx >= njobs) break;
+    const int robot = order[idx];
+#pragma unroll
+    for (int j = 0; j < C::TE; ++j) th.Mx[j] = 0;
+    bool pol;
+    {
+      Solver<H, Ex> sv = solver(robot);
+      sv.max_iter = max_iter;
+      sv.jobrec = sc + (size_t)robot * C::SC_LEN + C::SC_JOB;
+      pol = sv.admm_job();
+    }
+    // the job's results are device-coherent stores (MPC_GST): once they have completed -- a workgroup-scope release is the wait for
+    // that, with no L2 write-back -- the entry may be published
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    ex.par([&](WThread<H> &t) {
+      if (t.tid == 0) {
+        const int pos = atomicAdd(&sched[kSchedTail], 1);
+        __hip_atomic_store(&ready[pos], pol ? robot : -2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    });
+  }
+  for (;;) {     // ---- polish jobs, in completion order of the ADMM parts
+    ex.par([&](WThread<H> &t) {
+      if (t.tid == 0) {
+        const int pos = atomicAdd(&sched[kSchedHead], 1);
+        int e = -2;
+        if (pos < njobs) {
+          while ((e = __hip_atomic_load(&ready[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == -1) __builtin_amdgcn_s_sleep(32);
+        } else e = -3;
+        job = e;
+      }
+    });
+    const int e = job;
+    ex.par([](WThread<H> &) {});
+    if (e == -3) break;
+    if (e < 0) continue;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // (the ADMM job's results are read with device-coherent loads, MPC_GLD: no L2 invalidate)
+#pragma unroll
+    for (int j = 0; j < C::TE; ++j) th.Mx[j] = 0;
+    Solver<H, Ex> sv = solver(e);
+    sv.jobrec = sc + (size_t)e * C::SC_LEN + C::SC_JOB;
+    sv.polish_job();
+  }
 }
 
 // Workgroup -> robot order for the solve kernel of THIS launch: robots sorted by the shader cycles their previous solve took,
@@ -158,9 +239,15 @@ __global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES
 // short but runs long is what stretches the tail (tools/tail_model.py: ordering by the previous solve alone 0.717 ms per
 // launch on average, by this key 0.692, clairvoyant 0.650).
 constexpr int kOrderBuckets = 256, kOrderHistory = 10;
-__device__ void order_block(int n, const long long *__restrict__ prof, unsigned char *__restrict__ hist, int slot, int *__restrict__ order) {
+// Also the launch's job bookkeeping: only ACTIVE robots (active == null: all) enter the list, sched[kSchedJobs] = their number, the
+// job counters and the polish entries of mpc_solve_jobs_kernel are reset.
+__device__ void order_block(int n, const long long *__restrict__ prof, unsigned char *__restrict__ hist, int slot, int *__restrict__ order,
+                            const int *__restrict__ active, int *__restrict__ sched, int *__restrict__ ready) {
   __shared__ int cnt[kOrderBuckets], base[kOrderBuckets];
+  __shared__ int filled;
   for (int b = threadIdx.x; b < kOrderBuckets; b += blockDim.x) cnt[b] = 0;
+  for (int r = threadIdx.x; r < n; r += blockDim.x) ready[r] = -1;
+  if (threadIdx.x == 0) filled = 0;
   __syncthreads();
   constexpr int kPer = 8;                         // robots per thread held in registers (n <= 8192 per pass)
   for (int r0 = 0; r0 < n; r0 += kPer * blockDim.x) {
@@ -169,7 +256,7 @@ __device__ void order_block(int n, const long long *__restrict__ prof, unsigned 
     for (int i = 0; i < kPer; ++i) {
       const int r = r0 + i * blockDim.x + threadIdx.x;
       bk[i] = -1;
-      if (r < n) {
+      if (r < n && (!active || active[r])) {
         const long long c = prof[(size_t)r * kProfLen + kProfLen - 1] >> 14;
         unsigned char *hr = hist + (size_t)r * kOrderHistory;
         hr[slot] = (unsigned char)(c < 0 ? 0 : (c >= kOrderBuckets ? kOrderBuckets - 1 : c));
@@ -182,8 +269,9 @@ __device__ void order_block(int n, const long long *__restrict__ prof, unsigned 
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-      int acc = r0;                               // earlier passes fill the front of `order` (only n > 8192 has several)
+      int acc = filled;                           // earlier passes fill the front of `order` (only n > 8192 has several)
       for (int b = kOrderBuckets - 1; b >= 0; --b) { base[b] = acc; acc += cnt[b]; cnt[b] = 0; }
+      filled = acc;
     }
     __syncthreads();
 #pragma unroll
@@ -191,6 +279,7 @@ __device__ void order_block(int n, const long long *__restrict__ prof, unsigned 
       if (bk[i] >= 0) order[base[bk[i]] + rank[i]] = r0 + i * blockDim.x + threadIdx.x;
     __syncthreads();
   }
+  if (threadIdx.x == 0) { sched[kSchedNext] = 0; sched[kSchedHead] = 0; sched[kSchedTail] = 0; sched[kSchedJobs] = filled; }
 }
 
 // Prep kernel (mpc_core.h Assembler + Scaler): QP record (q, bounds, cone block, wrench form of P) and scale record (OSQP's Ruiz
@@ -199,11 +288,11 @@ template <int H>
 __global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= MPC_MIN_WAVES_MAX_T && Cfg<H>::NT == 1 ? MPC_SCALE_MIN_WAVES : 1)) void mpc_prep_kernel(
     int n, const RobotModel *__restrict__ models, const float *__restrict__ in, const double *__restrict__ in64, const double *__restrict__ state,
     double *__restrict__ qp, double *__restrict__ sc, long long *__restrict__ prof, const int *__restrict__ active, int *__restrict__ order,
-    unsigned char *__restrict__ hist, int hist_slot) {
+    unsigned char *__restrict__ hist, int hist_slot, int *__restrict__ sched, int *__restrict__ ready) {
   __shared__ __attribute__((aligned(16))) PrepShared<H> sh;
   using C = Cfg<H>;
-  if (blockIdx.x == 0) {      // the extra workgroup (first, so that it starts at once): dispatch order of the solve kernel that follows
-    if (order) order_block(n, prof, hist, hist_slot, order);
+  if (blockIdx.x == 0) {      // the extra workgroup (first, so that it starts at once): job list / dispatch order of the solve kernel that follows
+    order_block(n, prof, hist, hist_slot, order, active, sched, ready);
     return;
   }
   const int robot = (int)blockIdx.x - 1;
@@ -232,12 +321,15 @@ __global__ void reset_kernel(double *state, int state_len, const int *ids, int k
 
 template <int H>
 int launch(int n, const RobotModel *models, const float *in, const double *in64, double *state, double *qp, double *sc, double *forces, int *info,
-           long long *prof, const int *active, const int *order, unsigned char *hist, int hist_slot, hipEvent_t *ev, hipStream_t stream, int exact) {
+           long long *prof, const int *active, int *order, unsigned char *hist, int hist_slot, hipEvent_t *ev, hipStream_t stream, int exact, int max_iter,
+           int *sched, int *ready, int job_slots) {
   if (ev) (void)hipEventRecord(ev[0], stream);
-  hipLaunchKernelGGL(mpc_prep_kernel<H>, dim3(n + 1), dim3(Cfg<H>::T), 0, stream, n, models, in, in64, state, qp, sc, prof, active, const_cast<int *>(order), hist, hist_slot);
+  hipLaunchKernelGGL(mpc_prep_kernel<H>, dim3(n + 1), dim3(Cfg<H>::T), 0, stream, n, models, in, in64, state, qp, sc, prof, active, order, hist, hist_slot, sched, ready);
   if (ev) (void)hipEventRecord(ev[1], stream);
-  if (exact) hipLaunchKernelGGL((mpc_solve_kernel<H, true>), dim3(n), dim3(Cfg<H>::TW), 0, stream, n, models, state, qp, sc, forces, info, prof, active, order);
-  else hipLaunchKernelGGL((mpc_solve_kernel<H, false>), dim3(n), dim3(Cfg<H>::TW), 0, stream, n, models, state, qp, sc, forces, info, prof, active, order);
+  if (exact) hipLaunchKernelGGL((mpc_solve_kernel<H, true>), dim3(n), dim3(Cfg<H>::TW), 0, stream, n, models, state, qp, sc, forces, info, prof, order, sched, max_iter);
+  else if (job_slots > 0 && H == 10)   // the benchmark horizon: persistent waves, ADMM and polish as separate jobs
+    hipLaunchKernelGGL((mpc_solve_jobs_kernel<H>), dim3(n < job_slots ? n : job_slots), dim3(Cfg<H>::TW), 0, stream, models, state, qp, sc, forces, info, prof, order, sched, ready, max_iter);
+  else hipLaunchKernelGGL((mpc_solve_kernel<H, false>), dim3(n), dim3(Cfg<H>::TW), 0, stream, n, models, state, qp, sc, forces, info, prof, order, sched, max_iter);
   if (ev) (void)hipEventRecord(ev[2], stream);
   HIP_TRY(hipGetLastError());
   return MPC_OK;
@@ -255,18 +347,21 @@ struct mpc_batch {
   double *d_state = nullptr, *d_qp = nullptr, *d_sc = nullptr;   // warm start, QP record (q, l, u, cone, wrench form of P), scale record
   int *d_info = nullptr;   // used when the caller passes no info buffer
   long long *d_prof = nullptr;   // per-robot section cycle counts of the last solve
-  int *d_order = nullptr;        // workgroup -> robot map of the solve kernel (order_block, written by the assembly launch)
+  int *d_order = nullptr;        // job list of the solve kernel: the launch's active robots, longest expected solve first (order_block, written by the prep launch)
+  int *d_sched = nullptr;        // [kSchedLen] job counters of the launch; d_ready [n]: polish entries (mpc_solve_jobs_kernel)
+  int *d_ready = nullptr;
+  int job_slots = 0;             // wave slots of the device for the persistent job kernel (0: one workgroup per robot)
   bool timing = false;           // mpc_batch_enable_timing: HIP events around the two kernels of each launch
   hipEvent_t ev[kTimingRing][3];
   long long launches = 0;
   float *d_host_in = nullptr;    // staging for mpc_batch_solve_host
   double *d_host_in64 = nullptr; // ... and mpc_batch_solve_host_f64
   double *d_host_f = nullptr;
-  bool order_valid = false;
   unsigned char *d_hist = nullptr;   // [n][kOrderHistory] cycles / 16384 of the last solves (order_block's sort key is their maximum)
   unsigned long long order_launches = 0;
   int device = 0;                // the HIP device the handle was created on: every entry point makes it current
   int exact = 0;                 // mpc_batch_set_solver: 1 = the QP's exact optimum (the reference's qpOASES branch), cold on every call
+  int max_iter = kMaxIter;       // mpc_batch_set_max_iter: OSQP's max_iter setting (OSQP mode)
   long long bytes = 0;
 };
 
@@ -274,19 +369,19 @@ struct mpc_batch {
 // one solver launch on b's robots (+ the dispatch order for the next one)
 static int launch_solver(mpc_batch *b, const float *d_in, double *d_forces, int *d_info, const int *d_active, hipStream_t st, const double *d_in64 = nullptr) {
   HIP_TRY(hipSetDevice(b->device));
-  const int *order = b->order_valid ? b->d_order : nullptr;
   const int slot = (int)(b->order_launches++ % kOrderHistory);
   if (b->exact) HIP_TRY(hipMemsetAsync(b->d_state, 0, sizeof(double) * (size_t)b->n * b->state_len, st));   // no warm start in that branch (mpc_osqp.cc:906-919)
   hipEvent_t *ev = b->timing ? b->ev[b->launches % kTimingRing] : nullptr;
   int rc = MPC_E_HORIZON;
+#define MPC_LAUNCH(HH) launch<HH>(b->n, b->d_models, d_in, d_in64, b->d_state, b->d_qp, b->d_sc, d_forces, d_info, b->d_prof, d_active, b->d_order, b->d_hist, slot, ev, st, b->exact, b->max_iter, b->d_sched, b->d_ready, b->job_slots)
   switch (b->h) {
-    case 10: rc = launch<10>(b->n, b->d_models, d_in, d_in64, b->d_state, b->d_qp, b->d_sc, d_forces, d_info, b->d_prof, d_active, order, b->d_hist, slot, ev, st, b->exact); break;
-    case 16: rc = launch<16>(b->n, b->d_models, d_in, d_in64, b->d_state, b->d_qp, b->d_sc, d_forces, d_info, b->d_prof, d_active, order, b->d_hist, slot, ev, st, b->exact); break;
-    case 20: rc = launch<20>(b->n, b->d_models, d_in, d_in64, b->d_state, b->d_qp, b->d_sc, d_forces, d_info, b->d_prof, d_active, order, b->d_hist, slot, ev, st, b->exact); break;
+    case 10: rc = MPC_LAUNCH(10); break;
+    case 16: rc = MPC_LAUNCH(16); break;
+    case 20: rc = MPC_LAUNCH(20); break;
   }
+#undef MPC_LAUNCH
   if (rc == MPC_E_HORIZON) return fail(MPC_E_HORIZON, "solver launch: horizon not compiled in");
   if (rc != MPC_OK) return rc;
-  b->order_valid = true;     // from the second launch on there are cycle counts to sort by
   b->launches++;
   return MPC_OK;
 }
@@ -327,11 +422,20 @@ int mpc_batch_create(mpc_batch **out, int n, int horizon, double timestep, doubl
       (e = hipMalloc(&b->d_prof, sizeof(long long) * (size_t)n * kProfLen)) != hipSuccess ||
       (e = hipMalloc(&b->d_order, sizeof(int) * (size_t)n)) != hipSuccess ||
       (e = hipMalloc(&b->d_hist, (size_t)n * kOrderHistory)) != hipSuccess ||
+      (e = hipMalloc(&b->d_sched, sizeof(int) * kSchedLen)) != hipSuccess ||
+      (e = hipMalloc(&b->d_ready, sizeof(int) * (size_t)n)) != hipSuccess ||
+      (e = hipMemset(b->d_prof, 0, sizeof(long long) * (size_t)n * kProfLen)) != hipSuccess ||
       (e = hipMemcpy(b->d_models, models.data(), sizeof(RobotModel) * n, hipMemcpyHostToDevice)) != hipSuccess ||
       (e = hipMemset(b->d_hist, 0, (size_t)n * kOrderHistory)) != hipSuccess ||
       (e = hipMemset(b->d_state, 0, sizeof(double) * (size_t)n * b->state_len)) != hipSuccess) {
     cleanup();
     return fail(MPC_E_HIP, std::string("mpc_batch_create: ") + hipGetErrorString(e));
+  }
+  {   // the persistent job kernel runs one workgroup per wave slot: four single-wave workgroups per CU (one per SIMD, full register budget)
+    hipDeviceProp_t prop;
+    const char *env = getenv("MPC_SOLVE_JOBS");      // tuning hook: 0 = one workgroup per robot (the round-2 launch), N > 0 = that many slots
+    if (hipGetDeviceProperties(&prop, b->device) == hipSuccess) b->job_slots = 4 * prop.multiProcessorCount;
+    if (env) b->job_slots = atoi(env);
   }
   b->bytes = (long long)(sizeof(RobotModel) * n + sizeof(double) * (size_t)n * (b->state_len + qp_len + sc_len) + sizeof(int) * (size_t)n * kInfoLen);
   *out = b;
@@ -348,6 +452,8 @@ void mpc_batch_destroy(mpc_batch *b) {
   if (b->d_prof) (void)hipFree(b->d_prof);
   if (b->d_order) (void)hipFree(b->d_order);
   if (b->d_hist) (void)hipFree(b->d_hist);
+  if (b->d_sched) (void)hipFree(b->d_sched);
+  if (b->d_ready) (void)hipFree(b->d_ready);
   if (b->timing) for (auto &e3 : b->ev) for (auto &e : e3) (void)hipEventDestroy(e);
   if (b->d_host_in) (void)hipFree(b->d_host_in);
   if (b->d_host_in64) (void)hipFree(b->d_host_in64);
@@ -365,6 +471,12 @@ int mpc_batch_solve(mpc_batch *b, const float *d_in, double *d_forces, int *d_in
 int mpc_batch_set_solver(mpc_batch *b, int solver) {
   if (!b || (solver != MPC_SOLVER_OSQP && solver != MPC_SOLVER_EXACT)) return fail(MPC_E_ARG, "mpc_batch_set_solver: MPC_SOLVER_OSQP (0) or MPC_SOLVER_EXACT (1)");
   b->exact = solver == MPC_SOLVER_EXACT;
+  return MPC_OK;
+}
+
+int mpc_batch_set_max_iter(mpc_batch *b, int max_iter) {
+  if (!b || max_iter <= 0 || max_iter % kCheck != 0) return fail(MPC_E_ARG, "mpc_batch_set_max_iter: a positive multiple of 25 (OSQP's check_termination interval)");
+  b->max_iter = max_iter;
   return MPC_OK;
 }
 

@@ -50,7 +50,14 @@
 // Two adjacent doubles (16-byte aligned) as one ds_read_b128 that is neither hoisted out of a loop nor split
 typedef double mpc_double2 __attribute__((ext_vector_type(2)));
 #define MPC_LDS_LOAD128(p, lo, hi) do { const mpc_double2 v2_ = *(const volatile __attribute__((address_space(3))) mpc_double2 *)(p); (lo) = v2_.x; (hi) = v2_.y; } while (0)
+// Loads / stores of what one job of a solve hands to the other (mpc_wrench.h admm_job -> polish_job: the state record, forces, info): device-scope
+// coherent accesses (sc1: stores write through, loads do not trust a possibly stale line of this XCD's L2), so that the hand-over needs no
+// L2 write-back / invalidate -- the jobs of one solve may run on different XCDs, each with its own L2.
+#define MPC_GST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define MPC_GLD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #else
+#define MPC_GST(p, v) (*(p) = (v))
+#define MPC_GLD(p) (*(p))
 #define MPC_LDS_LOAD128(p, lo, hi) do { (lo) = (p)[0]; (hi) = (p)[1]; } while (0)
 #define MPC_LDS_STORE64(p, v) (*(p) = (v))
 #define MPC_LDS_LOAD64(p) (*(p))
@@ -90,7 +97,8 @@ constexpr int kPolishRefine = 3;
 constexpr double kGravity = 9.8, kMaxScale = 10.0, kMinScale = 0.1;  // mpc_osqp.cc:54-56
 
 // OSQP status values (constants.h:17-31)
-constexpr int kStSolved = 1, kStSolvedInaccurate = 2, kStMaxIter = -2, kStNonCvx = -7, kStUnsolved = -10;
+constexpr int kStSolved = 1, kStSolvedInaccurate = 2, kStPrimInfInaccurate = 3, kStDualInfInaccurate = 4, kStMaxIter = -2, kStPrimInf = -3, kStDualInf = -4,
+              kStNonCvx = -7, kStUnsolved = -10;
 
 template <int H>
 struct Cfg {
@@ -122,9 +130,10 @@ struct Cfg {
   //   q[N] l[M] u[M] cone[15] pad | B6[6 x 12] th1[6 x 6] th2[6] pad2   (the wrench-space description of P, mpc_wrench.h)
   static constexpr int QP_Q = 0, QP_L = N, QP_U = N + M, QP_CONE = N + 2 * M, QP_B6 = N + 2 * M + 16, QP_TH1 = QP_B6 + 72,
                        QP_TH2 = QP_TH1 + 36, QP_LEN = QP_TH2 + 8;
-  // The scale record the scaling kernel hands to the solve kernel: D[N] E[M] q_s[N] A_s[15 NF] l_s[M] u_s[M] c 1/c
+  // The scale record the scaling kernel hands to the solve kernel: D[N] E[M] q_s[N] A_s[15 NF] l_s[M] u_s[M] c 1/c | job[2]
+  // (job: primal / dual residual of the ADMM part's result, from the ADMM job of a solve to its polish job, mpc_wrench.h)
   static constexpr int SC_D = 0, SC_E = N, SC_QS = N + M, SC_AS = 2 * N + M, SC_LS = SC_AS + 15 * NF, SC_US = SC_LS + M,
-                       SC_C = SC_US + M, SC_LEN = SC_C + 2;
+                       SC_C = SC_US + M, SC_JOB = SC_C + 2, SC_LEN = SC_C + 4;
   // ---- wrench grid of the solve kernel (mpc_wrench.h): the 6 H x 6 H core matrix as H x H tiles of 6 x 6, one per thread
   static constexpr int NW = 6 * H, GW = H, MTW = H * (H + 1) / 2;
   static constexpr int TW = (((MTW > NW ? MTW : NW) + 63) / 64) * 64;   // solve-kernel workgroup: 64 (h = 10), 192, 256

@@ -90,7 +90,8 @@ template <int H>
 struct Shared {
   using C = Cfg<H>;
   static constexpr int RW = ((C::NF + 1) & ~1);                         // row stride of the residual scratch
-  static constexpr int PARTLEN_A = C::GW * C::NPW, PARTLEN_B = 14 * RW;
+  static constexpr int NRED = 21;                                       // residual / certificate reductions (Solver::residuals)
+  static constexpr int PARTLEN_A = C::GW * C::NPW, PARTLEN_B = NRED * RW;
   static constexpr int PARTLEN = PARTLEN_A > PARTLEN_B ? PARTLEN_A : PARTLEN_B;
   MPC_V B6[72]; MPC_V th1[36]; MPC_V th2[8];
   double c, cinv, rho, calpha;
@@ -101,6 +102,7 @@ struct Shared {
   MPC_V fa[C::NF * 16];                                 // 0-8: the non-zeros of the scaled cone block, 9: l of row 4, 10-14: u of the five rows
   MPC_V fr[C::NF * 10];                                 // 0-8: the cone block times rho of its row (factorisation)
   MPC_V Gf[C::NF * 18];                                 // per foot: G_f = T_k W_f (6 x 3) of the current factorisation
+  MPC_V dxy[C::NF * 8];                                 // per foot: delta_x (0-2) and delta_y (3-7) of the last iteration before a check (auxil.c:187-228)
   // the published pivot rows are double buffered -- except where the workgroup is a single wavefront in lock step (MPC_LOCKSTEP:
   // the device build at h = 10), whose LDS instructions execute in program order: every lane has read the pair before any lane
   // publishes the next one
@@ -113,12 +115,15 @@ struct Shared {
     MPC_V part[PARTLEN];                                // [slot][row] partial products of the tile mat-vec; residual scratch [14][RW]
     struct { MPC_V Lk[H * 36]; MPC_V Tk[H * 36]; };     // factorisation only: per step Z_k = L L^T, T = L^-1 (zero columns / rows at dropped pivots)
   };
-  unsigned long long red[16];
-  int first, iter, status, status_polish, rho_updates, nfact, done, bad, pol_ok, sig_changed, loose_ok;
+  unsigned long long red[24];
+  int first, iter, status, status_polish, rho_updates, nfact, done, bad, pol_ok, sig_changed, loose_ok, dual_cand;
   double pri_res, dua_res, rho_new;
 };
 #undef MPC_V
 
+#ifdef MPC_EMU_DEBUG
+static long g_checks = 0, g_dual_cands = 0;   // host emulation only: how often the dual certificate's expensive part runs
+#endif
 template <int H, class Exec>
 struct Solver {
   using C = Cfg<H>;
@@ -385,31 +390,33 @@ struct Solver {
       if (t.tid < NF) {
         const int f = t.tid;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { t.x[c] = state[3 * f + c]; t.q[c] = sc[C::SC_QS + 3 * f + c]; }
+        for (int c = 0; c < 3; ++c) { t.x[c] = MPC_GLD(state + 3 * f + c); t.q[c] = sc[C::SC_QS + 3 * f + c]; }
         const double *as = sc + C::SC_AS + 15 * f;
         s.fa[pidx(0, f)] = as[0]; s.fa[pidx(1, f)] = as[2]; s.fa[pidx(2, f)] = as[3]; s.fa[pidx(3, f)] = as[5]; s.fa[pidx(4, f)] = as[7];
         s.fa[pidx(5, f)] = as[8]; s.fa[pidx(6, f)] = as[10]; s.fa[pidx(7, f)] = as[11]; s.fa[pidx(8, f)] = as[14]; s.fa[pidx(15, f)] = 0.0;
         int tyb = 0;
 #pragma unroll
         for (int r = 0; r < 5; ++r) {
-          t.z[r] = state[N + 5 * f + r]; t.y[r] = state[N + M + 5 * f + r];   // scaled iterates of the previous call; zeros on the first call
+          t.z[r] = MPC_GLD(state + N + 5 * f + r); t.y[r] = MPC_GLD(state + N + M + 5 * f + r);   // scaled iterates of the previous call; zeros on the first call
           const double lo = sc[C::SC_LS + 5 * f + r], hi = sc[C::SC_US + 5 * f + r];
           s.fa[pidx(10 + r, f)] = hi;
           if (r == 4) s.fa[pidx(9, f)] = lo;
           // set_rho_vec / update_rho_vec (auxil.c:79-141): the row type is a function of the scaled bounds
           const int ty = (lo < -kInfty * kMinScaling && hi > kInfty * kMinScaling) ? 0 : (hi - lo < kRhoTol ? 2 : 1);
           tyb |= ty << (2 * r);
+          if (lo > hi) tyb |= 1 << 10;     // OSQP refuses such data (validate_data, auxil.c:795-830; the reference then has no workspace)
         }
         t.tyb = tyb;
       }
       if (t.tid == 0) {
-        const bool first = state[2 * N + 2 * M + 1] == 0.0;
+        const bool first = MPC_GLD(state + 2 * N + 2 * M + 1) == 0.0;
         s.first = first;
-        s.rho = first ? kRho0 : state[2 * N + 2 * M];
+        s.rho = first ? kRho0 : MPC_GLD(state + 2 * N + 2 * M);
         s.c = sc[C::SC_C]; s.cinv = sc[C::SC_C + 1]; s.calpha = sc[C::SC_C] * mdl.alpha;
         s.status = kStUnsolved; s.status_polish = 0; s.rho_updates = 0; s.nfact = 0; s.iter = 0; s.done = 0; s.bad = 0; s.pol_ok = 0; s.sig_changed = 0; s.loose_ok = 0;
       }
     });
+    ex.par([&](Th &t) { if (t.tid < NF && (t.tyb >> 10)) s.bad = 1; });
     lap(0);
   }
   // my foot's constants, fetched where they are used (volatile 64-bit LDS loads: the compiler neither hoists them out of the
@@ -847,6 +854,10 @@ struct Solver {
     });
   }
   static constexpr bool kBatchLoads = MPC_ADMM_BATCH_LOADS(T);
+  // LAST: the iteration a termination check follows.  OSQP keeps delta_x = x - x_prev and delta_y = rho (alpha z~ + (1 - alpha) z_prev - z)
+  // of every iteration (auxil.c:187-228); only the infeasibility certificates of the next check read them (auxil.c:364-515), so
+  // only this variant forms them, and hands them over through LDS (the check is far away in registers).
+  template <bool LAST = false>
   MPC_HD void admm_iter() {
     tile_product<kHeld>();
     recv<kHeld>();
@@ -878,6 +889,7 @@ struct Solver {
           const double tq = zr + t.y[r];
           const double zn = clampd(tq, lo[r], up[r]);
           const double yn = tq - zn;
+          if constexpr (LAST) s.dxy[pidx(3 + r, t.tid)] = rho_at(t, r) * (zr - zn);
           t.z[r] = zn;
           t.y[r] = yn;
           dd[r] = zn - yn;
@@ -887,6 +899,7 @@ struct Solver {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const double xn = kAlphaRelax * t.xt[c] + (1.0 - kAlphaRelax) * t.x[c];
+          if constexpr (LAST) s.dxy[pidx(c, t.tid)] = xn - t.x[c];
           t.x[c] = xn;
           t.b[c] = kSigma * xn - t.q[c] + acc[c];
         }
@@ -918,71 +931,170 @@ struct Solver {
   // residuals of (x, z, y) (auxil.c:243-306, 563-629) + the norms termination and rho need.
   // red[] slots: 0 pri_res 1 ||Einv z|| 2 ||Einv Ax|| 3 ||rp|| 4 ||z|| 5 ||Ax||
   //              6 ||Dinv rd|| 7 ||Dinv q|| 8 ||Dinv Aty|| 9 ||Dinv Px|| 10 ||rd|| 11 ||q|| 12 ||Aty|| 13 ||Px||
-  // Every foot lane forms the maxima over its five rows and three variables; 14 lanes finish.
-  template <class X, class Z, class Y, class PX>
+  // INF (the checks of the ADMM loop): the cheap parts of OSQP's infeasibility certificates on the last iteration's delta_x, delta_y
+  // (Shared::dxy; is_primal_infeasible / is_dual_infeasible, auxil.c:364-515):
+  //              14 ||E dy||   15 SUM u max(dy, 0) + l min(dy, 0)   16 ||Dinv A^T dy||        (dy projected on the recession cone's polar)
+  //              17 ||D dx||   18 SUM q dx   19 max(0, Einv A dx) over rows with finite u   20 max(0, -Einv A dx) over rows with finite l
+  // Every foot lane forms the maxima / sums over its five rows and three variables; NRED lanes finish.
+  template <bool INF = false, class X, class Z, class Y, class PX>
   MPC_HD void residuals(X &&xs, Z &&zs, Y &&ys, PX &&pxs) {
-    constexpr int RW = Sh::RW;
+    constexpr int RW = Sh::RW, NR = INF ? Sh::NRED : 14;
     ex.par([&](Th &t) {
       if (t.tid < NF) {
         const double *x = xs(t), *z = zs(t), *y = ys(t), *px = pxs(t);
-        double mx[14], ax[5], aty[3], a[9];
+        double mx[NR], ax[5], aty[3], a[9];
         foot_a(t, a);
 #pragma unroll
-        for (int k = 0; k < 14; ++k) mx[k] = 0;
+        for (int k = 0; k < NR; ++k) mx[k] = 0;
         a_mul(a, x, ax);
         at_mul(a, y, aty);
+        double ev[5], ei[5], di[3];
 #pragma unroll
         for (int r = 0; r < 5; ++r) {
-          const double rr = ax[r] - z[r], ei = 1.0 / sc[C::SC_E + 5 * t.tid + r];
-          mx[0] = dmax(mx[0], fabs(ei * rr)); mx[1] = dmax(mx[1], fabs(ei * z[r])); mx[2] = dmax(mx[2], fabs(ei * ax[r]));
+          const double rr = ax[r] - z[r];
+          ev[r] = sc[C::SC_E + 5 * t.tid + r];
+          ei[r] = 1.0 / ev[r];
+          mx[0] = dmax(mx[0], fabs(ei[r] * rr)); mx[1] = dmax(mx[1], fabs(ei[r] * z[r])); mx[2] = dmax(mx[2], fabs(ei[r] * ax[r]));
           mx[3] = dmax(mx[3], fabs(rr)); mx[4] = dmax(mx[4], fabs(z[r])); mx[5] = dmax(mx[5], fabs(ax[r]));
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          const double qv = t.q[c], rr = qv + px[c] + aty[c], di = 1.0 / Dat(t, c);
-          mx[6] = dmax(mx[6], fabs(di * rr)); mx[7] = dmax(mx[7], fabs(di * qv)); mx[8] = dmax(mx[8], fabs(di * aty[c]));
-          mx[9] = dmax(mx[9], fabs(di * px[c])); mx[10] = dmax(mx[10], fabs(rr)); mx[11] = dmax(mx[11], fabs(qv));
+          const double qv = t.q[c], rr = qv + px[c] + aty[c];
+          di[c] = 1.0 / Dat(t, c);
+          mx[6] = dmax(mx[6], fabs(di[c] * rr)); mx[7] = dmax(mx[7], fabs(di[c] * qv)); mx[8] = dmax(mx[8], fabs(di[c] * aty[c]));
+          mx[9] = dmax(mx[9], fabs(di[c] * px[c])); mx[10] = dmax(mx[10], fabs(rr)); mx[11] = dmax(mx[11], fabs(qv));
           mx[12] = dmax(mx[12], fabs(aty[c])); mx[13] = dmax(mx[13], fabs(px[c]));
         }
+        if constexpr (INF) {
+          double lo[5], up[5], dx[3], dy[5], adx[5], atdy[3];
+          foot_bounds(t, lo, up);
 #pragma unroll
-        for (int k = 0; k < 14; ++k) s.part[k * RW + t.tid] = mx[k];
+          for (int c = 0; c < 3; ++c) dx[c] = s.dxy[pidx(c, t.tid)];
+#pragma unroll
+          for (int r = 0; r < 5; ++r) {
+            double v = s.dxy[pidx(3 + r, t.tid)];
+            const bool uinf = up[r] > kInfty * kMinScaling, linf = lo[r] < -kInfty * kMinScaling;   // (auxil.c:377-391)
+            v = uinf ? (linf ? 0.0 : dmin(v, 0.0)) : (linf ? dmax(v, 0.0) : v);
+            dy[r] = v;
+            mx[14] = dmax(mx[14], fabs(ev[r] * v));                                                // E dy
+            mx[15] += up[r] * dmax(v, 0.0) + lo[r] * dmin(v, 0.0);
+          }
+          at_mul(a, dy, atdy);
+          a_mul(a, dx, adx);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            mx[16] = dmax(mx[16], fabs(di[c] * atdy[c]));
+            mx[17] = dmax(mx[17], fabs(Dat(t, c) * dx[c]));                                         // D dx
+            mx[18] += t.q[c] * dx[c];
+          }
+#pragma unroll
+          for (int r = 0; r < 5; ++r) {
+            const double v = ei[r] * adx[r];
+            if (up[r] < kInfty * kMinScaling) mx[19] = dmax(mx[19], v);
+            if (lo[r] > -kInfty * kMinScaling) mx[20] = dmax(mx[20], -v);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < NR; ++k) s.part[k * RW + t.tid] = mx[k];
       }
     });
     ex.par([&](Th &t) {
-      if (t.tid < 14) {
+      if (t.tid < NR) {
+        // (both folds for every lane, one select at the end: a per-lane choice inside the loop makes the compiler branch around every load)
         const double *p = s.part + t.tid * RW;
-        double m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+        double m0 = 0, m1 = 0, m2 = 0, m3 = 0, a0 = 0, a1 = 0, a2 = 0, a3 = 0;
         static_assert(NF % 4 == 0, "four feet per step");
-        for (int k = 0; k < NF; k += 4) { m0 = dmax(m0, p[k]); m1 = dmax(m1, p[k + 1]); m2 = dmax(m2, p[k + 2]); m3 = dmax(m3, p[k + 3]); }
-        s.red[t.tid] = dbits(dmax(dmax(m0, m1), dmax(m2, m3)));
+#pragma unroll
+        for (int k = 0; k < NF; k += 4) {
+          const double v0 = p[k], v1 = p[k + 1], v2 = p[k + 2], v3 = p[k + 3];
+          m0 = dmax(m0, v0); m1 = dmax(m1, v1); m2 = dmax(m2, v2); m3 = dmax(m3, v3);
+          if constexpr (INF) { a0 += v0; a1 += v1; a2 += v2; a3 += v3; }
+        }
+        const double mv = dmax(dmax(m0, m1), dmax(m2, m3)), av = (a0 + a1) + (a2 + a3);
+        s.red[t.tid] = dbits(INF && (t.tid == 15 || t.tid == 18) ? av : mv);
       }
     });
   }
 
-  // check_termination (auxil.c:684-793; infeasibility certificates not evaluated: the QP is always
-  // feasible and strictly convex) + adapt_rho decision (auxil.c:13-77).  One thread decides.
+  // check_termination (auxil.c:684-793) + adapt_rho decision (auxil.c:13-77).  One thread decides.  APPROX: the second look
+  // OSQP takes when max_iter is reached, every tolerance times ten (osqp.c:563-568) -> the *_INACCURATE statuses.
+  // The dual certificate's expensive part (P dx, the recession directions) is evaluated only when its cheap part holds: dual_cand.
+  static constexpr double kEpsPrimInf = 1e-4, kEpsDualInf = 1e-4;   // constants.h:64-65 (the reference keeps the defaults)
+  template <bool APPROX = false>
   MPC_HD void check_and_adapt(int iter) {
     ex.par([&](Th &t) {
       if (t.tid == 0) {
         const double pri = bitsd(s.red[0]), dua = s.cinv * bitsd(s.red[6]);
-        s.pri_res = pri; s.dua_res = dua; s.iter = iter; s.rho_new = 0;
+        const double tf = APPROX ? 10.0 : 1.0;
+        const double ea = tf * eps_abs, er = tf * eps_rel, epi = tf * kEpsPrimInf, edi = tf * kEpsDualInf;
+        s.pri_res = pri; s.dua_res = dua; s.iter = iter; s.rho_new = 0; s.dual_cand = 0;
         if (!(pri <= kInfty) || !(dua <= kInfty)) { s.status = kStNonCvx; s.done = 1; }
         else {
-          const double eps_prim = eps_abs + eps_rel * dmax(bitsd(s.red[1]), bitsd(s.red[2]));
-          const double eps_dual = eps_abs + eps_rel * s.cinv * dmax(dmax(bitsd(s.red[7]), bitsd(s.red[8])), bitsd(s.red[9]));
+          const double eps_prim = ea + er * dmax(bitsd(s.red[1]), bitsd(s.red[2]));
+          const double eps_dual = ea + er * s.cinv * dmax(dmax(bitsd(s.red[7]), bitsd(s.red[8])), bitsd(s.red[9]));
           s.sig_changed = 0;
-          s.loose_ok = pri < kEpsAbs + (eps_prim - eps_abs) * (kEpsRel / eps_rel) && dua < kEpsAbs + (eps_dual - eps_abs) * (kEpsRel / eps_rel);   // the 1e-3 test
-          if (pri < eps_prim && dua < eps_dual) { s.status = kStSolved; s.done = 1; }
+          s.loose_ok = pri < kEpsAbs + (eps_prim - ea) * (kEpsRel / er) && dua < kEpsAbs + (eps_dual - ea) * (kEpsRel / er);   // the 1e-3 test
+          const bool prim_ok = pri < eps_prim, dual_ok = dua < eps_dual;
+          if (prim_ok && dual_ok) { s.status = APPROX ? kStSolvedInaccurate : kStSolved; s.done = 1; }
           else {
-            double pr = bitsd(s.red[3]) / (dmax(bitsd(s.red[4]), bitsd(s.red[5])) + 1e-10);
-            double dr = bitsd(s.red[10]) / (dmax(dmax(bitsd(s.red[11]), bitsd(s.red[12])), bitsd(s.red[13])) + 1e-10);
-            double rn = s.rho * sqrt(pr / (dr + 1e-10));
-            rn = clampd(rn, kRhoMin, kRhoMax);
-            if ((rn > s.rho * kAdaptTol || rn < s.rho / kAdaptTol) && s.rho_updates < max_rho_updates) s.rho_new = rn;
+            bool prim_inf = false;
+            if (!prim_ok) {                       // is_primal_infeasible (auxil.c:364-424)
+              const double ndy = bitsd(s.red[14]);
+              if (ndy > epi && bitsd(s.red[15]) < -epi * ndy) prim_inf = bitsd(s.red[16]) < epi * ndy;
+            }
+            if (prim_inf) { s.status = APPROX ? kStPrimInfInaccurate : kStPrimInf; s.done = 1; }
+            else {
+              if (!dual_ok) {                     // is_dual_infeasible, first two tests (auxil.c:426-460)
+                const double ndx = bitsd(s.red[17]);
+                if (ndx > edi && bitsd(s.red[18]) < -s.c * edi * ndx) s.dual_cand = 1;
+              }
+              if (!APPROX) {
+                double pr = bitsd(s.red[3]) / (dmax(bitsd(s.red[4]), bitsd(s.red[5])) + 1e-10);
+                double dr = bitsd(s.red[10]) / (dmax(dmax(bitsd(s.red[11]), bitsd(s.red[12])), bitsd(s.red[13])) + 1e-10);
+                double rn = s.rho * sqrt(pr / (dr + 1e-10));
+                rn = clampd(rn, kRhoMin, kRhoMax);
+                if ((rn > s.rho * kAdaptTol || rn < s.rho / kAdaptTol) && s.rho_updates < max_rho_updates) s.rho_new = rn;
+              }
+            }
           }
         }
       }
     });
+#ifdef MPC_EMU_DEBUG
+    ++g_checks; if (s.dual_cand) ++g_dual_cands;
+#endif
+    if (s.dual_cand) dual_certificate<APPROX>();
+  }
+  // the rest of is_dual_infeasible (auxil.c:461-505): ||Dinv P dx|| < c eps ||D dx||, and A dx inside the recession cone of [l, u]
+  template <bool APPROX>
+  MPC_HD void dual_certificate() {
+    ex.seq([&](Th &t) {
+      if (t.tid < NF) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) t.xt[c] = s.dxy[pidx(c, t.tid)];   // (x~ is dead between a check and the next iteration)
+      }
+    });
+    mul_P([](Th &t) { return t.xt; }, [](Th &t) { return t.px; });
+    constexpr int RW = Sh::RW;
+    ex.par([&](Th &t) {
+      if (t.tid < NF) {
+        double m = 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) m = dmax(m, fabs(t.px[c] / Dat(t, c)));
+        s.part[t.tid] = m;
+      }
+    });
+    ex.par([&](Th &t) {
+      if (t.tid == 0) {
+        double m = 0;
+        for (int k = 0; k < NF; ++k) m = dmax(m, s.part[k]);
+        const double edi = (APPROX ? 10.0 : 1.0) * kEpsDualInf, ndx = bitsd(s.red[17]);
+        if (m < s.c * edi * ndx && !(bitsd(s.red[19]) > edi * ndx) && !(bitsd(s.red[20]) > edi * ndx)) {
+          s.status = APPROX ? kStDualInfInaccurate : kStDualInf; s.done = 1; s.rho_new = 0;
+        }
+      }
+    });
+    (void)RW;
   }
 
   // ================================ 4. polish (polish.c) =========================================================
@@ -1363,6 +1475,8 @@ struct Solver {
         s.pol_ok = verified ? 1 : 0;
         s.status_polish = take ? 1 : -1;
         if (take) { s.pri_res = pri; s.dua_res = dua; }
+        s.bad = 0;     // a breakdown inside the polish (non-positive pivot of the reduced system) only fails the polish (polish.c:263-273);
+                       // bad inputs were caught by the ADMM system's factorisation before any polish is tried
       }
     });
     ex.par([&](Th &t) {
@@ -1388,13 +1502,17 @@ struct Solver {
   MPC_HD bool admm_until_done(int &iter, int &stable) {
     while (!s.done && !s.bad && iter < max_iter) {
       y_scaled(true);
-      for (int k = 0; k < kCheck; ++k) admm_iter();
+      for (int k = 0; k < kCheck - 1; ++k) admm_iter();
+      admm_iter<true>();
       y_scaled(false);
       iter += kCheck;
       lap(8);
       mul_P([](Th &t) { return t.x; }, [](Th &t) { return t.px; });
-      residuals([](Th &t) { return t.x; }, [](Th &t) { return t.z; }, [](Th &t) { return t.y; }, [](Th &t) { return t.px; });
+      MPC_SUBLAP(6, 1);
+      residuals<true>([](Th &t) { return t.x; }, [](Th &t) { return t.z; }, [](Th &t) { return t.y; }, [](Th &t) { return t.px; });
+      MPC_SUBLAP(6, 2);
       check_and_adapt(iter);
+      if (MPC_PROFILE_SUB == 6) lap(3); else
       lap(10);
       if (!s.done) {
         if constexpr (EXACT) {
@@ -1423,10 +1541,38 @@ struct Solver {
     }
     return false;
   }
-  template <bool EXACT = false>
-  MPC_HD void run() {
-    const long long t0 = MPC_CLOCK();
-    tlast = t0;
+  // outputs + persistent state (store_solution, auxil.c:528-561; mpc_osqp.cc:788-790: forces = -x).  A non-convex / non-finite
+  // problem has no solution: OSQP cold-starts the iterates (auxil.c:539-563); here the whole record is cleared, so that the
+  // robot's next call is the cold "osqp_setup" call on clean data (with NaN inputs the vendored OSQP itself stays poisoned).
+  MPC_HD void store(long long t0) {
+    tc[15] = MPC_CLOCK() - t0;
+    ex.par([&](Th &t) {
+      const bool failed = s.bad || s.status == kStNonCvx;
+      const bool solved = s.status == kStSolved && !failed;
+      if (t.tid < NF) {
+        const int f = t.tid;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          if (solved) MPC_GST(forces + 3 * f + c, -(Dat(t, c) * t.x[c]));
+          MPC_GST(state + 3 * f + c, failed ? 0.0 : t.x[c]);
+          MPC_GST(state + N + 2 * M + 3 * f + c, failed ? 0.0 : qp[C::QP_Q + 3 * f + c]);
+        }
+#pragma unroll
+        for (int r = 0; r < 5; ++r) { MPC_GST(state + N + 5 * f + r, failed ? 0.0 : t.z[r]); MPC_GST(state + N + M + 5 * f + r, failed ? 0.0 : t.y[r]); }
+      }
+      if (t.tid == 0) {
+        const bool failed = s.bad || s.status == kStNonCvx;
+        MPC_GST(state + 2 * N + 2 * M, failed ? 0.0 : s.rho);
+        MPC_GST(state + 2 * N + 2 * M + 1, failed ? 0.0 : 1.0);
+        const int iv[8] = {s.iter, s.bad ? kStNonCvx : s.status, s.status_polish, s.rho_updates, s.nfact, s.first, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) MPC_GST(info + k, iv[k]);
+        if (prof) for (int k = 0; k < kProfLen; ++k) if ((k < 1 || k > 5 || MPC_PROFILE_SUB == 6) && !(MPC_PROFILE_SUB && MPC_PROFILE_SUB <= 4 && k >= 9 && k <= 13)) MPC_GST(prof + k, tc[k]);   // (1 .. 5, and 9 .. 13 of a prep sub-profile: the prep kernel's)
+      }
+    });
+  }
+  // OSQP mode up to the polish: load, factor, ADMM until a check ends it (osqp.c:354-568)
+  MPC_HD void admm_part() {
     load();
     set_rho_vec();
     factor();
@@ -1435,13 +1581,27 @@ struct Solver {
     lap(8);
     static_assert(kMaxIter % kCheck == 0, "the check falls on the last iteration");
     int iter = 0, stable = 0;
+    admm_until_done<false>(iter, stable);
+    if (!s.done && !s.bad) {   // max_iter reached (osqp.c:563-568): a second look at the last check's residuals with every tolerance
+      check_and_adapt<true>(iter);   // times ten (-> *_INACCURATE), else MAX_ITER_REACHED; only SOLVED counts for the reference
+      ex.par([&](Th &t) { if (t.tid == 0 && !s.done) s.status = kStMaxIter; });
+    }
+  }
+  template <bool EXACT = false>
+  MPC_HD void run() {
+    const long long t0 = MPC_CLOCK();
+    tlast = t0;
     if constexpr (!EXACT) {
-      admm_until_done<false>(iter, stable);
-      if (!s.done && !s.bad) {   // max_iter reached (osqp.c:564-568): only SOLVED counts for the reference
-        ex.par([&](Th &t) { if (t.tid == 0) s.status = kStMaxIter; });
-      }
+      admm_part();
       if (s.status == kStSolved && !s.bad) polish();
     } else {
+      load();
+      set_rho_vec();
+      factor();
+      lap(9);
+      admm_prepare();
+      lap(8);
+      int iter = 0, stable = 0;
       ex.seq([&](Th &t) { t.sig = -1; });
       for (;;) {
         const bool early = admm_until_done<true>(iter, stable);
@@ -1471,34 +1631,53 @@ struct Solver {
       }
     }
     lap(14);
-    tc[15] = MPC_CLOCK() - t0;
-    // outputs + persistent state (store_solution, auxil.c:528-561; mpc_osqp.cc:788-790: forces = -x).  A non-convex / non-finite
-    // problem has no solution: OSQP cold-starts the iterates (auxil.c:539-563); here the whole record is cleared, so that the
-    // robot's next call is the cold "osqp_setup" call on clean data (with NaN inputs the vendored OSQP itself stays poisoned).
+    store(t0);
+  }
+
+  // ---- the OSQP-mode solve as two jobs of a persistent wave (mpc_batch.hip: mpc_solve_jobs_kernel).  The ADMM part of a solve takes
+  // 25 ... 250+ iterations, the polish that follows is the same work for every robot and needs nothing of the ADMM part but its
+  // result (x, z, y and the two residuals its acceptance test compares with, polish.c:306-345): a separate job that any wave can
+  // run, which is what fills the tail of a launch.  admm_job leaves the complete result of a solve whose polish "has not
+  // happened yet" (status_polish 0); polish_job re-loads the problem, polishes and, if OSQP would take the polished point,
+  // overwrites x, z, y and the forces.  Returns true when a polish job has to follow.
+  MPC_HD bool admm_job() {
+    const long long t0 = MPC_CLOCK();
+    tlast = t0;
+    admm_part();
+    lap(14);
+    store(t0);
+    const bool pol = s.status == kStSolved && !s.bad;
+    if (pol) ex.par([&](Th &t) { if (t.tid == 0) { MPC_GST(jobrec, s.pri_res); MPC_GST(jobrec + 1, s.dua_res); } });
+    return pol;
+  }
+  MPC_HD void polish_job() {
+    const long long t0 = MPC_CLOCK();
+    tlast = t0;
+    load();          // (x, z, y of the state record are the ADMM part's result)
     ex.par([&](Th &t) {
-      const bool failed = s.bad || s.status == kStNonCvx;
-      const bool solved = s.status == kStSolved && !failed;
-      if (t.tid < NF) {
+      if (t.tid == 0) { s.pri_res = MPC_GLD(jobrec); s.dua_res = MPC_GLD(jobrec + 1); s.status = kStSolved; s.nfact = MPC_GLD(info + 4); }
+    });
+    lap(9);
+    polish();
+    lap(14);
+    ex.par([&](Th &t) {
+      if (s.status_polish == 1 && t.tid < NF) {
         const int f = t.tid;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          if (solved) forces[3 * f + c] = -(Dat(t, c) * t.x[c]);
-          state[3 * f + c] = failed ? 0.0 : t.x[c];
-          state[N + 2 * M + 3 * f + c] = failed ? 0.0 : qp[C::QP_Q + 3 * f + c];
-        }
+        for (int c = 0; c < 3; ++c) { MPC_GST(forces + 3 * f + c, -(Dat(t, c) * t.x[c])); MPC_GST(state + 3 * f + c, t.x[c]); }
 #pragma unroll
-        for (int r = 0; r < 5; ++r) { state[N + 5 * f + r] = failed ? 0.0 : t.z[r]; state[N + M + 5 * f + r] = failed ? 0.0 : t.y[r]; }
+        for (int r = 0; r < 5; ++r) { MPC_GST(state + N + 5 * f + r, t.z[r]); MPC_GST(state + N + M + 5 * f + r, t.y[r]); }
       }
       if (t.tid == 0) {
-        const bool failed = s.bad || s.status == kStNonCvx;
-        state[2 * N + 2 * M] = failed ? 0.0 : s.rho;
-        state[2 * N + 2 * M + 1] = failed ? 0.0 : 1.0;
-        info[0] = s.iter; info[1] = s.bad ? kStNonCvx : s.status; info[2] = s.status_polish; info[3] = s.rho_updates;
-        info[4] = s.nfact; info[5] = s.first; info[6] = 0; info[7] = 0;
-        if (prof) for (int k = 0; k < kProfLen; ++k) if ((k < 1 || k > 5) && !(MPC_PROFILE_SUB && MPC_PROFILE_SUB <= 4 && k >= 9 && k <= 13)) prof[k] = tc[k];   // (1 .. 5, and 9 .. 13 of a prep sub-profile: the prep kernel's)
+        MPC_GST(info + 2, s.status_polish); MPC_GST(info + 4, s.nfact);
+        if (prof) {   // (slot 0: the polish job as a whole; the sections add to the ADMM job's under MPC_SECTION_PROFILE)
+          for (int k = 6; k < 15; ++k) if (k != 8 && k != 10) MPC_GST(prof + k, MPC_GLD(prof + k) + tc[k]);
+          MPC_GST(prof, MPC_GLD(prof) + (MPC_CLOCK() - t0));
+        }
       }
     });
   }
+  double *jobrec = nullptr;   // [2] the ADMM part's residuals, handed to the polish job (scale record tail)
 };
 
 }  // namespace mpc

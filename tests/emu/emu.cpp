@@ -21,6 +21,8 @@ using namespace mpc;
 // zeroed, as the kernels do -- so that a read of anything the kernel has not written shows up as a changed (NaN) result.
 static int g_poison = 0;
 static inline int fill_byte() { return g_poison ? 0xFF : 0; }
+static int g_split = 0;      // emu_set_split: the OSQP-mode solve as ADMM job + polish job (the persistent kernel's path)
+static int g_max_iter = 0;   // emu_set_max_iter: OSQP's max_iter setting (0 = the default, kMaxIter)
 
 template <class TH, int NTHREADS>
 struct HostExec {
@@ -107,7 +109,26 @@ static void solve_one(const RobotModel &mdl, const float *in, double *state, dou
     Ex ex(reverse);
     Solver<H, Ex> sv{ex, *sh, mdl, state, qp.data(), sc.data(), forces, info, nullptr};
     sv.dbg = dbg;
+    if (g_max_iter > 0) sv.max_iter = g_max_iter;
     if (exact) { sv.exact(); sv.template run<true>(); }   // the exact-optimum mode (mpc_batch_set_solver); the caller clears the state record
+    else if (g_split) {                                   // the two jobs of mpc_solve_jobs_kernel: the polish on a fresh workgroup
+      sv.jobrec = sc.data() + C::SC_JOB;
+      const bool pol = sv.admm_job();
+      ph += ex.phases;
+      if (pol) {
+        Shared<H> *sh2 = new Shared<H>();
+        std::memset((void *)sh2, fill_byte(), sizeof(Shared<H>));
+        Ex ex2(reverse);
+        Solver<H, Ex> sv2{ex2, *sh2, mdl, state, qp.data(), sc.data(), forces, info, nullptr};
+        sv2.jobrec = sc.data() + C::SC_JOB;
+        sv2.polish_job();
+        ph += ex2.phases;
+        delete sh2;
+      }
+      delete sh;
+      if (phases) *phases = ph;
+      return;
+    }
     else sv.run();
     ph += ex.phases;
     delete sh;
@@ -271,6 +292,9 @@ int emu_estimator_update(int n, const float *body, const float *normal, float *e
 }
 
 void emu_set_poison(int on) { g_poison = on; }
+void emu_set_max_iter(int it) { g_max_iter = it; }
+void emu_set_split(int on) { g_split = on; }
+void emu_check_counts(long *out) { out[0] = g_checks; out[1] = g_dual_cands; }
 int emu_state_len(int h) { return 24 * h + 40 * h + 2; }
 int emu_shared_bytes(int h) { return h == 10 ? (int)sizeof(Shared<10>) : h == 16 ? (int)sizeof(Shared<16>) : h == 20 ? (int)sizeof(Shared<20>) : h == 6 ? (int)sizeof(Shared<6>) : -1; }
 

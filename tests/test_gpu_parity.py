@@ -266,7 +266,7 @@ def test_assembly_and_scaling_records_match_the_oracle(name):
         assert np.abs(P2 - P).max() <= 1e-13 * np.abs(P).max()
         np.testing.assert_allclose(sc[r, :N], st["D"], rtol=1e-11)
         np.testing.assert_allclose(sc[r, N:N + M], st["E"], rtol=1e-11)
-        assert abs(sc[r, -2] / st["c"] - 1) < 1e-11
+        assert abs(sc[r, 2 * N + 3 * M + 60 * h] / st["c"] - 1) < 1e-11       # D[N] E[M] q_s[N] A_s[15 * 4 h] l_s[M] u_s[M] c 1/c job[2]
 
 
 @pytest.mark.gpu

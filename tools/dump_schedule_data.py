@@ -1,0 +1,33 @@
+"""Per-robot records of consecutive solves (info + section cycles), for off-line scheduling models (tools/sched_model.py).
+
+  MPC_LIB_PATH=rl-mpc-locomotion_amd/csrc/variants/libmpc_batch_prof.so python tools/dump_schedule_data.py [n] [steps] [out.npz]
+
+With the product library only slot 15 (total cycles) of the profile record is filled; with the -DMPC_SECTION_PROFILE build all
+sixteen sections are.  The workload is bench.py's (config 2, seed 1000, the same perturbation sequence)."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import rl_mpc_locomotion_amd  # noqa
+from rl_mpc_locomotion_amd.batched import BatchedConvexMpc
+from rl_mpc_locomotion_amd.synthetic import make_solver_workload, perturb_workload
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+out = sys.argv[3] if len(sys.argv) > 3 else "gpurun_out/sched_data.npz"
+h = 10
+wl = make_solver_workload(n, h=h, seed=1000, config=2)
+inertia9 = np.zeros((n, 9)); inertia9[:, 0], inertia9[:, 4], inertia9[:, 8] = wl.inertia_diag.T
+sv = BatchedConvexMpc(wl.mass, inertia9, h, wl.dt_mpc, wl.alpha)
+sv.enable_timing()
+infos, profs, kms = [], [], []
+w = wl
+for s in range(steps):
+    f, info = sv.solve(torch.from_numpy(w.inputs).cuda())
+    torch.cuda.synchronize()
+    infos.append(info.cpu().numpy().copy())
+    profs.append(sv.get_profile().copy())
+    kms.append([float(x[-1]) for x in sv.kernel_times(1)])
+    w = perturb_workload(w, 7000 + 131 * s)
+np.savez_compressed(out, info=np.stack(infos), prof=np.stack(profs), kernel_ms=np.array(kms))
+print("wrote", out, "kernel ms (prep, solve) of the last steps:", np.array(kms)[-5:].round(4).tolist())
