@@ -327,8 +327,10 @@ int launch(int n, const RobotModel *models, const float *in, const double *in64,
   hipLaunchKernelGGL(mpc_prep_kernel<H>, dim3(n + 1), dim3(Cfg<H>::T), 0, stream, n, models, in, in64, state, qp, sc, prof, active, order, hist, hist_slot, sched, ready);
   if (ev) (void)hipEventRecord(ev[1], stream);
   if (exact) hipLaunchKernelGGL((mpc_solve_kernel<H, true>), dim3(n), dim3(Cfg<H>::TW), 0, stream, n, models, state, qp, sc, forces, info, prof, order, sched, max_iter);
-  else if (job_slots > 0 && H == 10)   // the benchmark horizon: persistent waves, ADMM and polish as separate jobs
-    hipLaunchKernelGGL((mpc_solve_jobs_kernel<H>), dim3(n < job_slots ? n : job_slots), dim3(Cfg<H>::TW), 0, stream, models, state, qp, sc, forces, info, prof, order, sched, ready, max_iter);
+  else if (job_slots > 0) {   // persistent workgroups, ADMM and polish as separate jobs (h = 16: 2.68 -> 2.28 ms, h = 20: 3.36 -> 2.78 ms per 4096 robots)
+    const int slots = H == 10 ? job_slots : job_slots / 2;                  // (multi-wave workgroups: two per CU)
+    hipLaunchKernelGGL((mpc_solve_jobs_kernel<H>), dim3(n < slots ? n : slots), dim3(Cfg<H>::TW), 0, stream, models, state, qp, sc, forces, info, prof, order, sched, ready, max_iter);
+  }
   else hipLaunchKernelGGL((mpc_solve_kernel<H, false>), dim3(n), dim3(Cfg<H>::TW), 0, stream, n, models, state, qp, sc, forces, info, prof, order, sched, max_iter);
   if (ev) (void)hipEventRecord(ev[2], stream);
   HIP_TRY(hipGetLastError());

@@ -85,6 +85,9 @@ struct WThread {
 #ifndef MPC_ADMM_BATCH_LOADS   // which workgroup sizes request every LDS constant of the foot phase in one batch up front (~90 more registers)
 #define MPC_ADMM_BATCH_LOADS(T) ((T) <= 64)
 #endif
+#ifndef MPC_SPLIT_RANGES
+#define MPC_SPLIT_RANGES 0   // (measured on the ISA: no help at present)
+#endif
 #define MPC_V alignas(16) double
 template <int H>
 struct Shared {
@@ -623,9 +626,29 @@ struct Solver {
       }
     });
     lap(6);
+    split_ranges();
     sweep_all();
+    split_ranges();
     ex.par([&](Th &t) { if (t.tid == 0) s.nfact++; });
     lap(7);
+  }
+  // A register-allocation hint, no code (multi-wave workgroups, which run at a 256-register cap): every value that lives across the
+  // sweep passes through an empty asm, which ends its live range and starts a new one.  Without such split points the allocator treats
+  // a foot lane's iterate as one range over the whole solve and, once the sweep is over budget, spills inside its loop; with them the
+  // foot state is spilled once before the sweep and reloaded once after it.
+  MPC_HD void split_ranges() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (T > 64 && MPC_SPLIT_RANGES) {
+      Th &t = ex.th;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { MPC_LAUNDER(t.x[k]); MPC_LAUNDER(t.q[k]); }
+#pragma unroll
+      for (int k = 0; k < 5; ++k) { MPC_LAUNDER(t.z[k]); MPC_LAUNDER(t.y[k]); }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) MPC_LAUNDER(t.Si[k]);
+      MPC_LAUNDER(t.dlq[0]); MPC_LAUNDER(t.dlq[1]);
+    }
+#endif
   }
   MPC_HD void factor() {
     ex.par([&](Th &t) {
@@ -1004,7 +1027,10 @@ struct Solver {
         const double *p = s.part + t.tid * RW;
         double m0 = 0, m1 = 0, m2 = 0, m3 = 0, a0 = 0, a1 = 0, a2 = 0, a3 = 0;
         static_assert(NF % 4 == 0, "four feet per step");
-#pragma unroll
+        // (unrolled in the multi-wave kernels it costs them registers they do not have: tools/isa_census.py)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll T <= 64 ? NF / 4 : 1
+#endif
         for (int k = 0; k < NF; k += 4) {
           const double v0 = p[k], v1 = p[k + 1], v2 = p[k + 2], v3 = p[k + 3];
           m0 = dmax(m0, v0); m1 = dmax(m1, v1); m2 = dmax(m2, v2); m3 = dmax(m3, v3);
@@ -1475,8 +1501,10 @@ struct Solver {
         s.pol_ok = verified ? 1 : 0;
         s.status_polish = take ? 1 : -1;
         if (take) { s.pri_res = pri; s.dua_res = dua; }
+#ifndef MPC_X_KEEPBAD
         s.bad = 0;     // a breakdown inside the polish (non-positive pivot of the reduced system) only fails the polish (polish.c:263-273);
                        // bad inputs were caught by the ADMM system's factorisation before any polish is tried
+#endif
       }
     });
     ex.par([&](Th &t) {
@@ -1587,21 +1615,28 @@ struct Solver {
       ex.par([&](Th &t) { if (t.tid == 0 && !s.done) s.status = kStMaxIter; });
     }
   }
+  // (the body of run() is kept in one piece rather than built from admm_part() + store(): at the 256-register cap of the long horizons
+  // the allocator's spill decisions inside the hot loops move with the code shape -- tools/isa_census.py, tests/test_isa_budget.py)
   template <bool EXACT = false>
   MPC_HD void run() {
     const long long t0 = MPC_CLOCK();
     tlast = t0;
+    load();
+    set_rho_vec();
+    factor();
+    lap(9);
+    admm_prepare();
+    lap(8);
+    static_assert(kMaxIter % kCheck == 0, "the check falls on the last iteration");
+    int iter = 0, stable = 0;
     if constexpr (!EXACT) {
-      admm_part();
+      admm_until_done<false>(iter, stable);
+      if (!s.done && !s.bad) {   // max_iter reached (osqp.c:563-568): a second look at the last check's residuals with every tolerance
+        check_and_adapt<true>(iter);   // times ten (-> *_INACCURATE), else MAX_ITER_REACHED; only SOLVED counts for the reference
+        ex.par([&](Th &t) { if (t.tid == 0 && !s.done) s.status = kStMaxIter; });
+      }
       if (s.status == kStSolved && !s.bad) polish();
     } else {
-      load();
-      set_rho_vec();
-      factor();
-      lap(9);
-      admm_prepare();
-      lap(8);
-      int iter = 0, stable = 0;
       ex.seq([&](Th &t) { t.sig = -1; });
       for (;;) {
         const bool early = admm_until_done<true>(iter, stable);
@@ -1631,7 +1666,31 @@ struct Solver {
       }
     }
     lap(14);
-    store(t0);
+    tc[15] = MPC_CLOCK() - t0;
+    // outputs + persistent state (store_solution, auxil.c:528-561; mpc_osqp.cc:788-790: forces = -x): see store()
+    ex.par([&](Th &t) {
+      const bool failed = s.bad || s.status == kStNonCvx;
+      const bool solved = s.status == kStSolved && !failed;
+      if (t.tid < NF) {
+        const int f = t.tid;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          if (solved) forces[3 * f + c] = -(Dat(t, c) * t.x[c]);
+          state[3 * f + c] = failed ? 0.0 : t.x[c];
+          state[N + 2 * M + 3 * f + c] = failed ? 0.0 : qp[C::QP_Q + 3 * f + c];
+        }
+#pragma unroll
+        for (int r = 0; r < 5; ++r) { state[N + 5 * f + r] = failed ? 0.0 : t.z[r]; state[N + M + 5 * f + r] = failed ? 0.0 : t.y[r]; }
+      }
+      if (t.tid == 0) {
+        const bool failed = s.bad || s.status == kStNonCvx;
+        state[2 * N + 2 * M] = failed ? 0.0 : s.rho;
+        state[2 * N + 2 * M + 1] = failed ? 0.0 : 1.0;
+        info[0] = s.iter; info[1] = s.bad ? kStNonCvx : s.status; info[2] = s.status_polish; info[3] = s.rho_updates;
+        info[4] = s.nfact; info[5] = s.first; info[6] = 0; info[7] = 0;
+        if (prof) for (int k = 0; k < kProfLen; ++k) if ((k < 1 || k > 5 || MPC_PROFILE_SUB == 6) && !(MPC_PROFILE_SUB && MPC_PROFILE_SUB <= 4 && k >= 9 && k <= 13)) prof[k] = tc[k];   // (1 .. 5, and 9 .. 13 of a prep sub-profile: the prep kernel's)
+      }
+    });
   }
 
   // ---- the OSQP-mode solve as two jobs of a persistent wave (mpc_batch.hip: mpc_solve_jobs_kernel).  The ADMM part of a solve takes

@@ -1,4 +1,5 @@
-"""Register-budget regression guard for the solve kernel (no GPU needed: hipcc cross-compiles gfx950).
+"""Register-budget regression guard for the solve kernel the OSQP mode runs -- the persistent job kernel mpc_solve_jobs_kernel<H>
+(no GPU needed: hipcc cross-compiles gfx950).
 
 The kernel's speed hinges on the register allocator keeping the 6x6 fp64 tile of every thread out of scratch memory inside
 the hot loops (a handful of spill instructions per sweep step cost integer factors, because all CUs
@@ -47,7 +48,7 @@ def test_spill_estimate_stays_bounded(asm):
     # weighted scratch instructions per wave and solve (tools/isa_census.py).  h = 10: one wave per SIMD with the full register budget
     # (AGPRs as spill space), no scratch memory at all.  h = 16 / 20: multi-wave workgroups at two waves per SIMD (256 registers), which
     # was measured 25 % faster in spite of the spill code it needs; the bound keeps that spill code from growing.
-    limits = {10: 50, 16: 4000, 20: 4000}
+    limits = {10: 50, 16: 3000, 20: 3000}
     for h, lim in limits.items():
         total, detail = isa_census.spill_cost(asm, h)
         assert total <= lim, (h, total, detail)
@@ -56,4 +57,6 @@ def test_spill_estimate_stays_bounded(asm):
 def test_long_horizon_admm_iteration_stays_nearly_scratch_free(asm):
     for h in (16, 20):
         admm = [a for a in isa_census.loop_stats(asm, h).values() if a["role"] == "admm-iteration"]
-        assert admm and all(a["scratch"] <= 8 for a in admm), (h, admm)
+        assert admm and all(a["scratch"] <= 12 for a in admm), (h, admm)
+        sweeps = [a for a in isa_census.loop_stats(asm, h).values() if a["role"] == "sweep"]
+        assert len(sweeps) == 3 and all(a["scratch"] <= 6 for a in sweeps), (h, sweeps)      # round 2: up to 29 per trip

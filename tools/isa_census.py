@@ -16,8 +16,12 @@ import re
 import subprocess
 import sys
 
-# (the OSQP-mode instantiation mpc_solve_kernel<H, false>; the exact-mode one, <H, true>, is not performance critical)
-KERNEL_RE = r'\n(_ZN[^\n]*mpc_solve_kernelILi%sELb0E[^\n:]*):[^\n]*\n(.*?)\n\.Lfunc_end'
+# (the kernel the OSQP mode runs: the persistent job kernel mpc_solve_jobs_kernel<H>; set KERNEL = "one" for the one-job-per-workgroup
+# instantiation mpc_solve_kernel<H, false>; the exact-mode one, <H, true>, is not performance critical)
+KERNELS = {"jobs": r'\n(_ZN[^\n]*mpc_solve_jobs_kernelILi%sEE[^\n:]*):[^\n]*\n(.*?)\n\.Lfunc_end',
+           "one": r'\n(_ZN[^\n]*mpc_solve_kernelILi%sELb0E[^\n:]*):[^\n]*\n(.*?)\n\.Lfunc_end'}
+KERNEL = "jobs"
+KERNEL_RE = KERNELS[KERNEL]
 
 
 def compile_to_asm(src, out, include_dir, extra=()):
@@ -85,12 +89,14 @@ def loop_stats(txt, H):
         a["dpp"] = a.get("dpp", 0) + sum(1 for l in ins if l.startswith('\tv_mov_b32_dpp'))
     for a in agg.values():
         # a sweep trip is six pivot steps with a reciprocal each (long horizons), or three pivot pairs with one reciprocal (of the
-        # pair's 2 x 2 determinant) each (h = 10)
+        # pair's 2 x 2 determinant) each (h = 10); the ADMM iteration is the tight loop with the quad exchanges (DPP moves) and no
+        # reciprocal; the loop around it (iterations + check + refactor) is the big one with DPP moves.  (Depths differ between the
+        # one-job kernel and the persistent job kernel, whose job loops sit outside: roles go by content.)
         if a.get("rcp", 0) in (3, 6) and a["ins"] < 1000:
             a["role"] = "sweep"
-        elif a["depth"] == 2 and a.get("dpp", 0):
+        elif a.get("dpp", 0) and a["ins"] < 700 and not a.get("rcp", 0):
             a["role"] = "admm-iteration"
-        elif a["depth"] == 1 and a["ins"] > 2000:
+        elif a["ins"] > 2000 and a.get("dpp", 0):
             a["role"] = "check-loop"
         else:
             a["role"] = ""
@@ -99,7 +105,8 @@ def loop_stats(txt, H):
 
 def spill_cost(txt, H):
     """Estimated scratch instructions executed per wave and solve: static counts weighted by rough trip counts (a sweep loop
-    runs H trips, the Ruiz loop 10, the ADMM iteration ~50, the check loop ~2, anything else 4; straight-line code once)."""
+    runs H trips -- each of the three sweep loops about once per solve --, the ADMM iteration ~50, the check loop ~2, anything else 4;
+    straight-line code once)."""
     loops = loop_stats(txt, H)
     trips = {"sweep": H, "admm-iteration": 50, "check-loop": 2, "ruiz-pass": 10}
     total, detail = 0, {}
@@ -111,7 +118,7 @@ def spill_cost(txt, H):
         w, name = 1, "straight-line"
         if key is not None:
             a = loops[key[0]]
-            w = trips.get(a["role"], 4) * (2 if a["depth"] == 2 else 1)   # depth 2: nested in the check loop
+            w = trips.get(a["role"], 4)
             name = f"{key[0]}({a['role'] or 'loop'})"
         total += sc * w
         detail[name] = detail.get(name, 0) + sc * w
