@@ -93,61 +93,103 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-control-loop", action="store_true", help="skip the secondary legs (profiling runs)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary single-GPU lines of the other configurations")
+    ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps each; `value` is the MEDIAN block (one block of ~20 steps is an 18 ms sample)")
+    ap.add_argument("--robots-total", type=int, default=None, help="(strong-scaling configurations: overrides the total that is sharded over the ranks)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the N > 1 launch (nccl = RCCL; gloo only with --emulate)")
+    ap.add_argument("--emulate", action="store_true",
+                    help="CPU dry run of this script's control flow (self-launch, sharding, barriers, gather leg, rank-0 JSON) with the host emulation of the "
+                         "kernels (tests/emu) standing in for the HIP library: for tests/test_bench_multirank.py, the numbers mean nothing")
     return ap.parse_args()
 
 
-def run_leg(cfg_id, n, h, K, W, dev, rank, world, dist):
-    """Warm up, then time exactly K steps bracketed by barrier + synchronize; returns the raw measurements of this rank."""
+class _EmulatedSolver:
+    """--emulate: the host emulation of the kernels behind BatchedConvexMpc's interface (CPU tensors)."""
+
+    def __init__(self, wl, h):
+        from tests.emu.emu import EmuBatch
+        self.e = EmuBatch(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
+
+    def enable_timing(self):
+        pass
+
+    def reset(self):
+        self.e.state[:] = 0.0
+
+    def solve(self, d_in, forces=None, info=None):
+        import torch
+        f = self.e.solve(d_in.numpy(), nthreads=2)
+        if forces is not None:
+            forces.copy_(torch.from_numpy(np.nan_to_num(f)))
+        if info is not None:
+            info.copy_(torch.from_numpy(self.e.info))
+
+    def kernel_times(self, k):
+        return np.full(k, 1e-3, np.float32), np.full(k, 1e-3, np.float32)
+
+
+def run_leg(cfg_id, n, h, K, W, dev, rank, world, dist, repeats=1, emulate=False):
+    """Warm up, then time `repeats` blocks of exactly K steps, each bracketed by barrier + synchronize; returns the raw measurements
+    of this rank (block times already reduced to the slowest rank)."""
     import torch
     from rl_mpc_locomotion_amd import layout as L
-    from rl_mpc_locomotion_amd.batched import BatchedConvexMpc
     from rl_mpc_locomotion_amd.synthetic import make_solver_workload, perturb_workload
 
+    R = max(1, repeats)
     wl = make_solver_workload(n, h=h, seed=1000 + rank, config=cfg_id)   # this rank's shard: its own seeded robots
     batches = []
     w = wl
-    for s in range(K + W):
+    for s in range(W + K):
         batches.append(w.inputs)
         w = perturb_workload(w, 7000 + 131 * s + rank)
     d_in = [torch.from_numpy(b).to(dev) for b in batches]          # resident in HBM before timing
-    inertia9 = np.zeros((n, 9)); inertia9[:, 0], inertia9[:, 4], inertia9[:, 8] = wl.inertia_diag.T
-    solver = BatchedConvexMpc(wl.mass, inertia9, h, wl.dt_mpc, wl.alpha, device=dev)
+    if emulate:
+        solver = _EmulatedSolver(wl, h)
+        sync = lambda: None
+    else:
+        from rl_mpc_locomotion_amd.batched import BatchedConvexMpc
+        inertia9 = np.zeros((n, 9)); inertia9[:, 0], inertia9[:, 4], inertia9[:, 8] = wl.inertia_diag.T
+        solver = BatchedConvexMpc(wl.mass, inertia9, h, wl.dt_mpc, wl.alpha, device=dev)
+        sync = lambda: torch.cuda.synchronize(dev)
     solver.enable_timing()                       # HIP events inside the library, around each kernel, on the launch stream
     infos = [torch.zeros((n, 8), dtype=torch.int32, device=dev) for _ in range(K)]
-
-    for s in range(W):
-        solver.solve(d_in[s])
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
     first_out = torch.zeros((n, 12 * h), dtype=torch.float64, device=dev)
-    for s in range(K):
-        ev[s][0].record()                      # HIP events on the stream the kernels are launched on
-        solver.solve(d_in[W + s], forces=first_out if s == 0 else None, info=infos[s])
-        ev[s][1].record()
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        from rl_mpc_locomotion_amd.sharding import max_over_ranks
-        elapsed = max_over_ranks(elapsed, dev)
 
-    step_ms = np.array([a.elapsed_time(b) for a, b in ev])        # both kernels of one step
-    kt = min(K, 64)
-    prep_ms, solve_ms = (a.astype(np.float64) for a in solver.kernel_times(kt))
-    info = torch.stack(infos).cpu().numpy()                         # [K, n, 8]
-    flops = asm_flops = 0.0
-    for s in range(K):
-        contact = batches[W + s][:, L.IN_CONTACT:L.IN_CONTACT + 4 * h]
-        fa, fs = algorithmic_flops(h, contact, info[s, :, 0].astype(np.float64), info[s, :, 4].astype(np.float64))
+    # Every block is the SAME experiment -- cold start, the W warm-up steps, then the K timed steps on the same seeded sequence -- so the
+    # blocks are repeated samples of one quantity and their median is meaningful (a longer sequence would drift: the states random-walk).
+    block_s, prep_ms, solve_ms = [], [], []
+    for r in range(R):
+        if r:
+            solver.reset()
+        for s in range(W):
+            solver.solve(d_in[s])
+        sync()
+        if dist is not None:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for s in range(K):
+            solver.solve(d_in[W + s], forces=first_out if s == 0 else None, info=infos[s])
+        sync()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            from rl_mpc_locomotion_amd.sharding import max_over_ranks
+            elapsed = max_over_ranks(elapsed, dev)
+        block_s.append(elapsed)
+        a, b = solver.kernel_times(min(K, 64))
+        prep_ms.append(a.astype(np.float64)); solve_ms.append(b.astype(np.float64))
+    prep_ms, solve_ms = np.concatenate(prep_ms), np.concatenate(solve_ms)
+    info = torch.stack(infos).cpu().numpy()                         # [K, n, 8] (the last block's; every block solves the same problems)
+    flops = asm_flops = exec_flops = 0.0
+    for j in range(K):
+        contact = batches[W + j][:, L.IN_CONTACT:L.IN_CONTACT + 4 * h]
+        it, nf = info[j, :, 0].astype(np.float64), info[j, :, 4].astype(np.float64)
+        fa, fs = algorithmic_flops(h, contact, it, nf)
         flops += fs; asm_flops += fa
-    exec_flops = sum(executed_flops(h, info[s, :, 0].astype(np.float64), info[s, :, 4].astype(np.float64)) for s in range(K)) / K
-    return dict(wl=wl, batches=batches, solver=solver, elapsed=elapsed, step_ms=step_ms, prep_ms=prep_ms, solve_ms=solve_ms, info=info,
-                first_forces=first_out.cpu().numpy(), flops_per_launch=flops / K, prep_flops_per_launch=asm_flops / K, exec_flops=exec_flops)
+        exec_flops += executed_flops(h, it, nf)
+    return dict(wl=wl, batches=batches, solver=solver, block_s=np.array(block_s), elapsed=float(np.median(block_s)), prep_ms=prep_ms, solve_ms=solve_ms, info=info,
+                first_forces=first_out.cpu().numpy(), flops_per_launch=flops / K, prep_flops_per_launch=asm_flops / K, exec_flops=exec_flops / K)
 
 
 def main():
@@ -167,31 +209,38 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
-    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+    if args.backend == "gloo" and not args.emulate:
+        raise SystemExit("bench.py: --backend gloo is the CPU dry run, it needs --emulate (the product path has no CPU fallback)")
+    if not args.emulate and (not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank):
         raise SystemExit(f"bench.py: rank {rank} has no GPU {local_rank} ({torch.cuda.device_count()} visible)")
+    dev = torch.device("cpu") if args.emulate else torch.device(f"cuda:{local_rank}")
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
-        assert dist.get_world_size() == args.gpus, "RCCL saw a different number of ranks than --gpus"
-    dev = torch.device(f"cuda:{local_rank}")
-    torch.cuda.set_device(dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo")
+        assert dist.get_world_size() == args.gpus, "the process group has a different number of ranks than --gpus"
+    if not args.emulate:
+        torch.cuda.set_device(dev)
 
     cfg = CONFIGS[args.config]
     h = args.horizon or cfg["h"]
     K, W = args.steps, args.warmup
+    robots_total = args.robots_total or cfg["robots_total"]
     if args.robots:
         n = args.robots
     elif cfg["robots_per_gpu"]:
         n = cfg["robots_per_gpu"]
     else:
         from rl_mpc_locomotion_amd.sharding import shard_bounds
-        lo, hi = shard_bounds(cfg["robots_total"], rank, world)
+        lo, hi = shard_bounds(robots_total, rank, world)
         n = hi - lo
-    n_total = n * world if (args.robots or cfg["robots_per_gpu"]) else cfg["robots_total"]
+    n_total = n * world if (args.robots or cfg["robots_per_gpu"]) else robots_total
 
-    m = run_leg(args.config, n, h, K, W, dev, rank, world, dist)
+    m = run_leg(args.config, n, h, K, W, dev, rank, world, dist, repeats=args.repeats, emulate=args.emulate)
     gather = all_gather_leg(n, n_total, dev, dist) if dist is not None else None
 
     if rank != 0:
@@ -219,6 +268,10 @@ def main():
         "steps": K,
         "warmup": W,
         "ms_per_step": m["elapsed"] / K * 1e3,
+        "repeats": len(m["block_s"]),
+        "timed": f"median of {len(m['block_s'])} blocks; a block = cold start, {W} untimed warm-up steps, then exactly {K} timed steps bracketed by barrier + synchronize "
+                 "(max over ranks per block); every block runs the same seeded sequence",
+        "block_ms_per_step": [float(b) / K * 1e3 for b in m["block_s"]],
         "higher_is_better": True,
         "scaling": cfg["scaling"],
         "vs_baseline": None,
@@ -237,7 +290,7 @@ def main():
                              "mean duration of mpc_solve_kernel from HIP events on the launch stream; `peak` is the FP32 vector rate SURVEY 8(d) "
                              "prescribes, the kernel's arithmetic is fp64 (frac_fp64_peak, peak 78.6 TF)",
                      "kernel": "mpc_solve_kernel", "kernel_ms": float(solve_ms.mean()), "prep_kernel_ms": float(prep_ms.mean()),
-                     "step_ms_all_kernels": float(m["step_ms"].mean()), "flops_per_launch": m["flops_per_launch"],
+                     "step_ms_all_kernels": float((prep_ms + solve_ms).mean()), "flops_per_launch": m["flops_per_launch"],
                      "prep_kernel_flops_per_launch": m["prep_flops_per_launch"],
                      "frac_fp64_peak": achieved_tflops / FP64_VECTOR_PEAK_TFLOPS,
                      "executed": {"flops_per_launch": m["exec_flops"], "tflops": m["exec_flops"] / (solve_ms.mean() * 1e-3) / 1e12,
@@ -245,13 +298,23 @@ def main():
                                   "note": "operations the solve kernel executes (bench.py executed_flops: OSQP on all 12 h variables through the 6 h x 6 h "
                                           "wrench-space core), for orientation only -- `achieved` / `frac` use the SURVEY 8(d) minimal-algorithm count"}},
     }
+    if args.emulate:
+        out["data"] = "synthetic; EMULATED kernels on the CPU (control-flow dry run: the numbers mean nothing)"
     if gather is not None:
         out["all_gather_torques"] = gather
+    if args.emulate:
+        print(json.dumps(out))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if world == 1 and not args.no_secondary and args.config == 2 and not args.robots:
         out["secondary"] = secondary_lines(dev)          # the other BASELINE configurations at their per-GPU sizes (N = 1 only)
     if not args.no_control_loop and world == 1:      # secondary legs: single-GPU runs only
         out["control_loop"] = control_loop_leg(n, h, dev)
+        out["control_loop_with_resets"] = control_loop_leg(n, h, dev, reset_every=37)
         out["policy"] = policy_leg(n, dev)
+        # the SURVEY 8(d) unit of work includes the leg-torque map (a22), which `value` does not: the same robots through the whole controller.run seam
+        out["control_steps_per_s_incl_torque_map"] = out["control_loop"]["control_steps_per_s_incl_torque_map"]
     if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
         out["cpu_baseline"] = cpu_baseline(m["wl"], m["batches"], W, h, gpu_first_forces=m["first_forces"])
         out["max_grf_err_vs_osqp"] = out["cpu_baseline"].pop("_gpu_err", None)
@@ -277,51 +340,73 @@ def secondary_lines(dev, steps=5, warm=2):
 
 def all_gather_leg(n, n_total, dev, dist, reps=50, warm=5):
     """The optional exchange of SURVEY 8(e): RCCL all-gather of the per-robot torques ([n_local, 12] float32 per rank) on a side
-    stream, timed with HIP events on that stream; reported separately, never part of `value`."""
+    stream, timed with HIP events on that stream; reported separately, never part of `value`.  (CPU dry run: same calls over gloo,
+    wall-clock timed.)"""
     import torch
     from rl_mpc_locomotion_amd.sharding import all_gather_torques
-    side = torch.cuda.Stream(device=dev)
     local = torch.randn((n, 12), dtype=torch.float32, device=dev)
-    torch.cuda.synchronize(dev)
-    with torch.cuda.stream(side):
-        for _ in range(warm):
-            all_gather_torques(local, n_total)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(side)
-        for _ in range(reps):
+    if dev.type != "cuda":
+        for _ in range(2):
             out = all_gather_torques(local, n_total)
-        e1.record(side)
-    side.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+        t0 = time.perf_counter()
+        for _ in range(3):
+            out = all_gather_torques(local, n_total)
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+    else:
+        side = torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize(dev)
+        with torch.cuda.stream(side):
+            for _ in range(warm):
+                all_gather_torques(local, n_total)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(side)
+            for _ in range(reps):
+                out = all_gather_torques(local, n_total)
+            e1.record(side)
+        side.synchronize()
+        ms = e0.elapsed_time(e1) / reps
     ok = bool(tuple(out.shape) == (n_total, 12))
     return {"ms": ms, "bytes_per_rank": n * 48, "robots_total": n_total, "shape_ok": ok,
             "note": "one all_gather_into_tensor of [n_local, 12] float32 per rank over RCCL / xGMI on a side stream; latency-bound"}
 
 
-def control_loop_leg(n, h, dev, ticks=40, warm=10):
+def control_loop_leg(n, h, dev, ticks=40, warm=10, reset_every=0):
     """Secondary figure (NOT `value`): robot-ticks/s of the whole controller.run seam on device tensors --
     state estimator + leg kinematics + gait / foot placement + the MPC solve on every second tick (the
-    reference's cadence, RobotRunnerMin.py:21-22) + swing / stance commands + joint torques."""
+    reference's cadence, RobotRunnerMin.py:21-22) + swing / stance commands + joint torques.
+    reset_every > 0: every that many ticks 1/64 of the robots are reset through a DEVICE tensor of indices, as VecTask.reset_idx does
+    (RL_Environment/tasks/aliengo.py:321-334) -- after which the robots' MPC phases are no longer aligned and every tick has solves due."""
     import torch
     from rl_mpc_locomotion_amd.locomotion import BatchedLocomotion
     from rl_mpc_locomotion_amd.synthetic import TickStream
     ts = TickStream(n, seed=4242, config=2)
     ctl = BatchedLocomotion(ts.robot_type, ts.gait_id, horizon=h, device=dev)
     ins = [tuple(torch.from_numpy(a).to(dev) for a in ts.tick(k)) for k in range(warm + ticks)]
+    rng = np.random.default_rng(5)
+    ids = [torch.from_numpy(rng.choice(n, max(1, n // 64), replace=False).astype(np.int32)).to(dev) for _ in range(warm + ticks)]
     for k in range(warm):
         ctl.run(*ins[k])
+        if reset_every and (k + 1) % 7 == 0:
+            ctl.reset(ids[k])
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for k in range(warm, warm + ticks):
         ctl.run(*ins[k])
+        if reset_every and (k + 1) % reset_every == 0:
+            ctl.reset(ids[k])
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     solved = float((ctl.solver_info()[:, 1] == 1).mean())
-    return {"robot_ticks_per_s": n * ticks / dt, "ms_per_tick": dt / ticks * 1e3, "ticks": ticks, "mpc_every_n_ticks": 2,
-            "control_steps_per_s_incl_torque_map": n * ticks / dt / 2,
-            "solved_fraction_last_mpc": solved,
-            "note": "controller.run for every robot per tick (estimator, gait, foot placement, MPC solve on every 2nd tick, swing / stance "
-                    "commands, leg-torque map a22); robot_ticks_per_s is ~2x the control-step rate by construction"}
+    out = {"robot_ticks_per_s": n * ticks / dt, "ms_per_tick": dt / ticks * 1e3, "ticks": ticks, "mpc_every_n_ticks": 2,
+           "control_steps_per_s_incl_torque_map": n * ticks / dt / 2,
+           "solved_fraction_last_mpc": solved,
+           "note": "controller.run for every robot per tick (estimator, gait, foot placement, MPC solve on every 2nd tick, swing / stance "
+                   "commands, leg-torque map a22); robot_ticks_per_s is ~2x the control-step rate by construction"}
+    if reset_every:
+        out["reset_every_ticks"] = reset_every
+        out["note"] = ("the same loop with reset(env_ids on the device) of n/64 robots every %d ticks (and a few during warm-up, so the robots' MPC phases "
+                       "are mixed: solves are due on every tick)" % reset_every)
+    return out
 
 
 def policy_leg(n, dev, steps=50, warm=5):

@@ -134,9 +134,10 @@ int mpc_batch_get_scale(mpc_batch *b, double *h_sc);
  * `last_k` launches (oldest first, at most 64). */
 int mpc_batch_enable_timing(mpc_batch *b);
 int mpc_batch_kernel_times(mpc_batch *b, int last_k, float *ms_prep, float *ms_solve);
-/* Shader-clock cycles of the last solve, [n, 16] int64: slot 15 = the whole solve kernel (always; the longest of a robot's last ten
- * values orders the next launch longest-first); slots 0-14 = per section (csrc/mpc_core.h), filled only by a library built with
- * -DMPC_SECTION_PROFILE (tools/section_profile.py) and zero otherwise -- the counters cost registers. */
+/* Shader-clock cycles of the last solve, [n, 16] int64: slot 15 = the ADMM part of the solve (always; NEGATED when the solve was a
+ * cold one; the longest of a robot's last ten warm values orders the next launch's jobs longest-first), slot 0 = its polish job;
+ * slots 1-14 = per section (csrc/mpc_core.h), filled only by a library built with -DMPC_SECTION_PROFILE (tools/section_profile.py)
+ * and zero otherwise -- the counters cost registers. */
 int mpc_batch_get_profile(mpc_batch *b, long long *h_prof);
 
 /* ---- per-tick controller (the rest of the hot path around the solve) -------------------------------

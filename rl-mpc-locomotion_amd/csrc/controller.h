@@ -395,11 +395,12 @@ MPC_HD void ctrl_pre(CtrlState &s, const RobotConst &rc, const GaitTable &gt, co
   if (s.do_solve) {
     const int h = cp.horizon;
     // weights from the command (DesiredStateCommand.py:24-28), or Quadruped._mpc_weights when the command carries none
-    // (mpc_weights is None, ConvexMPCLocomotion.py:132-135: the 3-entry commands of the interactive runners) -- here: cmd[3] is NaN.
+    // (mpc_weights is None, ConvexMPCLocomotion.py:132-135: the 3-entry commands of the interactive runners) -- here: cmd[3 .. 15] all NaN.
     // The reference asserts w >= 0 (DesiredStateCommand.py:21,27); a negative weight makes this robot's record non-finite, so its
     // solve reports NON_CVX and its previous forces stay in place.
     {
-      const bool dflt = cmd[3] != cmd[3];
+      bool dflt = true;                      // "no weights" = ALL thirteen entries NaN (what BatchedLocomotion sends for a 3-entry command); a NaN
+      for (int k = 0; k < 13; ++k) dflt = dflt && (cmd[3 + k] != cmd[3 + k]);   // among real weights (a diverged policy) poisons the record -> NON_CVX
       bool neg = false;
       for (int k = 0; k < 13; ++k) { const float w = dflt ? rc.weights[k] : cmd[3 + k]; neg = neg || (w < 0.f); rec[IN_W + k] = w; }
       if (neg) for (int k = 0; k < 13; ++k) rec[IN_W + k] = __builtin_nanf("");

@@ -41,6 +41,18 @@ namespace {
 
 thread_local std::string g_err;
 int fail(int code, const std::string &msg) { g_err = msg; return code; }
+// Every entry point works on the device its handle was created on and leaves the caller's current device as it found it
+// (a process may hold handles on several GPUs, and the caller -- torch -- has a current device of its own).
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+  DeviceGuard(const DeviceGuard &) = delete;
+  DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
 #define HIP_TRY(expr)                                                                          \
   do {                                                                                         \
     hipError_t e_ = (expr);                                                                    \
@@ -361,7 +373,7 @@ struct mpc_batch {
   double *d_host_f = nullptr;
   unsigned char *d_hist = nullptr;   // [n][kOrderHistory] cycles / 16384 of the last solves (order_block's sort key is their maximum)
   unsigned long long order_launches = 0;
-  int device = 0;                // the HIP device the handle was created on: every entry point makes it current
+  int device = 0;                // the HIP device the handle was created on: every entry point runs under a DeviceGuard for it
   int exact = 0;                 // mpc_batch_set_solver: 1 = the QP's exact optimum (the reference's qpOASES branch), cold on every call
   int max_iter = kMaxIter;       // mpc_batch_set_max_iter: OSQP's max_iter setting (OSQP mode)
   long long bytes = 0;
@@ -370,7 +382,7 @@ struct mpc_batch {
 
 // one solver launch on b's robots (+ the dispatch order for the next one)
 static int launch_solver(mpc_batch *b, const float *d_in, double *d_forces, int *d_info, const int *d_active, hipStream_t st, const double *d_in64 = nullptr) {
-  HIP_TRY(hipSetDevice(b->device));
+  DeviceGuard guard_(b->device);
   const int slot = (int)(b->order_launches++ % kOrderHistory);
   if (b->exact) HIP_TRY(hipMemsetAsync(b->d_state, 0, sizeof(double) * (size_t)b->n * b->state_len, st));   // no warm start in that branch (mpc_osqp.cc:906-919)
   hipEvent_t *ev = b->timing ? b->ev[b->launches % kTimingRing] : nullptr;
@@ -489,7 +501,7 @@ int mpc_batch_solve_f64(mpc_batch *b, const double *d_in, double *d_forces, int 
 
 int mpc_batch_reset(mpc_batch *b, const int *ids, int k, void *stream) {
   if (!b) return fail(MPC_E_ARG, "mpc_batch_reset: bad argument");
-  HIP_TRY(hipSetDevice(b->device));
+  DeviceGuard guard_(b->device);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!ids) {
     HIP_TRY(hipMemsetAsync(b->d_state, 0, sizeof(double) * (size_t)b->n * b->state_len, st));
@@ -507,7 +519,7 @@ int mpc_batch_reset(mpc_batch *b, const int *ids, int k, void *stream) {
 
 int mpc_batch_reset_device(mpc_batch *b, const int *d_ids, int k, void *stream) {
   if (!b || !d_ids || k < 0) return fail(MPC_E_ARG, "mpc_batch_reset_device: bad argument");
-  HIP_TRY(hipSetDevice(b->device));
+  DeviceGuard guard_(b->device);
   if (k == 0) return MPC_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(reset_kernel, dim3(k), dim3(256), 0, st, b->d_state, b->state_len, d_ids, k, b->n);
@@ -517,6 +529,7 @@ int mpc_batch_reset_device(mpc_batch *b, const int *d_ids, int k, void *stream) 
 
 int mpc_batch_solve_host(mpc_batch *b, const float *h_in, double *h_forces, int *h_info) {
   if (!b || !h_in || !h_forces) return fail(MPC_E_ARG, "mpc_batch_solve_host: bad argument");
+  DeviceGuard guard_(b->device);
   const size_t inlen = 56 + 4 * (size_t)b->h, N = 12 * (size_t)b->h;
   if (!b->d_host_in) {   // staging buffers of the host-pointer entry point, kept for the life of the handle
     HIP_TRY(hipMalloc(&b->d_host_in, sizeof(float) * b->n * inlen));
@@ -533,6 +546,7 @@ int mpc_batch_solve_host(mpc_batch *b, const float *h_in, double *h_forces, int 
 
 int mpc_batch_solve_host_f64(mpc_batch *b, const double *h_in, double *h_forces, int *h_info) {
   if (!b || !h_in || !h_forces) return fail(MPC_E_ARG, "mpc_batch_solve_host_f64: bad argument");
+  DeviceGuard guard_(b->device);
   const size_t inlen = 56 + 4 * (size_t)b->h, N = 12 * (size_t)b->h;
   if (!b->d_host_in64) {
     HIP_TRY(hipMalloc(&b->d_host_in64, sizeof(double) * b->n * inlen));
@@ -559,6 +573,7 @@ int mpc_batch_enable_timing(mpc_batch *b) {
 int mpc_batch_kernel_times(mpc_batch *b, int last_k, float *ms_assemble, float *ms_solve) {
   if (!b || !b->timing || last_k <= 0 || last_k > kTimingRing || last_k > b->launches || !ms_assemble || !ms_solve)
     return fail(MPC_E_ARG, "mpc_batch_kernel_times: bad argument (enable timing first; at most 64 launches back)");
+  DeviceGuard guard_(b->device);
   HIP_TRY(hipDeviceSynchronize());
   for (int i = 0; i < last_k; ++i) {
     hipEvent_t *e = b->ev[(b->launches - last_k + i) % kTimingRing];
@@ -573,7 +588,7 @@ long long mpc_batch_device_bytes(const mpc_batch *b) { return b ? b->bytes : 0; 
 int mpc_batch_state_len(const mpc_batch *b) { return b ? b->state_len : 0; }
 int mpc_batch_get_state(mpc_batch *b, double *h_state) {
   if (!b || !h_state) return fail(MPC_E_ARG, "mpc_batch_get_state: bad argument");
-  HIP_TRY(hipSetDevice(b->device));
+  DeviceGuard guard_(b->device);
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(h_state, b->d_state, sizeof(double) * (size_t)b->n * b->state_len, hipMemcpyDeviceToHost));
   return MPC_OK;
@@ -585,25 +600,28 @@ int mpc_batch_qp_len(const mpc_batch *b) { return b ? (int)qp_len_of(b->h) : 0; 
 int mpc_batch_scale_len(const mpc_batch *b) { return b ? (int)sc_len_of(b->h) : 0; }
 int mpc_batch_get_qp(mpc_batch *b, double *h_qp) {
   if (!b || !h_qp) return fail(MPC_E_ARG, "mpc_batch_get_qp: bad argument");
+  DeviceGuard guard_(b->device);
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(h_qp, b->d_qp, sizeof(double) * (size_t)b->n * qp_len_of(b->h), hipMemcpyDeviceToHost));
   return MPC_OK;
 }
 int mpc_batch_get_scale(mpc_batch *b, double *h_sc) {
   if (!b || !h_sc) return fail(MPC_E_ARG, "mpc_batch_get_scale: bad argument");
+  DeviceGuard guard_(b->device);
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(h_sc, b->d_sc, sizeof(double) * (size_t)b->n * sc_len_of(b->h), hipMemcpyDeviceToHost));
   return MPC_OK;
 }
 int mpc_batch_get_profile(mpc_batch *b, long long *h_prof) {
   if (!b || !h_prof) return fail(MPC_E_ARG, "mpc_batch_get_profile: bad argument");
+  DeviceGuard guard_(b->device);
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(h_prof, b->d_prof, sizeof(long long) * (size_t)b->n * kProfLen, hipMemcpyDeviceToHost));
   return MPC_OK;
 }
 int mpc_batch_set_state(mpc_batch *b, const double *h_state) {
   if (!b || !h_state) return fail(MPC_E_ARG, "mpc_batch_set_state: bad argument");
-  HIP_TRY(hipSetDevice(b->device));
+  DeviceGuard guard_(b->device);
   HIP_TRY(hipMemcpy(b->d_state, h_state, sizeof(double) * (size_t)b->n * b->state_len, hipMemcpyHostToDevice));
   return MPC_OK;
 }
@@ -787,7 +805,7 @@ int mpc_ctrl_create(mpc_ctrl **out, int n, int horizon, double controller_dt, in
 
 int mpc_ctrl_step(mpc_ctrl *c, const float *d_dof, const float *d_est, const float *d_cmd, float *d_torques, void *stream) {
   if (!c || !d_dof || !d_est || !d_cmd || !d_torques) return fail(MPC_E_ARG, "mpc_ctrl_step: bad argument");
-  HIP_TRY(hipSetDevice(c->solver->device));
+  DeviceGuard guard_(c->solver->device);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int n = c->n, blocks = (n + kCtrlThreads - 1) / kCtrlThreads;
   bool any_due = true;
@@ -810,7 +828,7 @@ int mpc_ctrl_step(mpc_ctrl *c, const float *d_dof, const float *d_est, const flo
 
 int mpc_ctrl_run(mpc_ctrl *c, const float *d_dof, const float *d_body, const float *d_cmd, float *d_torques, void *stream) {
   if (!c || !d_dof || !d_body || !d_cmd || !d_torques) return fail(MPC_E_ARG, "mpc_ctrl_run: bad argument");
-  HIP_TRY(hipSetDevice(c->solver->device));
+  DeviceGuard guard_(c->solver->device);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(estimator_kernel, dim3((c->n + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, st, c->n, c->d_state, d_body, c->d_est);
   HIP_TRY(hipGetLastError());
@@ -819,7 +837,7 @@ int mpc_ctrl_run(mpc_ctrl *c, const float *d_dof, const float *d_body, const flo
 
 int mpc_ctrl_reset(mpc_ctrl *c, const int *ids, int k, void *stream) {
   if (!c) return fail(MPC_E_ARG, "mpc_ctrl_reset: bad argument");
-  HIP_TRY(hipSetDevice(c->solver->device));
+  DeviceGuard guard_(c->solver->device);
   if (!ids) c->h_iter.assign(c->n, 0);
   else for (int i = 0; i < k; ++i) if (ids[i] >= 0 && ids[i] < c->n && (int)c->h_iter.size() == c->n) c->h_iter[ids[i]] = 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -842,7 +860,7 @@ int mpc_ctrl_reset(mpc_ctrl *c, const int *ids, int k, void *stream) {
 
 int mpc_ctrl_reset_device(mpc_ctrl *c, const int *d_ids, int k, void *stream) {
   if (!c || !d_ids || k < 0) return fail(MPC_E_ARG, "mpc_ctrl_reset_device: bad argument");
-  HIP_TRY(hipSetDevice(c->solver->device));
+  DeviceGuard guard_(c->solver->device);
   if (k == 0) return MPC_OK;
   c->mirror_valid = false;     // the host copy of the MPC counters cannot follow ids it never sees: launch the solver on every tick (active mask)
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -855,7 +873,7 @@ int mpc_ctrl_reset_device(mpc_ctrl *c, const int *d_ids, int k, void *stream) {
 
 int mpc_ctrl_set_gait(mpc_ctrl *c, const int *gait_id, void *stream) {
   if (!c || !gait_id) return fail(MPC_E_ARG, "mpc_ctrl_set_gait: bad argument");
-  HIP_TRY(hipSetDevice(c->solver->device));
+  DeviceGuard guard_(c->solver->device);
   for (int r = 0; r < c->n; ++r) if (gait_id[r] < 0 || gait_id[r] >= kNumGaitIds) return fail(MPC_E_ARG, "mpc_ctrl_set_gait: gait id out of range");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   HIP_TRY(hipMemcpyAsync(c->d_gait, gait_id, sizeof(int) * c->n, hipMemcpyHostToDevice, st));
@@ -866,7 +884,7 @@ int mpc_ctrl_set_gait(mpc_ctrl *c, const int *gait_id, void *stream) {
 
 int mpc_ctrl_fsm_init(mpc_ctrl *c, const int *control_mode, int operating_mode, int check_safety, void *stream) {
   if (!c || !control_mode || (operating_mode != kOpTest && operating_mode != kOpNormal)) return fail(MPC_E_ARG, "mpc_ctrl_fsm_init: bad argument");
-  HIP_TRY(hipSetDevice(c->solver->device));
+  DeviceGuard guard_(c->solver->device);
   for (int r = 0; r < c->n; ++r)
     if (control_mode[r] != kFsmPassive && control_mode[r] != kFsmLocomotion && control_mode[r] != kFsmRecoveryStand)
       return fail(MPC_E_ARG, "mpc_ctrl_fsm_init: control mode must be 0 (PASSIVE), 4 (LOCOMOTION) or 6 (RECOVERY_STAND)");
@@ -891,7 +909,7 @@ int mpc_ctrl_fsm_init(mpc_ctrl *c, const int *control_mode, int operating_mode, 
 
 int mpc_ctrl_fsm_reset(mpc_ctrl *c, const int *ids, int k, const int *control_mode, void *stream) {
   if (!c || !c->d_fsm || (ids && k < 0)) return fail(MPC_E_ARG, "mpc_ctrl_fsm_reset: bad argument (mpc_ctrl_fsm_init first)");
-  HIP_TRY(hipSetDevice(c->solver->device));
+  DeviceGuard guard_(c->solver->device);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (control_mode) {   // [n] entries, like mpc_ctrl_fsm_init
     for (int r = 0; r < c->n; ++r)
@@ -916,7 +934,7 @@ int mpc_ctrl_fsm_reset(mpc_ctrl *c, const int *ids, int k, const int *control_mo
 
 int mpc_ctrl_run_fsm(mpc_ctrl *c, const float *d_dof, const float *d_body, const float *d_cmd, const int *d_request, float *d_torques, void *stream) {
   if (!c || !d_dof || !d_body || !d_cmd || !d_request || !d_torques) return fail(MPC_E_ARG, "mpc_ctrl_run_fsm: bad argument");
-  HIP_TRY(hipSetDevice(c->solver->device));
+  DeviceGuard guard_(c->solver->device);
   if (!c->d_fsm) return fail(MPC_E_ARG, "mpc_ctrl_run_fsm: call mpc_ctrl_fsm_init first");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int n = c->n, blocks = (n + kCtrlThreads - 1) / kCtrlThreads;
@@ -934,6 +952,7 @@ int mpc_ctrl_run_fsm(mpc_ctrl *c, const float *d_dof, const float *d_body, const
 
 int mpc_ctrl_fsm_state(mpc_ctrl *c, int *h_out) {
   if (!c || !c->d_fsm || !h_out) return fail(MPC_E_ARG, "mpc_ctrl_fsm_state: bad argument");
+  DeviceGuard guard_(c->solver->device);
   std::vector<FsmState> h(c->n);
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(h.data(), c->d_fsm, sizeof(FsmState) * c->n, hipMemcpyDeviceToHost));
@@ -943,6 +962,7 @@ int mpc_ctrl_fsm_state(mpc_ctrl *c, int *h_out) {
 
 int mpc_ctrl_solver_info(mpc_ctrl *c, int *h_info) {
   if (!c || !h_info) return fail(MPC_E_ARG, "mpc_ctrl_solver_info: bad argument");
+  DeviceGuard guard_(c->solver->device);
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(h_info, c->d_info, sizeof(int) * (size_t)c->n * kInfoLen, hipMemcpyDeviceToHost));
   return MPC_OK;
@@ -1035,6 +1055,7 @@ int mpc_pack_commands(int n, const float *d_cmd3, const float *d_weights12, floa
 
 int mpc_ctrl_update_estimate(mpc_ctrl *c, const float *d_body, void *stream) {
   if (!c || !d_body) return fail(MPC_E_ARG, "mpc_ctrl_update_estimate: bad argument");
+  DeviceGuard guard_(c->solver->device);
   hipLaunchKernelGGL(estimator_kernel, dim3((c->n + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, (hipStream_t)stream, c->n, c->d_state, d_body, c->d_est);
   HIP_TRY(hipGetLastError());
   return MPC_OK;
@@ -1042,6 +1063,7 @@ int mpc_ctrl_update_estimate(mpc_ctrl *c, const float *d_body, void *stream) {
 
 int mpc_ctrl_estimate(mpc_ctrl *c, float *d_est, float *d_ground_normal, void *stream) {
   if (!c || (!d_est && !d_ground_normal)) return fail(MPC_E_ARG, "mpc_ctrl_estimate: bad argument");
+  DeviceGuard guard_(c->solver->device);
   hipLaunchKernelGGL(ctrl_estimate_kernel, dim3((c->n + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, (hipStream_t)stream, c->n, c->d_state, c->d_est, d_est, d_ground_normal);
   HIP_TRY(hipGetLastError());
   return MPC_OK;

@@ -1574,6 +1574,7 @@ struct Solver {
   // robot's next call is the cold "osqp_setup" call on clean data (with NaN inputs the vendored OSQP itself stays poisoned).
   MPC_HD void store(long long t0) {
     tc[15] = MPC_CLOCK() - t0;
+    if (s.first) tc[15] = -tc[15];   // a cold solve is no predictor of the robot's next (warm) one: negative = ignored by the dispatch order (order_block)
     ex.par([&](Th &t) {
       const bool failed = s.bad || s.status == kStNonCvx;
       const bool solved = s.status == kStSolved && !failed;
@@ -1667,6 +1668,7 @@ struct Solver {
     }
     lap(14);
     tc[15] = MPC_CLOCK() - t0;
+    if (s.first) tc[15] = -tc[15];   // a cold solve is no predictor of the robot's next (warm) one: negative = ignored by the dispatch order (order_block)
     // outputs + persistent state (store_solution, auxil.c:528-561; mpc_osqp.cc:788-790: forces = -x): see store()
     ex.par([&](Th &t) {
       const bool failed = s.bad || s.status == kStNonCvx;

@@ -45,6 +45,7 @@ class BatchedLocomotion:
         """dof_states [N,12,2] (or [N*12,2]), est [N,18], commands [N,16]: contiguous cuda float32.
         Returns torques [N,12] float32 (FL FR RL RR x hip, thigh, calf)."""
         import torch
+        commands = self._full_commands(commands)
         for name, t, numel in (("dof_states", dof_states, self.n * 24), ("est", est, self.n * 18), ("commands", commands, self.n * 16)):
             if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or t.numel() != numel:
                 raise ValueError(f"{name} must be a contiguous cuda float32 tensor with {numel} elements")

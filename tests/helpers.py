@@ -33,3 +33,17 @@ def inertia9_from_diag(d):
     out = np.zeros((len(d), 9))
     out[:, 0], out[:, 4], out[:, 8] = d[:, 0], d[:, 1], d[:, 2]
     return out
+
+
+def infeasible_workload(n=24, h=10, seed=5):
+    """A config-2 batch whose first third has NEGATIVE friction coefficients (mu = -0.4): the pyramid rows then demand f_z <= 0 while
+    the f_z row demands f_z >= f_min > 0 on every stance foot -- a primal infeasible QP with valid bounds (l <= u everywhere), which
+    OSQP detects at its first or second termination check (auxil.c:364-424).  Returns (workload, inputs)."""
+    import rl_mpc_locomotion_amd  # noqa: F401
+    from rl_mpc_locomotion_amd import layout as L
+    from rl_mpc_locomotion_amd.synthetic import make_solver_workload
+    wl = make_solver_workload(n, h=h, seed=seed, config=2)
+    inp = wl.inputs.copy()
+    fr = L.in_friction(h)
+    inp[:n // 3, fr:fr + 4] = -0.4
+    return wl, inp

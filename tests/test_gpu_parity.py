@@ -269,6 +269,65 @@ def test_assembly_and_scaling_records_match_the_oracle(name):
         assert abs(sc[r, 2 * N + 3 * M + 60 * h] / st["c"] - 1) < 1e-11       # D[N] E[M] q_s[N] A_s[15 * 4 h] l_s[M] u_s[M] c 1/c job[2]
 
 
+def test_non_solved_statuses_match_osqp():
+    """info[:, :4] of robots that do not end SOLVED against the vendored OSQP: primal infeasible QPs (status -3 at the check where OSQP
+    finds its certificate, auxil.c:364-424) and a small max_iter (MAX_ITER_REACHED / SOLVED_INACCURATE, osqp.c:563-568); their force
+    rows stay untouched (the reference returns [], mpc_osqp.cc:788-794)."""
+    from oracle.refmpc import RefBatch
+    from tests.helpers import infeasible_workload
+    wl, inp = infeasible_workload(n=48)
+    n, h = len(wl.mass), 10
+    gpu = _gpu(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
+    ref = RefBatch(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
+    import torch
+    for step in range(3):
+        gpu.forces.fill_(777.0)
+        f, info = _solve(gpu, inp)
+        fr = ref.solve(inp, nthreads=8)
+        assert np.array_equal(info[:, :4], ref.info[:, :4].astype(np.int32)), step
+        assert (info[:n // 3, 1] == -3).all() and (f[:n // 3] == 777.0).all()
+        ok = ref.info[:, 1] == 1
+        assert grf_relerr(f[ok], fr[ok]).max() < GRF_RTOL
+    gpu = _gpu(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
+    gpu.set_max_iter(25)
+    ref = RefBatch(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
+    ref.set_max_iter(25)
+    seen = set()
+    w = wl
+    for step in range(3):
+        f, info = _solve(gpu, w.inputs)
+        ref.solve(w.inputs, nthreads=8)
+        assert np.array_equal(info[:, :4], ref.info[:, :4].astype(np.int32)), step
+        seen |= set(info[:, 1].tolist())
+        w = perturb_workload(w, 3 + step)
+    assert {-2, 2} <= seen
+
+
+def test_one_infeasible_robot_does_not_hold_the_launch():
+    """4096 robots, one of them with an infeasible QP: OSQP's certificate ends it after 25-50 iterations (it ran to max_iter = 4000,
+    ~7 launches' worth of time, before the certificates were evaluated); the launch takes what it takes without that robot."""
+    import torch
+    n, h = 4096, 10
+    wl = make_solver_workload(n, h=h, seed=0, config=2)
+    from rl_mpc_locomotion_amd import layout as L
+    bad = wl.inputs.copy()
+    bad[17, L.in_friction(h):L.in_friction(h) + 4] = -0.4
+    times = {}
+    for name, inp in (("clean", wl.inputs), ("one infeasible", bad)):
+        gpu = _gpu(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
+        gpu.enable_timing()
+        d = torch.from_numpy(inp).to("cuda:0")
+        for _ in range(3):
+            f, info = gpu.solve(d)
+        torch.cuda.synchronize()
+        times[name] = float(gpu.kernel_times(1)[1][-1])
+        st = info.cpu().numpy()
+        assert (np.delete(st[:, 1], 17) == 1).all()
+        if name != "clean":
+            assert st[17, 1] == -3 and st[17, 0] <= 50
+    assert times["one infeasible"] < 1.25 * times["clean"], times
+
+
 @pytest.mark.gpu
 def test_bench_contract_line():
     """`python bench.py` prints ONE JSON line with the keys the driver reads (small sizes; the CPU baseline leg uses the oracle)."""

@@ -26,7 +26,7 @@ for s in range(steps):
     f, info = sv.solve(torch.from_numpy(w.inputs).cuda())
     torch.cuda.synchronize()
     infos.append(info.cpu().numpy().copy())
-    profs.append(sv.get_profile().copy())
+    profs.append(np.abs(sv.get_profile()))
     kms.append([float(x[-1]) for x in sv.kernel_times(1)])
     w = perturb_workload(w, 7000 + 131 * s)
 np.savez_compressed(out, info=np.stack(infos), prof=np.stack(profs), kernel_ms=np.array(kms))

@@ -25,7 +25,7 @@ for step in range(4):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     f, info = sv.solve(d)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    p = sv.get_profile().astype(np.float64); i = info.cpu().numpy()
+    p = np.abs(sv.get_profile()).astype(np.float64); i = info.cpu().numpy()
     print(f"step {step}: {dt*1e3:.2f} ms  iters {i[:,0].mean():.1f} nfact {i[:,4].mean():.2f} | mean kcycles/robot: " +
           " ".join(f"{nm}={p[:,k].mean()/1e3:.0f}" for k, nm in enumerate(names)) +
           f" | per-iter admm {p[:,8].sum()/i[:,0].sum():.0f} cyc, per-sweep {p[:,7].sum()/np.maximum(i[:,4]-1,1).sum():.0f} cyc")

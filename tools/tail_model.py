@@ -36,7 +36,7 @@ w = wl
 for s in range(8):
     solver.solve(torch.from_numpy(w.inputs).to(dev))
     torch.cuda.synchronize()
-    cyc = solver.get_profile()[:, 15].astype(np.int64)
+    cyc = np.abs(solver.get_profile()[:, 15]).astype(np.int64)
     _, c = solver.kernel_times(1)
     if prev is not None:
         lb = cyc.sum() / slots
@@ -56,7 +56,7 @@ if "--predict" in sys.argv:
     for s in range(10):
         f, info = solver.solve(torch.from_numpy(w.inputs).to(dev))
         torch.cuda.synchronize()
-        cyc = solver.get_profile()[:, 15].astype(np.float64)
+        cyc = np.abs(solver.get_profile()[:, 15]).astype(np.float64)
         it = info.cpu().numpy()[:, 0]
         tab = w.inputs[:, L.IN_CONTACT:L.IN_CONTACT + 40].copy()
         if prev_c is not None:
@@ -77,7 +77,7 @@ if "--orders" in sys.argv:
     for s in range(34):
         solver.solve(torch.from_numpy(w.inputs).to(dev))
         torch.cuda.synchronize()
-        cyc = solver.get_profile()[:, 15].astype(np.float64)
+        cyc = np.abs(solver.get_profile()[:, 15]).astype(np.float64)
         if len(hist) >= 10:
             preds = {"previous": hist[-1], "max of last 2": np.maximum(hist[-1], hist[-2]), "max of last 3": np.maximum.reduce(hist[-3:]),
                      "one gait period ago (10)": hist[-10], "max(previous, 10 ago)": np.maximum(hist[-1], hist[-10]),
@@ -97,7 +97,7 @@ if "--split" in sys.argv:
     for s in range(10):
         solver.solve(torch.from_numpy(w.inputs).to(dev))
         torch.cuda.synchronize()
-        cyc = solver.get_profile()[:, 15].astype(np.float64)
+        cyc = np.abs(solver.get_profile()[:, 15]).astype(np.float64)
         if prev is not None and s >= 4:
             one = schedule(np.argsort(-prev, kind="stable"), cyc)
             a = schedule(np.argsort(-prev, kind="stable"), cyc - polish)
@@ -135,7 +135,7 @@ if "--packing" in sys.argv:
     for s in range(22):
         solver.solve(torch.from_numpy(w.inputs).to(dev))
         torch.cuda.synchronize()
-        cyc = solver.get_profile()[:, 15].astype(np.float64)
+        cyc = np.abs(solver.get_profile()[:, 15]).astype(np.float64)
         if len(hist) >= 10 and s % 3 == 0:
             pred = np.maximum.reduce(hist[-10:])
             res["longest-first by max of last 10"].append(schedule(np.argsort(-pred, kind="stable"), cyc))
