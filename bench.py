@@ -309,6 +309,8 @@ def main():
         return
     if world == 1 and not args.no_secondary and args.config == 2 and not args.robots:
         out["secondary"] = secondary_lines(dev)          # the other BASELINE configurations at their per-GPU sizes (N = 1 only)
+    if world == 1 and not args.no_secondary and args.config == 2 and not args.robots:
+        out["secondary"]["exact"] = exact_leg(m["wl"], m["batches"], W, h, dev)
     if not args.no_control_loop and world == 1:      # secondary legs: single-GPU runs only
         out["control_loop"] = control_loop_leg(n, h, dev)
         out["control_loop_with_resets"] = control_loop_leg(n, h, dev, reset_every=37)
@@ -335,6 +337,49 @@ def secondary_lines(dev, steps=5, warm=2):
                                "solve_kernel_ms": float(m["solve_ms"].mean()), "solved_fraction": float((m["info"][..., 1] == 1).mean()),
                                "mean_admm_iters": float(m["info"][..., 0].mean()), "what": CONFIGS[cid]["what"]}
         del m
+    return out
+
+
+def exact_leg(wl, batches, W, h, dev, steps=5, sample=256):
+    """The exact-optimum mode (MPC_SOLVER_EXACT: what the reference AS SHIPPED asks for, mpc.QPOASES, ConvexMPCLocomotion.py:108) on the
+    headline workload: steps/s, kernel times, and on a sample of robots the error against the oracle's exact optimum (vendored OSQP, cold,
+    eps 1e-9, polish) and the KKT conditions of the oracle-assembled QP.  Not `value`."""
+    import torch
+    from rl_mpc_locomotion_amd.batched import BatchedConvexMpc
+    n = len(wl.mass)
+    inertia9 = np.zeros((n, 9)); inertia9[:, 0], inertia9[:, 4], inertia9[:, 8] = wl.inertia_diag.T
+    sv = BatchedConvexMpc(wl.mass, inertia9, h, wl.dt_mpc, wl.alpha, device=dev, solver="exact")
+    sv.enable_timing()
+    d_in = [torch.from_numpy(batches[W + s]).to(dev) for s in range(steps)]
+    sv.solve(d_in[0])
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for s in range(steps):
+        f, info = sv.solve(d_in[s])
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    prep, solve = sv.kernel_times(steps)
+    f, info = f.cpu().numpy(), info.cpu().numpy()
+    out = {"robots": n, "horizon": h, "steps": steps, "control_steps_per_s": n * steps / dt, "ms_per_step": dt / steps * 1e3, "prep_kernel_ms": float(prep.mean()),
+           "solve_kernels_ms": float(solve.mean()), "solved_fraction": float((info[:, 1] == 1).mean()), "working_set_changes_mean": float(info[:, 0].mean()),
+           "working_set_changes_max": int(info[:, 0].max()),
+           "what": "MPC_SOLVER_EXACT: dual active-set method + verified polish (first launch), ADMM route for robots it does not certify (second launch); cold every call"}
+    try:
+        from oracle.refmpc import RefConvexMpc
+        from tests.helpers import kkt_certificate
+        pick = np.arange(0, n, max(1, n // sample))[:sample]
+        errs, kp, ks = [], 0.0, 0.0
+        for r in pick:
+            ref = RefConvexMpc(wl.mass[r], list(inertia9[r]), 4, h, wl.dt_mpc, wl.alpha)
+            fx = ref.solve_exact(batches[W + steps - 1][r])
+            errs.append(float(np.abs(f[r] - fx).max() / max(np.abs(fx).max(), 1.0)))
+            if len(errs) <= 32:
+                P, q, l, u, cone = ref.qp()
+                pv, sr = kkt_certificate(P, q, cone, l, u, -f[r])
+                kp, ks = max(kp, pv), max(ks, sr)
+        out.update({"max_rel_err_vs_oracle_optimum": float(np.max(errs)), "sample": len(errs), "kkt_max_primal_violation": kp, "kkt_max_stationarity": ks})
+    except Exception as e:      # the checker is optional here; never fail the bench line on it
+        out["check_error"] = repr(e)
     return out
 
 

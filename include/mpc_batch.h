@@ -83,8 +83,13 @@ void mpc_batch_destroy(mpc_batch *b);
  *                    from the previous call -- BASELINE.json's comparator;
  *   MPC_SOLVER_EXACT the qpOASES branch (:797-947, what the shipped Python selects, ConvexMPCLocomotion.py:108): the QP's optimum
  *                    (unique: the Hessian is 2 B^T Q B + alpha I), cold on every call like that branch.  qpOASES itself is an empty
- *                    submodule in the reference; its RESULT is reproduced (the same ADMM run to 1e-9 and polished), swing-foot
- *                    forces come out as ~1e-10 instead of qpOASES' exact zeros. */
+ *                    submodule in the reference; its RESULT is reproduced, by an active-set method of this library's own
+ *                    (csrc/mpc_wrench.h active_set: Goldfarb-Idnani's dual method on the problem with the swing feet eliminated,
+ *                    like :838-856, then the polish on its set, accepted only if it passes the optimality conditions at 1e-10;
+ *                    info[0] = working-set changes).  Eliminated feet return exact 0.0 (:924-927).  That branch returns its
+ *                    vector whatever its solver's status (:906-947): so does this mode -- a robot that the fall-back route (ADMM
+ *                    towards 1e-9) leaves unfinished reports SOLVED_INACCURATE / MAX_ITER_REACHED WITH its iterate written; only
+ *                    a non-finite / non-convex problem (NON_CVX) writes nothing. */
 enum { MPC_SOLVER_OSQP = 0, MPC_SOLVER_EXACT = 1 };
 int mpc_batch_set_solver(mpc_batch *b, int solver);
 
@@ -176,6 +181,9 @@ int mpc_ctrl_run(mpc_ctrl *c, const float *d_dof, const float *d_body, const flo
 int mpc_ctrl_reset(mpc_ctrl *c, const int *ids, int k, void *stream);      /* HOST ids; NULL = all */
 int mpc_ctrl_reset_device(mpc_ctrl *c, const int *d_ids, int k, void *stream);   /* DEVICE ids (env_ids tensor), stream-ordered */
 int mpc_ctrl_set_gait(mpc_ctrl *c, const int *gait_id, void *stream);       /* HOST [n] */
+/* The QPSolverName argument of the controller's ConvexMpc objects (ConvexMPCLocomotion.py:102-108; the shipped Python passes QPOASES):
+ * MPC_SOLVER_OSQP (default here: BASELINE's comparator) or MPC_SOLVER_EXACT, see mpc_batch_set_solver. */
+int mpc_ctrl_set_solver(mpc_ctrl *c, int solver);
 int mpc_ctrl_solver_info(mpc_ctrl *c, int *h_info);                          /* [n, 8] of the last solves */
 
 /* ---- control FSM around the controller (RobotRunnerFSM) -------------------------------------------

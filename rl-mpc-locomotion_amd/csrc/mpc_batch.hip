@@ -79,6 +79,7 @@ __device__ __forceinline__ double read_lane(double v, int lane) {   // a lane's 
 template <class TH, bool WAVE = false>
 struct DeviceExec {
   TH &th;
+  __device__ __forceinline__ TH &first() { return th; }   // (after a workgroup-wide reduction every thread holds the same value)
   template <class F>
   __device__ __forceinline__ void par(F &&f) {
     f(th);
@@ -113,6 +114,50 @@ struct DeviceExec {
     v[0] = (read_lane(a, 0) + read_lane(a, 16)) + (read_lane(a, 32) + read_lane(a, 48));
     v[1] = fmax(fmax(read_lane(m, 0), read_lane(m, 16)), fmax(read_lane(m, 32), read_lane(m, 48)));
   }
+  // val(th)[0] <- the maximum over the workgroup's threads, idx(th) <- the lowest thread holding it (the same in every thread).
+  // One wavefront: DPP row reductions + readlane + a ballot; several: LDS scratch (>= blockDim.x doubles) and two barriers.
+  template <class V, class I>
+  __device__ __forceinline__ void wg_argmax(V &&val, I &&idx, double *scratch) {
+    double *v = val(th);
+    if constexpr (WAVE) {
+      double m = v[0];
+      m = fmax(m, quad_perm<quad_ctrl(1, 0, 3, 2)>(m));
+      m = fmax(m, quad_perm<quad_ctrl(2, 3, 0, 1)>(m));
+      m = fmax(m, quad_perm<0x141>(m));
+      m = fmax(m, quad_perm<0x140>(m));
+      m = fmax(fmax(read_lane(m, 0), read_lane(m, 16)), fmax(read_lane(m, 32), read_lane(m, 48)));
+      const unsigned long long who = __ballot(v[0] == m);
+      idx(th) = who ? __ffsll((long long)who) - 1 : 0;
+      v[0] = m;
+    } else {
+      scratch[threadIdx.x] = v[0];
+      __syncthreads();
+      double m = scratch[0];
+      int ml = 0;
+      for (int i = 1; i < (int)blockDim.x; ++i) { const double x = scratch[i]; if (x > m) { m = x; ml = i; } }
+      __syncthreads();
+      v[0] = m; idx(th) = ml;
+    }
+  }
+  template <class V>
+  __device__ __forceinline__ void wg_sum(V &&val, double *scratch) {
+    double *v = val(th);
+    double a = v[0];
+    a += quad_perm<quad_ctrl(1, 0, 3, 2)>(a);
+    a += quad_perm<quad_ctrl(2, 3, 0, 1)>(a);
+    a += quad_perm<0x141>(a);
+    a += quad_perm<0x140>(a);
+    a = (read_lane(a, 0) + read_lane(a, 16)) + (read_lane(a, 32) + read_lane(a, 48));
+    if constexpr (WAVE) v[0] = a;
+    else {
+      if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = a;
+      __syncthreads();
+      double tot = scratch[0];
+      for (int w = 1; w < (int)(blockDim.x >> 6); ++w) tot += scratch[w];
+      __syncthreads();
+      v[0] = tot;
+    }
+  }
   // dst(th)[r] <- src(lane r & 3 of the quad)[r >> 2], r = 0 .. 5
   template <class S, class D>
   __device__ __forceinline__ void quad_gather6(S &&src, D &&dst) {
@@ -136,12 +181,15 @@ template <int H, bool EXACT>
 __global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES : MPC_SOLVE_MIN_WAVES_WIDE)) void mpc_solve_kernel(
     int n, const RobotModel *__restrict__ models, double *__restrict__ state, const double *__restrict__ qp,
     const double *__restrict__ sc, double *__restrict__ forces, int *__restrict__ info, long long *__restrict__ prof,
-    const int *__restrict__ order, const int *__restrict__ sched, int max_iter) {
+    const int *__restrict__ order, const int *__restrict__ sched, const int *__restrict__ ready, int max_iter) {
   // static LDS: absolute addresses fold into the ds_* offset fields
   __shared__ __attribute__((aligned(16))) Shared<H> sh;
   using C = Cfg<H>;
-  if ((int)blockIdx.x >= sched[kSchedJobs]) return;   // (the job list holds the active robots only: robots whose controller is between two MPC updates have no job)
-  const int robot = order[blockIdx.x];                // longest-expected solves first (order_block)
+  // OSQP mode: the job list holds the launch's active robots (robots whose controller is between two MPC updates have no job), longest
+  // expected solve first (order_block).  Exact mode: this kernel is the second launch -- the robots whose active set mpc_exact_kernel
+  // could not certify, listed in `ready` -- and takes the ADMM route.
+  if ((int)blockIdx.x >= (EXACT ? sched[kSchedTail] : sched[kSchedJobs])) return;
+  const int robot = EXACT ? ready[blockIdx.x] : order[blockIdx.x];
   WThread<H> th;
   th.init(threadIdx.x);
 #pragma unroll
@@ -161,6 +209,33 @@ __global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES
   if constexpr (EXACT) sv.exact();
   else sv.max_iter = max_iter;
   sv.template run<EXACT>();
+}
+
+// Exact mode (the reference's qpOASES branch), first launch: the dual active-set method + the polish on its set (mpc_wrench.h
+// active_set / run_active_set), one workgroup per robot.  A robot whose set is not certified (the polished point fails the optimality
+// test, the working set overflows its slots) is appended to `ready` for the second launch, mpc_solve_kernel<H, true>.
+template <int H>
+__global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES : MPC_SOLVE_MIN_WAVES_WIDE)) void mpc_exact_kernel(
+    const RobotModel *__restrict__ models, double *__restrict__ state, const double *__restrict__ qp, const double *__restrict__ sc,
+    double *__restrict__ forces, int *__restrict__ info, long long *__restrict__ prof, const int *__restrict__ order, int *__restrict__ sched,
+    int *__restrict__ ready) {
+  __shared__ __attribute__((aligned(16))) Shared<H> sh;
+  __shared__ __attribute__((aligned(16))) GiShared<H> gsh;
+  using C = Cfg<H>;
+  if ((int)blockIdx.x >= sched[kSchedJobs]) return;
+  const int robot = order[blockIdx.x];
+  WThread<H> th;
+  th.init(threadIdx.x);
+#pragma unroll
+  for (int j = 0; j < C::TE; ++j) th.Mx[j] = 0;
+  using Ex = DeviceExec<WThread<H>, (C::TW <= 64)>;
+  Ex ex{th};
+  Solver<H, Ex> sv{ex, sh, models[robot], state + (size_t)robot * state_len<H>(), qp + (size_t)robot * C::QP_LEN, sc + (size_t)robot * C::SC_LEN,
+                   forces + (size_t)robot * C::N, info + (size_t)robot * kInfoLen, prof ? prof + (size_t)robot * kProfLen : nullptr};
+  sv.exact();
+  sv.gi = &gsh;
+  const bool ok = sv.run_active_set();
+  if (!ok && threadIdx.x == 0) ready[atomicAdd(&sched[kSchedTail], 1)] = robot;
 }
 
 // The OSQP-mode solve as a PERSISTENT kernel: one workgroup per wave slot of the chip, each pulling jobs until none is left.  A solve
@@ -338,12 +413,15 @@ int launch(int n, const RobotModel *models, const float *in, const double *in64,
   if (ev) (void)hipEventRecord(ev[0], stream);
   hipLaunchKernelGGL(mpc_prep_kernel<H>, dim3(n + 1), dim3(Cfg<H>::T), 0, stream, n, models, in, in64, state, qp, sc, prof, active, order, hist, hist_slot, sched, ready);
   if (ev) (void)hipEventRecord(ev[1], stream);
-  if (exact) hipLaunchKernelGGL((mpc_solve_kernel<H, true>), dim3(n), dim3(Cfg<H>::TW), 0, stream, n, models, state, qp, sc, forces, info, prof, order, sched, max_iter);
+  if (exact) {
+    hipLaunchKernelGGL((mpc_exact_kernel<H>), dim3(n), dim3(Cfg<H>::TW), 0, stream, models, state, qp, sc, forces, info, prof, order, sched, ready);
+    hipLaunchKernelGGL((mpc_solve_kernel<H, true>), dim3(n), dim3(Cfg<H>::TW), 0, stream, n, models, state, qp, sc, forces, info, prof, order, sched, ready, max_iter);
+  }
   else if (job_slots > 0) {   // persistent workgroups, ADMM and polish as separate jobs (h = 16: 2.68 -> 2.28 ms, h = 20: 3.36 -> 2.78 ms per 4096 robots)
     const int slots = H == 10 ? job_slots : job_slots / 2;                  // (multi-wave workgroups: two per CU)
     hipLaunchKernelGGL((mpc_solve_jobs_kernel<H>), dim3(n < slots ? n : slots), dim3(Cfg<H>::TW), 0, stream, models, state, qp, sc, forces, info, prof, order, sched, ready, max_iter);
   }
-  else hipLaunchKernelGGL((mpc_solve_kernel<H, false>), dim3(n), dim3(Cfg<H>::TW), 0, stream, n, models, state, qp, sc, forces, info, prof, order, sched, max_iter);
+  else hipLaunchKernelGGL((mpc_solve_kernel<H, false>), dim3(n), dim3(Cfg<H>::TW), 0, stream, n, models, state, qp, sc, forces, info, prof, order, sched, ready, max_iter);
   if (ev) (void)hipEventRecord(ev[2], stream);
   HIP_TRY(hipGetLastError());
   return MPC_OK;
@@ -869,6 +947,11 @@ int mpc_ctrl_reset_device(mpc_ctrl *c, const int *d_ids, int k, void *stream) {
   hipLaunchKernelGGL(ctrl_reset_kernel, dim3((k + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, st, c->n, c->d_state, c->d_rc, d_ids, k);
   HIP_TRY(hipGetLastError());
   return MPC_OK;
+}
+
+int mpc_ctrl_set_solver(mpc_ctrl *c, int solver) {
+  if (!c) return fail(MPC_E_ARG, "mpc_ctrl_set_solver: bad argument");
+  return mpc_batch_set_solver(c->solver, solver);
 }
 
 int mpc_ctrl_set_gait(mpc_ctrl *c, const int *gait_id, void *stream) {

@@ -262,6 +262,15 @@ MPC_HD double raw_min(double a, double b) {
 // (equal to the c_max / c_min selects of OSQP whenever lo and hi are not NaN)
 MPC_HD double clampd(double v, double lo, double hi) { return raw_min(raw_max(v, lo), hi); }
 
+// index of the lowest set bit (v != 0)
+MPC_HD int mpc_ffs64(unsigned long long v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __ffsll((long long)v) - 1;
+#else
+  return __builtin_ctzll(v);
+#endif
+}
+
 MPC_HD unsigned long long dbits(double v) {
   union { double d; unsigned long long u; } c;
   c.d = v;

@@ -32,6 +32,10 @@
 #pragma once
 
 #include "mpc_core.h"
+#ifdef MPC_EMU_DEBUG
+#include <cstdio>
+#include <cstdlib>
+#endif
 
 namespace mpc {
 
@@ -55,6 +59,10 @@ struct WThread {
   int sig;                                       // exact mode: my rows' active-set guess at the last check (base-3 code)
   // polish (foot lane)
   int act[5];
+  int gslot[5], gfix, gbrow, gbside;            // exact mode (active_set): slot of each of my rows in the working set (-1: none); all my rows are equalities; my best candidate row
+  double gx[3], gv[3], gbviol;                   //   the dual method's primal iterate, H^-1 n_p of my variables, my best candidate's violation
+  double grn[5], gtol[5], gax[5], gred[1];       //   1 / |row|, violation tolerance and A x of my rows; operand of the workgroup reductions
+  int gidx;                                      //   their index result
   double pG[9], pC[9], pu0[3], pg[3], pr[3], pt[3], pxN[3], pPu[3], pw[3];
   double pQ[18], pR[21], pv[3], pn[6];           // orthogonalisation of the step's wrench columns (polish)
   double xp[3], zp[5], yp[5];
@@ -84,6 +92,28 @@ struct WThread {
 #endif
 #ifndef MPC_ADMM_BATCH_LOADS   // which workgroup sizes request every LDS constant of the foot phase in one batch up front (~90 more registers)
 #define MPC_ADMM_BATCH_LOADS(T) ((T) <= 64)
+#endif
+// LDS of the exact mode's active-set phase (Solver::active_set): the working set of the dual method and the inverse of its
+// Gram matrix N^T H^-1 N, one slot per working constraint.
+template <int H>
+struct GiShared {
+  static constexpr int NWMAX = H <= 6 ? 40 : H <= 10 ? 56 : (H <= 16 ? 72 : 88);      // slots (the optimum's active stance rows: 24 / 32 / 40 / 51 on
+  static constexpr int NF = 4 * H;                                       //   average for configs 2 / 3 / 4 / 5, up to 34 / 44 / 54 / 67)
+  static constexpr int TL = NWMAX > NF ? NWMAX : NF;
+  alignas(16) double ci[NWMAX * (NWMAX + 1) / 2];   // packed lower triangle, (i, j <= i) at i (i + 1) / 2 + j; zero rows / columns at free slots
+  // (the method's vectors -- d = N^T H^-1 n_p, the dual direction r, the multipliers, two scratch rows -- live in Shared::fr, which only
+  // the ADMM iteration uses: with them here four workgroups would not fit a CU's 160 KB)
+  int owner[NWMAX];                                 // foot * 8 + row of the slot's constraint, -1: free
+  unsigned long long freem[2];                      // bit i: slot i is free
+  int hi, p_foot, p_row, p_side, p_slot, k1, converged, fail, passes, adds, drops;
+  double p_viol, gamma, zeta, t1, lam_p, tstep;
+};
+
+#ifndef MPC_EXACT_REFINE
+#define MPC_EXACT_REFINE 16   // refinement steps of the exact mode's polish (10 leave 1 % of the certified sets just above the 1e-10 dual test; x 1.5 at the long horizons)
+#endif
+#ifndef MPC_GI_DELTA
+#define MPC_GI_DELTA 0.0
 #endif
 #ifndef MPC_SPLIT_RANGES
 #define MPC_SPLIT_RANGES 0   // (measured on the ISA: no help at present)
@@ -119,7 +149,7 @@ struct Shared {
     struct { MPC_V Lk[H * 36]; MPC_V Tk[H * 36]; };     // factorisation only: per step Z_k = L L^T, T = L^-1 (zero columns / rows at dropped pivots)
   };
   unsigned long long red[24];
-  int first, iter, status, status_polish, rho_updates, nfact, done, bad, pol_ok, sig_changed, loose_ok, dual_cand;
+  int first, iter, status, status_polish, rho_updates, nfact, done, bad, pol_ok, pol_near, sig_changed, loose_ok, dual_cand;
   double pri_res, dua_res, rho_new;
 };
 #undef MPC_V
@@ -155,8 +185,10 @@ struct Solver {
   double eps_abs = kEpsAbs, eps_rel = kEpsRel, eps_exact = 0.0;
   int max_iter = kMaxIter, polish_refine = kPolishRefine, max_rho_updates = 1 << 30;
   bool polish_must_verify = false;   // (set around an early polish of the exact mode)
+  bool act_given = false;            // polish(): the active set is in t.act already (active_set) instead of OSQP's guess from (z, y)
+  GiShared<H> *gi = nullptr;         // LDS of the exact mode's active-set phase (null in the OSQP mode)
   static constexpr int kStableChecks = MPC_STABLE_CHECKS;
-  MPC_HD void exact() { eps_exact = MPC_EPS_EXACT; eps_abs = eps_rel = kEpsAdmmFloor; max_iter = 5 * kMaxIter; polish_refine = 10; max_rho_updates = MPC_EXACT_RHO_UPDATES; }   // then run<true>()
+  MPC_HD void exact() { eps_exact = MPC_EPS_EXACT; eps_abs = eps_rel = kEpsAdmmFloor; max_iter = 5 * kMaxIter; polish_refine = H > 10 ? MPC_EXACT_REFINE + MPC_EXACT_REFINE / 2 : MPC_EXACT_REFINE; max_rho_updates = MPC_EXACT_RHO_UPDATES; }   // then run<true>()
 #ifdef MPC_EMU_DEBUG
   double *dbg = nullptr;   // host emulation only: per foot 20 doubles of the first polish application (tests/emu)
 #endif
@@ -1243,6 +1275,8 @@ struct Solver {
     factor_tail();
   }
 
+  // ROUNDS (the exact mode's calls): extra refinement rounds for a near miss of the optimality test, see below
+  template <bool ROUNDS = false>
   MPC_HD void polish() {
     ex.par([&](Th &t) {
       if (t.tid < NF) {
@@ -1252,7 +1286,7 @@ struct Solver {
         // rows of the scaled cone block (static indexing)
         const double A[15] = {a[0], 0, a[1], a[2], 0, a[3], 0, a[4], a[5], 0, a[6], a[7], 0, 0, a[8]};
 #pragma unroll
-        for (int r = 0; r < 5; ++r) t.act[r] = (t.z[r] - lo[r] < -t.y[r]) ? -1 : ((up[r] - t.z[r] < t.y[r]) ? 1 : 0);
+        for (int r = 0; r < 5; ++r) if (!act_given) t.act[r] = (t.z[r] - lo[r] < -t.y[r]) ? -1 : ((up[r] - t.z[r] < t.y[r]) ? 1 : 0);
         // orthonormal basis Q of the active rows (rank r), null basis Nn (rows, 3 - r of them); rows of Q beyond the
         // current rank are zero, so projecting on all three rows equals projecting on the first r of them
         double Q[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Nn[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1417,7 +1451,25 @@ struct Solver {
     //   w <- w + Omega (g - P_s w).   With an exact Omega the residual obeys r_{k+1} = delta Omega r_k and needs no product with
     // P; Omega is only accurate to ~1e-10 |Xi|, so the true residual is formed (one Theta product per step) -- which is also
     // what OSQP does, and what keeps the refinement self-correcting.  The last product is the P_s xN the finish needs anyway.
-    for (int it = 0; it <= polish_refine; ++it) {
+    // (Exact mode: a polish that must pass the optimality test and misses the dual test by less than 1000x -- the right set, the
+    // refinement not yet converged -- goes round again with eight more steps, at most three times.)
+    for (int round = 0;; ++round) {
+    const int nsteps = round == 0 ? polish_refine : 8;
+    if (ROUNDS && round > 0) {      // the residual of the current xN, as the loop's last iteration would have left it
+      ex.seq([&](Th &t) { if (t.tid < NF) put_wrench(t, t.pxN); });
+      product<kTheta>();
+      ex.seq([&](Th &t) {
+        if (t.tid < NF) {
+          double wy[3];
+          get_wrench(t, wy);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) t.pr[c] = t.pg[c] - ((s.calpha * Dat(t, c) * Dat(t, c)) * t.pxN[c] + wy[c]);
+          ct_mul(t.pC, t.pr, t.pt);
+          put_g(t, t.pt);
+        }
+      });
+    }
+    for (int it = round == 0 ? 0 : 1; it <= nsteps; ++it) {
       omega_apply();
 #ifdef MPC_EMU_DEBUG
       if (dbg && it == 0) ex.par([&](Th &t) {
@@ -1438,7 +1490,7 @@ struct Solver {
         }
       });
       product<kTheta>();                                  // c Theta W xN  (-> P_s xN)
-      if (it < polish_refine) {
+      if (it < nsteps) {
         ex.seq([&](Th &t) {
           if (t.tid < NF) {
             double wy[3];
@@ -1478,12 +1530,15 @@ struct Solver {
           t.yp[r] = tt - zc;
         }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) t.pPu[c] += pxn[c];   // P_s x_pol
+        for (int c = 0; c < 3; ++c) {   // P_s x_pol (with ROUNDS in its own array: P_s u0 is needed again)
+          if constexpr (ROUNDS) t.px[c] = t.pPu[c] + pxn[c];
+          else t.pPu[c] += pxn[c];
+        }
       }
     });
     // residuals at the polished point, acceptance (polish.c:306-345)
     const double pri0 = s.pri_res, dua0 = s.dua_res;
-    residuals([](Th &t) { return t.xp; }, [](Th &t) { return t.zp; }, [](Th &t) { return t.yp; }, [](Th &t) { return t.pPu; });
+    residuals([](Th &t) { return t.xp; }, [](Th &t) { return t.zp; }, [](Th &t) { return t.yp; }, [](Th &t) { return ROUNDS ? t.px : t.pPu; });
     ex.par([&](Th &t) {
       if (t.tid == 0) {
         const double pri = bitsd(s.red[0]), dua = s.cinv * bitsd(s.red[6]);
@@ -1495,6 +1550,10 @@ struct Solver {
         const double ep = eps_exact + eps_exact * dmax(bitsd(s.red[1]), bitsd(s.red[2]));
         const double ed = eps_exact + eps_exact * s.cinv * dmax(dmax(bitsd(s.red[7]), bitsd(s.red[8])), bitsd(s.red[9]));
         const bool verified = !s.bad && pri < ep && dua < ed;
+        s.pol_near = polish_must_verify && !verified && !s.bad && pri < ep && dua < 1e3 * ed;
+#ifdef MPC_EMU_DEBUG
+        if (getenv("EMU_GI_TRACE")) fprintf(stderr, "  polish: pri %.3e (tol %.3e) dua %.3e (tol %.3e) bad %d\n", pri, ep, dua, ed, (int)s.bad);
+#endif
         // an early polish of the exact mode is taken only when it is verified (an unverified one would bend the ADMM trajectory
         // that the final polish relies on); everything else follows OSQP: take it when it improves the residuals
         const bool take = polish_must_verify ? verified : ok;
@@ -1507,6 +1566,8 @@ struct Solver {
 #endif
       }
     });
+    if (!(ROUNDS && s.pol_near && round < 3)) break;
+    }
     ex.par([&](Th &t) {
       if (s.status_polish == 1 && t.tid < NF) {
 #pragma unroll
@@ -1518,6 +1579,298 @@ struct Solver {
   }
   static constexpr MPC_HD int pk3(int r, int c) {   // packed symmetric 3 x 3: 00 01 02 11 12 22
     return r <= c ? (r == 0 ? c : (r == 1 ? 2 + c : 5)) : (c == 0 ? r : (c == 1 ? 2 + r : 5));
+  }
+
+  // ================================ 5. exact mode: the optimal active set by a dual active-set method =================================
+  // The reference's qpOASES branch (mpc_osqp.cc:797-947) returns THE optimum of the strictly convex QP; which route leads there is
+  // free.  Goldfarb-Idnani's dual method on the problem with the fixed feet eliminated (rows with l = u: the swing feet, which that
+  // branch eliminates as well, :838-856): start at the unconstrained minimum x = -H^-1 q with an empty working set; while some row
+  // is violated, take the most violated one, n_p, and move along  z = H^-1 (n_p - N r),  r = (N^T H^-1 N)^-1 N^T H^-1 n_p  (N: the
+  // working set's normals) until the row is satisfied -- add it -- or a multiplier of the working set reaches zero -- drop that row
+  // and go on towards n_p.  Every iterate is optimal for the rows it holds, the dual objective rises strictly, so the method ends at
+  // the optimum after about as many steps as it has active rows (25-60 here; ADMM needs 250+ iterations to pin the same set).
+  //   H^-1 is the polish's operator for "no row active on a free foot, every row active on a fixed one" (polish_factor / omega_apply:
+  //   Omega = C (I - V V^T + V M^-1 V^T) C^T with C C^T = (c alpha D^2 + delta)^-1 per free foot): ONE factorisation for the whole
+  //   method, two applications per added row.  The delta keeps |C C^T| <= 1e6 like in the polish; it bends the iterates by ~1e-6 but
+  //   not the set they end on, and the polish that follows (on that set, refined against the unregularised system and verified
+  //   against the optimality conditions at 1e-10) is what produces the returned point -- or rejects the set, in which case the
+  //   robot takes the ADMM route of run<true>().
+  //   The inverse of the Gram matrix N^T H^-1 N is kept explicitly (packed, one lane per slot): bordering adds a row, a rank-one
+  //   downdate drops one, free slots keep zero rows -- no triangular solves, nothing to compact.
+  // Lane roles: foot lanes own x, their rows' status (t.act: -1 lower, +1 upper) and slots; lane i < NWMAX also serves slot i.
+  static constexpr int kGiMaxPass = 8 * NF;        // adds + drops (observed: <= 1.3 x the final set)
+  MPC_HD double gi_ci(int i, int j) const { return i >= j ? gi->ci[i * (i + 1) / 2 + j] : gi->ci[j * (j + 1) / 2 + i]; }
+  // t.pw <- H^-1 r for the per-foot vector r given by rv(t) (zero on fixed feet whatever rv says: C = 0 there)
+  template <class RV>
+  MPC_HD void gi_apply(RV &&rv) {
+    ex.seq([&](Th &t) {
+      if (t.tid < NF) {
+        double r3[3];
+        rv(t, r3);
+        ct_mul(t.pC, r3, t.pt);
+        put_g(t, t.pt);
+      }
+    });
+    omega_apply();
+  }
+  // row r of the scaled cone block (see a_mul).  (Masked sums, not a chain of selects: with a run-time r the compiler turns select chains
+  // over array elements into an indexed load, which puts the array into scratch memory.)
+  static MPC_HD double gi_pick(const double *v, int r) {   // v[r], r = 0 .. 4
+    double o = 0.0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) o += (k == r) ? v[k] : 0.0;
+    return o;
+  }
+  static MPC_HD void gi_row(const double *a, int r, double *n) {
+    const double m0 = r == 0 ? 1.0 : 0.0, m1 = r == 1 ? 1.0 : 0.0, m2 = r == 2 ? 1.0 : 0.0, m3 = r == 3 ? 1.0 : 0.0, m4 = r == 4 ? 1.0 : 0.0;
+    n[0] = m0 * a[0] + m1 * a[2];
+    n[1] = m2 * a[4] + m3 * a[6];
+    n[2] = (m0 * a[1] + m1 * a[3]) + (m2 * a[5] + m3 * a[7]) + m4 * a[8];
+  }
+  // row i of the packed inverse, columns j < hi (j <= i): row[j] <- f(j, row[j], vec[j]), in blocks of eight -- all loads of a block are
+  // requested before its first store (LDS accesses that may alias are not reordered by the compiler: element by element, every
+  // iteration would wait out a full LDS round trip)
+  template <class F>
+  static MPC_HD void gi_row_update(double *row, const double *vec, int i, int hi, F &&f) {
+    for (int j0 = 0; j0 < hi && j0 <= i; j0 += 8) {
+      double rv[8], vv[8];
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) MPC_LDS_LOAD128(vec + j0 + u, vv[u], vv[u + 1]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) rv[u] = MPC_LDS_LOAD64(row + (j0 + u <= i ? j0 + u : i));
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (j0 + u <= i && j0 + u < hi) MPC_LDS_STORE64(row + j0 + u, f(j0 + u, rv[u], vv[u]));
+    }
+  }
+  MPC_HD bool active_set() {
+    GiShared<H> &g = *gi;
+    constexpr int NW = GiShared<H>::NWMAX, TL = GiShared<H>::TL;
+    static_assert(3 * NW + 2 * TL <= NF * 10, "the method's vectors must fit Shared::fr");
+    double *const gd = s.fr, *const gr = s.fr + NW, *const glam = s.fr + 2 * NW, *const gtmp = s.fr + 3 * NW, *const gtmp2 = s.fr + 3 * NW + TL;
+    ex.par([&](Th &t) {
+      for (int i = t.tid; i < NW * (NW + 1) / 2; i += T) g.ci[i] = 0.0;
+      if (t.tid < NW) { g.owner[t.tid] = -1; glam[t.tid] = 0.0; gd[t.tid] = 0.0; gr[t.tid] = 0.0; }
+      if (t.tid == 0) {
+        g.hi = 0; g.converged = 0; g.fail = 0; g.passes = 0; g.adds = 0; g.drops = 0;
+        g.freem[0] = NW >= 64 ? ~0ull : ((1ull << (NW & 63)) - 1); g.freem[1] = NW > 64 ? ((1ull << (NW - 64)) - 1) : 0ull;
+      }
+      if (t.tid < NF) {
+        const int fixed = ((t.tyb & 0x3ff) == 0x2aa);                 // all five rows are equalities (set_rho_vec's test: u - l < 1e-4)
+        t.gfix = fixed;
+        double a[9], lo[5], up[5];
+        foot_a(t, a);
+        foot_bounds(t, lo, up);
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+          double n[3];
+          gi_row(a, r, n);
+          t.act[r] = fixed ? -1 : 0; t.gslot[r] = -1;
+          t.grn[r] = fast_rsqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+          t.gtol[r] = 1e-9 * dmax(1.0, dmax(fabs(lo[r]), up[r] < kInfty * kMinScaling ? fabs(up[r]) : 0.0));
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) t.pC[k] = 0.0;
+        if (!fixed) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) t.pC[4 * c] = fast_rsqrt(s.calpha * Dat(t, c) * Dat(t, c) + MPC_GI_DELTA);
+        }
+      }
+    });
+    polish_factor();
+    if (s.bad) return false;
+    gi_apply([&](Th &t, double *r3) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) r3[c] = -t.q[c];
+    });
+    ex.seq([&](Th &t) {
+      if (t.tid < NF) {
+        double a[9];
+        foot_a(t, a);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) t.gx[c] = t.pw[c];
+        a_mul(a, t.gx, t.gax);
+      }
+    });
+    // The method's scalars (slots in use, free-slot mask, multiplier of row p, step lengths) are kept by every thread in registers -- the
+    // same values everywhere, from workgroup-wide reductions -- not in LDS, where one thread's read-modify-write chains would cost a
+    // round trip each.
+    bool new_p = true, converged = false, fail = false;
+    int hi = 0, passes = 0, adds = 0, drops = 0;
+    unsigned long long free0 = NW >= 64 ? ~0ull : ((1ull << (NW & 63)) - 1), free1 = NW > 64 ? ((1ull << (NW - 64)) - 1) : 0ull;
+    double lam_p = 0.0;
+    for (int pass = 0; pass < kGiMaxPass; ++pass) {
+      if (new_p) {
+        // ---- A. the most violated row outside the working set (violation over the row's norm)
+        ex.seq([&](Th &t) {
+          double best = -1.0;
+          t.gbrow = 0; t.gbside = 0;
+          if (t.tid < NF && !t.gfix) {
+            double lo[5], up[5];
+            foot_bounds(t, lo, up);
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+              const double vl = lo[r] - t.gax[r], vu = t.gax[r] - up[r];
+              const double v = dmax(vl, vu), sv = v * t.grn[r];
+              if (t.act[r] == 0 && v > t.gtol[r] && sv > best) { best = sv; t.gbrow = r; t.gbside = vl >= vu ? -1 : 1; }
+            }
+          }
+          t.gred[0] = best;
+        });
+        ex.wg_argmax([](Th &t) { return t.gred; }, [](Th &t) -> int & { return t.gidx; }, gtmp);
+        if (!(ex.first().gred[0] > 0.0)) { converged = true; break; }
+        ex.par([&](Th &t) { if (t.tid == t.gidx) { g.p_foot = t.tid; g.p_row = t.gbrow; g.p_side = t.gbside; } });
+        lam_p = 0.0;
+        MPC_SUBLAP(7, 1);
+        // ---- B. v = H^-1 n_p;  d = N^T v,  gamma = n_p^T v      (n = side * row: the normal of "row >= l" is +row, of "row <= u" is -row)
+        gi_apply([&](Th &t, double *r3) {
+          double a[9];
+          foot_a(t, a);
+          gi_row(a, g.p_row, r3);
+          const double sg = t.tid == g.p_foot ? (g.p_side < 0 ? 1.0 : -1.0) : 0.0;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) r3[c] *= sg;
+        });
+        ex.par([&](Th &t) {
+          if (t.tid < NF) {
+            double a[9], av[5];
+            foot_a(t, a);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) t.gv[c] = t.pw[c];
+            a_mul(a, t.gv, av);
+#pragma unroll
+            for (int r = 0; r < 5; ++r)
+              if (t.gslot[r] >= 0) gd[t.gslot[r]] = (t.act[r] < 0 ? 1.0 : -1.0) * av[r];
+            if (t.tid == g.p_foot) g.gamma = (g.p_side < 0 ? 1.0 : -1.0) * gi_pick(av, g.p_row);
+          }
+        });
+        MPC_SUBLAP(7, 2);
+      }
+      // ---- C. r = (N^T H^-1 N)^-1 d;  zeta = gamma - d^T r = n_p^T z;  the largest dual step t1 that keeps every multiplier >= 0
+      ex.par([&](Th &t) {
+        double dr = 0.0, ratio = kInfty;
+        if (t.tid < NW) {
+          const int i = t.tid, rowb = i * (i + 1) / 2;
+          double acc = 0.0;
+          for (int j0 = 0; j0 < hi; j0 += 8) {     // (zero rows at free slots; blocks of eight: all loads of a block in flight together)
+            double cv[8], dv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) MPC_LDS_LOAD128(gd + j0 + u, dv[u], dv[u + 1]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int j = j0 + u < NW ? j0 + u : NW - 1; cv[u] = MPC_LDS_LOAD64(g.ci + (j <= i ? rowb + j : j * (j + 1) / 2 + i)); }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += (j0 + u < hi ? cv[u] : 0.0) * dv[u];
+          }
+          const bool live = i < hi && g.owner[i] >= 0;
+          gr[i] = live ? acc : 0.0;
+          if (live) { dr = gd[i] * acc; if (acc > 0.0) ratio = glam[i] * fast_recip(acc); }
+        }
+        t.gred[0] = dr;
+        t.gbviol = ratio;
+      });
+      ex.wg_sum([](Th &t) { return t.gred; }, gtmp);
+      const double zeta = g.gamma - ex.first().gred[0];
+      ex.seq([&](Th &t) { t.gred[0] = -t.gbviol; });
+      ex.wg_argmax([](Th &t) { return t.gred; }, [](Th &t) -> int & { return t.gidx; }, gtmp);
+      const double t1 = -ex.first().gred[0];
+      const int k1 = ex.first().gidx;
+      MPC_SUBLAP(7, 3);
+      const bool moves = zeta > 1e-10 * g.gamma;      // else n_p is a combination of the working set's normals: z = 0
+      // ---- D. z = H^-1 (n_p - N r)
+      if (moves) {
+        gi_apply([&](Th &t, double *r3) {
+          double a[9], w[5];
+          foot_a(t, a);
+#pragma unroll
+          for (int r = 0; r < 5; ++r) {     // the combination of my rows: +-1 for row p, -(+-r_slot) for my working rows
+            double c = (t.tid == g.p_foot && r == g.p_row) ? (g.p_side < 0 ? 1.0 : -1.0) : 0.0;
+            if (t.gslot[r] >= 0) c -= (t.act[r] < 0 ? 1.0 : -1.0) * gr[t.gslot[r]];
+            w[r] = c;
+          }
+          at_mul(a, w, r3);
+        });
+      }
+      MPC_SUBLAP(7, 4);
+      // ---- E. the step: t2 = (violation of row p now) / zeta brings the row to its bound; t = min(t1, t2)
+      ex.seq([&](Th &t) {
+        double viol = -kInfty;
+        if (t.tid == g.p_foot) {
+          double lo[5], up[5];
+          foot_bounds(t, lo, up);
+          const double lo_p = gi_pick(lo, g.p_row), up_p = gi_pick(up, g.p_row), ax_p = gi_pick(t.gax, g.p_row);
+          viol = dmax(g.p_side < 0 ? lo_p - ax_p : ax_p - up_p, 0.0);
+        }
+        t.gred[0] = viol;
+      });
+      ex.wg_argmax([](Th &t) { return t.gred; }, [](Th &t) -> int & { return t.gidx; }, gtmp);
+      const double zinv = moves ? fast_recip(zeta) : 0.0;
+      const double t2 = moves ? ex.first().gred[0] * zinv : kInfty;
+      const double ts = dmin(t1, t2);
+      if (!(ts < kInfty)) { fail = true; break; }      // (an infeasible QP: not this path's business)
+      const bool add = t2 <= t1;
+      lam_p += ts; ++passes;
+      int ps = -1;
+      if (add) {   // the lowest free slot
+        ps = free0 ? mpc_ffs64(free0) : (free1 ? 64 + mpc_ffs64(free1) : -1);
+        if (ps < 0) { fail = true; break; }
+        if (ps < 64) free0 &= ~(1ull << ps); else free1 &= ~(1ull << (ps - 64));
+        ++adds;
+      } else {
+        if (k1 < 64) free0 |= 1ull << k1; else free1 |= 1ull << (k1 - 64);
+        ++drops;
+      }
+      const int hi_new = add && hi < ps + 1 ? ps + 1 : hi;
+      if (!add) ex.par([&](Th &t) {   // column k of the inverse, before the rows change
+        if (t.tid < NW && t.tid < hi) gtmp[t.tid] = t.tid == k1 ? 0.0 : gi_ci(t.tid, k1);
+        if (t.tid == 0) gtmp2[0] = fast_recip(gi_ci(k1, k1));
+      });
+      ex.par([&](Th &t) {
+        if (t.tid < NF && moves) {
+          double a[9], az[5];
+          foot_a(t, a);
+          a_mul(a, t.pw, az);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) t.gx[c] += ts * t.pw[c];
+#pragma unroll
+          for (int r = 0; r < 5; ++r) t.gax[r] += ts * az[r];
+        }
+        if (t.tid < NW && t.tid < hi_new) {
+          const int i = t.tid;
+          const bool live = i < hi && g.owner[i] >= 0;
+          if (live) glam[i] = dmax(glam[i] - ts * gr[i], 0.0);
+          if (add) {
+            // bordering: the rest gains r r^T / zeta (the new slot's own row / column was zero and r there is zero: the general update
+            // leaves it alone), then the new row -r / zeta -- element (ps, i) or (i, ps) by the lane that holds r_i -- and 1 / zeta
+            const double zi = zinv, ri = gr[i] * zi;
+            if (i != ps) gi_row_update(g.ci + i * (i + 1) / 2, gr, i, hi_new, [&](int, double cv, double rj) { return cv + ri * rj; });
+            if (i == ps) { g.ci[ps * (ps + 1) / 2 + ps] = zi; g.owner[ps] = g.p_foot * 8 + g.p_row; glam[ps] = lam_p; gd[ps] = 0.0; }
+            else g.ci[i > ps ? i * (i + 1) / 2 + ps : ps * (ps + 1) / 2 + i] = -ri;
+          } else {
+            // drop slot k: a rank-one downdate with column k, then row / column k are zero again and the slot is free
+            const double ci_k = i == k1 ? 0.0 : gtmp[i] * gtmp2[0];
+            if (i != k1) gi_row_update(g.ci + i * (i + 1) / 2, gtmp, i, hi, [&](int, double cv, double ck) { return cv - ci_k * ck; });
+            g.ci[i >= k1 ? i * (i + 1) / 2 + k1 : k1 * (k1 + 1) / 2 + i] = 0.0;
+            if (i == k1) { g.owner[k1] = -1; glam[k1] = 0.0; gd[k1] = 0.0; }
+          }
+        }
+        if (t.tid < NF) {
+          if (add) {
+            if (t.tid == g.p_foot) {
+#pragma unroll
+              for (int r = 0; r < 5; ++r) if (r == g.p_row) { t.act[r] = g.p_side; t.gslot[r] = ps; }
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 5; ++r) if (t.gslot[r] == k1) { t.act[r] = 0; t.gslot[r] = -1; }
+          }
+        }
+      });
+      hi = hi_new;
+      new_p = add;
+      MPC_SUBLAP(7, 5);
+    }
+    ex.par([&](Th &t) { if (t.tid == 0) { g.passes = passes; g.adds = adds; g.drops = drops; g.hi = hi; g.converged = converged; g.fail = fail; } });
+    return converged && !fail && !s.bad;
   }
 
   // ================================ driver ======================================================================
@@ -1577,12 +1930,14 @@ struct Solver {
     if (s.first) tc[15] = -tc[15];   // a cold solve is no predictor of the robot's next (warm) one: negative = ignored by the dispatch order (order_block)
     ex.par([&](Th &t) {
       const bool failed = s.bad || s.status == kStNonCvx;
-      const bool solved = s.status == kStSolved && !failed;
+      // (the reference's qpOASES branch returns its vector whatever the solver's status, mpc_osqp.cc:906-947: in the exact mode an iterate that
+      // ran out of iterations is written too, with its status)
+      const bool solved = (s.status == kStSolved || (eps_exact > 0 && (s.status == kStSolvedInaccurate || s.status == kStMaxIter))) && !failed;
       if (t.tid < NF) {
         const int f = t.tid;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          if (solved) MPC_GST(forces + 3 * f + c, -(Dat(t, c) * t.x[c]));
+          if (solved) MPC_GST(forces + 3 * f + c, 0.0 - Dat(t, c) * t.x[c]);   // (-x, mpc_osqp.cc:789-790; an eliminated foot's exact zero comes out as +0.0)
           MPC_GST(state + 3 * f + c, failed ? 0.0 : t.x[c]);
           MPC_GST(state + N + 2 * M + 3 * f + c, failed ? 0.0 : qp[C::QP_Q + 3 * f + c]);
         }
@@ -1596,7 +1951,7 @@ struct Solver {
         const int iv[8] = {s.iter, s.bad ? kStNonCvx : s.status, s.status_polish, s.rho_updates, s.nfact, s.first, 0, 0};
 #pragma unroll
         for (int k = 0; k < 8; ++k) MPC_GST(info + k, iv[k]);
-        if (prof) for (int k = 0; k < kProfLen; ++k) if ((k < 1 || k > 5 || MPC_PROFILE_SUB == 6) && !(MPC_PROFILE_SUB && MPC_PROFILE_SUB <= 4 && k >= 9 && k <= 13)) MPC_GST(prof + k, tc[k]);   // (1 .. 5, and 9 .. 13 of a prep sub-profile: the prep kernel's)
+        if (prof) for (int k = 0; k < kProfLen; ++k) if ((k < 1 || k > 5 || MPC_PROFILE_SUB >= 6) && !(MPC_PROFILE_SUB && MPC_PROFILE_SUB <= 4 && k >= 9 && k <= 13)) MPC_GST(prof + k, tc[k]);   // (1 .. 5, and 9 .. 13 of a prep sub-profile: the prep kernel's)
       }
     });
   }
@@ -1643,12 +1998,12 @@ struct Solver {
         const bool early = admm_until_done<true>(iter, stable);
         if (s.bad) break;
         if (!early) {                 // converged at the ADMM floor (then OSQP's own polish rule), or out of iterations
-          if (!s.done) ex.par([&](Th &t) { if (t.tid == 0) s.status = kStMaxIter; });
+          if (!s.done) ex.par([&](Th &t) { if (t.tid == 0) s.status = s.loose_ok ? kStSolvedInaccurate : kStMaxIter; });   // (out of iterations: the iterate is the result, see store)
           else if (s.status == kStSolved) polish();
           break;
         }
         polish_must_verify = true;
-        polish();
+        polish<true>();
         polish_must_verify = false;
         if (s.bad) break;
         if (s.pol_ok) {
@@ -1672,12 +2027,14 @@ struct Solver {
     // outputs + persistent state (store_solution, auxil.c:528-561; mpc_osqp.cc:788-790: forces = -x): see store()
     ex.par([&](Th &t) {
       const bool failed = s.bad || s.status == kStNonCvx;
-      const bool solved = s.status == kStSolved && !failed;
+      // (the reference's qpOASES branch returns its vector whatever the solver's status, mpc_osqp.cc:906-947: in the exact mode an iterate that
+      // ran out of iterations is written too, with its status)
+      const bool solved = (s.status == kStSolved || (eps_exact > 0 && (s.status == kStSolvedInaccurate || s.status == kStMaxIter))) && !failed;
       if (t.tid < NF) {
         const int f = t.tid;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          if (solved) forces[3 * f + c] = -(Dat(t, c) * t.x[c]);
+          if (solved) forces[3 * f + c] = 0.0 - Dat(t, c) * t.x[c];
           state[3 * f + c] = failed ? 0.0 : t.x[c];
           state[N + 2 * M + 3 * f + c] = failed ? 0.0 : qp[C::QP_Q + 3 * f + c];
         }
@@ -1690,9 +2047,43 @@ struct Solver {
         state[2 * N + 2 * M + 1] = failed ? 0.0 : 1.0;
         info[0] = s.iter; info[1] = s.bad ? kStNonCvx : s.status; info[2] = s.status_polish; info[3] = s.rho_updates;
         info[4] = s.nfact; info[5] = s.first; info[6] = 0; info[7] = 0;
-        if (prof) for (int k = 0; k < kProfLen; ++k) if ((k < 1 || k > 5 || MPC_PROFILE_SUB == 6) && !(MPC_PROFILE_SUB && MPC_PROFILE_SUB <= 4 && k >= 9 && k <= 13)) prof[k] = tc[k];   // (1 .. 5, and 9 .. 13 of a prep sub-profile: the prep kernel's)
+        if (prof) for (int k = 0; k < kProfLen; ++k) if ((k < 1 || k > 5 || MPC_PROFILE_SUB >= 6) && !(MPC_PROFILE_SUB && MPC_PROFILE_SUB <= 4 && k >= 9 && k <= 13)) prof[k] = tc[k];   // (1 .. 5, and 9 .. 13 of a prep sub-profile: the prep kernel's)
       }
     });
+  }
+
+  // Exact mode, first attempt: the active-set method, then the polish on its set as the returned point -- if that point passes the
+  // optimality test (eps_exact; after exact()).  false: nothing was written, the robot takes run<true>() (a second launch).
+  MPC_HD bool run_active_set() {
+    const long long t0 = MPC_CLOCK();
+    tlast = t0;
+    load();
+    lap(9);
+    const bool found = active_set();
+    lap(8);
+    bool ok = false;
+    if (found) {
+      ex.par([&](Th &t) { if (t.tid == 0) { s.pri_res = kInfty; s.dua_res = kInfty; s.status = kStSolved; } });
+      act_given = true; polish_must_verify = true;
+      polish<true>();
+      act_given = false; polish_must_verify = false;
+      ok = s.pol_ok && s.status_polish == 1;
+    }
+    lap(14);
+#ifdef MPC_EMU_DEBUG
+    if (!ok && getenv("EMU_GI_DUMP")) {   // debugging: the dual method's iterate and working set of a robot whose set was rejected
+      ex.par([&](Th &t) {
+        if (t.tid < NF) {
+          for (int c = 0; c < 3; ++c) forces[3 * t.tid + c] = 0.0 - Dat(t, c) * t.gx[c];
+          for (int r = 0; r < 5; ++r) state[N + 5 * t.tid + r] = t.act[r];
+        }
+      });
+    }
+#endif
+    if (!ok) return false;
+    ex.par([&](Th &t) { if (t.tid == 0) { s.iter = gi->passes; s.rho_updates = 0; } });
+    store(t0);
+    return true;
   }
 
   // ---- the OSQP-mode solve as two jobs of a persistent wave (mpc_batch.hip: mpc_solve_jobs_kernel).  The ADMM part of a solve takes
@@ -1725,7 +2116,7 @@ struct Solver {
       if (s.status_polish == 1 && t.tid < NF) {
         const int f = t.tid;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { MPC_GST(forces + 3 * f + c, -(Dat(t, c) * t.x[c])); MPC_GST(state + 3 * f + c, t.x[c]); }
+        for (int c = 0; c < 3; ++c) { MPC_GST(forces + 3 * f + c, 0.0 - Dat(t, c) * t.x[c]); MPC_GST(state + 3 * f + c, t.x[c]); }
 #pragma unroll
         for (int r = 0; r < 5; ++r) { MPC_GST(state + N + 5 * f + r, t.z[r]); MPC_GST(state + N + M + 5 * f + r, t.y[r]); }
       }

@@ -16,7 +16,9 @@ from .quadruped import ROBOT_TABLE64
 
 
 class BatchedLocomotion:
-    def __init__(self, robot_type, gait_id, horizon=10, controller_dt=0.01, alpha=1e-5, flat_ground=False, device=None):
+    def __init__(self, robot_type, gait_id, horizon=10, controller_dt=0.01, alpha=1e-5, flat_ground=False, device=None, solver="osqp"):
+        """solver: "osqp" (the reference's OSQP branch, BASELINE's comparator) or "exact" (its qpOASES branch -- what the shipped
+        Python passes, ConvexMPCLocomotion.py:108 -- the QP's optimum, cold every call); see BatchedConvexMpc."""
         import torch
         if not torch.cuda.is_available():
             raise _lib.MpcLibraryError("BatchedLocomotion needs a GPU (torch.cuda.is_available() is False); no CPU fallback")
@@ -33,6 +35,9 @@ class BatchedLocomotion:
         _lib.check(_lib.lib().mpc_ctrl_create(C.byref(self._handle), self.n, self.h, float(controller_dt), iters, float(alpha),
                                               int(bool(flat_ground)), rt.ctypes.data, gi.ctypes.data, tab.shape[0], tab.ctypes.data,
                                               off.ctypes.data, dur.ctypes.data), "mpc_ctrl_create")
+        if solver not in ("osqp", "exact"):
+            raise ValueError("solver must be 'osqp' or 'exact'")
+        _lib.check(_lib.lib().mpc_ctrl_set_solver(self._handle, 1 if solver == "exact" else 0), "mpc_ctrl_set_solver")
         self.torques = torch.zeros((self.n, 12), dtype=torch.float32, device=self.device)
 
     def __del__(self):

@@ -46,7 +46,8 @@ class ConvexMpc:
         m = np.array([float(mass)])
         _lib.check(_lib.lib().mpc_batch_create(C.byref(self._handle), 1, self._h, float(timestep), float(alpha),
                                                m.ctypes.data, inertia.ctypes.data), "mpc_batch_create")
-        _lib.check(_lib.lib().mpc_batch_set_solver(self._handle, 1 if int(qp_solver_name) == int(QPOASES) else 0), "mpc_batch_set_solver")
+        self._exact = int(qp_solver_name) == int(QPOASES)
+        _lib.check(_lib.lib().mpc_batch_set_solver(self._handle, 1 if self._exact else 0), "mpc_batch_set_solver")
         self._rec = np.zeros(in_len(self._h), dtype=np.float64)     # pybind11 widens every argument to double (mpc_osqp.cc:578-591)
         self._out = np.zeros(12 * self._h, dtype=np.float64)
         self.info = np.zeros(8, dtype=np.int32)
@@ -70,7 +71,9 @@ class ConvexMpc:
                   desired_com_angular_velocity, out=self._rec)
         _lib.check(_lib.lib().mpc_batch_solve_host_f64(self._handle, self._rec.ctypes.data, self._out.ctypes.data,
                                                        self.info.ctypes.data), "mpc_batch_solve_host_f64")
-        if self.info[1] != 1:      # not OSQP_SOLVED -> empty vector (mpc_osqp.cc:781-794)
+        if self._exact:            # the qpOASES branch returns its vector whatever the solver's status (mpc_osqp.cc:906-947); only a
+            return [] if self.info[1] == -7 else self._out.tolist()      # non-finite / non-convex problem has nothing to return
+        if self.info[1] != 1:      # OSQP branch: not OSQP_SOLVED -> empty vector (mpc_osqp.cc:781-794)
             return []
         return self._out.tolist()
 

@@ -4,6 +4,7 @@
 // exposes intra-phase races).  Lets the CPU test-suite check the kernel's algorithm against the
 // oracle without a GPU.
 #define MPC_EMU_DEBUG 1
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -21,6 +22,7 @@ using namespace mpc;
 // zeroed, as the kernels do -- so that a read of anything the kernel has not written shows up as a changed (NaN) result.
 static int g_poison = 0;
 static inline int fill_byte() { return g_poison ? 0xFF : 0; }
+static int g_exact_route = 0;   // emu_set_exact_route: 0 = active set, then ADMM if it fails (the product); 1 = ADMM route only; 2 = active set only
 static int g_split = 0;      // emu_set_split: the OSQP-mode solve as ADMM job + polish job (the persistent kernel's path)
 static int g_max_iter = 0;   // emu_set_max_iter: OSQP's max_iter setting (0 = the default, kMaxIter)
 
@@ -36,6 +38,7 @@ struct HostExec {
       for (size_t e = 0; e < sizeof(th[i].Mx) / sizeof(double); ++e) th[i].Mx[e] = 0;   // (the kernels zero their tile registers)
     }
   }
+  TH &first() { return th[0]; }   // a representative thread (after a workgroup-wide reduction every thread holds the same value)
   template <class F> void par(F &&f) {
     ++phases;
     if (!reverse) for (int i = 0; i < NTHREADS; ++i) f(th[i]);
@@ -70,6 +73,35 @@ struct HostExec {
       const double sum = (rs[0] + rs[1]) + (rs[2] + rs[3]), mx = std::fmax(std::fmax(rmx[0], rmx[1]), std::fmax(rmx[2], rmx[3]));
       for (int i = 0; i < 64; ++i) { acc(th[w + i])[0] = sum; acc(th[w + i])[1] = mx; }
     }
+  }
+  // workgroup-wide argmax / sum (the device: DPP + readlane inside one wavefront, LDS scratch + barriers across several)
+  template <class V, class I> void wg_argmax(V &&val, I &&idx, double *) {
+    double m = val(th[0])[0];
+    int ml = 0;
+    for (int i = 1; i < NTHREADS; ++i) if (val(th[i])[0] > m) { m = val(th[i])[0]; ml = i; }
+    for (int i = 0; i < NTHREADS; ++i) { val(th[i])[0] = m; idx(th[i]) = ml; }
+  }
+  template <class V> void wg_sum(V &&val, double *) {
+    // (the device's association order: within a wavefront quad, half row, row, four rows; then the wavefronts in order)
+    double tot = 0;
+    for (int w = 0; w < NTHREADS; w += 64) {
+      double rs[4];
+      for (int r = 0; r < 4; ++r) {
+        double hs[2];
+        for (int hh = 0; hh < 2; ++hh) {
+          double qs[2];
+          for (int q = 0; q < 2; ++q) {
+            const int b = w + 16 * r + 8 * hh + 4 * q;
+            qs[q] = (val(th[b])[0] + val(th[b + 1])[0]) + (val(th[b + 2])[0] + val(th[b + 3])[0]);
+          }
+          hs[hh] = qs[0] + qs[1];
+        }
+        rs[r] = hs[0] + hs[1];
+      }
+      const double ws = (rs[0] + rs[1]) + (rs[2] + rs[3]);
+      tot = w == 0 ? ws : tot + ws;
+    }
+    for (int i = 0; i < NTHREADS; ++i) val(th[i])[0] = tot;
   }
   template <class S, class D> void quad_gather6(S &&src, D &&dst) {
     for (int q = 0; q + 3 < NTHREADS; q += 4) {
@@ -110,7 +142,29 @@ static void solve_one(const RobotModel &mdl, const float *in, double *state, dou
     Solver<H, Ex> sv{ex, *sh, mdl, state, qp.data(), sc.data(), forces, info, nullptr};
     sv.dbg = dbg;
     if (g_max_iter > 0) sv.max_iter = g_max_iter;
-    if (exact) { sv.exact(); sv.template run<true>(); }   // the exact-optimum mode (mpc_batch_set_solver); the caller clears the state record
+    if (exact) {   // the exact-optimum mode (mpc_batch_set_solver); the caller clears the state record
+      GiShared<H> *gs = new GiShared<H>();
+      std::memset((void *)gs, fill_byte(), sizeof(GiShared<H>));
+      sv.exact();
+      sv.gi = gs;
+      const bool ok = g_exact_route == 1 ? false : sv.run_active_set();          // first launch: the active-set method
+      if (getenv("EMU_GI_TRACE")) fprintf(stderr, "active_set ok=%d passes=%d adds=%d drops=%d conv=%d fail=%d hi=%d\n", (int)ok, gs->passes, gs->adds, gs->drops, gs->converged, gs->fail, gs->hi);
+      ph += ex.phases;
+      delete gs;
+      if (!ok && g_exact_route != 2) {   // second launch: the ADMM route on a fresh workgroup
+        Shared<H> *sh2 = new Shared<H>();
+        std::memset((void *)sh2, fill_byte(), sizeof(Shared<H>));
+        Ex ex2(reverse);
+        Solver<H, Ex> sv2{ex2, *sh2, mdl, state, qp.data(), sc.data(), forces, info, nullptr};
+        sv2.exact();
+        sv2.template run<true>();
+        ph += ex2.phases;
+        delete sh2;
+      } else if (!ok) info[1] = -99;
+      delete sh;
+      if (phases) *phases = ph;
+      return;
+    }
     else if (g_split) {                                   // the two jobs of mpc_solve_jobs_kernel: the polish on a fresh workgroup
       sv.jobrec = sc.data() + C::SC_JOB;
       const bool pol = sv.admm_job();
@@ -294,6 +348,7 @@ int emu_estimator_update(int n, const float *body, const float *normal, float *e
 void emu_set_poison(int on) { g_poison = on; }
 void emu_set_max_iter(int it) { g_max_iter = it; }
 void emu_set_split(int on) { g_split = on; }
+void emu_set_exact_route(int r) { g_exact_route = r; }
 void emu_check_counts(long *out) { out[0] = g_checks; out[1] = g_dual_cands; }
 int emu_state_len(int h) { return 24 * h + 40 * h + 2; }
 int emu_shared_bytes(int h) { return h == 10 ? (int)sizeof(Shared<10>) : h == 16 ? (int)sizeof(Shared<16>) : h == 20 ? (int)sizeof(Shared<20>) : h == 6 ? (int)sizeof(Shared<6>) : -1; }

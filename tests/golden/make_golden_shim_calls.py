@@ -21,6 +21,7 @@ from oracle.refmpc import RefConvexMpc  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CALLS = {"ctor": None, "rec": [], "out": [], "ok": [], "exact": []}
+RETURN_EXACT = [False]      # second replay: the seam returns the exact optimum (what the reference's own choice, mpc.QPOASES, asks for)
 
 
 class Recording(RefConvexMpc):
@@ -31,6 +32,8 @@ class Recording(RefConvexMpc):
     def compute_contact_forces(self, *args):
         rec = np.zeros(in_len(self.h), dtype=np.float64)
         pack_args(self.h, *args, out=rec)
+        if RETURN_EXACT[0]:
+            return self.solve_exact(rec).tolist()
         CALLS["exact"].append(self.solve_exact(rec).copy())       # what the qpOASES branch would return (oracle/README.md)
         out = super().compute_contact_forces(*args)
         CALLS["rec"].append(rec)
@@ -50,7 +53,7 @@ from MPC_Controller.robot_runner.RobotRunnerMin import RobotRunnerMin  # noqa: E
 from MPC_Controller.common.Quadruped import RobotType  # noqa: E402
 
 
-def main(ticks=400):
+def main(ticks=1000):
     g = np.load(os.path.join(HERE, "controller_h10_config1.npz"))
     Parameters.flat_ground = bool(g["flat_ground"])
     Parameters.cmpc_gait = GaitType.TROT
@@ -60,9 +63,16 @@ def main(ticks=400):
     for k in range(ticks):
         tau[k] = runner.run(g["dof"][k, 0], g["body"][k, 0], g["cmd"][k, 0])
     assert np.array_equal(tau, g["torque"][:ticks, 0]), "replay does not reproduce the controller golden"
+    # the same replay with the exact optimum behind the seam: the torques of the reference AS SHIPPED (it passes mpc.QPOASES)
+    RETURN_EXACT[0] = True
+    runner = RobotRunnerMin()
+    runner.init(RobotType.ALIENGO)
+    tau_exact = np.zeros((ticks, 12), np.float32)
+    for k in range(ticks):
+        tau_exact[k] = runner.run(g["dof"][k, 0], g["body"][k, 0], g["cmd"][k, 0])
     c = CALLS["ctor"]
     np.savez_compressed(os.path.join(HERE, "shim_calls_config1.npz"), mass=c[0], inertia=c[1], num_legs=c[2], horizon=c[3], timestep=c[4],
-                        alpha=c[5], solver=c[6], rec=np.array(CALLS["rec"]), out=np.array(CALLS["out"]), ok=np.array(CALLS["ok"]), out_exact=np.array(CALLS["exact"]), ticks=ticks)
+                        alpha=c[5], solver=c[6], rec=np.array(CALLS["rec"]), out=np.array(CALLS["out"]), ok=np.array(CALLS["ok"]), out_exact=np.array(CALLS["exact"]), ticks=ticks, torque_exact=tau_exact)
     print("shim_calls_config1 written:", len(CALLS["rec"]), "calls, ctor", [x.tolist() if hasattr(x, "tolist") else x for x in c])
 
 

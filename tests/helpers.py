@@ -47,3 +47,33 @@ def infeasible_workload(n=24, h=10, seed=5):
     fr = L.in_friction(h)
     inp[:n // 3, fr:fr + 4] = -0.4
     return wl, inp
+
+
+def kkt_certificate(P, q, cone, l, u, x, active_tol=1e-7):
+    """Optimality of x for  min 1/2 x'Px + q'x  s.t.  l <= A x <= u  (A = blockdiag of the 5 x 3 cone block), checked from the KKT conditions
+    alone -- no second solver involved: returns (primal violation relative to max(1, |bound|), stationarity residual relative to |q|_inf)
+    where the multipliers are the best sign-correct ones (non-negative least squares per foot over the rows that sit on a bound).
+    For a strictly convex QP both ~ 0 certify x as THE optimum (what the reference's qpOASES branch returns, mpc_osqp.cc:797-947)."""
+    from scipy.optimize import nnls
+    nf = len(q) // 3
+    g = P @ x + q
+    pv, sr = 0.0, 0.0
+    for f in range(nf):
+        xf, lf, uf = x[3 * f:3 * f + 3], l[5 * f:5 * f + 5], u[5 * f:5 * f + 5]
+        s = cone @ xf
+        sc = np.maximum(1.0, np.maximum(np.abs(lf), np.where(np.abs(uf) < 1e20, np.abs(uf), 0.0)))
+        pv = max(pv, float(np.max(np.maximum(lf - s, s - uf) / sc)))
+        cols = []
+        for r in range(5):
+            at_l, at_u = abs(s[r] - lf[r]) <= active_tol * sc[r], abs(uf[r] - s[r]) <= active_tol * sc[r]
+            if at_l:
+                cols.append(-cone[r])        # y_r <= 0: A'y contributes -w a_r, w >= 0
+            if at_u:
+                cols.append(cone[r])
+        gf = g[3 * f:3 * f + 3]
+        if cols:
+            _, rn = nnls(np.array(cols).T, -gf)
+        else:
+            rn = float(np.linalg.norm(gf))
+        sr = max(sr, rn)
+    return pv, sr / max(float(np.abs(q).max()), 1e-30)

@@ -57,6 +57,14 @@ def test_spill_estimate_stays_bounded(asm):
 def test_long_horizon_admm_iteration_stays_nearly_scratch_free(asm):
     for h in (16, 20):
         admm = [a for a in isa_census.loop_stats(asm, h).values() if a["role"] == "admm-iteration"]
-        assert admm and all(a["scratch"] <= 12 for a in admm), (h, admm)
+        assert admm and all(a["scratch"] <= 16 for a in admm), (h, admm)
         sweeps = [a for a in isa_census.loop_stats(asm, h).values() if a["role"] == "sweep"]
         assert len(sweeps) == 3 and all(a["scratch"] <= 6 for a in sweeps), (h, sweeps)      # round 2: up to 29 per trip
+
+
+def test_exact_mode_kernel_runs_without_scratch(asm):
+    """mpc_exact_kernel<10> (the exact mode's first launch: active-set method + polish): one wave per SIMD, no scratch memory."""
+    import re
+    m = re.search(r'\.amdhsa_kernel [^\n]*mpc_exact_kernelILi10E.*?\.end_amdhsa_kernel', asm, re.S)
+    assert m, "no mpc_exact_kernel<10> in the assembly"
+    assert re.search(r'\.amdhsa_private_segment_fixed_size 0\b', m.group(0)), re.findall(r'private_segment_fixed_size \d+', m.group(0))
