@@ -172,6 +172,13 @@ struct DeviceExec {
   }
 };
 
+// The planning horizons compiled into the library (ConvexMpc accepts any planning_horizon, mpc_osqp.cc:186-190, 508-574; the shipped
+// Python uses 10, ConvexMPCLocomotion.py:27; BASELINE's configurations 10, 16, 20).  Every entry instantiates the prep, solve (job),
+// exact and fall-back kernels for that horizon: -DMPC_HORIZON_LIST to build another set (any h >= 2 whose workgroups fit: h <= 20).
+#ifndef MPC_HORIZON_LIST
+#define MPC_HORIZON_LIST(X) X(8) X(10) X(12) X(16) X(20)
+#endif
+
 constexpr int kSchedNext = 0, kSchedHead = 1, kSchedTail = 2, kSchedJobs = 3, kSchedLen = 4;   // job bookkeeping of a launch (mpc_solve_jobs_kernel)
 
 // Solve kernel (mpc_wrench.h Solver): ADMM + polish of every active robot, from the QP and scale records.  EXACT: the
@@ -418,7 +425,7 @@ int launch(int n, const RobotModel *models, const float *in, const double *in64,
     hipLaunchKernelGGL((mpc_solve_kernel<H, true>), dim3(n), dim3(Cfg<H>::TW), 0, stream, n, models, state, qp, sc, forces, info, prof, order, sched, ready, max_iter);
   }
   else if (job_slots > 0) {   // persistent workgroups, ADMM and polish as separate jobs (h = 16: 2.68 -> 2.28 ms, h = 20: 3.36 -> 2.78 ms per 4096 robots)
-    const int slots = H == 10 ? job_slots : job_slots / 2;                  // (multi-wave workgroups: two per CU)
+    const int slots = Cfg<H>::TW <= 64 ? job_slots : job_slots / 2;         // (multi-wave workgroups: two per CU)
     hipLaunchKernelGGL((mpc_solve_jobs_kernel<H>), dim3(n < slots ? n : slots), dim3(Cfg<H>::TW), 0, stream, models, state, qp, sc, forces, info, prof, order, sched, ready, max_iter);
   }
   else hipLaunchKernelGGL((mpc_solve_kernel<H, false>), dim3(n), dim3(Cfg<H>::TW), 0, stream, n, models, state, qp, sc, forces, info, prof, order, sched, ready, max_iter);
@@ -467,9 +474,9 @@ static int launch_solver(mpc_batch *b, const float *d_in, double *d_forces, int 
   int rc = MPC_E_HORIZON;
 #define MPC_LAUNCH(HH) launch<HH>(b->n, b->d_models, d_in, d_in64, b->d_state, b->d_qp, b->d_sc, d_forces, d_info, b->d_prof, d_active, b->d_order, b->d_hist, slot, ev, st, b->exact, b->max_iter, b->d_sched, b->d_ready, b->job_slots)
   switch (b->h) {
-    case 10: rc = MPC_LAUNCH(10); break;
-    case 16: rc = MPC_LAUNCH(16); break;
-    case 20: rc = MPC_LAUNCH(20); break;
+#define MPC_CASE(HH) case HH: rc = MPC_LAUNCH(HH); break;
+    MPC_HORIZON_LIST(MPC_CASE)
+#undef MPC_CASE
   }
 #undef MPC_LAUNCH
   if (rc == MPC_E_HORIZON) return fail(MPC_E_HORIZON, "solver launch: horizon not compiled in");
@@ -478,12 +485,21 @@ static int launch_solver(mpc_batch *b, const float *d_in, double *d_forces, int 
   return MPC_OK;
 }
 
+#define MPC_QP(HH) if (h == HH) return Cfg<HH>::QP_LEN;
+#define MPC_SC(HH) if (h == HH) return Cfg<HH>::SC_LEN;
+static size_t qp_len_of(int h) { MPC_HORIZON_LIST(MPC_QP) return 0; }     // (0: horizon not compiled in)
+static size_t sc_len_of(int h) { MPC_HORIZON_LIST(MPC_SC) return 0; }
+#undef MPC_QP
+#undef MPC_SC
+
 extern "C" {
 
 const char *mpc_last_error(void) { return g_err.c_str(); }
 int mpc_input_len(int horizon) { return 56 + 4 * horizon; }
 int mpc_supported_horizons(int *out, int cap) {
-  const int hs[] = {10, 16, 20};
+#define MPC_ITEM(HH) HH,
+  const int hs[] = {MPC_HORIZON_LIST(MPC_ITEM)};
+#undef MPC_ITEM
   const int cnt = (int)(sizeof hs / sizeof *hs);
   for (int i = 0; i < cnt && i < cap; ++i) out[i] = hs[i];
   return cnt;
@@ -492,15 +508,14 @@ int mpc_supported_horizons(int *out, int cap) {
 int mpc_batch_create(mpc_batch **out, int n, int horizon, double timestep, double alpha, const double *mass,
                      const double *inertia9) {
   if (!out || n <= 0 || !mass || !inertia9) return fail(MPC_E_ARG, "mpc_batch_create: bad argument");
-  if (horizon != 10 && horizon != 16 && horizon != 20) return fail(MPC_E_HORIZON, "mpc_batch_create: horizon not compiled in (10, 16, 20)");
+  if (qp_len_of(horizon) == 0) return fail(MPC_E_HORIZON, "mpc_batch_create: planning horizon not compiled in (see mpc_supported_horizons; -DMPC_HORIZON_LIST builds another set)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MPC_E_NODEVICE, "mpc_batch_create: no HIP device");
   mpc_batch *b = new mpc_batch();
   (void)hipGetDevice(&b->device);
   b->n = n;
   b->h = horizon;
-  const size_t qp_len = horizon == 10 ? Cfg<10>::QP_LEN : horizon == 16 ? Cfg<16>::QP_LEN : Cfg<20>::QP_LEN;
-  const size_t sc_len = horizon == 10 ? Cfg<10>::SC_LEN : horizon == 16 ? Cfg<16>::SC_LEN : Cfg<20>::SC_LEN;
+  const size_t qp_len = qp_len_of(horizon), sc_len = sc_len_of(horizon);
   b->state_len = (int)(64 * horizon + 2);
   std::vector<RobotModel> models(n);
   for (int i = 0; i < n; ++i) models[i] = make_model(mass[i], inertia9 + 9 * (size_t)i, timestep, alpha);
@@ -672,8 +687,6 @@ int mpc_batch_get_state(mpc_batch *b, double *h_state) {
   return MPC_OK;
 }
 // Test / debugging access to what the prep kernel handed to the solve kernel in the last launch
-static size_t qp_len_of(int h) { return h == 10 ? Cfg<10>::QP_LEN : h == 16 ? Cfg<16>::QP_LEN : Cfg<20>::QP_LEN; }
-static size_t sc_len_of(int h) { return h == 10 ? Cfg<10>::SC_LEN : h == 16 ? Cfg<16>::SC_LEN : Cfg<20>::SC_LEN; }
 int mpc_batch_qp_len(const mpc_batch *b) { return b ? (int)qp_len_of(b->h) : 0; }
 int mpc_batch_scale_len(const mpc_batch *b) { return b ? (int)sc_len_of(b->h) : 0; }
 int mpc_batch_get_qp(mpc_batch *b, double *h_qp) {

@@ -85,6 +85,55 @@ def test_recorded_reference_calls_through_the_hip_module(solver):
     print(f"compute_contact_forces({solver}) through the HIP module: median {np.median(t_call) * 1e3:.3f} ms per call (one robot, host buffers)")
 
 
+def test_pybind11_module_has_the_reference_interface():
+    """The pybind11 extension `mpc_osqp` (rl-mpc-locomotion_amd/pybind, built by __graft_entry__.build()) exposes what mpc_osqp.cc:952-983
+    does: QPSolverName with exported values, ConvexMpc with the 7-argument constructor, compute_contact_forces, reset_solver,
+    __version__, TEST; and it fails loudly, not silently, where there is no GPU."""
+    pyb = os.path.join(ROOT, "rl-mpc-locomotion_amd", "pybind")
+    code = (f"import sys; sys.path.insert(0, {pyb!r}); import mpc_osqp as mpc\n"
+            "assert int(mpc.OSQP) == 0 and int(mpc.QPOASES) == 1 and mpc.QPSolverName.QPOASES == mpc.QPOASES and mpc.TEST == 42 and mpc.__version__ == 'dev'\n"
+            "assert all(hasattr(mpc.ConvexMpc, a) for a in ('compute_contact_forces', 'reset_solver'))\n"
+            "import torch\n"
+            "try:\n"
+            "    c = mpc.ConvexMpc(18.0, [0.03, 0, 0, 0, 0.16, 0, 0, 0, 0.17], 4, 10, 0.02, 1e-5, mpc.QPOASES)\n"
+            "    print('HAVE_GPU' if torch.cuda.is_available() else 'SILENT_FALLBACK')\n"
+            "except RuntimeError as e:\n"
+            "    print('LOUD', e)\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "SILENT_FALLBACK" not in out.stdout and ("LOUD" in out.stdout or "HAVE_GPU" in out.stdout)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["OSQP", "QPOASES"])
+def test_recorded_reference_calls_through_the_pybind11_module(solver):
+    """The same replay as test_recorded_reference_calls_through_the_hip_module through the pybind11 extension module (the binding
+    north_star words: a thin pybind11 layer over the C ABI), in a fresh interpreter that imports it as `mpc_osqp`."""
+    pyb = os.path.join(ROOT, "rl-mpc-locomotion_amd", "pybind")
+    code = f"""
+import sys, numpy as np
+sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {pyb!r})
+import mpc_osqp as mpc
+import rl_mpc_locomotion_amd
+from rl_mpc_locomotion_amd import layout as L
+g = np.load({os.path.join(GOLDEN, "shim_calls_config1.npz")!r})
+h = int(g["horizon"][0])
+cpp_mpc = mpc.ConvexMpc(float(g["mass"][0]), g["inertia"].tolist(), int(g["num_legs"][0]), h, float(g["timestep"][0]), float(g["alpha"][0]), mpc.{solver})
+wants = g["out"] if "{solver}" == "OSQP" else g["out_exact"]
+worst = 0.0
+for rec, want, ok in zip(g["rec"], wants, g["ok"]):
+    got = cpp_mpc.compute_contact_forces(*[list(map(float, a)) for a in L.unpack_args(h, rec)])
+    assert isinstance(got, list) and (len(got) == 12 * h) == (bool(ok) or "{solver}" == "QPOASES")
+    if len(got):
+        worst = max(worst, float(np.abs(np.array(got) - want).max() / max(np.abs(want).max(), 1.0)))
+print("PYBIND_WORST", worst)
+"""
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    worst = float([l for l in out.stdout.splitlines() if l.startswith("PYBIND_WORST")][0].split()[1])
+    assert worst < (1e-5 if solver == "OSQP" else 1e-6), worst
+
+
 def _check_exact(solve, name, n, steps=2):
     """The exact mode's result against (i) the KKT conditions of the oracle-assembled QP -- a certificate that needs no second solver --
     and (ii) the oracle's 'exact' solve (vendored OSQP, cold, eps 1e-9, polish), which at the long horizons is the LESS accurate side

@@ -139,3 +139,22 @@ def test_job_split_equals_the_single_pass():
             finally:
                 lib().emu_set_split(0); lib().emu_set_poison(0)
             assert np.array_equal(fa, fb) and np.array_equal(a.info, b.info) and np.array_equal(a.state, b.state), name
+
+
+@pytest.mark.parametrize("h", [8, 12])
+def test_other_planning_horizons_match_osqp(h):
+    """ConvexMpc accepts any planning_horizon (mpc_osqp.cc:186-190); the library compiles a list of them (mpc_supported_horizons).  The
+    horizons beyond BASELINE's 10 / 16 / 20 against the live oracle: decisions identical, forces within the tolerance, both modes."""
+    from oracle.refmpc import RefBatch
+    from rl_mpc_locomotion_amd.synthetic import make_solver_workload, perturb_workload
+    wl = make_solver_workload(10, h=h, seed=3, config=2)
+    emu = EmuBatch(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
+    ref = RefBatch(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
+    for s in range(3):
+        f = emu.solve(wl.inputs)
+        fr = ref.solve(wl.inputs, nthreads=4)
+        assert np.array_equal(emu.info[:, :4], ref.info[:, :4]), (h, s)
+        assert grf_relerr(f, fr, first_step_only=False).max() < GRF_RTOL
+        wl = perturb_workload(wl, 4 + s)
+    emu.solve(wl.inputs, exact=True)
+    assert (emu.info[:, 1] == 1).all()

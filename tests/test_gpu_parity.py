@@ -48,6 +48,28 @@ def test_hip_matches_live_oracle(config, n):
         wl = perturb_workload(wl, 500 + s)
 
 
+@pytest.mark.parametrize("h", [8, 12])
+def test_other_planning_horizons_match_live_oracle(h):
+    """planning_horizon beyond BASELINE's 10 / 16 / 20 (mpc_osqp.cc:186-190 accepts any; mpc_supported_horizons lists what is compiled)."""
+    from oracle.refmpc import RefBatch
+    from rl_mpc_locomotion_amd import _lib
+    import ctypes as C
+    hs = (C.c_int * 16)()
+    cnt = _lib.lib().mpc_supported_horizons(hs, 16)
+    assert h in list(hs[:cnt]) and {10, 16, 20} <= set(hs[:cnt])
+    n = 96
+    wl = make_solver_workload(n, h=h, seed=40 + h, config=2)
+    gpu = _gpu(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
+    ref = RefBatch(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
+    for s in range(3):
+        f, info = _solve(gpu, wl.inputs)
+        fr = ref.solve(wl.inputs, nthreads=8)
+        assert np.array_equal(info[:, :4], ref.info[:, :4].astype(np.int32)), (h, s)
+        ok = ref.info[:, 1] == 1
+        assert grf_relerr(f[ok], fr[ok], first_step_only=False).max() < GRF_RTOL
+        wl = perturb_workload(wl, 600 + s)
+
+
 def test_full_size_properties_4096():
     """BASELINE configs[1] at full size: size-independent properties instead of the (slow) oracle --
     determinism across two handles, swing-leg forces vanish, stance forces inside the friction

@@ -26,7 +26,7 @@ def asm(tmp_path_factory):
 
 
 def test_all_horizons_are_instantiated(asm):
-    assert isa_census.horizons(asm) == [10, 16, 20]
+    assert isa_census.horizons(asm) == [8, 10, 12, 16, 20]
 
 
 def test_benchmark_horizon_hot_loops_are_scratch_free(asm):
