@@ -275,6 +275,7 @@ __global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES
                          forces + (size_t)robot * C::N, info + (size_t)robot * kInfoLen, prof ? prof + (size_t)robot * kProfLen : nullptr};
   };
   for (;;) {     // ---- ADMM jobs, in the dispatch order of order_block
+    [[maybe_unused]] const long long tf0 = MPC_CLOCK();
     ex.par([&](WThread<H> &t) { if (t.tid == 0) job = atomicAdd(&sched[kSchedNext], 1); });
     const int idx = job;
     ex.par([](WThread<H> &) {});     // (everybody has read `job` before thread 0 overwrites it)
@@ -288,6 +289,7 @@ __global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES
       sv.max_iter = max_iter;
       sv.jobrec = sc + (size_t)robot * C::SC_LEN + C::SC_JOB;
       pol = sv.admm_job();
+      if (MPC_PROFILE_SUB == 8 && prof && threadIdx.x == 0) MPC_GST(prof + (size_t)robot * kProfLen + 1, (long long)(sv.t_start - tf0));
     }
     // the job's results are device-coherent stores (MPC_GST): once they have completed -- a workgroup-scope release is the wait for
     // that, with no L2 write-back -- the entry may be published
@@ -300,6 +302,7 @@ __global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES
     });
   }
   for (;;) {     // ---- polish jobs, in completion order of the ADMM parts
+    [[maybe_unused]] const long long tf0 = MPC_CLOCK();
     ex.par([&](WThread<H> &t) {
       if (t.tid == 0) {
         const int pos = atomicAdd(&sched[kSchedHead], 1);
@@ -320,6 +323,7 @@ __global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES
     Solver<H, Ex> sv = solver(e);
     sv.jobrec = sc + (size_t)e * C::SC_LEN + C::SC_JOB;
     sv.polish_job();
+    if (MPC_PROFILE_SUB == 8 && prof && threadIdx.x == 0) MPC_GST(prof + (size_t)e * kProfLen + 2, (long long)(sv.t_start - tf0));
   }
 }
 

@@ -417,22 +417,27 @@ struct Solver {
   }
 
   // ================================ 1. load ======================================================================
+  // (The state record crosses between the two jobs of a solve with device-coherent accesses, MPC_GLD / MPC_GST, which go past this
+  // XCD's L2: it is moved with lane-contiguous addresses -- whole lines per instruction -- through an LDS stage (s.part, free at both
+  // ends of a job); a foot lane fetching its own 3 + 5 + 5 values straight from HBM touched every line of the record several times.)
+  static constexpr int SL = 2 * N + 2 * M + 2;   // state record: x[N] z[M] y[M] q_old[N] rho flag
+  static_assert(SL + N <= Sh::PARTLEN, "the state / force stage must fit Shared::part");
   MPC_HD void load() {
     ex.par([&](Th &t) {
+      for (int i = t.tid; i < SL; i += T) s.part[i] = MPC_GLD(state + i);
       for (int i = t.tid; i < 72; i += T) s.B6[i] = qp[C::QP_B6 + i];
       for (int i = t.tid; i < 36; i += T) s.th1[i] = qp[C::QP_TH1 + i];
       for (int i = t.tid; i < 6; i += T) s.th2[i] = qp[C::QP_TH2 + i];
       if (t.tid < NF) {
         const int f = t.tid;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { t.x[c] = MPC_GLD(state + 3 * f + c); t.q[c] = sc[C::SC_QS + 3 * f + c]; }
+        for (int c = 0; c < 3; ++c) t.q[c] = sc[C::SC_QS + 3 * f + c];
         const double *as = sc + C::SC_AS + 15 * f;
         s.fa[pidx(0, f)] = as[0]; s.fa[pidx(1, f)] = as[2]; s.fa[pidx(2, f)] = as[3]; s.fa[pidx(3, f)] = as[5]; s.fa[pidx(4, f)] = as[7];
         s.fa[pidx(5, f)] = as[8]; s.fa[pidx(6, f)] = as[10]; s.fa[pidx(7, f)] = as[11]; s.fa[pidx(8, f)] = as[14]; s.fa[pidx(15, f)] = 0.0;
         int tyb = 0;
 #pragma unroll
         for (int r = 0; r < 5; ++r) {
-          t.z[r] = MPC_GLD(state + N + 5 * f + r); t.y[r] = MPC_GLD(state + N + M + 5 * f + r);   // scaled iterates of the previous call; zeros on the first call
           const double lo = sc[C::SC_LS + 5 * f + r], hi = sc[C::SC_US + 5 * f + r];
           s.fa[pidx(10 + r, f)] = hi;
           if (r == 4) s.fa[pidx(9, f)] = lo;
@@ -444,14 +449,26 @@ struct Solver {
         t.tyb = tyb;
       }
       if (t.tid == 0) {
-        const bool first = MPC_GLD(state + 2 * N + 2 * M + 1) == 0.0;
-        s.first = first;
-        s.rho = first ? kRho0 : MPC_GLD(state + 2 * N + 2 * M);
         s.c = sc[C::SC_C]; s.cinv = sc[C::SC_C + 1]; s.calpha = sc[C::SC_C] * mdl.alpha;
         s.status = kStUnsolved; s.status_polish = 0; s.rho_updates = 0; s.nfact = 0; s.iter = 0; s.done = 0; s.bad = 0; s.pol_ok = 0; s.sig_changed = 0; s.loose_ok = 0;
       }
     });
-    ex.par([&](Th &t) { if (t.tid < NF && (t.tyb >> 10)) s.bad = 1; });
+    ex.par([&](Th &t) {
+      if (t.tid < NF) {
+        const int f = t.tid;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) t.x[c] = s.part[3 * f + c];      // scaled iterates of the previous call; zeros on the first call
+#pragma unroll
+        for (int r = 0; r < 5; ++r) { t.z[r] = s.part[N + 5 * f + r]; t.y[r] = s.part[N + M + 5 * f + r]; }
+        if (t.tyb >> 10) s.bad = 1;
+      }
+      if (t.tid == 0) {
+        const bool first = s.part[2 * N + 2 * M + 1] == 0.0;
+        s.first = first;
+        s.rho = first ? kRho0 : s.part[2 * N + 2 * M];
+      }
+    });
+    ex.par([](Th &) {});      // (the stage is read before anything else writes s.part)
     lap(0);
   }
   // my foot's constants, fetched where they are used (volatile 64-bit LDS loads: the compiler neither hoists them out of the
@@ -1928,30 +1945,32 @@ struct Solver {
   MPC_HD void store(long long t0) {
     tc[15] = MPC_CLOCK() - t0;
     if (s.first) tc[15] = -tc[15];   // a cold solve is no predictor of the robot's next (warm) one: negative = ignored by the dispatch order (order_block)
-    ex.par([&](Th &t) {
-      const bool failed = s.bad || s.status == kStNonCvx;
-      // (the reference's qpOASES branch returns its vector whatever the solver's status, mpc_osqp.cc:906-947: in the exact mode an iterate that
-      // ran out of iterations is written too, with its status)
-      const bool solved = (s.status == kStSolved || (eps_exact > 0 && (s.status == kStSolvedInaccurate || s.status == kStMaxIter))) && !failed;
+    const bool failed = s.bad || s.status == kStNonCvx;
+    // (the reference's qpOASES branch returns its vector whatever the solver's status, mpc_osqp.cc:906-947: in the exact mode an iterate that
+    // ran out of iterations is written too, with its status)
+    const bool solved = (s.status == kStSolved || (eps_exact > 0 && (s.status == kStSolvedInaccurate || s.status == kStMaxIter))) && !failed;
+    ex.par([&](Th &t) {      // the record and the forces into the LDS stage (see load) ...
       if (t.tid < NF) {
         const int f = t.tid;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          if (solved) MPC_GST(forces + 3 * f + c, 0.0 - Dat(t, c) * t.x[c]);   // (-x, mpc_osqp.cc:789-790; an eliminated foot's exact zero comes out as +0.0)
-          MPC_GST(state + 3 * f + c, failed ? 0.0 : t.x[c]);
-          MPC_GST(state + N + 2 * M + 3 * f + c, failed ? 0.0 : qp[C::QP_Q + 3 * f + c]);
+          s.part[SL + 3 * f + c] = 0.0 - Dat(t, c) * t.x[c];   // (-x, mpc_osqp.cc:789-790; an eliminated foot's exact zero comes out as +0.0)
+          s.part[3 * f + c] = failed ? 0.0 : t.x[c];
+          s.part[N + 2 * M + 3 * f + c] = failed ? 0.0 : qp[C::QP_Q + 3 * f + c];
         }
 #pragma unroll
-        for (int r = 0; r < 5; ++r) { MPC_GST(state + N + 5 * f + r, failed ? 0.0 : t.z[r]); MPC_GST(state + N + M + 5 * f + r, failed ? 0.0 : t.y[r]); }
+        for (int r = 0; r < 5; ++r) { s.part[N + 5 * f + r] = failed ? 0.0 : t.z[r]; s.part[N + M + 5 * f + r] = failed ? 0.0 : t.y[r]; }
       }
+      if (t.tid == 0) { s.part[2 * N + 2 * M] = failed ? 0.0 : s.rho; s.part[2 * N + 2 * M + 1] = failed ? 0.0 : 1.0; }
+    });
+    ex.par([&](Th &t) {      // ... and out with lane-contiguous addresses
+      for (int i = t.tid; i < SL; i += T) MPC_GST(state + i, s.part[i]);
+      if (solved) for (int i = t.tid; i < N; i += T) MPC_GST(forces + i, s.part[SL + i]);
       if (t.tid == 0) {
-        const bool failed = s.bad || s.status == kStNonCvx;
-        MPC_GST(state + 2 * N + 2 * M, failed ? 0.0 : s.rho);
-        MPC_GST(state + 2 * N + 2 * M + 1, failed ? 0.0 : 1.0);
         const int iv[8] = {s.iter, s.bad ? kStNonCvx : s.status, s.status_polish, s.rho_updates, s.nfact, s.first, 0, 0};
 #pragma unroll
         for (int k = 0; k < 8; ++k) MPC_GST(info + k, iv[k]);
-        if (prof) for (int k = 0; k < kProfLen; ++k) if ((k < 1 || k > 5 || MPC_PROFILE_SUB >= 6) && !(MPC_PROFILE_SUB && MPC_PROFILE_SUB <= 4 && k >= 9 && k <= 13)) MPC_GST(prof + k, tc[k]);   // (1 .. 5, and 9 .. 13 of a prep sub-profile: the prep kernel's)
+        if (prof) for (int k = 0; k < kProfLen; ++k) if ((k < 1 || k > 5 || (MPC_PROFILE_SUB >= 6 && MPC_PROFILE_SUB != 8)) && !(MPC_PROFILE_SUB && MPC_PROFILE_SUB <= 4 && k >= 9 && k <= 13)) MPC_GST(prof + k, tc[k]);   // (1 .. 5, and 9 .. 13 of a prep sub-profile: the prep kernel's)
       }
     });
   }
@@ -2047,7 +2066,7 @@ struct Solver {
         state[2 * N + 2 * M + 1] = failed ? 0.0 : 1.0;
         info[0] = s.iter; info[1] = s.bad ? kStNonCvx : s.status; info[2] = s.status_polish; info[3] = s.rho_updates;
         info[4] = s.nfact; info[5] = s.first; info[6] = 0; info[7] = 0;
-        if (prof) for (int k = 0; k < kProfLen; ++k) if ((k < 1 || k > 5 || MPC_PROFILE_SUB >= 6) && !(MPC_PROFILE_SUB && MPC_PROFILE_SUB <= 4 && k >= 9 && k <= 13)) prof[k] = tc[k];   // (1 .. 5, and 9 .. 13 of a prep sub-profile: the prep kernel's)
+        if (prof) for (int k = 0; k < kProfLen; ++k) if ((k < 1 || k > 5 || (MPC_PROFILE_SUB >= 6 && MPC_PROFILE_SUB != 8)) && !(MPC_PROFILE_SUB && MPC_PROFILE_SUB <= 4 && k >= 9 && k <= 13)) prof[k] = tc[k];   // (1 .. 5, and 9 .. 13 of a prep sub-profile: the prep kernel's)
       }
     });
   }
@@ -2092,9 +2111,10 @@ struct Solver {
   // run, which is what fills the tail of a launch.  admm_job leaves the complete result of a solve whose polish "has not
   // happened yet" (status_polish 0); polish_job re-loads the problem, polishes and, if OSQP would take the polished point,
   // overwrites x, z, y and the forces.  Returns true when a polish job has to follow.
+  long long t_start = 0;   // (profiling builds: when the job started)
   MPC_HD bool admm_job() {
     const long long t0 = MPC_CLOCK();
-    tlast = t0;
+    tlast = t0; if (MPC_PROFILE_SUB == 8) t_start = t0;
     admm_part();
     lap(14);
     store(t0);
@@ -2104,7 +2124,7 @@ struct Solver {
   }
   MPC_HD void polish_job() {
     const long long t0 = MPC_CLOCK();
-    tlast = t0;
+    tlast = t0; if (MPC_PROFILE_SUB == 8) t_start = t0;
     load();          // (x, z, y of the state record are the ADMM part's result)
     ex.par([&](Th &t) {
       if (t.tid == 0) { s.pri_res = MPC_GLD(jobrec); s.dua_res = MPC_GLD(jobrec + 1); s.status = kStSolved; s.nfact = MPC_GLD(info + 4); }
@@ -2113,12 +2133,18 @@ struct Solver {
     polish();
     lap(14);
     ex.par([&](Th &t) {
-      if (s.status_polish == 1 && t.tid < NF) {
+      if (s.status_polish == 1 && t.tid < NF) {      // OSQP takes the polished point: x, z, y and the forces again, through the stage (see load)
         const int f = t.tid;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { MPC_GST(forces + 3 * f + c, 0.0 - Dat(t, c) * t.x[c]); MPC_GST(state + 3 * f + c, t.x[c]); }
+        for (int c = 0; c < 3; ++c) { s.part[SL + 3 * f + c] = 0.0 - Dat(t, c) * t.x[c]; s.part[3 * f + c] = t.x[c]; }
 #pragma unroll
-        for (int r = 0; r < 5; ++r) { MPC_GST(state + N + 5 * f + r, t.z[r]); MPC_GST(state + N + M + 5 * f + r, t.y[r]); }
+        for (int r = 0; r < 5; ++r) { s.part[N + 5 * f + r] = t.z[r]; s.part[N + M + 5 * f + r] = t.y[r]; }
+      }
+    });
+    ex.par([&](Th &t) {
+      if (s.status_polish == 1) {
+        for (int i = t.tid; i < N + 2 * M; i += T) MPC_GST(state + i, s.part[i]);
+        for (int i = t.tid; i < N; i += T) MPC_GST(forces + i, s.part[SL + i]);
       }
       if (t.tid == 0) {
         MPC_GST(info + 2, s.status_polish); MPC_GST(info + 4, s.nfact);
