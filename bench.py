@@ -249,14 +249,17 @@ def main():
 
     info, solve_ms, prep_ms = m["info"], m["solve_ms"], m["prep_ms"]
     achieved_tflops = m["flops_per_launch"] / (solve_ms.mean() * 1e-3) / 1e12
-    # HBM traffic of the solve kernel is a rocprofv3 PMC measurement taken offline on this same command
-    # (tools/pmc_passes.sh -> profiles/rNN_pmc_summary.json); bench.py cannot run the profiler on itself.
-    traffic = None
+    # HBM-side traffic is a rocprofv3 PMC measurement taken offline on this same command (tools/pmc_passes.sh ->
+    # profiles/rNN_pmc_summary[_prep]_h10.json); bench.py cannot run the profiler on itself.  Both kernels of a step are counted.
+    traffic, traffic_parts = None, None
     try:
         import glob
-        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
-        if pm and n == 4096 and h == 10 and args.config == 2:
-            traffic = float(json.load(open(pm[-1]))["hbm_traffic_bytes_per_launch"])
+        ps = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary_h10.json")))
+        pp = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary_prep_h10.json")))
+        if ps and pp and n == 4096 and h == 10 and args.config == 2:
+            t_solve = float(json.load(open(ps[-1]))["hbm_traffic_bytes_per_launch"])
+            t_prep = float(json.load(open(pp[-1]))["hbm_traffic_bytes_per_launch"])
+            traffic, traffic_parts = t_solve + t_prep, {"solve_kernel": t_solve, "prep_kernel": t_prep, "from": [os.path.basename(ps[-1]), os.path.basename(pp[-1])]}
     except (OSError, ValueError, KeyError):
         traffic = None
     value = n_total * K / m["elapsed"]
@@ -285,11 +288,13 @@ def main():
         "mean_factorisations": float(info[..., 4].mean()),
         "roofline": {"bound": "vector_fp64", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic,
-                     "traffic_note": "HBM-side bytes per launch of the solve kernel from rocprofv3 PMC (profiles/*_pmc_summary.json, measured offline on this command)",
+                     "traffic_parts": traffic_parts,
+                     "traffic_note": "HBM-side bytes per step, BOTH kernels (prep + solve), from rocprofv3 PMC (profiles/*_pmc_summary*_h10.json, measured offline on this command); "
+                                     "algorithmic bytes per step: input 384 B + forces 960 B + state 2 x 5136 B per robot = 47.7 MB",
                      "note": "vector-FP bound, no MFMA / HBM roofline applies (SURVEY 8d): algorithmic flops (n_r formula, solve-kernel share) / "
-                             "mean duration of mpc_solve_kernel from HIP events on the launch stream; `peak` is the FP32 vector rate SURVEY 8(d) "
+                             "mean duration of the solve kernel (mpc_solve_jobs_kernel) from HIP events on the launch stream; `peak` is the FP32 vector rate SURVEY 8(d) "
                              "prescribes, the kernel's arithmetic is fp64 (frac_fp64_peak, peak 78.6 TF)",
-                     "kernel": "mpc_solve_kernel", "kernel_ms": float(solve_ms.mean()), "prep_kernel_ms": float(prep_ms.mean()),
+                     "kernel": "mpc_solve_jobs_kernel<10> (persistent: ADMM and polish jobs of every robot)", "kernel_ms": float(solve_ms.mean()), "prep_kernel_ms": float(prep_ms.mean()),
                      "step_ms_all_kernels": float((prep_ms + solve_ms).mean()), "flops_per_launch": m["flops_per_launch"],
                      "prep_kernel_flops_per_launch": m["prep_flops_per_launch"],
                      "frac_fp64_peak": achieved_tflops / FP64_VECTOR_PEAK_TFLOPS,
