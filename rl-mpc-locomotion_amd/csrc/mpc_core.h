@@ -332,36 +332,51 @@ struct Assembler {
       for (int i = t.tid; i < 156; i += T) s.b_dt[i] = 0;
       for (int i = t.tid; i < 72; i += T) { qp[C::QP_B6 + i] = 0; s.B6[i] = 0; }
     });
-    // ---- A dt, B dt (mpc_osqp.cc:299-336, 606-617, 661-673): every 3 x 3 product is one entry per thread, all
-    // operands in LDS (a thread-local array indexed by a runtime entry number would live in scratch memory).
-    // The intermediates use the not yet used xk / sdiff areas:
-    //   xk:    tan(pitch); m1 = Rx Ry; m2 = Rz Ry; rxyz; rzyx; fw[12]; t2 = rzyx I^-1; iw
-    //   sdiff: [26..53) Rx, Ry, Rz; [53..62) I^-1 (body)
-    double *const tp_ = s.xk, *const m1 = s.xk + 7, *const m2 = s.xk + 16, *const rxyz = s.xk + 25, *const rzyx = s.xk + 34,
-                 *const fw = s.xk + 43, *const t2 = s.xk + 55, *const iw = s.xk + 64;
-    double *const rxm = s.sdiff + 26, *const rym = s.sdiff + 35, *const rzm = s.sdiff + 44, *const iib = s.sdiff + 53;
+    // ---- A dt, B dt (mpc_osqp.cc:299-336, 606-617, 661-673).  The chain of 3 x 3 products behind them (rotations in both of the
+    // reference's conventions, the world-frame feet, the world inertia) is ~250 dependent-free FMAs: ONE thread carries it through
+    // registers (static indices) while the others set up x0, x_ref and the bounds -- four barrier phases of one-entry-per-thread
+    // products before (a phase costs ~1.5 k cycles of barrier and LDS latency here, whatever it computes).
+    //   xk: [0..7) cos / sin of roll, pitch, yaw and tan(pitch); [43..55) fw; [64..73) iw        sdiff: [53..62) I^-1 (body)
+    double *const trig = s.xk, *const fw = s.xk + 43, *const iw = s.xk + 64;
+    double *const iib = s.sdiff + 53;
     static_assert(13 * H >= 73, "xk / sdiff too small for the set-up scratch");
     ex.par([&](Th &t) {
-      if (t.tid < 27) {   // entry k of rotation `which` about x / y / z: 0, 1, cos, sin or -sin of its angle
-        const int which = t.tid / 9, k = t.tid - 9 * which;
-        const int ax = which, u = (ax + 1) % 3, v = (ax + 2) % 3, r = k / 3, c = k - 3 * r;
-        const double ang = s.in[IN_RPY + which];
-        double val;
-        if (r == ax || c == ax) val = (r == c) ? 1.0 : 0.0;
-        else if (r == c) val = cos(ang);
-        else val = (r == v && c == u) ? sin(ang) : -sin(ang);     // R[u][v] = -sin, R[v][u] = +sin
-        rxm[t.tid] = val;
-      } else if (t.tid == 64) {
-        tp_[0] = tan(s.in[IN_RPY + 1]);
+      for (int i = t.tid; i < C::IN_LEN; i += T) s.in[i] = in64 ? in64[i] : (double)in[i];
+      for (int i = t.tid; i < 169; i += T) s.a_dt[i] = 0;
+      for (int i = t.tid; i < 156; i += T) s.b_dt[i] = 0;
+      for (int i = t.tid; i < 72; i += T) { qp[C::QP_B6 + i] = 0; s.B6[i] = 0; }
+      if (t.tid >= 64 && t.tid < 67) {          // (one wave-front's worth of trigonometry, off the first wavefront)
+        const int k = t.tid - 64;
+        const double ang = in64 ? in64[IN_RPY + k] : (double)in[IN_RPY + k];
+        trig[2 * k] = cos(ang); trig[2 * k + 1] = sin(ang);
+        if (k == 1) trig[6] = tan(ang);
       } else if (t.tid >= 96 && t.tid < 105) {
         iib[t.tid - 96] = mdl.inv_inertia[t.tid - 96];
       }
     });
     MPC_SUBLAP(4, 9);
-    ex.par([&](Th &t) {   // m1 = Rx Ry (feet, :606-609), m2 = Rz Ry (inertia, :283-291)
-      if (t.tid < 18) {
-        const int e = t.tid % 9;
-        (t.tid < 9 ? m1 : m2)[e] = mat3e(t.tid < 9 ? rxm : rzm, rym, e);
+    ex.par([&](Th &t) {
+      if (t.tid == 0) {
+        const double cr = trig[0], sr = trig[1], cp = trig[2], sp = trig[3], cy = trig[4], sy = trig[5];
+        const double rx[9] = {1.0, 0.0, 0.0, 0.0, cr, -sr, 0.0, sr, cr};      // (entry (v, u) = +sin, (u, v) = -sin about axis x / y / z)
+        const double ry[9] = {cp, 0.0, sp, 0.0, 1.0, 0.0, -sp, 0.0, cp};
+        const double rz[9] = {cy, -sy, 0.0, sy, cy, 0.0, 0.0, 0.0, 1.0};
+        double m1[9], m2[9], rxyz[9], rzyx[9], t2[9], ib[9];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) { m1[e] = mat3e(rx, ry, e); m2[e] = mat3e(rz, ry, e); ib[e] = iib[e]; }   // Rx Ry (feet, :606-609), Rz Ry (inertia, :283-291)
+#pragma unroll
+        for (int e = 0; e < 9; ++e) { rxyz[e] = mat3e(m1, rz, e); rzyx[e] = mat3e(m2, rx, e); }
+        const double *fb = s.in + in_foot<H>();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 3; ++r) fw[3 * i + r] = rxyz[3 * r] * fb[3 * i] + rxyz[3 * r + 1] * fb[3 * i + 1] + rxyz[3 * r + 2] * fb[3 * i + 2];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) t2[e] = mat3e(rzyx, ib, e);                 // rzyx I^-1 (:670)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) iw[3 * i + j] = t2[3 * i] * rzyx[3 * j] + t2[3 * i + 1] * rzyx[3 * j + 1] + t2[3 * i + 2] * rzyx[3 * j + 2];   // ... rzyx^T (:671)
       }
       // x0 (:630-633)
       if (t.tid >= 32 && t.tid < 45) {
@@ -377,13 +392,6 @@ struct Assembler {
         qp[C::QP_L + i] = dmax(r < 4 ? 0.0 : fzmin * cst, -kInfty);
         qp[C::QP_U + i] = dmin(r < 4 ? (mu0 + 1) * fzmax * cst : fzmax * cst, kInfty);
       }
-    });
-    MPC_SUBLAP(4, 10);
-    ex.par([&](Th &t) {   // rxyz = (Rx Ry) Rz, rzyx = (Rz Ry) Rx
-      if (t.tid < 18) {
-        const int e = t.tid % 9;
-        (t.tid < 9 ? rxyz : rzyx)[e] = mat3e(t.tid < 9 ? m1 : m2, t.tid < 9 ? rzm : rxm, e);
-      }
       // x_ref (:635-659): row r of step i is base_r + dt (i + 1) slope_r  (slope 0 for the constant rows)
       for (int k = t.tid; k < 13 * H; k += T) {
         const int i = k / 13, r = k - 13 * i;
@@ -396,23 +404,7 @@ struct Assembler {
         s.xref[k] = r == 11 ? 0.0 : r == 12 ? -kGravity : v;
       }
     });
-    MPC_SUBLAP(4, 11);
-    ex.par([&](Th &t) {   // feet in the world frame; t2 = rzyx I^-1 (:670)
-      if (t.tid < 12) {
-        const int i = t.tid / 3, r = t.tid - 3 * i;
-        const double *fb = s.in + in_foot<H>();
-        fw[t.tid] = rxyz[3 * r] * fb[3 * i] + rxyz[3 * r + 1] * fb[3 * i + 1] + rxyz[3 * r + 2] * fb[3 * i + 2];
-      } else if (t.tid < 21) {
-        t2[t.tid - 12] = mat3e(rzyx, iib, t.tid - 12);
-      }
-    });
     MPC_SUBLAP(4, 12);
-    ex.par([&](Th &t) {   // iw = t2 rzyx^T (:671)
-      if (t.tid < 9) {
-        const int i = t.tid / 3, j = t.tid - 3 * i;
-        iw[t.tid] = t2[3 * i] * rzyx[3 * j] + t2[3 * i + 1] * rzyx[3 * j + 1] + t2[3 * i + 2] * rzyx[3 * j + 2];
-      }
-    });
     ex.par([&](Th &t) {
       const double dt = mdl.dt;
       if (t.tid < 36) {   // B rows 6-8: I_w^-1 [r_i]x (:324-336); [v]x = {0, -v2, v1; v2, 0, -v0; -v1, v0, 0}
@@ -434,7 +426,7 @@ struct Assembler {
         s.B6[(3 + r) * 12 + 3 * i + r] = mdl.inv_mass;
       } else if (t.tid < 57) {   // A rows 0-2: omega -> rpy rates (:311-312): {cy/cp, sy/cp, 0; -sy, cy, 0; cy tp, sy tp, 1}
         const int e = t.tid - 48, r = e / 3, c = e - 3 * r;
-        const double cp = rym[0], cy = rzm[0], sy = rzm[3], tp = tp_[0];
+        const double cp = trig[2], cy = trig[4], sy = trig[5], tp = trig[6];
         const double num = c == 0 ? cy : sy;
         double val;
         if (c == 2) val = r == 2 ? 1.0 : 0.0;
@@ -456,19 +448,37 @@ struct Assembler {
     MPC_SUBLAP(4, 13);
     // exact exponential (mpc_osqp.cc:338-351; M^3 = 0): A_exp = I + A dt + (A dt)^2/2, B_exp = B dt + (A dt)(B dt)/2.
     // A dt is nonzero only at rows 0-2 x cols 6-8, (3+i, 9+i) and rows 9-11 x col 12; the dense products of the
-    // reference add exact zeros elsewhere, so only the nonzero terms are formed (same order, same values).
+    // reference add exact zeros elsewhere, so only the nonzero terms are formed (same order, same values).  (A_exp itself is never
+    // needed: A_exp^k acts through the closed forms below.)
+    // A^k B (:368-373) and the free response A^{i+1} x0, i < H-1 (:360-364; the last A_qp block stays 0).
+    // A dt is nilpotent, so A_exp^k = exp(k A dt) = I + k A dt + k^2 (A dt)^2 / 2 exactly, and (A dt)^2 B_exp = 0
+    // (its only column, 12, meets the zero row 12 of B_exp):  A_exp^k B_exp = B_exp + k U,  U = (A dt) B_exp,
+    // which is nonzero in rows 0-5 only and meets B_exp in its rows 6-11 only -- where B_exp = B dt (rows 6-12 of A dt are zero up to
+    // column 12): U needs no phase of its own.  All k are formed at once (the reference multiplies k times; the two
+    // agree to rounding).  U -> the (unused) a_exp area, (A dt) x0 and (A dt)^2 x0 -> the first 26 slots of sdiff.
+    double *const U = s.a_exp;
     ex.par([&](Th &t) {
-      for (int k = t.tid; k < 169 + 156; k += T) {
-        if (k < 169) {
-          const int r = k / 13, c = k - 13 * r;
-          const double acc = (r >= 3 && r < 6 && c == 12) ? s.a_dt[r * 13 + r + 6] * s.a_dt[(r + 6) * 13 + 12] : 0.0;
-          s.a_exp[k] = (r == c ? 1.0 : 0.0) + s.a_dt[k] + acc / 2;
-        } else {
-          const int kk = k - 169, r = kk / 12, c = kk - 12 * r;
+      for (int kk = t.tid; kk < 156; kk += T) {
+        const int r = kk / 12, c = kk - 12 * r;
+        double acc = 0;
+        if (r < 3) { for (int j = 6; j < 9; ++j) acc += s.a_dt[r * 13 + j] * s.b_dt[j * 12 + c]; }
+        else if (r < 6) acc += s.a_dt[r * 13 + r + 6] * s.b_dt[(r + 6) * 12 + c];
+        s.b_exp[kk] = s.b_dt[kk] + acc / 2;
+      }
+      for (int e2 = T - 1 - t.tid; e2 < 72 + 13; e2 += T) {     // (from the last thread down: the first ones carry b_exp and th1 / th2)
+        if (e2 < 72) {
+          const int e = e2, r = e / 12, c = e - 12 * r;
           double acc = 0;
           if (r < 3) { for (int j = 6; j < 9; ++j) acc += s.a_dt[r * 13 + j] * s.b_dt[j * 12 + c]; }
-          else if (r < 6) acc += s.a_dt[r * 13 + r + 6] * s.b_dt[(r + 6) * 12 + c];
-          s.b_exp[kk] = s.b_dt[kk] + acc / 2;
+          else acc = s.a_dt[r * 13 + r + 6] * s.b_dt[(r + 6) * 12 + c];
+          U[e] = acc;
+        } else {
+          const int r = e2 - 72;
+          double a1 = 0, a2 = 0;
+          if (r < 3) { for (int j = 6; j < 9; ++j) a1 += s.a_dt[r * 13 + j] * s.x0[j]; }
+          else if (r < 6) { a1 = s.a_dt[r * 13 + r + 6] * s.x0[r + 6]; a2 = (s.a_dt[r * 13 + r + 6] * s.a_dt[(r + 6) * 13 + 12]) * s.x0[12]; }
+          else if (r >= 9 && r < 12) a1 = s.a_dt[r * 13 + 12] * s.x0[12];
+          s.sdiff[r] = a1; s.sdiff[13 + r] = a2;
         }
       }
       // The wrench-space description of P (mpc_wrench.h): A_exp^k B_exp = Gamma_k B6 with Gamma_k = [dt^2 (k + 1/2) That ; dt I6],
@@ -491,31 +501,10 @@ struct Assembler {
       }
     });
     MPC_SUBLAP(1, 10);
-    // A^k B (:368-373) and the free response A^{i+1} x0, i < H-1 (:360-364; the last A_qp block stays 0).
-    // A dt is nilpotent, so A_exp^k = exp(k A dt) = I + k A dt + k^2 (A dt)^2 / 2 exactly, and (A dt)^2 B_exp = 0
-    // (its only column, 12, meets the zero row 12 of B_exp):  A_exp^k B_exp = B_exp + k U,  U = (A dt) B_exp,
-    // which is nonzero in rows 0-5 only.  All k are formed at once (the reference multiplies k times; the two
-    // agree to rounding).  U overwrites b_dt, (A dt) x0 and (A dt)^2 x0 go to the first 26 slots of sdiff.
-    ex.par([&](Th &t) {
-      if (t.tid < 72) {
-        const int r = t.tid / 12, c = t.tid - 12 * r;
-        double acc = 0;
-        if (r < 3) { for (int j = 6; j < 9; ++j) acc += s.a_dt[r * 13 + j] * s.b_exp[j * 12 + c]; }
-        else acc = s.a_dt[r * 13 + r + 6] * s.b_exp[(r + 6) * 12 + c];
-        s.b_dt[t.tid] = acc;
-      } else if (t.tid < 72 + 13) {
-        const int r = t.tid - 72;
-        double a1 = 0, a2 = 0;
-        if (r < 3) { for (int j = 6; j < 9; ++j) a1 += s.a_dt[r * 13 + j] * s.x0[j]; }
-        else if (r < 6) { a1 = s.a_dt[r * 13 + r + 6] * s.x0[r + 6]; a2 = (s.a_dt[r * 13 + r + 6] * s.a_dt[(r + 6) * 13 + 12]) * s.x0[12]; }
-        else if (r >= 9 && r < 12) a1 = s.a_dt[r * 13 + 12] * s.x0[12];
-        s.sdiff[r] = a1; s.sdiff[13 + r] = a2;
-      }
-    });
     ex.par([&](Th &t) {
       for (int e = t.tid; e < H * 156; e += T) {
         const int k = e / 156, rc = e - 156 * k, r = rc / 12;
-        const double v = r < 6 ? s.b_exp[rc] + (double)k * s.b_dt[rc] : s.b_exp[rc];
+        const double v = r < 6 ? s.b_exp[rc] + (double)k * U[rc] : s.b_exp[rc];
         s.wanb[e] = s.in[IN_W + r] * v;
       }
       for (int e = t.tid; e < 13 * (H - 1); e += T) {   // (this overwrites the set-up scratch, which is dead by now)
