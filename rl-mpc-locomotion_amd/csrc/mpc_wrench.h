@@ -110,7 +110,14 @@ struct GiShared {
 };
 
 #ifndef MPC_EXACT_REFINE
-#define MPC_EXACT_REFINE 16   // refinement steps of the exact mode's polish (10 leave 1 % of the certified sets just above the 1e-10 dual test; x 1.5 at the long horizons)
+#define MPC_EXACT_REFINE 8    // refinement steps of the exact mode's polish before its first optimality test (83 % of the certified sets pass it at
+                               // h = 10; the rest go round again, MPC_EXACT_ROUND_STEPS more steps each time; x 1.5 at the long horizons)
+#endif
+#ifndef MPC_EXACT_ROUND_STEPS
+#define MPC_EXACT_ROUND_STEPS 4
+#endif
+#ifndef MPC_EXACT_ROUNDS
+#define MPC_EXACT_ROUNDS 6
 #endif
 #ifndef MPC_GI_DELTA
 #define MPC_GI_DELTA 0.0
@@ -149,7 +156,7 @@ struct Shared {
     struct { MPC_V Lk[H * 36]; MPC_V Tk[H * 36]; };     // factorisation only: per step Z_k = L L^T, T = L^-1 (zero columns / rows at dropped pivots)
   };
   unsigned long long red[24];
-  int first, iter, status, status_polish, rho_updates, nfact, done, bad, pol_ok, pol_near, sig_changed, loose_ok, dual_cand;
+  int first, iter, status, status_polish, rho_updates, nfact, done, bad, pol_ok, pol_near, pol_rounds, sig_changed, loose_ok, dual_cand;
   double pri_res, dua_res, rho_new;
 };
 #undef MPC_V
@@ -1468,10 +1475,11 @@ struct Solver {
     //   w <- w + Omega (g - P_s w).   With an exact Omega the residual obeys r_{k+1} = delta Omega r_k and needs no product with
     // P; Omega is only accurate to ~1e-10 |Xi|, so the true residual is formed (one Theta product per step) -- which is also
     // what OSQP does, and what keeps the refinement self-correcting.  The last product is the P_s xN the finish needs anyway.
-    // (Exact mode: a polish that must pass the optimality test and misses the dual test by less than 1000x -- the right set, the
-    // refinement not yet converged -- goes round again with eight more steps, at most three times.)
+    // (Exact mode: a polish that must pass the optimality test and misses the dual test by less than 1e4 x -- the right set, the
+    // refinement not yet converged -- goes round again with MPC_EXACT_ROUND_STEPS more steps, at most MPC_EXACT_ROUNDS times: most sets
+    // pass after the first eight steps, and the test costs less than two steps.)
     for (int round = 0;; ++round) {
-    const int nsteps = round == 0 ? polish_refine : 8;
+    const int nsteps = round == 0 ? polish_refine : MPC_EXACT_ROUND_STEPS;
     if (ROUNDS && round > 0) {      // the residual of the current xN, as the loop's last iteration would have left it
       ex.seq([&](Th &t) { if (t.tid < NF) put_wrench(t, t.pxN); });
       product<kTheta>();
@@ -1567,7 +1575,8 @@ struct Solver {
         const double ep = eps_exact + eps_exact * dmax(bitsd(s.red[1]), bitsd(s.red[2]));
         const double ed = eps_exact + eps_exact * s.cinv * dmax(dmax(bitsd(s.red[7]), bitsd(s.red[8])), bitsd(s.red[9]));
         const bool verified = !s.bad && pri < ep && dua < ed;
-        s.pol_near = polish_must_verify && !verified && !s.bad && pri < ep && dua < 1e3 * ed;
+        s.pol_near = polish_must_verify && !verified && !s.bad && pri < ep && dua < 1e4 * ed;
+        s.pol_rounds = round + 1;
 #ifdef MPC_EMU_DEBUG
         if (getenv("EMU_GI_TRACE")) fprintf(stderr, "  polish: pri %.3e (tol %.3e) dua %.3e (tol %.3e) bad %d\n", pri, ep, dua, ed, (int)s.bad);
 #endif
@@ -1583,7 +1592,7 @@ struct Solver {
 #endif
       }
     });
-    if (!(ROUNDS && s.pol_near && round < 3)) break;
+    if (!(ROUNDS && s.pol_near && round < MPC_EXACT_ROUNDS)) break;
     }
     ex.par([&](Th &t) {
       if (s.status_polish == 1 && t.tid < NF) {
@@ -1967,7 +1976,7 @@ struct Solver {
       for (int i = t.tid; i < SL; i += T) MPC_GST(state + i, s.part[i]);
       if (solved) for (int i = t.tid; i < N; i += T) MPC_GST(forces + i, s.part[SL + i]);
       if (t.tid == 0) {
-        const int iv[8] = {s.iter, s.bad ? kStNonCvx : s.status, s.status_polish, s.rho_updates, s.nfact, s.first, 0, 0};
+        const int iv[8] = {s.iter, s.bad ? kStNonCvx : s.status, s.status_polish, s.rho_updates, s.nfact, s.first, eps_exact > 0 ? s.pol_rounds : 0, 0};
 #pragma unroll
         for (int k = 0; k < 8; ++k) MPC_GST(info + k, iv[k]);
         if (prof) for (int k = 0; k < kProfLen; ++k) if ((k < 1 || k > 5 || (MPC_PROFILE_SUB >= 6 && MPC_PROFILE_SUB != 8)) && !(MPC_PROFILE_SUB && MPC_PROFILE_SUB <= 4 && k >= 9 && k <= 13)) MPC_GST(prof + k, tc[k]);   // (1 .. 5, and 9 .. 13 of a prep sub-profile: the prep kernel's)
