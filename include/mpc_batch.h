@@ -129,7 +129,9 @@ int mpc_batch_set_state(mpc_batch *b, const double *h_state);
  *   QP record    [n, mpc_batch_qp_len]    q[12h] l[20h] u[20h] cone[15] pad | B6[6x12] th1[6x6] th2[6] pad -- the QP of
  *                mpc_osqp.cc:606-688 with its Hessian in the wrench form P = BB^T Theta BB + alpha I (csrc/mpc_wrench.h);
  *   scale record [n, mpc_batch_scale_len] D[12h] E[20h] q_s[12h] A_s[15*4h] l_s[20h] u_s[20h] c 1/c -- OSQP's scaling.c output -- and two
- *                doubles of job hand-over (the ADMM part's residuals, read by the solve's polish job). */
+ *                doubles of job hand-over (the ADMM part's residuals, read by the solve's polish job).
+ * (On the device the records are shorter -- three bound values and the nine structural cone entries per foot, csrc/mpc_core.h -- and
+ * the accessors expand them with the solve kernel's own arithmetic: l_s = E l, u_s = E u.) */
 int mpc_batch_qp_len(const mpc_batch *b);
 int mpc_batch_scale_len(const mpc_batch *b);
 int mpc_batch_get_qp(mpc_batch *b, double *h_qp);

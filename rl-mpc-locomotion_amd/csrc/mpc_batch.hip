@@ -491,10 +491,59 @@ static int launch_solver(mpc_batch *b, const float *d_in, double *d_forces, int 
 
 #define MPC_QP(HH) if (h == HH) return Cfg<HH>::QP_LEN;
 #define MPC_SC(HH) if (h == HH) return Cfg<HH>::SC_LEN;
+#define MPC_XQP(HH) if (h == HH) return Cfg<HH>::XQP_LEN;
+#define MPC_XSC(HH) if (h == HH) return Cfg<HH>::XSC_LEN;
 static size_t qp_len_of(int h) { MPC_HORIZON_LIST(MPC_QP) return 0; }     // (0: horizon not compiled in)
 static size_t sc_len_of(int h) { MPC_HORIZON_LIST(MPC_SC) return 0; }
+static size_t xqp_len_of(int h) { MPC_HORIZON_LIST(MPC_XQP) return 0; }   // the records as the accessors hand them out
+static size_t xsc_len_of(int h) { MPC_HORIZON_LIST(MPC_XSC) return 0; }
 #undef MPC_QP
 #undef MPC_SC
+#undef MPC_XQP
+#undef MPC_XSC
+// The device records keep three bound values and nine cone entries per foot (mpc_core.h); the accessors hand out every bound and the
+// dense cone block, formed here exactly as the solve kernel forms them (E times the bound).
+template <int H>
+static void expand_records(const double *qp, const double *sc, double *xqp, double *xsc) {
+  using C = Cfg<H>;
+  if (xqp) {
+    for (int i = 0; i < C::N; ++i) xqp[i] = qp[C::QP_Q + i];
+    for (int f = 0; f < C::NF; ++f)
+      for (int r = 0; r < 5; ++r) {
+        xqp[C::XQP_L + 5 * f + r] = r < 4 ? 0.0 : qp[C::QP_BND + 3 * f];
+        xqp[C::XQP_U + 5 * f + r] = r < 4 ? qp[C::QP_BND + 3 * f + 1] : qp[C::QP_BND + 3 * f + 2];
+      }
+    for (int i = 0; i < 16 + 72 + 36 + 8; ++i) xqp[C::XQP_CONE + i] = qp[C::QP_CONE + i];
+  }
+  if (xsc) {
+    for (int i = 0; i < 2 * C::N + C::M; ++i) xsc[i] = sc[i];      // D, E, q_s
+    for (int f = 0; f < C::NF; ++f) {
+      for (int k = 0; k < 15; ++k) xsc[C::XSC_AS + 15 * f + k] = 0.0;
+      for (int k = 0; k < 9; ++k) xsc[C::XSC_AS + 15 * f + kAsPos[k]] = sc[C::SC_AS + 9 * f + k];
+      for (int r = 0; r < 5; ++r) {
+        const double e = sc[C::SC_E + 5 * f + r];
+        xsc[C::XSC_LS + 5 * f + r] = e * (r < 4 ? 0.0 : qp[C::QP_BND + 3 * f]);
+        xsc[C::XSC_US + 5 * f + r] = e * (r < 4 ? qp[C::QP_BND + 3 * f + 1] : qp[C::QP_BND + 3 * f + 2]);
+      }
+    }
+    for (int i = 0; i < 4; ++i) xsc[C::XSC_C + i] = sc[C::SC_C + i];
+  }
+}
+static int fetch_records(mpc_batch *b, double *h_qp, double *h_sc) {
+  const size_t ql = qp_len_of(b->h), sl = sc_len_of(b->h), xql = xqp_len_of(b->h), xsl = xsc_len_of(b->h);
+  std::vector<double> qp((size_t)b->n * ql), sc((size_t)b->n * sl);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(qp.data(), b->d_qp, sizeof(double) * qp.size(), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(sc.data(), b->d_sc, sizeof(double) * sc.size(), hipMemcpyDeviceToHost));
+  for (int r = 0; r < b->n; ++r) {
+    const double *q = qp.data() + (size_t)r * ql, *c = sc.data() + (size_t)r * sl;
+    double *xq = h_qp ? h_qp + (size_t)r * xql : nullptr, *xs = h_sc ? h_sc + (size_t)r * xsl : nullptr;
+#define MPC_X(HH) if (b->h == HH) expand_records<HH>(q, c, xq, xs);
+    MPC_HORIZON_LIST(MPC_X)
+#undef MPC_X
+  }
+  return MPC_OK;
+}
 
 extern "C" {
 
@@ -691,21 +740,17 @@ int mpc_batch_get_state(mpc_batch *b, double *h_state) {
   return MPC_OK;
 }
 // Test / debugging access to what the prep kernel handed to the solve kernel in the last launch
-int mpc_batch_qp_len(const mpc_batch *b) { return b ? (int)qp_len_of(b->h) : 0; }
-int mpc_batch_scale_len(const mpc_batch *b) { return b ? (int)sc_len_of(b->h) : 0; }
+int mpc_batch_qp_len(const mpc_batch *b) { return b ? (int)xqp_len_of(b->h) : 0; }
+int mpc_batch_scale_len(const mpc_batch *b) { return b ? (int)xsc_len_of(b->h) : 0; }
 int mpc_batch_get_qp(mpc_batch *b, double *h_qp) {
   if (!b || !h_qp) return fail(MPC_E_ARG, "mpc_batch_get_qp: bad argument");
   DeviceGuard guard_(b->device);
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(h_qp, b->d_qp, sizeof(double) * (size_t)b->n * qp_len_of(b->h), hipMemcpyDeviceToHost));
-  return MPC_OK;
+  return fetch_records(b, h_qp, nullptr);
 }
 int mpc_batch_get_scale(mpc_batch *b, double *h_sc) {
   if (!b || !h_sc) return fail(MPC_E_ARG, "mpc_batch_get_scale: bad argument");
   DeviceGuard guard_(b->device);
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(h_sc, b->d_sc, sizeof(double) * (size_t)b->n * sc_len_of(b->h), hipMemcpyDeviceToHost));
-  return MPC_OK;
+  return fetch_records(b, nullptr, h_sc);
 }
 int mpc_batch_get_profile(mpc_batch *b, long long *h_prof) {
   if (!b || !h_prof) return fail(MPC_E_ARG, "mpc_batch_get_profile: bad argument");

@@ -100,6 +100,9 @@ constexpr double kGravity = 9.8, kMaxScale = 10.0, kMinScale = 0.1;  // mpc_osqp
 constexpr int kStSolved = 1, kStSolvedInaccurate = 2, kStPrimInfInaccurate = 3, kStDualInfInaccurate = 4, kStMaxIter = -2, kStPrimInf = -3, kStDualInf = -4,
               kStNonCvx = -7, kStUnsolved = -10;
 
+// positions of the structural nonzeros of the 5 x 3 cone block {-1 0 mu; 1 0 mu; 0 -1 mu; 0 1 mu; 0 0 1} (mpc_osqp.cc:437-447), row-major
+constexpr int kAsPos[9] = {0, 2, 3, 5, 7, 8, 10, 11, 14};
+
 template <int H>
 struct Cfg {
   static constexpr int N = 12 * H, M = 20 * H, NF = 4 * H;
@@ -127,13 +130,19 @@ struct Cfg {
   static constexpr int kPinMask = H > 16 ? 3 : 17;
 #endif
   // The QP record the assembly kernel hands to the scaling and solve kernels (doubles per robot):
-  //   q[N] l[M] u[M] cone[15] pad | B6[6 x 12] th1[6 x 6] th2[6] pad2   (the wrench-space description of P, mpc_wrench.h)
-  static constexpr int QP_Q = 0, QP_L = N, QP_U = N + M, QP_CONE = N + 2 * M, QP_B6 = N + 2 * M + 16, QP_TH1 = QP_B6 + 72,
+  //   q[N] bnd[3 NF] cone[15] pad | B6[6 x 12] th1[6 x 6] th2[6] pad2   (the wrench-space description of P, mpc_wrench.h)
+  // bnd: per foot l of row 4 and u of rows 0-3 / of row 4 -- l of rows 0-3 is 0 and the four u are equal (mpc_osqp.cc:449-477), so
+  // three numbers stand for the foot's ten bounds, and E times them is bit for bit what scaling.c:152-153 computes.
+  static constexpr int QP_Q = 0, QP_BND = N, QP_CONE = N + 3 * NF, QP_B6 = QP_CONE + 16, QP_TH1 = QP_B6 + 72,
                        QP_TH2 = QP_TH1 + 36, QP_LEN = QP_TH2 + 8;
-  // The scale record the scaling kernel hands to the solve kernel: D[N] E[M] q_s[N] A_s[15 NF] l_s[M] u_s[M] c 1/c | job[2]
-  // (job: primal / dual residual of the ADMM part's result, from the ADMM job of a solve to its polish job, mpc_wrench.h)
-  static constexpr int SC_D = 0, SC_E = N, SC_QS = N + M, SC_AS = 2 * N + M, SC_LS = SC_AS + 15 * NF, SC_US = SC_LS + M,
-                       SC_C = SC_US + M, SC_JOB = SC_C + 2, SC_LEN = SC_C + 4;
+  // The scale record the scaling kernel hands to the solve kernel: D[N] E[M] q_s[N] A_s[9 NF] c 1/c | job[2]
+  // (A_s: the nine structural nonzeros of a foot's 5 x 3 cone block, kAsPos; the scaled bounds are E times the QP record's;
+  // job: primal / dual residual of the ADMM part's result, from the ADMM job of a solve to its polish job, mpc_wrench.h)
+  static constexpr int SC_D = 0, SC_E = N, SC_QS = N + M, SC_AS = 2 * N + M, SC_C = SC_AS + 9 * NF, SC_JOB = SC_C + 2, SC_LEN = SC_C + 4;
+  // The same two records as mpc_batch_get_qp / mpc_batch_get_scale hand them out (include/mpc_batch.h: every bound, the dense cone
+  // block): q[N] l[M] u[M] cone[15] pad | B6 th1 th2 pad2   and   D[N] E[M] q_s[N] A_s[15 NF] l_s[M] u_s[M] c 1/c | job[2]
+  static constexpr int XQP_L = N, XQP_U = N + M, XQP_CONE = N + 2 * M, XQP_LEN = XQP_CONE + 16 + 72 + 36 + 8;
+  static constexpr int XSC_AS = 2 * N + M, XSC_LS = XSC_AS + 15 * NF, XSC_US = XSC_LS + M, XSC_C = XSC_US + M, XSC_LEN = XSC_C + 4;
   // ---- wrench grid of the solve kernel (mpc_wrench.h): the 6 H x 6 H core matrix as H x H tiles of 6 x 6, one per thread
   static constexpr int NW = 6 * H, GW = H, MTW = H * (H + 1) / 2;
   static constexpr int TW = (((MTW > NW ? MTW : NW) + 63) / 64) * 64;   // solve-kernel workgroup: 64 (h = 10), 192, 256
@@ -171,7 +180,7 @@ template <int H>
 struct ScaleShared {
   using C = Cfg<H>;
   MPC_V q[C::kQInLds ? C::N : 2];                       // unscaled q, unless it is re-read from the HBM record
-  MPC_V qs[C::N]; MPC_V ls[C::M]; MPC_V us[C::M]; MPC_V As[C::NF * 15];   // scaled problem
+  MPC_V qs[C::N]; MPC_V As[C::NF * 15];   // scaled problem (the bounds are scaled once, at the end: E times the QP record's)
   MPC_V D[C::N]; MPC_V E[C::M];
   double c, cinv, ctmp;
   int first;
@@ -384,13 +393,13 @@ struct Assembler {
         s.x0[i] = i < 3 ? s.in[IN_RPY + i] : i < 6 ? s.in[IN_POS + i - 3] : i < 9 ? s.in[IN_ANG + i - 6] : i < 12 ? s.in[IN_VEL + i - 9] : -kGravity;
       }
       // bounds (:449-477, 685-688, 720-721)
-      for (int i = t.tid; i < M; i += T) {
-        const int f = i / 5, r = i - 5 * f;
+      for (int f = t.tid; f < NF; f += T) {
         const double cst = s.in[IN_CONTACT + f];
         const double fzmax = mdl.mass * kGravity * kMaxScale, fzmin = mdl.mass * kGravity * kMinScale;
         const double mu0 = s.in[in_fric<H>()];
-        qp[C::QP_L + i] = dmax(r < 4 ? 0.0 : fzmin * cst, -kInfty);
-        qp[C::QP_U + i] = dmin(r < 4 ? (mu0 + 1) * fzmax * cst : fzmax * cst, kInfty);
+        qp[C::QP_BND + 3 * f] = dmax(fzmin * cst, -kInfty);                  // l of row 4 (rows 0-3: max(0, -inf) = 0)
+        qp[C::QP_BND + 3 * f + 1] = dmin((mu0 + 1) * fzmax * cst, kInfty);   // u of rows 0-3
+        qp[C::QP_BND + 3 * f + 2] = dmin(fzmax * cst, kInfty);               // u of row 4
       }
       // x_ref (:635-659): row r of step i is base_r + dt (i + 1) slope_r  (slope 0 for the constant rows)
       for (int k = t.tid; k < 13 * H; k += T) {
@@ -810,12 +819,8 @@ struct Scaler {
         sc[C::SC_QS + t.tid] = qv;
         sc[C::SC_D + t.tid] = s.D[t.tid];
       }
-      for_rows(t, [&](int i) {
-        sc[C::SC_E + i] = s.E[i];
-        sc[C::SC_LS + i] = s.E[i] * qp[C::QP_L + i];      // (the unscaled bounds stay in the QP record: LDS is what limits the robots per CU)
-        sc[C::SC_US + i] = s.E[i] * qp[C::QP_U + i];
-      });
-      for (int k = t.tid; k < NF * 15; k += T) sc[C::SC_AS + k] = s.As[k];
+      for_rows(t, [&](int i) { sc[C::SC_E + i] = s.E[i]; });
+      for (int k = t.tid; k < NF * 9; k += T) { const int f = k / 9; sc[C::SC_AS + k] = s.As[15 * f + kAsPos[k - 9 * f]]; }
     });
     lap(5);
     if (prof) {

@@ -175,8 +175,8 @@ struct Solver {
   Sh &s;
   const RobotModel &mdl;
   double *state;       // [state_len<H>()]
-  const double *qp;    // [QP_LEN]  q, l, u, cone, wrench description from the assembly kernel
-  const double *sc;    // [SC_LEN]  D, E, q_s, A_s, l_s, u_s, c from the scaling kernel
+  const double *qp;    // [QP_LEN]  q, bounds, cone, wrench description from the assembly kernel
+  const double *sc;    // [SC_LEN]  D, E, q_s, A_s, c from the scaling kernel
   double *forces;      // [N]   out: -D x (all horizon steps), untouched on failure
   int *info;           // [kInfoLen]
   long long *prof;     // [kProfLen] shader-clock cycles per section (may be null)
@@ -439,13 +439,17 @@ struct Solver {
         const int f = t.tid;
 #pragma unroll
         for (int c = 0; c < 3; ++c) t.q[c] = sc[C::SC_QS + 3 * f + c];
-        const double *as = sc + C::SC_AS + 15 * f;
-        s.fa[pidx(0, f)] = as[0]; s.fa[pidx(1, f)] = as[2]; s.fa[pidx(2, f)] = as[3]; s.fa[pidx(3, f)] = as[5]; s.fa[pidx(4, f)] = as[7];
-        s.fa[pidx(5, f)] = as[8]; s.fa[pidx(6, f)] = as[10]; s.fa[pidx(7, f)] = as[11]; s.fa[pidx(8, f)] = as[14]; s.fa[pidx(15, f)] = 0.0;
+        const double *as = sc + C::SC_AS + 9 * f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s.fa[pidx(k, f)] = as[k];
+        s.fa[pidx(15, f)] = 0.0;
+        const double *bnd = qp + C::QP_BND + 3 * f;
         int tyb = 0;
 #pragma unroll
         for (int r = 0; r < 5; ++r) {
-          const double lo = sc[C::SC_LS + 5 * f + r], hi = sc[C::SC_US + 5 * f + r];
+          // l_s = E l, u_s = E u (scaling.c:152-153) from the foot's three bound values (l of rows 0-3 is 0)
+          const double e = sc[C::SC_E + 5 * f + r];
+          const double lo = e * (r < 4 ? 0.0 : bnd[0]), hi = e * (r < 4 ? bnd[1] : bnd[2]);
           s.fa[pidx(10 + r, f)] = hi;
           if (r == 4) s.fa[pidx(9, f)] = lo;
           // set_rho_vec / update_rho_vec (auxil.c:79-141): the row type is a function of the scaled bounds

@@ -20,7 +20,7 @@ for name, d in per.items():
 traffic = (2 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024
 N, M = 12 * h, 20 * h
 alg = n * ((56 + 4 * h) * 4 + (2 * N + 2 * M + 2) * 8 * 2 + N * 8 + 8 * 4)   # path level: input record, warm-start state r+w, forces, info
-rec = n * ((2 * N + 3 * M + 60 * h + 2) + (N + 2 * M + 16 + 116)) * 8 * 2            # scale + QP records handed from the prep kernel to the solve kernel (written once, read once)
+rec = n * ((2 * N + M + 36 * h + 4) + (2 * N + 16 + 116)) * 8 * 2                     # scale + QP records handed from the prep kernel to the solve kernel (written once, read once; csrc/mpc_core.h: SC_LEN, QP_LEN)
 c = counters
 summary = {
     "command": "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-control-loop --no-secondary (tools/pmc_passes.sh: one rocprofv3 --pmc pass per counter group, --kernel-trace only)",
