@@ -101,6 +101,24 @@ struct DeviceExec {
       v[i] = a + quad_perm<quad_ctrl(2, 3, 0, 1)>(a);
     }
   }
+  // Reduce-scatter of six per-lane values over the quad: dst(th)[0] <- the quad's sum of src[j] in lane j, dst(th)[1] <- the sum of
+  // src[4 + (j & 1)], each with the association of quad_allsum, (l_j + l_j^1) + (l_j^2 + l_j^3).  A lane hands its partner what the
+  // partner keeps: three exchanges with lane j ^ 1, two with lane j ^ 2 (the all-sum of all six takes twelve, and a select after it).
+  template <class S, class D>
+  __device__ __forceinline__ void quad_scatter6(S &&src, D &&dst) {
+    const double *w = src(th);
+    double *g = dst(th);
+    const bool odd = threadIdx.x & 1, hi = threadIdx.x & 2;
+    double a[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {      // lanes 0, 2 keep the components 0, 2, 4 of their pair; lanes 1, 3 keep 1, 3, 5
+      const double keep = odd ? w[2 * p + 1] : w[2 * p], give = odd ? w[2 * p] : w[2 * p + 1];
+      a[p] = keep + quad_perm<quad_ctrl(1, 0, 3, 2)>(give);
+    }
+    const double keep = hi ? a[1] : a[0], give = hi ? a[0] : a[1];     // lanes 0, 1 end with component 0 / 1, lanes 2, 3 with 2 / 3
+    g[0] = keep + quad_perm<quad_ctrl(2, 3, 0, 1)>(give);
+    g[1] = a[2] + quad_perm<quad_ctrl(2, 3, 0, 1)>(a[2]);
+  }
   // acc(th)[0] <- the sum, acc(th)[1] <- the maximum (of non-negative values) over the 64 lanes of the wavefront, the same bits in
   // every lane: four DPP steps leave every lane with its row's (16 lanes) result, v_readlane fetches the four rows
   template <class A>

@@ -68,6 +68,14 @@ typedef double mpc_double2 __attribute__((ext_vector_type(2)));
 //   MPC_NT_H16 / MPC_NT_H20   dense-P tiles per thread of the prep kernel at h = 16 / 20
 //   MPC_PIN_MASK              live-range split points of the prep kernel's tile registers
 //   MPC_PROW_SKEW             1: pivot rows of the solve kernel 8 bytes off the 16-byte grid
+//   MPC_PART_ROWMAJOR         1: partial products of the solve kernel's tile mat-vec as [row][slot] (0: [slot][row])
+//   MPC_QUAD_SCATTER          1: the per-step wrench sums as a quad reduce-scatter (0: all-sum of all six, then a select)
+#ifndef MPC_PART_ROWMAJOR
+#define MPC_PART_ROWMAJOR 1
+#endif
+#ifndef MPC_QUAD_SCATTER
+#define MPC_QUAD_SCATTER 1
+#endif
 #ifndef MPC_PROW_SKEW
 #define MPC_PROW_SKEW 0
 #endif

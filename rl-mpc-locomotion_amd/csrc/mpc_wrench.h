@@ -365,6 +365,17 @@ struct Solver {
             ar[aa] += m * vc[bb];
             ac[bb] += m * vr[aa];
           }
+#if MPC_PART_ROWMAJOR
+        // [row][slot]: the G partials of a row are contiguous, and sum_parts fetches them as G / 2 ds_read_b128 (the [slot][row] layout
+        // costs the reader G ds_read_b64; the writer's stride-G stores pair up as ds_write2_b64 either way)
+        double *pd = s.part + (TS * t.ti) * GP + t.tj, *pt = s.part + (TS * t.tj) * GP + t.ti;
+#pragma unroll
+        for (int aa = 0; aa < TS; ++aa) pd[aa * GP] = ar[aa];
+        if (!t.dia) {
+#pragma unroll
+          for (int bb = 0; bb < TS; ++bb) pt[bb * GP] = ac[bb];
+        }
+#else
         double *pd = s.part + t.tj * NP + TS * t.ti, *pt = s.part + t.ti * NP + TS * t.tj;
 #pragma unroll
         for (int aa = 0; aa < TS; ++aa) pd[aa] = ar[aa];
@@ -372,13 +383,21 @@ struct Solver {
 #pragma unroll
           for (int bb = 0; bb < TS; ++bb) pt[bb] = ac[bb];
         }
+#endif
       }
     });
   }
+  static constexpr int GP = (G + 1) & ~1;   // row stride of the [row][slot] layout: even, so that a row starts on a 16-byte boundary
+  static_assert(NW * GP <= Sh::PARTLEN, "the partial products must fit Shared::part");
   static MPC_HD double sum_parts(const Sh &s, int row) {   // fixed pairwise order
-    double v[G];
+    double v[GP];
+#if MPC_PART_ROWMAJOR
+#pragma unroll
+    for (int k = 0; k < GP; k += 2) MPC_LDS_LOAD128(s.part + row * GP + k, v[k], v[k + 1]);
+#else
 #pragma unroll
     for (int k = 0; k < G; ++k) v[k] = MPC_LDS_LOAD64(s.part + k * NP + row);
+#endif
 #pragma unroll
     for (int w = 1; w < G; w *= 2)
 #pragma unroll
@@ -389,13 +408,21 @@ struct Solver {
   // (I - M^-1) g = g - dl Mh^-1 (dl g).  KIND = kTheta: c Theta g.
   template <int KIND>
   MPC_HD void send() {
+#if MPC_QUAD_SCATTER
+    ex.quad_scatter6([](Th &t) { return t.w6; }, [](Th &t) { return t.gq; });
+#else
     ex.template quad_allsum<6>([](Th &t) { return t.w6; });
+#endif
     ex.par([&](Th &t) {
       if (t.tid < NF) {
         const int k = t.tid >> 2, j = t.tid & 3;
+#if MPC_QUAD_SCATTER
+        const double g0 = t.gq[0], g1 = t.gq[1];
+#else
         const double g0 = j == 0 ? t.w6[0] : (j == 1 ? t.w6[1] : (j == 2 ? t.w6[2] : t.w6[3]));
         const double g1 = j == 0 ? t.w6[4] : t.w6[5];
         t.gq[0] = g0; t.gq[1] = g1;
+#endif
         s.gh[6 * k + j] = KIND == kHeld ? t.dlq[0] * g0 : g0;
         if (j < 2) s.gh[6 * k + 4 + j] = KIND == kHeld ? t.dlq[1] * g1 : g1;
       }

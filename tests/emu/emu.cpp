@@ -53,6 +53,14 @@ struct HostExec {
         for (int j = 0; j < 4; ++j) acc(th[q + j])[i] = v;
       }
   }
+  template <class S, class D> void quad_scatter6(S &&src, D &&dst) {   // (the device's association: own pair first, then the other pair)
+    for (int q = 0; q + 3 < NTHREADS; q += 4) {
+      double v[6][4];
+      for (int r = 0; r < 6; ++r)
+        for (int j = 0; j < 4; ++j) v[r][j] = (src(th[q + j])[r] + src(th[q + (j ^ 1)])[r]) + (src(th[q + (j ^ 2)])[r] + src(th[q + (j ^ 3)])[r]);
+      for (int j = 0; j < 4; ++j) { dst(th[q + j])[0] = v[j][j]; dst(th[q + j])[1] = v[4 + (j & 1)][j]; }
+    }
+  }
   // the device's wavefront reduction (same association order: quad, half row, row, then the four rows)
   template <class A> void wave_sum_max(A &&acc) {
     for (int w = 0; w + 63 < NTHREADS; w += 64) {

@@ -51,7 +51,7 @@ def _loop_of(block):
     lines = block.split('\n')
     first = lines[0]
     lab = block.split(':')[0]
-    head = ' '.join(lines[:2])          # an inner loop header carries "Parent Loop .." first and "=> This Inner Loop Header" on the next line
+    head = ' '.join(l for l in lines[:4] if l.lstrip().startswith((';', '.L')))   # an inner loop header carries a "Parent Loop .." line per enclosing loop first, then "=> This Inner Loop Header"
     if 'Loop Header' in head:
         return lab[2:], int(re.findall(r'Loop Header: Depth=(\d+)', head)[-1])
     h = re.search(r'Header=(BB\d+_\d+) Depth=(\d+)', first)
