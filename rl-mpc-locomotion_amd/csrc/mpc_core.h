@@ -70,6 +70,10 @@ typedef double mpc_double2 __attribute__((ext_vector_type(2)));
 //   MPC_PROW_SKEW             1: pivot rows of the solve kernel 8 bytes off the 16-byte grid
 //   MPC_PART_ROWMAJOR         1: partial products of the solve kernel's tile mat-vec as [row][slot] (0: [slot][row])
 //   MPC_QUAD_SCATTER          1: the per-step wrench sums as a quad reduce-scatter (0: all-sum of all six, then a select)
+//   MPC_GS_FORM               1: Shared::Gf holds G_f S_f^-1 and WThread::b holds S^-1 b (one 3 x 3 product less per ADMM iteration)
+#ifndef MPC_GS_FORM
+#define MPC_GS_FORM 1
+#endif
 #ifndef MPC_PART_ROWMAJOR
 #define MPC_PART_ROWMAJOR 1
 #endif

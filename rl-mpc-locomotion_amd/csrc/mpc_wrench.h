@@ -654,8 +654,17 @@ struct Solver {
         double w[18], gf[18];
         foot_w(t, w);
         mul_tk(t, w, gf);
+#if MPC_GS_FORM
+        // G_f X_f is what the iteration uses:  x~ = X b - (G X)^T y_w,  the wrench of the next right-hand side = (G X) b
+        double hs[18];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) sym3_mul(xs(t), gf + 3 * r, hs + 3 * r);
+#pragma unroll
+        for (int k = 0; k < 18; ++k) s.Gf[pidx(k, t.tid)] = hs[k];
+#else
 #pragma unroll
         for (int k = 0; k < 18; ++k) s.Gf[pidx(k, t.tid)] = gf[k];
+#endif
       }
     });
     factor_tail();
@@ -942,9 +951,15 @@ struct Solver {
     for (int r = 0; r < 5; ++r) tm[r] = rho_at(t, r) * t.z[r] - t.y[r];
     at_mul(a, tm, acc);
 #pragma unroll
+#if MPC_GS_FORM
+    for (int c = 0; c < 3; ++c) v[c] = kSigma * t.x[c] - t.q[c] + acc[c];
+    sym3_mul(t.Si, v, t.b);       // t.b holds S^-1 b
+    put_g(t, v);                  // (G S^-1) b
+#else
     for (int c = 0; c < 3; ++c) t.b[c] = kSigma * t.x[c] - t.q[c] + acc[c];
     sym3_mul(t.Si, t.b, v);
     put_g(t, v);
+#endif
   }
   MPC_HD void admm_prepare() {
     ex.seq([&](Th &t) { if (t.tid < NF) foot_rhs(t); });
@@ -988,9 +1003,15 @@ struct Solver {
           double wy = 0;
 #pragma unroll
           for (int r = 0; r < 6; ++r) wy += gf[3 * r + c] * t.w6[r];
+#if MPC_GS_FORM
+          t.xt[c] = t.b[c] - wy;      // S^-1 b - (G S^-1)^T y_w
+#else
           tt[c] = t.b[c] - wy;
+#endif
         }
+#if !MPC_GS_FORM
         sym3_mul(t.Si, tt, t.xt);
+#endif
         a_mul(a, t.xt, zt);
         if constexpr (!kBatchLoads) foot_bounds(t, lo, up);
 #pragma unroll
@@ -1011,9 +1032,17 @@ struct Solver {
           const double xn = kAlphaRelax * t.xt[c] + (1.0 - kAlphaRelax) * t.x[c];
           if constexpr (LAST) s.dxy[pidx(c, t.tid)] = xn - t.x[c];
           t.x[c] = xn;
+#if MPC_GS_FORM
+          v[c] = kSigma * xn - t.q[c] + acc[c];
+#else
           t.b[c] = kSigma * xn - t.q[c] + acc[c];
+#endif
         }
+#if MPC_GS_FORM
+        sym3_mul(t.Si, v, t.b);
+#else
         sym3_mul(t.Si, t.b, v);
+#endif
 #pragma unroll
         for (int r = 0; r < 6; ++r) t.w6[r] = gf[3 * r] * v[0] + gf[3 * r + 1] * v[1] + gf[3 * r + 2] * v[2];
       }
