@@ -84,6 +84,9 @@ struct WThread {
 #ifndef MPC_EPS_EXACT            // exact mode: optimality tolerance of an accepted active-set step (relative, OSQP's termination test)
 #define MPC_EPS_EXACT 1e-10   // (the polished point of the right active set has a dual residual of ~1e-10 of the norms; 1e-11 rejects it, 1e-9 lets 0.04 % of the robots end 1e-6 off)
 #endif
+#ifndef MPC_EXACT_DIRECT          // exact mode: the active-set method's iterate is tested for optimality before any polish refinement
+#define MPC_EXACT_DIRECT 1
+#endif
 #ifndef MPC_PAIR_SWEEP          // which workgroup sizes sweep two pivots per phase (see sweep_all)
 #define MPC_PAIR_SWEEP(T) ((T) <= 64)
 #endif
@@ -156,6 +159,7 @@ struct Shared {
     struct { MPC_V Lk[H * 36]; MPC_V Tk[H * 36]; };     // factorisation only: per step Z_k = L L^T, T = L^-1 (zero columns / rows at dropped pivots)
   };
   unsigned long long red[24];
+  double dua_last;                                      // exact mode: the dual residual of the previous polish round (Solver::polish)
   int first, iter, status, status_polish, rho_updates, nfact, done, bad, pol_ok, pol_near, pol_rounds, sig_changed, loose_ok, dual_cand;
   double pri_res, dua_res, rho_new;
 };
@@ -193,6 +197,7 @@ struct Solver {
   int max_iter = kMaxIter, polish_refine = kPolishRefine, max_rho_updates = 1 << 30;
   bool polish_must_verify = false;   // (set around an early polish of the exact mode)
   bool act_given = false;            // polish(): the active set is in t.act already (active_set) instead of OSQP's guess from (z, y)
+  bool xn_given = false;             // polish<true>(): Shared::dxy holds the candidate optimum of that set (active_set's iterate): checked first, refined only if the check fails
   GiShared<H> *gi = nullptr;         // LDS of the exact mode's active-set phase (null in the OSQP mode)
   static constexpr int kStableChecks = MPC_STABLE_CHECKS;
   MPC_HD void exact() { eps_exact = MPC_EPS_EXACT; eps_abs = eps_rel = kEpsAdmmFloor; max_iter = 5 * kMaxIter; polish_refine = H > 10 ? MPC_EXACT_REFINE + MPC_EXACT_REFINE / 2 : MPC_EXACT_REFINE; max_rho_updates = MPC_EXACT_RHO_UPDATES; }   // then run<true>()
@@ -1528,9 +1533,9 @@ struct Solver {
       }
     });
     lap(11);
-    polish_factor();
-    ex.seq([&](Th &t) { if (t.tid < NF) put_g(t, t.pt); });
-    lap(12);
+    // (Exact mode, after the active-set method: its iterate t.gx is the optimum of the working set already -- the method's H^-1 carries
+    // no regularisation -- so the first round only checks it: xN = gx - u0, one Theta product, the finish and the optimality test; the
+    // reduced system is factorised, and refined from that xN, only if the test fails.)
     // w_0 = Omega g, then kPolishRefine steps of iterative refinement against the UN-regularised system (polish.c:102-160):
     //   w <- w + Omega (g - P_s w).   With an exact Omega the residual obeys r_{k+1} = delta Omega r_k and needs no product with
     // P; Omega is only accurate to ~1e-10 |Xi|, so the true residual is formed (one Theta product per step) -- which is also
@@ -1539,7 +1544,24 @@ struct Solver {
     // refinement not yet converged -- goes round again with MPC_EXACT_ROUND_STEPS more steps, at most MPC_EXACT_ROUNDS times: most sets
     // pass after the first eight steps, and the test costs less than two steps.)
     for (int round = 0;; ++round) {
-    const int nsteps = round == 0 ? polish_refine : MPC_EXACT_ROUND_STEPS;
+    const bool direct = ROUNDS && xn_given && round == 0;
+    const bool first = round == 0 || (ROUNDS && xn_given && round == 1);      // the first round that refines
+    const int nsteps = first ? polish_refine : MPC_EXACT_ROUND_STEPS;
+    if (first && !direct) {
+      polish_factor();
+      if (round == 0) ex.seq([&](Th &t) { if (t.tid < NF) put_g(t, t.pt); });
+      lap(12);
+    }
+    if (direct) {
+      ex.seq([&](Th &t) {
+        if (t.tid < NF) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) t.pxN[c] = s.dxy[pidx(c, t.tid)] - t.pu0[c];      // (the method's iterate, parked by run_active_set)
+          put_wrench(t, t.pxN);
+        }
+      });
+      product<kTheta>();
+    }
     if (ROUNDS && round > 0) {      // the residual of the current xN, as the loop's last iteration would have left it
       ex.seq([&](Th &t) { if (t.tid < NF) put_wrench(t, t.pxN); });
       product<kTheta>();
@@ -1554,7 +1576,7 @@ struct Solver {
         }
       });
     }
-    for (int it = round == 0 ? 0 : 1; it <= nsteps; ++it) {
+    for (int it = round == 0 ? 0 : 1; it <= nsteps && !direct; ++it) {
       omega_apply();
 #ifdef MPC_EMU_DEBUG
       if (dbg && it == 0) ex.par([&](Th &t) {
@@ -1634,7 +1656,17 @@ struct Solver {
         // exact mode: is the polished point the optimum?  (the termination test of auxil.c:684-793 at eps_exact)
         const double ep = eps_exact + eps_exact * dmax(bitsd(s.red[1]), bitsd(s.red[2]));
         const double ed = eps_exact + eps_exact * s.cinv * dmax(dmax(bitsd(s.red[7]), bitsd(s.red[8])), bitsd(s.red[9]));
-        const bool verified = !s.bad && pri < ep && dua < ed;
+        bool verified = !s.bad && pri < ep && dua < ed;
+#ifdef MPC_EMU_DEBUG
+        if (direct && getenv("EMU_FORCE_DIRECT_FAIL")) verified = false;
+#endif
+        if constexpr (ROUNDS) {
+          // The active-set method's own set, refined to where rounding stops it: a dual residual that a round of refinement no longer
+          // lowers and that misses the test by less than 10 x is the floor of this problem's arithmetic (multipliers of 1e5 against
+          // forces of 1e2), not a wrong set -- those miss by orders of magnitude.
+          if (act_given && !verified && !s.bad && round > 0 && pri < ep && dua < 10.0 * ed && dua > 0.5 * s.dua_last) verified = true;
+          s.dua_last = dua;
+        }
         s.pol_near = polish_must_verify && !verified && !s.bad && pri < ep && dua < 1e4 * ed;
         s.pol_rounds = round + 1;
 #ifdef MPC_EMU_DEBUG
@@ -1652,7 +1684,7 @@ struct Solver {
 #endif
       }
     });
-    if (!(ROUNDS && s.pol_near && round < MPC_EXACT_ROUNDS)) break;
+    if (!(ROUNDS && (s.pol_near || (direct && !s.pol_ok)) && round < MPC_EXACT_ROUNDS + (xn_given ? 1 : 0))) break;      // (the direct check is not one of the refinement rounds)
     }
     ex.par([&](Th &t) {
       if (s.status_polish == 1 && t.tid < NF) {
@@ -2152,9 +2184,15 @@ struct Solver {
     bool ok = false;
     if (found) {
       ex.par([&](Th &t) { if (t.tid == 0) { s.pri_res = kInfty; s.dua_res = kInfty; s.status = kStSolved; } });
-      act_given = true; polish_must_verify = true;
+      act_given = true; polish_must_verify = true; xn_given = MPC_EXACT_DIRECT;
+      if (xn_given) ex.par([&](Th &t) {      // (through LDS, not registers: nothing of the method stays live across the polish set-up)
+        if (t.tid < NF) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) s.dxy[pidx(c, t.tid)] = t.gx[c];
+        }
+      });
       polish<true>();
-      act_given = false; polish_must_verify = false;
+      act_given = false; polish_must_verify = false; xn_given = false;
       ok = s.pol_ok && s.status_polish == 1;
     }
     lap(14);

@@ -177,13 +177,17 @@ def test_exact_solver_batch_is_the_unique_optimum(name):
 
 
 @pytest.mark.parametrize("name,n,route", [("solver_h10_cfg3", 8, 0), ("solver_h10_edge", 10, 0), ("solver_h16_cfg4", 3, 0), ("solver_h20_cfg5", 2, 0),
-                                          ("solver_h10_cfg3", 4, 1), ("solver_h16_cfg4", 2, 1)])
+                                          ("solver_h10_cfg3", 4, 1), ("solver_h16_cfg4", 2, 1), ("solver_h10_cfg3", 6, 3), ("solver_h16_cfg4", 2, 3)])
 def test_exact_solver_on_the_host_emulation_is_the_unique_optimum(name, n, route):
     """The exact-optimum mode of the kernel code on the host emulation.  route 0: as the product runs it (the dual active-set method of
-    mpc_wrench.h active_set + the verifying polish; the ADMM route only if that fails); route 1: the ADMM route alone (run<true>: staged
-    ADMM + verified active-set polish), which is the product's second launch."""
+    mpc_wrench.h active_set, its iterate checked for optimality, the verifying polish refining it only if that check fails; the ADMM route
+    only if that fails too); route 1: the ADMM route alone (run<true>: staged ADMM + verified active-set polish), which is the product's
+    second launch; route 3: route 0 with the direct check forced to fail (every robot takes the factorise-and-refine rounds)."""
+    import os
     from tests.emu.emu import EmuBatch, lib
     handle = {}
+    if route == 3:
+        os.environ["EMU_FORCE_DIRECT_FAIL"] = "1"
 
     def solve(g, n, s):
         if "emu" not in handle:
@@ -191,10 +195,13 @@ def test_exact_solver_on_the_host_emulation_is_the_unique_optimum(name, n, route
         f = handle["emu"].solve(g[f"inputs_{s}"][:n], exact=True)
         return f, handle["emu"].info.copy()
     try:
-        lib().emu_set_exact_route(route)
+        lib().emu_set_exact_route(0 if route == 3 else route)
         _check_exact(solve, name, n)
+        if route == 3:
+            assert (handle["emu"].info[:, 6] >= 2).all(), handle["emu"].info[:, 6]      # polish rounds: the direct check + at least one refinement round
     finally:
         lib().emu_set_exact_route(0)
+        os.environ.pop("EMU_FORCE_DIRECT_FAIL", None)
 
 
 def test_active_set_method_alone_certifies_nearly_every_robot():
