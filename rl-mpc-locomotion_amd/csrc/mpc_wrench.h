@@ -1745,21 +1745,22 @@ struct Solver {
     n[1] = m2 * a[4] + m3 * a[6];
     n[2] = (m0 * a[1] + m1 * a[3]) + (m2 * a[5] + m3 * a[7]) + m4 * a[8];
   }
-  // row i of the packed inverse, columns j < hi (j <= i): row[j] <- f(j, row[j], vec[j]), in blocks of eight -- all loads of a block are
-  // requested before its first store (LDS accesses that may alias are not reordered by the compiler: element by element, every
-  // iteration would wait out a full LDS round trip)
-  template <class F>
-  static MPC_HD void gi_row_update(double *row, const double *vec, int i, int hi, F &&f) {
-    for (int j0 = 0; j0 < hi && j0 <= i; j0 += 8) {
-      double rv[8], vv[8];
-#pragma unroll
-      for (int u = 0; u < 8; u += 2) MPC_LDS_LOAD128(vec + j0 + u, vv[u], vv[u + 1]);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) rv[u] = MPC_LDS_LOAD64(row + (j0 + u <= i ? j0 + u : i));
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (j0 + u <= i && j0 + u < hi) MPC_LDS_STORE64(row + j0 + u, f(j0 + u, rv[u], vv[u]));
-    }
+  // ci <- ci + alpha u u^T on the slots below hi, except row / column `skip` (the slot being added or dropped, which the caller writes):
+  // the packed lower triangle in 8 x 8 blocks, one entry per lane -- every lane has work in every block, where a row-per-lane
+  // form runs as long as its longest row.
+  MPC_HD void gi_rank1(const Th &t, const double *u, double alpha, int hi, int skip) {
+    const int l = t.tid & 63, li = l >> 3, lj = l & 7, w = t.tid >> 6;
+    constexpr int NWAVE = T / 64;
+    const int nb = (hi + 7) >> 3;
+    for (int bi = 0, b = 0; bi < nb; ++bi)
+      for (int bj = 0; bj <= bi; ++bj, ++b) {
+        if (NWAVE > 1 && b % NWAVE != w) continue;
+        const int i = 8 * bi + li, j = 8 * bj + lj;
+        if (j <= i && i < hi && i != skip && j != skip) {
+          double *e = gi->ci + (i * (i + 1) / 2 + j);
+          *e += (alpha * u[i]) * u[j];
+        }
+      }
   }
   MPC_HD bool active_set() {
     GiShared<H> &g = *gi;
@@ -1910,19 +1911,16 @@ struct Solver {
       }
       MPC_SUBLAP(7, 4);
       // ---- E. the step: t2 = (violation of row p now) / zeta brings the row to its bound; t = min(t1, t2)
-      ex.seq([&](Th &t) {
-        double viol = -kInfty;
+      ex.par([&](Th &t) {      // (row p's foot lane publishes the violation: one LDS round trip, where a reduction takes six exchanges)
         if (t.tid == g.p_foot) {
           double lo[5], up[5];
           foot_bounds(t, lo, up);
           const double lo_p = gi_pick(lo, g.p_row), up_p = gi_pick(up, g.p_row), ax_p = gi_pick(t.gax, g.p_row);
-          viol = dmax(g.p_side < 0 ? lo_p - ax_p : ax_p - up_p, 0.0);
+          g.p_viol = dmax(g.p_side < 0 ? lo_p - ax_p : ax_p - up_p, 0.0);
         }
-        t.gred[0] = viol;
       });
-      ex.wg_argmax([](Th &t) { return t.gred; }, [](Th &t) -> int & { return t.gidx; }, gtmp);
       const double zinv = moves ? fast_recip(zeta) : 0.0;
-      const double t2 = moves ? ex.first().gred[0] * zinv : kInfty;
+      const double t2 = moves ? g.p_viol * zinv : kInfty;
       const double ts = dmin(t1, t2);
       if (!(ts < kInfty)) { fail = true; break; }      // (an infeasible QP: not this path's business)
       const bool add = t2 <= t1;
@@ -1952,21 +1950,19 @@ struct Solver {
 #pragma unroll
           for (int r = 0; r < 5; ++r) t.gax[r] += ts * az[r];
         }
+        // bordering (add): the rest gains r r^T / zeta, then the new row -r / zeta -- element (ps, i) or (i, ps) by the lane that holds
+        // r_i -- and 1 / zeta.  Drop slot k: a rank-one downdate with column k, then row / column k are zero again and the slot is free.
+        if (add) gi_rank1(t, gr, zinv, hi_new, ps);
+        else gi_rank1(t, gtmp, -gtmp2[0], hi, k1);
         if (t.tid < NW && t.tid < hi_new) {
           const int i = t.tid;
           const bool live = i < hi && g.owner[i] >= 0;
           if (live) glam[i] = dmax(glam[i] - ts * gr[i], 0.0);
           if (add) {
-            // bordering: the rest gains r r^T / zeta (the new slot's own row / column was zero and r there is zero: the general update
-            // leaves it alone), then the new row -r / zeta -- element (ps, i) or (i, ps) by the lane that holds r_i -- and 1 / zeta
             const double zi = zinv, ri = gr[i] * zi;
-            if (i != ps) gi_row_update(g.ci + i * (i + 1) / 2, gr, i, hi_new, [&](int, double cv, double rj) { return cv + ri * rj; });
             if (i == ps) { g.ci[ps * (ps + 1) / 2 + ps] = zi; g.owner[ps] = g.p_foot * 8 + g.p_row; glam[ps] = lam_p; gd[ps] = 0.0; }
             else g.ci[i > ps ? i * (i + 1) / 2 + ps : ps * (ps + 1) / 2 + i] = -ri;
           } else {
-            // drop slot k: a rank-one downdate with column k, then row / column k are zero again and the slot is free
-            const double ci_k = i == k1 ? 0.0 : gtmp[i] * gtmp2[0];
-            if (i != k1) gi_row_update(g.ci + i * (i + 1) / 2, gtmp, i, hi, [&](int, double cv, double ck) { return cv - ci_k * ck; });
             g.ci[i >= k1 ? i * (i + 1) / 2 + k1 : k1 * (k1 + 1) / 2 + i] = 0.0;
             if (i == k1) { g.owner[k1] = -1; glam[k1] = 0.0; gd[k1] = 0.0; }
           }
