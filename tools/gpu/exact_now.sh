@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
-bash tools/gpu/ab_exact.sh xd1 xd2 | grep -v "^step 0"
-python -m pytest tests -m gpu -x -q -k "exact or dropin" 2>&1 | tail -2
+bash tools/gpu/ab_exact.sh xd2 xd3 | grep -v "^step 0"
+python tools/gpu/exact_pack.py 2>&1 | tail -3
+python tools/exact_sweep.py 2>&1 | grep -v EXACT_JSON | tail -4 | cut -c1-420
