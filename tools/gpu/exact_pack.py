@@ -12,8 +12,8 @@ inertia9 = np.zeros((n, 9)); inertia9[:, 0], inertia9[:, 4], inertia9[:, 8] = wl
 sv = BatchedConvexMpc(wl.mass, inertia9, h, wl.dt_mpc, wl.alpha, solver="exact")
 sv.enable_timing()
 w = wl
-prev = None
-for s in range(4):
+hist = []
+for s in range(14):
     f, info = sv.solve(torch.from_numpy(w.inputs).cuda()); torch.cuda.synchronize()
     cyc = np.abs(sv.get_profile()[:, 15]).astype(np.float64)
     ms = float(sv.kernel_times(1)[-1][-1])
@@ -24,7 +24,9 @@ for s in range(4):
         return max(hp)
     ghz = 2.09
     line = f"step {s}: kernel {ms:.3f} ms | work/slot {cyc.sum() / slots / ghz / 1e6:.3f} ms | longest robot {cyc.max() / ghz / 1e6:.3f} ms | clairvoyant LPT {lpt(np.argsort(-cyc)) / ghz / 1e6:.3f} | robot order {lpt(np.arange(n)) / ghz / 1e6:.3f}"
-    if prev is not None: line += f" | LPT by the previous call {lpt(np.argsort(-prev)) / ghz / 1e6:.3f}"
+    if hist:
+        line += f" | LPT by the previous call {lpt(np.argsort(-hist[-1])) / ghz / 1e6:.3f}"
+        line += f" | by the max of the last 3 {lpt(np.argsort(-np.max(hist[-3:], axis=0))) / ghz / 1e6:.3f} | of the last 10 {lpt(np.argsort(-np.max(hist[-10:], axis=0))) / ghz / 1e6:.3f}"
     print(line)
-    prev = cyc
+    hist.append(cyc)
     w = perturb_workload(w, 7000 + 131 * s)
