@@ -1072,6 +1072,14 @@ struct Solver {
     });
   }
 
+  // 1 / E, 1 / D of the unscaled residual norms: they feed tolerance tests and the rho estimate, nothing that must be rounded like a
+  // division -- v_rcp_f64 + two Newton steps (to the last ulp or two) where the IEEE sequence costs a dozen dependent instructions.
+  // (Single-wave kernels only: at the 256-register cap of the long horizons the shorter sequence moves the allocator's spills into the
+  // sweep loops -- h = 16: 2.24 -> 2.47 ms.)
+  static MPC_HD double norm_recip(double d) {
+    if constexpr (T <= 64) return fast_recip(d);
+    else return 1.0 / d;
+  }
   // residuals of (x, z, y) (auxil.c:243-306, 563-629) + the norms termination and rho need.
   // red[] slots: 0 pri_res 1 ||Einv z|| 2 ||Einv Ax|| 3 ||rp|| 4 ||z|| 5 ||Ax||
   //              6 ||Dinv rd|| 7 ||Dinv q|| 8 ||Dinv Aty|| 9 ||Dinv Px|| 10 ||rd|| 11 ||q|| 12 ||Aty|| 13 ||Px||
@@ -1097,14 +1105,14 @@ struct Solver {
         for (int r = 0; r < 5; ++r) {
           const double rr = ax[r] - z[r];
           ev[r] = sc[C::SC_E + 5 * t.tid + r];
-          ei[r] = 1.0 / ev[r];
+          ei[r] = norm_recip(ev[r]);
           mx[0] = dmax(mx[0], fabs(ei[r] * rr)); mx[1] = dmax(mx[1], fabs(ei[r] * z[r])); mx[2] = dmax(mx[2], fabs(ei[r] * ax[r]));
           mx[3] = dmax(mx[3], fabs(rr)); mx[4] = dmax(mx[4], fabs(z[r])); mx[5] = dmax(mx[5], fabs(ax[r]));
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const double qv = t.q[c], rr = qv + px[c] + aty[c];
-          di[c] = 1.0 / Dat(t, c);
+          di[c] = norm_recip(Dat(t, c));
           mx[6] = dmax(mx[6], fabs(di[c] * rr)); mx[7] = dmax(mx[7], fabs(di[c] * qv)); mx[8] = dmax(mx[8], fabs(di[c] * aty[c]));
           mx[9] = dmax(mx[9], fabs(di[c] * px[c])); mx[10] = dmax(mx[10], fabs(rr)); mx[11] = dmax(mx[11], fabs(qv));
           mx[12] = dmax(mx[12], fabs(aty[c])); mx[13] = dmax(mx[13], fabs(px[c]));
@@ -1227,7 +1235,7 @@ struct Solver {
       if (t.tid < NF) {
         double m = 0;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) m = dmax(m, fabs(t.px[c] / Dat(t, c)));
+        for (int c = 0; c < 3; ++c) m = dmax(m, fabs(t.px[c] * norm_recip(Dat(t, c))));
         s.part[t.tid] = m;
       }
     });
@@ -1384,7 +1392,7 @@ struct Solver {
         for (int row = 0; row < 5; ++row) {
           const bool cand = r < 3 && t.act[row];
           double v[3] = {A[3 * row], A[3 * row + 1], A[3 * row + 2]};
-          const double n0 = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+          const double n02 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
 #pragma unroll
           for (int pass = 0; pass < 2; ++pass)
 #pragma unroll
@@ -1392,9 +1400,12 @@ struct Solver {
               const double d = v[0] * Q[3 * k] + v[1] * Q[3 * k + 1] + v[2] * Q[3 * k + 2];
               v[0] -= d * Q[3 * k]; v[1] -= d * Q[3 * k + 1]; v[2] -= d * Q[3 * k + 2];
             }
-          const double nr = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-          const bool take = cand && nr > 1e-6 * n0;
-          const double q0 = v[0] / nr, q1 = v[1] / nr, q2 = v[2] / nr;
+          // (one reciprocal square root per row -- the test is on the squares -- where two square roots and three divisions stood:
+          // a foot lane's set-up is one long dependent chain, and nothing else of the wave runs beside it)
+          const double nr2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+          const bool take = cand && nr2 > 1e-12 * n02;
+          const double ninv = fast_rsqrt(take ? nr2 : 1.0);
+          const double q0 = v[0] * ninv, q1 = v[1] * ninv, q2 = v[2] * ninv;
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
             const bool here = take && r == k;
@@ -1408,13 +1419,13 @@ struct Solver {
           const double e[3] = {imin == 0 ? 1.0 : 0.0, imin == 1 ? 1.0 : 0.0, imin == 2 ? 1.0 : 0.0};
           const double d = imin == 0 ? Q[0] : imin == 1 ? Q[1] : Q[2];
           double v[3] = {e[0] - d * Q[0], e[1] - d * Q[1], e[2] - d * Q[2]};
-          const double nr = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-          Nn[0] = v[0] / nr; Nn[1] = v[1] / nr; Nn[2] = v[2] / nr;
+          const double ninv = fast_rsqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);      // (>= 2 / 3: e is the axis Q leans on least)
+          Nn[0] = v[0] * ninv; Nn[1] = v[1] * ninv; Nn[2] = v[2] * ninv;
           Nn[3] = Q[1] * Nn[2] - Q[2] * Nn[1]; Nn[4] = Q[2] * Nn[0] - Q[0] * Nn[2]; Nn[5] = Q[0] * Nn[1] - Q[1] * Nn[0];
         } else if (r == 2) {
           Nn[0] = Q[1] * Q[5] - Q[2] * Q[4]; Nn[1] = Q[2] * Q[3] - Q[0] * Q[5]; Nn[2] = Q[0] * Q[4] - Q[1] * Q[3];
-          const double nr = sqrt(Nn[0] * Nn[0] + Nn[1] * Nn[1] + Nn[2] * Nn[2]);
-          Nn[0] /= nr; Nn[1] /= nr; Nn[2] /= nr;
+          const double ninv = fast_rsqrt(Nn[0] * Nn[0] + Nn[1] * Nn[1] + Nn[2] * Nn[2]);    // (= 1 up to rounding: the cross product of two orthonormal rows)
+          Nn[0] *= ninv; Nn[1] *= ninv; Nn[2] *= ninv;
         }
         const int nn = 3 - r;
         // Gamma = Q (Q^T B Q)^{-1} Q^T with B = A_act^T A_act
@@ -1441,7 +1452,7 @@ struct Solver {
         // Gauss-Jordan on the (identity padded) 3x3
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-          const double d = 1.0 / Gq[3 * p + p];
+          const double d = fast_recip(Gq[3 * p + p]);
 #pragma unroll
           for (int j = 0; j < 3; ++j) { Gq[3 * p + j] *= d; Gi[3 * p + j] *= d; }
 #pragma unroll
