@@ -37,18 +37,20 @@ def test_benchmark_horizon_hot_loops_are_scratch_free(asm):
     for a in sweeps + admm:
         assert a["scratch"] == 0 and a["barriers"] == 0, a          # one wavefront per robot: no workgroup barrier anywhere
     # three pivot pairs per trip: 72 FMA + 24 for the pair's B-transformed row per thread and pair are the floor (32 per pivot step);
-    # everything else stays below 100 instructions per pivot step
+    # everything else stays below 95 instructions per pivot step (round 3: 87-91, depending on what the allocator parks in AGPRs)
     for a in sweeps:
-        assert a["ins"] <= 6 * 100, a
-    # the ADMM iteration: tile product (72 FMA) + the foot phase; round 2 ends at ~430 instructions
-    assert admm[0]["ins"] <= 480, admm[0]
+        assert a["ins"] <= 6 * 95, a
+    # the ADMM iteration: tile product (72 FMA) + the foot phase.  Round 2 ended at 427 instructions; round 3 (quad reduce-scatter instead
+    # of all-sum + select, [row][slot] partials, G S^-1 form) at 375-389 -- a branch cascade or a layout that costs the reader twice the
+    # loads shows up here
+    assert admm[0]["ins"] <= 400 and admm[0]["f64"] <= 210, admm[0]
 
 
 def test_spill_estimate_stays_bounded(asm):
     # weighted scratch instructions per wave and solve (tools/isa_census.py).  h = 10: one wave per SIMD with the full register budget
     # (AGPRs as spill space), no scratch memory at all.  h = 16 / 20: multi-wave workgroups at two waves per SIMD (256 registers), which
     # was measured 25 % faster in spite of the spill code it needs; the bound keeps that spill code from growing.
-    limits = {10: 50, 16: 3000, 20: 3000}
+    limits = {10: 50, 12: 2800, 16: 2800, 20: 2800}      # (round 3: 16 / 2362 / 2169 / 2309)
     for h, lim in limits.items():
         total, detail = isa_census.spill_cost(asm, h)
         assert total <= lim, (h, total, detail)
