@@ -74,6 +74,12 @@ typedef double mpc_double2 __attribute__((ext_vector_type(2)));
 #ifndef MPC_GS_FORM
 #define MPC_GS_FORM 1
 #endif
+#ifndef MPC_SHARE_ROLE_REGS       // tile and foot state of a solve-kernel thread in the same registers where the roles are different threads
+#define MPC_SHARE_ROLE_REGS 1
+#endif
+#ifndef MPC_FOOT0                 // first foot lane of the solve kernel's workgroup for horizon H with MTW tile lanes
+#define MPC_FOOT0(H, MTW) (((H) == 12 || (H) == 16) ? (((MTW) + 3) / 4) * 4 : 0)
+#endif
 #ifndef MPC_PART_ROWMAJOR
 #define MPC_PART_ROWMAJOR 1
 #endif
@@ -157,7 +163,10 @@ struct Cfg {
   static constexpr int XSC_AS = 2 * N + M, XSC_LS = XSC_AS + 15 * NF, XSC_US = XSC_LS + M, XSC_C = XSC_US + M, XSC_LEN = XSC_C + 4;
   // ---- wrench grid of the solve kernel (mpc_wrench.h): the 6 H x 6 H core matrix as H x H tiles of 6 x 6, one per thread
   static constexpr int NW = 6 * H, GW = H, MTW = H * (H + 1) / 2;
-  static constexpr int TW = (((MTW > NW ? MTW : NW) + 63) / 64) * 64;   // solve-kernel workgroup: 64 (h = 10), 192, 256
+  // Foot lanes of the solve kernel: threads FOOT0 .. FOOT0 + NF - 1 (a multiple of four: the feet of a step are a hardware quad).
+  static constexpr int FOOT0 = MPC_FOOT0(H, MTW);
+  static constexpr int TWMIN = FOOT0 + NF > MTW ? FOOT0 + NF : MTW;
+  static constexpr int TW = (((TWMIN > NW ? TWMIN : NW) + 63) / 64) * 64;   // solve-kernel workgroup: 64 (h = 10), 192, 256
   static constexpr int NPW = NW + 2;                     // row stride of the solve kernel's part[]
 };
 

@@ -41,17 +41,36 @@ namespace mpc {
 
 constexpr double kEpsAdmmFloor = 1e-9;   // exact mode: the tightest ADMM stage (what its first version ran from the start)
 
+// The registers of a thread's role.  Where tile lanes and foot lanes are different threads (Cfg::FOOT0 != 0: h = 12, 16) a thread is one or
+// the other, and the tile and the foot's iterate share their registers -- at the 256-register cap of the multi-wave workgroups the sum of
+// both was what spilled.  (Every write to the foot members sits behind `t.foot`, every use of Mx behind `t.mact`.)
+template <int TE, bool SHARED>
+struct RoleRegs {
+  double Mx[TE];
+  double x[3], px[3], z[5], y[5], b[3], xt[3];   // iterates, P_s x, the right-hand side, x~
+  double q[3], Si[6];                            // scaled q, S^{-1}   (cone block and bounds: Shared::fa)
+};
+template <int TE>
+struct RoleRegs<TE, true> {
+  union {
+    double Mx[TE];
+    struct {
+      double x[3], px[3], z[5], y[5], b[3], xt[3];
+      double q[3], Si[6];
+    };
+  };
+};
+
 template <int H>
-struct WThread {
+struct WThread : RoleRegs<Cfg<H>::TE, (Cfg<H>::FOOT0 != 0 && MPC_SHARE_ROLE_REGS)> {
   using C = Cfg<H>;
   int tid;
   // ---- tile lane (tid < MTW): my tile of the wrench grid
   int ti, tj;
   bool mact, dia;
-  double Mx[C::TE];
-  // ---- foot lane (tid < NF): step tid / 4, foot tid % 4
-  double x[3], px[3], z[5], y[5], b[3], xt[3];   // iterates, P_s x, the right-hand side, x~
-  double q[3], Si[6];                            // scaled q, S^{-1}   (cone block and bounds: Shared::fa)
+  // ---- foot lane: threads FOOT0 .. FOOT0 + NF - 1 (Cfg::FOOT0: 0 where a thread is tile lane and foot lane at once)
+  int fid;                                       // foot index: step fid / 4, foot fid % 4 (the four lanes of a step are a hardware quad)
+  bool foot;
   double w6[6];                                  // wrench exchange: my contribution out, the step's six numbers back
   double gq[2], yq[2], dlq[2];                   // rows j and j + 4 of my step (j = tid & 3): g, y, diag(M)^-1/2
   double zq[21];                                 // factorisation: W_f X_f W_f^T (packed lower triangle), then the step's sum
@@ -68,6 +87,8 @@ struct WThread {
   double xp[3], zp[5], yp[5];
   MPC_HD void init(int id) {
     tid = id;
+    fid = id - C::FOOT0;
+    foot = fid >= 0 && fid < C::NF;
     mact = id < C::MTW;
     int r = 0;
     while ((r + 1) * (r + 2) / 2 <= id) ++r;
@@ -226,7 +247,7 @@ struct Solver {
   // Theta_{ti,tj} = s2 th1 + nn diag(th2):  s2 = sum_{i < m} (i + 1/2)(i + d + 1/2) = m (4 m^2 - 1) / 12 + d m^2 / 2,  nn = m = H - ti,  d = ti - tj
   static MPC_HD double th_nn(const Th &t) { return (double)(H - t.ti); }
   static MPC_HD double th_s2(const Th &t) { const double m = (double)(H - t.ti), d = (double)(t.ti - t.tj); return m * (4.0 * m * m - 1.0) / 12.0 + d * (m * m) * 0.5; }
-  MPC_HD double Dat(const Th &t, int c) const { return sc[C::SC_D + 3 * t.tid + c]; }   // D of my variables (scale record; not worth registers)
+  MPC_HD double Dat(const Th &t, int c) const { return sc[C::SC_D + 3 * t.fid + c]; }   // D of my variables (scale record; not worth registers)
   // rho / 1 / rho of row r of my foot (three uniform values, selected by the row's type code)
   MPC_HD double rho_at(const Th &t, int r) const {
     const int ty = (t.tyb >> (2 * r)) & 3;
@@ -277,7 +298,7 @@ struct Solver {
   }
   // my foot's wrench map W_f = B6[:, 3 j .. 3 j + 2] diag(D)  (6 x 3, row-major in w[18])
   MPC_HD void foot_w(const Th &t, double *w) const {
-    const int j = t.tid & 3;
+    const int j = t.fid & 3;
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
@@ -304,7 +325,7 @@ struct Solver {
   }
   // out = T_k w  (T lower triangular, w 6 x 3)
   MPC_HD void mul_tk(const Th &t, const double *w, double *out) const {
-    const double *tk = s.Tk + 36 * (t.tid >> 2);
+    const double *tk = s.Tk + 36 * (t.fid >> 2);
     double o[18];
 #pragma unroll
     for (int r = 0; r < 6; ++r)
@@ -323,7 +344,7 @@ struct Solver {
   static constexpr MPC_HD int pidx(int k, int f) { return ((k >> 1) * NF + f) * 2 + (k & 1); }   // pair layout (see Shared::fa)
   MPC_HD void load_g(const Th &t, double *gf) const {
 #pragma unroll
-    for (int k = 0; k < 18; k += 2) MPC_LDS_LOAD128(s.Gf + pidx(k, t.tid), gf[k], gf[k + 1]);
+    for (int k = 0; k < 18; k += 2) MPC_LDS_LOAD128(s.Gf + pidx(k, t.fid), gf[k], gf[k + 1]);
   }
   MPC_HD void put_g(Th &t, const double *v) const {
     double gf[18];
@@ -419,8 +440,8 @@ struct Solver {
     ex.template quad_allsum<6>([](Th &t) { return t.w6; });
 #endif
     ex.par([&](Th &t) {
-      if (t.tid < NF) {
-        const int k = t.tid >> 2, j = t.tid & 3;
+      if (t.foot) {
+        const int k = t.fid >> 2, j = t.fid & 3;
 #if MPC_QUAD_SCATTER
         const double g0 = t.gq[0], g1 = t.gq[1];
 #else
@@ -436,8 +457,8 @@ struct Solver {
   template <int KIND>
   MPC_HD void recv() {
     ex.seq([&](Th &t) {
-      if (t.tid < NF) {
-        const int k = t.tid >> 2, j = t.tid & 3;
+      if (t.foot) {
+        const int k = t.fid >> 2, j = t.fid & 3;
         const double s0 = sum_parts(s, 6 * k + j), s1 = sum_parts(s, 6 * k + 4 + (j & 1));   // (lanes 2, 3 have no second row: ignored)
         if (KIND == kHeld) {
           t.yq[0] = t.gq[0] - t.dlq[0] * (2.0 * (t.dlq[0] * t.gq[0]) - s0);
@@ -467,8 +488,8 @@ struct Solver {
       for (int i = t.tid; i < 72; i += T) s.B6[i] = qp[C::QP_B6 + i];
       for (int i = t.tid; i < 36; i += T) s.th1[i] = qp[C::QP_TH1 + i];
       for (int i = t.tid; i < 6; i += T) s.th2[i] = qp[C::QP_TH2 + i];
-      if (t.tid < NF) {
-        const int f = t.tid;
+      if (t.foot) {
+        const int f = t.fid;
 #pragma unroll
         for (int c = 0; c < 3; ++c) t.q[c] = sc[C::SC_QS + 3 * f + c];
         const double *as = sc + C::SC_AS + 9 * f;
@@ -497,8 +518,8 @@ struct Solver {
       }
     });
     ex.par([&](Th &t) {
-      if (t.tid < NF) {
-        const int f = t.tid;
+      if (t.foot) {
+        const int f = t.fid;
 #pragma unroll
         for (int c = 0; c < 3; ++c) t.x[c] = s.part[3 * f + c];      // scaled iterates of the previous call; zeros on the first call
 #pragma unroll
@@ -519,23 +540,23 @@ struct Solver {
   MPC_HD void foot_a(const Th &t, double *a) const {
     double dummy;
 #pragma unroll
-    for (int k = 0; k < 8; k += 2) MPC_LDS_LOAD128(s.fa + pidx(k, t.tid), a[k], a[k + 1]);
-    MPC_LDS_LOAD128(s.fa + pidx(8, t.tid), a[8], dummy);
+    for (int k = 0; k < 8; k += 2) MPC_LDS_LOAD128(s.fa + pidx(k, t.fid), a[k], a[k + 1]);
+    MPC_LDS_LOAD128(s.fa + pidx(8, t.fid), a[8], dummy);
   }
   MPC_HD void foot_ar(const Th &t, double *a) const {   // the cone block times rho of its row
     double dummy;
 #pragma unroll
-    for (int k = 0; k < 8; k += 2) MPC_LDS_LOAD128(s.fr + pidx(k, t.tid), a[k], a[k + 1]);
-    MPC_LDS_LOAD128(s.fr + pidx(8, t.tid), a[8], dummy);
+    for (int k = 0; k < 8; k += 2) MPC_LDS_LOAD128(s.fr + pidx(k, t.fid), a[k], a[k + 1]);
+    MPC_LDS_LOAD128(s.fr + pidx(8, t.fid), a[8], dummy);
   }
   MPC_HD void foot_bounds(const Th &t, double *lo, double *up) const {   // rows 0-3 have l = 0 (mpc_osqp.cc:449-477)
     double dummy;
 #pragma unroll
     for (int r = 0; r < 4; ++r) lo[r] = 0.0;
-    MPC_LDS_LOAD128(s.fa + pidx(8, t.tid), dummy, lo[4]);
-    MPC_LDS_LOAD128(s.fa + pidx(10, t.tid), up[0], up[1]);
-    MPC_LDS_LOAD128(s.fa + pidx(12, t.tid), up[2], up[3]);
-    MPC_LDS_LOAD128(s.fa + pidx(14, t.tid), up[4], dummy);
+    MPC_LDS_LOAD128(s.fa + pidx(8, t.fid), dummy, lo[4]);
+    MPC_LDS_LOAD128(s.fa + pidx(10, t.fid), up[0], up[1]);
+    MPC_LDS_LOAD128(s.fa + pidx(12, t.fid), up[2], up[3]);
+    MPC_LDS_LOAD128(s.fa + pidx(14, t.fid), up[4], dummy);
   }
 
   MPC_HD void set_rho_vec() {   // rho per row type (auxil.c:79-96, osqp.c:1267-1310)
@@ -603,8 +624,8 @@ struct Solver {
   MPC_HD void step_factor() {
     ex.template quad_allsum<21>([](Th &t) { return t.zq; });
     ex.par([&](Th &t) {
-      if (t.tid < NF && (t.tid & 3) == 0) {
-        const int kk = t.tid >> 2;
+      if (t.foot && (t.fid & 3) == 0) {
+        const int kk = t.fid >> 2;
         const double *zz = t.zq;
         double l[21], d[6], li[21];
         double mxd = 0;
@@ -647,7 +668,7 @@ struct Solver {
   template <class XS>
   MPC_HD void factor_core(XS &&xs) {
     ex.seq([&](Th &t) {
-      if (t.tid < NF) {
+      if (t.foot) {
         double w[18];
         foot_w(t, w);
         put_zf(t, xs(t), w);
@@ -655,7 +676,7 @@ struct Solver {
     });
     step_factor();
     ex.par([&](Th &t) {
-      if (t.tid < NF) {   // G_f = T_k W_f
+      if (t.foot) {   // G_f = T_k W_f
         double w[18], gf[18];
         foot_w(t, w);
         mul_tk(t, w, gf);
@@ -665,10 +686,10 @@ struct Solver {
 #pragma unroll
         for (int r = 0; r < 6; ++r) sym3_mul(xs(t), gf + 3 * r, hs + 3 * r);
 #pragma unroll
-        for (int k = 0; k < 18; ++k) s.Gf[pidx(k, t.tid)] = hs[k];
+        for (int k = 0; k < 18; ++k) s.Gf[pidx(k, t.fid)] = hs[k];
 #else
 #pragma unroll
-        for (int k = 0; k < 18; ++k) s.Gf[pidx(k, t.tid)] = gf[k];
+        for (int k = 0; k < 18; ++k) s.Gf[pidx(k, t.fid)] = gf[k];
 #endif
       }
     });
@@ -677,8 +698,8 @@ struct Solver {
   // from L_k (LDS) to the held tiles: dl = diag(M)^-1/2 of my rows, the unit-diagonal tile of Mh, the sweep
   MPC_HD void factor_tail() {
     ex.par([&](Th &t) {
-      if (t.tid < NF) {   // M_rr = 1 + l_r^T (c Theta_kk) l_r  (l_r: column r of L_k)
-        const int k = t.tid >> 2, j = t.tid & 3;
+      if (t.foot) {   // M_rr = 1 + l_r^T (c Theta_kk) l_r  (l_r: column r of L_k)
+        const int k = t.fid >> 2, j = t.fid & 3;
         const double mm = (double)(H - k), s2kk = mm * (4.0 * mm * mm - 1.0) / 12.0;   // sum_{i < m} (i + 1/2)^2
         const double *lk = s.Lk + 36 * k;
 #pragma unroll
@@ -753,7 +774,7 @@ struct Solver {
   }
   MPC_HD void factor() {
     ex.par([&](Th &t) {
-      if (t.tid < NF) {   // S_f = c alpha D^2 + sigma I + A_f^T R A_f  ->  S_f^-1
+      if (t.foot) {   // S_f = c alpha D^2 + sigma I + A_f^T R A_f  ->  S_f^-1
         double rv[5];
 #pragma unroll
         for (int r = 0; r < 5; ++r) rv[r] = rho_at(t, r);
@@ -770,8 +791,8 @@ struct Solver {
         // the cone block times rho of its row, for the iteration's A^T R (.)
         const double ar[9] = {a[0] * rv[0], a[1] * rv[0], a[2] * rv[1], a[3] * rv[1], a[4] * rv[2], a[5] * rv[2], a[6] * rv[3], a[7] * rv[3], a[8] * rv[4]};
 #pragma unroll
-        for (int k = 0; k < 9; ++k) s.fr[pidx(k, t.tid)] = ar[k];
-        s.fr[pidx(9, t.tid)] = 0.0;
+        for (int k = 0; k < 9; ++k) s.fr[pidx(k, t.fid)] = ar[k];
+        s.fr[pidx(9, t.fid)] = 0.0;
       }
     });
     factor_core([](Th &t) { return t.Si; });
@@ -967,7 +988,7 @@ struct Solver {
 #endif
   }
   MPC_HD void admm_prepare() {
-    ex.seq([&](Th &t) { if (t.tid < NF) foot_rhs(t); });
+    ex.seq([&](Th &t) { if (t.foot) foot_rhs(t); });
     send<kHeld>();
   }
   // One ADMM iteration = two phases: the tile product, and the foot phase, which finishes the KKT solve
@@ -977,7 +998,7 @@ struct Solver {
   // z = clip(z_r + yh),  yh <- (z_r + yh) - z,  and  rho z - y = rho (z - yh)  takes its rho from the pre-multiplied cone block (fr).
   MPC_HD void y_scaled(bool to) {
     ex.seq([&](Th &t) {
-      if (t.tid < NF) {
+      if (t.foot) {
 #pragma unroll
         for (int r = 0; r < 5; ++r) t.y[r] *= to ? rinv_at(t, r) : rho_at(t, r);
       }
@@ -992,7 +1013,7 @@ struct Solver {
     tile_product<kHeld>();
     recv<kHeld>();
     ex.seq([&](Th &t) {
-      if (t.tid < NF) {
+      if (t.foot) {
         // every LDS constant of the phase is requested up front, as one batch behind a single wait (a wave that runs alone on its
         // SIMD has nobody to hide five separate round trips behind; the registers are there: 512 per lane)
         double gf[18], a[9], ar[9], lo[5], up[5];
@@ -1025,7 +1046,7 @@ struct Solver {
           const double tq = zr + t.y[r];
           const double zn = clampd(tq, lo[r], up[r]);
           const double yn = tq - zn;
-          if constexpr (LAST) s.dxy[pidx(3 + r, t.tid)] = rho_at(t, r) * (zr - zn);
+          if constexpr (LAST) s.dxy[pidx(3 + r, t.fid)] = rho_at(t, r) * (zr - zn);
           t.z[r] = zn;
           t.y[r] = yn;
           dd[r] = zn - yn;
@@ -1035,7 +1056,7 @@ struct Solver {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const double xn = kAlphaRelax * t.xt[c] + (1.0 - kAlphaRelax) * t.x[c];
-          if constexpr (LAST) s.dxy[pidx(c, t.tid)] = xn - t.x[c];
+          if constexpr (LAST) s.dxy[pidx(c, t.fid)] = xn - t.x[c];
           t.x[c] = xn;
 #if MPC_GS_FORM
           v[c] = kSigma * xn - t.q[c] + acc[c];
@@ -1058,10 +1079,10 @@ struct Solver {
   // P_s v for a per-foot vector given by sel(t): out = c alpha D^2 v + W^T (c Theta (W v)).  `in` and `out` are members of Th.
   template <class In, class Out>
   MPC_HD void mul_P(In &&in, Out &&out) {
-    ex.seq([&](Th &t) { if (t.tid < NF) put_wrench(t, in(t)); });
+    ex.seq([&](Th &t) { if (t.foot) put_wrench(t, in(t)); });
     product<kTheta>();
     ex.seq([&](Th &t) {
-      if (t.tid < NF) {
+      if (t.foot) {
         double wy[3];
         get_wrench(t, wy);
         const double *v = in(t);
@@ -1092,7 +1113,7 @@ struct Solver {
   MPC_HD void residuals(X &&xs, Z &&zs, Y &&ys, PX &&pxs) {
     constexpr int RW = Sh::RW, NR = INF ? Sh::NRED : 14;
     ex.par([&](Th &t) {
-      if (t.tid < NF) {
+      if (t.foot) {
         const double *x = xs(t), *z = zs(t), *y = ys(t), *px = pxs(t);
         double mx[NR], ax[5], aty[3], a[9];
         foot_a(t, a);
@@ -1104,7 +1125,7 @@ struct Solver {
 #pragma unroll
         for (int r = 0; r < 5; ++r) {
           const double rr = ax[r] - z[r];
-          ev[r] = sc[C::SC_E + 5 * t.tid + r];
+          ev[r] = sc[C::SC_E + 5 * t.fid + r];
           ei[r] = norm_recip(ev[r]);
           mx[0] = dmax(mx[0], fabs(ei[r] * rr)); mx[1] = dmax(mx[1], fabs(ei[r] * z[r])); mx[2] = dmax(mx[2], fabs(ei[r] * ax[r]));
           mx[3] = dmax(mx[3], fabs(rr)); mx[4] = dmax(mx[4], fabs(z[r])); mx[5] = dmax(mx[5], fabs(ax[r]));
@@ -1121,10 +1142,10 @@ struct Solver {
           double lo[5], up[5], dx[3], dy[5], adx[5], atdy[3];
           foot_bounds(t, lo, up);
 #pragma unroll
-          for (int c = 0; c < 3; ++c) dx[c] = s.dxy[pidx(c, t.tid)];
+          for (int c = 0; c < 3; ++c) dx[c] = s.dxy[pidx(c, t.fid)];
 #pragma unroll
           for (int r = 0; r < 5; ++r) {
-            double v = s.dxy[pidx(3 + r, t.tid)];
+            double v = s.dxy[pidx(3 + r, t.fid)];
             const bool uinf = up[r] > kInfty * kMinScaling, linf = lo[r] < -kInfty * kMinScaling;   // (auxil.c:377-391)
             v = uinf ? (linf ? 0.0 : dmin(v, 0.0)) : (linf ? dmax(v, 0.0) : v);
             dy[r] = v;
@@ -1147,7 +1168,7 @@ struct Solver {
           }
         }
 #pragma unroll
-        for (int k = 0; k < NR; ++k) s.part[k * RW + t.tid] = mx[k];
+        for (int k = 0; k < NR; ++k) s.part[k * RW + t.fid] = mx[k];
       }
     });
     ex.par([&](Th &t) {
@@ -1224,19 +1245,19 @@ struct Solver {
   template <bool APPROX>
   MPC_HD void dual_certificate() {
     ex.seq([&](Th &t) {
-      if (t.tid < NF) {
+      if (t.foot) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) t.xt[c] = s.dxy[pidx(c, t.tid)];   // (x~ is dead between a check and the next iteration)
+        for (int c = 0; c < 3; ++c) t.xt[c] = s.dxy[pidx(c, t.fid)];   // (x~ is dead between a check and the next iteration)
       }
     });
     mul_P([](Th &t) { return t.xt; }, [](Th &t) { return t.px; });
     constexpr int RW = Sh::RW;
     ex.par([&](Th &t) {
-      if (t.tid < NF) {
+      if (t.foot) {
         double m = 0;
 #pragma unroll
         for (int c = 0; c < 3; ++c) m = dmax(m, fabs(t.px[c] * norm_recip(Dat(t, c))));
-        s.part[t.tid] = m;
+        s.part[t.fid] = m;
       }
     });
     ex.par([&](Th &t) {
@@ -1262,7 +1283,7 @@ struct Solver {
   MPC_HD void omega_apply() {   // in: t.w6 = V_f^T u from the foot lanes, pt = u = C^T r;  out: pw = Omega r = C (u - V_f (I - M^-1) V^T u)
     product<kHeld>();
     ex.seq([&](Th &t) {
-      if (t.tid < NF) {
+      if (t.foot) {
         double vy[3], d[3];
         get_g(t, vy);
 #pragma unroll
@@ -1287,7 +1308,7 @@ struct Solver {
   MPC_HD void orth_col() {
     if constexpr (J < 6) {
       ex.seq([&](Th &t) {
-        if (t.tid < NF) {
+        if (t.foot) {
 #pragma unroll
           for (int k = 0; k < 3; ++k) t.pv[k] = t.zq[3 * J + k];
 #pragma unroll
@@ -1297,11 +1318,11 @@ struct Solver {
       for (int rep = 0; rep < 2; ++rep) {
         ex.seq([&](Th &t) {
 #pragma unroll
-          for (int i = 0; i < 6; ++i) t.w6[i] = (i < J && t.tid < NF) ? t.pQ[3 * i] * t.pv[0] + t.pQ[3 * i + 1] * t.pv[1] + t.pQ[3 * i + 2] * t.pv[2] : 0.0;
+          for (int i = 0; i < 6; ++i) t.w6[i] = (i < J && t.foot) ? t.pQ[3 * i] * t.pv[0] + t.pQ[3 * i + 1] * t.pv[1] + t.pQ[3 * i + 2] * t.pv[2] : 0.0;
         });
         ex.template quad_allsum<6>([](Th &t) { return t.w6; });
         ex.seq([&](Th &t) {
-          if (t.tid < NF) {
+          if (t.foot) {
 #pragma unroll
             for (int i = 0; i < J; ++i) {
 #pragma unroll
@@ -1314,11 +1335,11 @@ struct Solver {
       ex.seq([&](Th &t) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) t.w6[i] = 0.0;
-        if (t.tid < NF) t.w6[0] = t.pv[0] * t.pv[0] + t.pv[1] * t.pv[1] + t.pv[2] * t.pv[2];
+        if (t.foot) t.w6[0] = t.pv[0] * t.pv[0] + t.pv[1] * t.pv[1] + t.pv[2] * t.pv[2];
       });
       ex.template quad_allsum<6>([](Th &t) { return t.w6; });
       ex.seq([&](Th &t) {
-        if (t.tid < NF) {
+        if (t.foot) {
           const double n2 = t.w6[0];
           const bool keep = n2 > 1e-24 * t.pn[J];
           const double inv = keep ? fast_rsqrt(keep ? n2 : 1.0) : 0.0;
@@ -1334,7 +1355,7 @@ struct Solver {
     ex.seq([&](Th &t) {
 #pragma unroll
       for (int r = 0; r < 6; ++r) t.w6[r] = 0.0;
-      if (t.tid < NF) {   // F_f[k][r] = sum_c C[c][k] W[r][c]  ->  zq[3 r + k]; squared column lengths
+      if (t.foot) {   // F_f[k][r] = sum_c C[c][k] W[r][c]  ->  zq[3 r + k]; squared column lengths
         double w[18];
         foot_w(t, w);
 #pragma unroll
@@ -1357,11 +1378,11 @@ struct Solver {
     });
     orth_col<0>();
     ex.par([&](Th &t) {
-      if (t.tid < NF) {
+      if (t.foot) {
 #pragma unroll
-        for (int k = 0; k < 18; ++k) s.Gf[pidx(k, t.tid)] = t.pQ[k];          // "G_f" = V_f^T (6 x 3)
-        if ((t.tid & 3) == 0) {   // L = R^T (pR[pk(j, i)] = R[i][j], i <= j)
-          double *ol = s.Lk + 36 * (t.tid >> 2);
+        for (int k = 0; k < 18; ++k) s.Gf[pidx(k, t.fid)] = t.pQ[k];          // "G_f" = V_f^T (6 x 3)
+        if ((t.fid & 3) == 0) {   // L = R^T (pR[pk(j, i)] = R[i][j], i <= j)
+          double *ol = s.Lk + 36 * (t.fid >> 2);
 #pragma unroll
           for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -1376,7 +1397,7 @@ struct Solver {
   template <bool ROUNDS = false>
   MPC_HD void polish() {
     ex.par([&](Th &t) {
-      if (t.tid < NF) {
+      if (t.foot) {
         double a[9], lo[5], up[5];
         foot_a(t, a);
         foot_bounds(t, lo, up);
@@ -1531,7 +1552,7 @@ struct Solver {
     });
     product<kTheta>();
     ex.seq([&](Th &t) {
-      if (t.tid < NF) {   // P_s u0;  g = -q - P_s u0;  t = Xi g
+      if (t.foot) {   // P_s u0;  g = -q - P_s u0;  t = Xi g
         double wy[3];
         get_wrench(t, wy);
 #pragma unroll
@@ -1560,24 +1581,24 @@ struct Solver {
     const int nsteps = first ? polish_refine : MPC_EXACT_ROUND_STEPS;
     if (first && !direct) {
       polish_factor();
-      if (round == 0) ex.seq([&](Th &t) { if (t.tid < NF) put_g(t, t.pt); });
+      if (round == 0) ex.seq([&](Th &t) { if (t.foot) put_g(t, t.pt); });
       lap(12);
     }
     if (direct) {
       ex.seq([&](Th &t) {
-        if (t.tid < NF) {
+        if (t.foot) {
 #pragma unroll
-          for (int c = 0; c < 3; ++c) t.pxN[c] = s.dxy[pidx(c, t.tid)] - t.pu0[c];      // (the method's iterate, parked by run_active_set)
+          for (int c = 0; c < 3; ++c) t.pxN[c] = s.dxy[pidx(c, t.fid)] - t.pu0[c];      // (the method's iterate, parked by run_active_set)
           put_wrench(t, t.pxN);
         }
       });
       product<kTheta>();
     }
     if (ROUNDS && round > 0) {      // the residual of the current xN, as the loop's last iteration would have left it
-      ex.seq([&](Th &t) { if (t.tid < NF) put_wrench(t, t.pxN); });
+      ex.seq([&](Th &t) { if (t.foot) put_wrench(t, t.pxN); });
       product<kTheta>();
       ex.seq([&](Th &t) {
-        if (t.tid < NF) {
+        if (t.foot) {
           double wy[3];
           get_wrench(t, wy);
 #pragma unroll
@@ -1591,17 +1612,17 @@ struct Solver {
       omega_apply();
 #ifdef MPC_EMU_DEBUG
       if (dbg && it == 0) ex.par([&](Th &t) {
-        if (t.tid < NF) {
-          double *o = dbg + 38 * t.tid;
+        if (t.foot) {
+          double *o = dbg + 38 * t.fid;
           for (int r = 0; r < 5; ++r) o[r] = t.act[r];
           for (int c1 = 0, e = 0; c1 < 3; ++c1) for (int c2 = c1; c2 < 3; ++c2, ++e) o[5 + e] = t.pC[3 * c1] * t.pC[3 * c2] + t.pC[3 * c1 + 1] * t.pC[3 * c2 + 1] + t.pC[3 * c1 + 2] * t.pC[3 * c2 + 2];
           for (int c = 0; c < 3; ++c) { o[11 + c] = t.pg[c]; o[14 + c] = t.pC[3 * c] * t.pt[0] + t.pC[3 * c + 1] * t.pt[1] + t.pC[3 * c + 2] * t.pt[2]; o[17 + c] = t.pw[c]; }
-          for (int k = 0; k < 18; ++k) o[20 + k] = s.Gf[pidx(k, t.tid)];
+          for (int k = 0; k < 18; ++k) o[20 + k] = s.Gf[pidx(k, t.fid)];
         }
       });
 #endif
       ex.seq([&](Th &t) {
-        if (t.tid < NF) {
+        if (t.foot) {
 #pragma unroll
           for (int c = 0; c < 3; ++c) t.pxN[c] += t.pw[c];
           put_wrench(t, t.pxN);
@@ -1610,7 +1631,7 @@ struct Solver {
       product<kTheta>();                                  // c Theta W xN  (-> P_s xN)
       if (it < nsteps) {
         ex.seq([&](Th &t) {
-          if (t.tid < NF) {
+          if (t.foot) {
             double wy[3];
             get_wrench(t, wy);
 #pragma unroll
@@ -1624,7 +1645,7 @@ struct Solver {
     lap(13);
     // x = u + xN ; y = A Gamma (g - P xN) on active rows ; z = A x ; normal-cone projection (proj.c:17-31)
     ex.par([&](Th &t) {
-      if (t.tid < NF) {
+      if (t.foot) {
         double wy[3], pxn[3], gg[3], rwv[3], ax[5], ay[5], a[9], lo[5], up[5];
         foot_a(t, a);
         foot_bounds(t, lo, up);
@@ -1701,7 +1722,7 @@ struct Solver {
     if (!(ROUNDS && (s.pol_near || (direct && !s.pol_ok)) && round < MPC_EXACT_ROUNDS + (xn_given ? 1 : 0))) break;      // (the direct check is not one of the refinement rounds)
     }
     ex.par([&](Th &t) {
-      if (s.status_polish == 1 && t.tid < NF) {
+      if (s.status_polish == 1 && t.foot) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) t.x[c] = t.xp[c];
 #pragma unroll
@@ -1736,7 +1757,7 @@ struct Solver {
   template <class RV>
   MPC_HD void gi_apply(RV &&rv) {
     ex.seq([&](Th &t) {
-      if (t.tid < NF) {
+      if (t.foot) {
         double r3[3];
         rv(t, r3);
         ct_mul(t.pC, r3, t.pt);
@@ -1788,7 +1809,7 @@ struct Solver {
         g.hi = 0; g.converged = 0; g.fail = 0; g.passes = 0; g.adds = 0; g.drops = 0;
         g.freem[0] = NW >= 64 ? ~0ull : ((1ull << (NW & 63)) - 1); g.freem[1] = NW > 64 ? ((1ull << (NW - 64)) - 1) : 0ull;
       }
-      if (t.tid < NF) {
+      if (t.foot) {
         const int fixed = ((t.tyb & 0x3ff) == 0x2aa);                 // all five rows are equalities (set_rho_vec's test: u - l < 1e-4)
         t.gfix = fixed;
         double a[9], lo[5], up[5];
@@ -1817,7 +1838,7 @@ struct Solver {
       for (int c = 0; c < 3; ++c) r3[c] = -t.q[c];
     });
     ex.seq([&](Th &t) {
-      if (t.tid < NF) {
+      if (t.foot) {
         double a[9];
         foot_a(t, a);
 #pragma unroll
@@ -1838,7 +1859,7 @@ struct Solver {
         ex.seq([&](Th &t) {
           double best = -1.0;
           t.gbrow = 0; t.gbside = 0;
-          if (t.tid < NF && !t.gfix) {
+          if (t.foot && !t.gfix) {
             double lo[5], up[5];
             foot_bounds(t, lo, up);
 #pragma unroll
@@ -1852,7 +1873,7 @@ struct Solver {
         });
         ex.wg_argmax([](Th &t) { return t.gred; }, [](Th &t) -> int & { return t.gidx; }, gtmp);
         if (!(ex.first().gred[0] > 0.0)) { converged = true; break; }
-        ex.par([&](Th &t) { if (t.tid == t.gidx) { g.p_foot = t.tid; g.p_row = t.gbrow; g.p_side = t.gbside; } });
+        ex.par([&](Th &t) { if (t.tid == t.gidx) { g.p_foot = t.fid; g.p_row = t.gbrow; g.p_side = t.gbside; } });
         lam_p = 0.0;
         MPC_SUBLAP(7, 1);
         // ---- B. v = H^-1 n_p;  d = N^T v,  gamma = n_p^T v      (n = side * row: the normal of "row >= l" is +row, of "row <= u" is -row)
@@ -1860,12 +1881,12 @@ struct Solver {
           double a[9];
           foot_a(t, a);
           gi_row(a, g.p_row, r3);
-          const double sg = t.tid == g.p_foot ? (g.p_side < 0 ? 1.0 : -1.0) : 0.0;
+          const double sg = (t.foot && t.fid == g.p_foot) ? (g.p_side < 0 ? 1.0 : -1.0) : 0.0;
 #pragma unroll
           for (int c = 0; c < 3; ++c) r3[c] *= sg;
         });
         ex.par([&](Th &t) {
-          if (t.tid < NF) {
+          if (t.foot) {
             double a[9], av[5];
             foot_a(t, a);
 #pragma unroll
@@ -1874,7 +1895,7 @@ struct Solver {
 #pragma unroll
             for (int r = 0; r < 5; ++r)
               if (t.gslot[r] >= 0) gd[t.gslot[r]] = (t.act[r] < 0 ? 1.0 : -1.0) * av[r];
-            if (t.tid == g.p_foot) g.gamma = (g.p_side < 0 ? 1.0 : -1.0) * gi_pick(av, g.p_row);
+            if ((t.foot && t.fid == g.p_foot)) g.gamma = (g.p_side < 0 ? 1.0 : -1.0) * gi_pick(av, g.p_row);
           }
         });
         MPC_SUBLAP(7, 2);
@@ -1916,7 +1937,7 @@ struct Solver {
           foot_a(t, a);
 #pragma unroll
           for (int r = 0; r < 5; ++r) {     // the combination of my rows: +-1 for row p, -(+-r_slot) for my working rows
-            double c = (t.tid == g.p_foot && r == g.p_row) ? (g.p_side < 0 ? 1.0 : -1.0) : 0.0;
+            double c = ((t.foot && t.fid == g.p_foot) && r == g.p_row) ? (g.p_side < 0 ? 1.0 : -1.0) : 0.0;
             if (t.gslot[r] >= 0) c -= (t.act[r] < 0 ? 1.0 : -1.0) * gr[t.gslot[r]];
             w[r] = c;
           }
@@ -1926,7 +1947,7 @@ struct Solver {
       MPC_SUBLAP(7, 4);
       // ---- E. the step: t2 = (violation of row p now) / zeta brings the row to its bound; t = min(t1, t2)
       ex.par([&](Th &t) {      // (row p's foot lane publishes the violation: one LDS round trip, where a reduction takes six exchanges)
-        if (t.tid == g.p_foot) {
+        if ((t.foot && t.fid == g.p_foot)) {
           double lo[5], up[5];
           foot_bounds(t, lo, up);
           const double lo_p = gi_pick(lo, g.p_row), up_p = gi_pick(up, g.p_row), ax_p = gi_pick(t.gax, g.p_row);
@@ -1955,7 +1976,7 @@ struct Solver {
         if (t.tid == 0) gtmp2[0] = fast_recip(gi_ci(k1, k1));
       });
       ex.par([&](Th &t) {
-        if (t.tid < NF && moves) {
+        if (t.foot && moves) {
           double a[9], az[5];
           foot_a(t, a);
           a_mul(a, t.pw, az);
@@ -1981,9 +2002,9 @@ struct Solver {
             if (i == k1) { g.owner[k1] = -1; glam[k1] = 0.0; gd[k1] = 0.0; }
           }
         }
-        if (t.tid < NF) {
+        if (t.foot) {
           if (add) {
-            if (t.tid == g.p_foot) {
+            if ((t.foot && t.fid == g.p_foot)) {
 #pragma unroll
               for (int r = 0; r < 5; ++r) if (r == g.p_row) { t.act[r] = g.p_side; t.gslot[r] = ps; }
             }
@@ -2026,7 +2047,7 @@ struct Solver {
       if (!s.done) {
         if constexpr (EXACT) {
           ex.par([&](Th &t) {   // the active-set guess of my rows (polish.c:36-52), as a base-3 code; did it change since the last check?
-            if (t.tid < NF) {
+            if (t.foot) {
               double lo[5], up[5];
               foot_bounds(t, lo, up);
               int sig = 0;
@@ -2061,8 +2082,8 @@ struct Solver {
     // ran out of iterations is written too, with its status)
     const bool solved = (s.status == kStSolved || (eps_exact > 0 && (s.status == kStSolvedInaccurate || s.status == kStMaxIter))) && !failed;
     ex.par([&](Th &t) {      // the record and the forces into the LDS stage (see load) ...
-      if (t.tid < NF) {
-        const int f = t.tid;
+      if (t.foot) {
+        const int f = t.fid;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           s.part[SL + 3 * f + c] = 0.0 - Dat(t, c) * t.x[c];   // (-x, mpc_osqp.cc:789-790; an eliminated foot's exact zero comes out as +0.0)
@@ -2160,8 +2181,8 @@ struct Solver {
       // (the reference's qpOASES branch returns its vector whatever the solver's status, mpc_osqp.cc:906-947: in the exact mode an iterate that
       // ran out of iterations is written too, with its status)
       const bool solved = (s.status == kStSolved || (eps_exact > 0 && (s.status == kStSolvedInaccurate || s.status == kStMaxIter))) && !failed;
-      if (t.tid < NF) {
-        const int f = t.tid;
+      if (t.foot) {
+        const int f = t.fid;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           if (solved) forces[3 * f + c] = 0.0 - Dat(t, c) * t.x[c];
@@ -2196,9 +2217,9 @@ struct Solver {
       ex.par([&](Th &t) { if (t.tid == 0) { s.pri_res = kInfty; s.dua_res = kInfty; s.status = kStSolved; } });
       act_given = true; polish_must_verify = true; xn_given = MPC_EXACT_DIRECT;
       if (xn_given) ex.par([&](Th &t) {      // (through LDS, not registers: nothing of the method stays live across the polish set-up)
-        if (t.tid < NF) {
+        if (t.foot) {
 #pragma unroll
-          for (int c = 0; c < 3; ++c) s.dxy[pidx(c, t.tid)] = t.gx[c];
+          for (int c = 0; c < 3; ++c) s.dxy[pidx(c, t.fid)] = t.gx[c];
         }
       });
       polish<true>();
@@ -2209,9 +2230,9 @@ struct Solver {
 #ifdef MPC_EMU_DEBUG
     if (!ok && getenv("EMU_GI_DUMP")) {   // debugging: the dual method's iterate and working set of a robot whose set was rejected
       ex.par([&](Th &t) {
-        if (t.tid < NF) {
-          for (int c = 0; c < 3; ++c) forces[3 * t.tid + c] = 0.0 - Dat(t, c) * t.gx[c];
-          for (int r = 0; r < 5; ++r) state[N + 5 * t.tid + r] = t.act[r];
+        if (t.foot) {
+          for (int c = 0; c < 3; ++c) forces[3 * t.fid + c] = 0.0 - Dat(t, c) * t.gx[c];
+          for (int r = 0; r < 5; ++r) state[N + 5 * t.fid + r] = t.act[r];
         }
       });
     }
@@ -2250,8 +2271,8 @@ struct Solver {
     polish();
     lap(14);
     ex.par([&](Th &t) {
-      if (s.status_polish == 1 && t.tid < NF) {      // OSQP takes the polished point: x, z, y and the forces again, through the stage (see load)
-        const int f = t.tid;
+      if (s.status_polish == 1 && t.foot) {      // OSQP takes the polished point: x, z, y and the forces again, through the stage (see load)
+        const int f = t.fid;
 #pragma unroll
         for (int c = 0; c < 3; ++c) { s.part[SL + 3 * f + c] = 0.0 - Dat(t, c) * t.x[c]; s.part[3 * f + c] = t.x[c]; }
 #pragma unroll

@@ -215,9 +215,9 @@ static void ksolve_one(const RobotModel &mdl, const float *in, double rho, const
   sv.set_rho_vec();
   sv.factor();
   ex.seq([&](WThread<H> &t) {
-    if (t.tid < C::NF) {
+    if (t.foot) {
       double v[3];
-      for (int c = 0; c < 3; ++c) t.b[c] = b[3 * t.tid + c];
+      for (int c = 0; c < 3; ++c) t.b[c] = b[3 * t.fid + c];
       Solver<H, Ex>::sym3_mul(t.Si, t.b, v);
 #if MPC_GS_FORM
       for (int c = 0; c < 3; ++c) t.xt[c] = v[c];      // S^-1 b
@@ -229,7 +229,7 @@ static void ksolve_one(const RobotModel &mdl, const float *in, double rho, const
   });
   sv.template product<Solver<H, Ex>::kHeld>();
   ex.seq([&](WThread<H> &t) {
-    if (t.tid < C::NF) {
+    if (t.foot) {
       double wy[3], tt[3], o[3];
       sv.get_g(t, wy);
 #if MPC_GS_FORM
@@ -238,7 +238,7 @@ static void ksolve_one(const RobotModel &mdl, const float *in, double rho, const
       for (int c = 0; c < 3; ++c) tt[c] = t.b[c] - wy[c];
       Solver<H, Ex>::sym3_mul(t.Si, tt, o);
 #endif
-      for (int c = 0; c < 3; ++c) xt[3 * t.tid + c] = o[c];
+      for (int c = 0; c < 3; ++c) xt[3 * t.fid + c] = o[c];
     }
   });
   for (int i = 0; i < C::SC_LEN; ++i) sc_out[i] = sc[i];

@@ -50,18 +50,19 @@ def test_spill_estimate_stays_bounded(asm):
     # weighted scratch instructions per wave and solve (tools/isa_census.py).  h = 10: one wave per SIMD with the full register budget
     # (AGPRs as spill space), no scratch memory at all.  h = 16 / 20: multi-wave workgroups at two waves per SIMD (256 registers), which
     # was measured 25 % faster in spite of the spill code it needs; the bound keeps that spill code from growing.
-    limits = {10: 50, 12: 2800, 16: 2800, 20: 2800}      # (round 3: 16 / 2362 / 2169 / 2309)
+    limits = {10: 50, 12: 2100, 16: 2100, 20: 2800}      # (round 3: 8 / 1814 / 1825 / 2274; h = 12, 16: tile and foot lanes are different threads
+    #  that share their registers, Cfg::FOOT0)
     for h, lim in limits.items():
         total, detail = isa_census.spill_cost(asm, h)
         assert total <= lim, (h, total, detail)
 
 
 def test_long_horizon_admm_iteration_stays_nearly_scratch_free(asm):
-    for h in (16, 20):
+    for h, lim_admm, lim_sweep in ((12, 4, 2), (16, 4, 2), (20, 16, 6)):      # (h = 12, 16 with separate foot threads: none at all)
         admm = [a for a in isa_census.loop_stats(asm, h).values() if a["role"] == "admm-iteration"]
-        assert admm and all(a["scratch"] <= 16 for a in admm), (h, admm)
+        assert admm and all(a["scratch"] <= lim_admm for a in admm), (h, admm)
         sweeps = [a for a in isa_census.loop_stats(asm, h).values() if a["role"] == "sweep"]
-        assert len(sweeps) == 3 and all(a["scratch"] <= 6 for a in sweeps), (h, sweeps)      # round 2: up to 29 per trip
+        assert len(sweeps) == 3 and all(a["scratch"] <= lim_sweep for a in sweeps), (h, sweeps)      # round 2: up to 29 per trip
 
 
 def test_exact_mode_kernel_runs_without_scratch(asm):

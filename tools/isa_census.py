@@ -92,7 +92,7 @@ def loop_stats(txt, H):
         # pair's 2 x 2 determinant) each (h = 10); the ADMM iteration is the tight loop with the quad exchanges (DPP moves) and no
         # reciprocal; the loop around it (iterations + check + refactor) is the big one with DPP moves.  (Depths differ between the
         # one-job kernel and the persistent job kernel, whose job loops sit outside: roles go by content.)
-        if a.get("rcp", 0) in (3, 6) and a["ins"] < 1000:
+        if a.get("rcp", 0) in (3, 6) and a["ins"] < 1000 and a["lds"] > 40:      # (a sweep trip publishes and fetches pivot rows: 100+ LDS instructions)
             a["role"] = "sweep"
         elif a.get("dpp", 0) and a["ins"] < 700 and not a.get("rcp", 0):
             a["role"] = "admm-iteration"
