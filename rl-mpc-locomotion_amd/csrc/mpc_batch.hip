@@ -33,7 +33,7 @@ using namespace mpc;
 #ifndef MPC_SOLVE_MIN_WAVES
 #define MPC_SOLVE_MIN_WAVES 1
 #endif
-#ifndef MPC_SOLVE_MIN_WAVES_WIDE   // the multi-wave workgroups of the long horizons (192 threads at h = 16, 256 at h = 20): two waves per
+#ifndef MPC_SOLVE_MIN_WAVES_WIDE   // the multi-wave workgroups of the long horizons (128 threads at h = 12, 256 at h = 16 / 20): two waves per
 #define MPC_SOLVE_MIN_WAVES_WIDE 2  // SIMD hide their barriers (measured: h = 16 3.00 -> 2.35 ms, h = 20 3.55 -> 2.83 ms per 4096 robots)
 #endif
 

@@ -166,7 +166,7 @@ struct Cfg {
   // Foot lanes of the solve kernel: threads FOOT0 .. FOOT0 + NF - 1 (a multiple of four: the feet of a step are a hardware quad).
   static constexpr int FOOT0 = MPC_FOOT0(H, MTW);
   static constexpr int TWMIN = FOOT0 + NF > MTW ? FOOT0 + NF : MTW;
-  static constexpr int TW = (((TWMIN > NW ? TWMIN : NW) + 63) / 64) * 64;   // solve-kernel workgroup: 64 (h = 10), 192, 256
+  static constexpr int TW = (((TWMIN > NW ? TWMIN : NW) + 63) / 64) * 64;   // solve-kernel workgroup: 64 (h <= 10), 128 (h = 12), 256 (h = 16, 20)
   static constexpr int NPW = NW + 2;                     // row stride of the solve kernel's part[]
 };
 

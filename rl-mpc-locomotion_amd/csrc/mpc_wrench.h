@@ -20,7 +20,7 @@
 // 60 x 60 at h = 10 instead of 120 x 120 -- an eighth of the factorisation work and a quarter of the matrix-vector work per
 // ADMM iteration, exact (no swing-leg elimination, any gait), and small enough that ONE WAVEFRONT holds it: I - M^-1 lives as
 // the lower triangle of an h x h grid of 6 x 6 register tiles, 55 tiles at h = 10 -> one tile per lane, no workgroup barrier
-// anywhere in the solve (136 tiles / 192 threads at h = 16, 210 / 256 at h = 20).  Everything that belongs to one (step, foot)
+// anywhere in the solve (136 tiles + 64 foot lanes in 256 threads at h = 16, 210 tiles in 256 threads at h = 20).  Everything that belongs to one (step, foot)
 // -- three force variables, five cone rows, their iterates x, z, y, the scaled cone block, bounds, S^-1, G_f -- lives in the
 // registers of one "foot lane"; the wrench space is the only communication between lanes: six numbers per foot out (G_f v_f),
 // six per step back.
