@@ -351,6 +351,10 @@ MPC_HD void ctrl_pre(CtrlState &s, const RobotConst &rc, const GaitTable &gt, co
   const float stance_time = (float)cp.dt_mpc * stance_seg;                    // getCurrentStanceTime
   for (int l = 0; l < 4; ++l) s.swing_times[l] = swing_time;
   const float posz = s.pos_z;
+  // coordinateRotation(Z, -yaw_rate * stance_time / 2): float16 matrix (orientation_tools.py:13,20-37) -- the same for the four legs
+  const float theta = -yaw_rate * stance_time / 2.f;
+  const float cz = round_to_half((float)cos((double)theta)), sz = round_to_half((float)sin((double)theta));
+  const float msz = round_to_half((float)(-sin((double)theta)));
   for (int i = 0; i < 4; ++i) {
     if (s.first_swing[i]) s.swing_time_remaining[i] = (double)s.swing_times[i];
     else s.swing_time_remaining[i] -= cp.dt;
@@ -358,10 +362,6 @@ MPC_HD void ctrl_pre(CtrlState &s, const RobotConst &rc, const GaitTable &gt, co
     float pr[3];
     hip_location(rc, i, pr);
     pr[1] = pr[1] + (float)((double)side * rc.abad);
-    // coordinateRotation(Z, -yaw_rate * stance_time / 2): float16 matrix (orientation_tools.py:13,20-37)
-    const float theta = -yaw_rate * stance_time / 2.f;
-    const float cz = round_to_half((float)cos((double)theta)), sz = round_to_half((float)sin((double)theta));
-    const float msz = round_to_half((float)(-sin((double)theta)));
     const float pyc[3] = {cz * pr[0] + sz * pr[1] + 0.f * pr[2], msz * pr[0] + cz * pr[1] + 0.f * pr[2], 0.f * pr[0] + 0.f * pr[1] + 1.f * pr[2]};
     const float str = (float)s.swing_time_remaining[i];
     float Pf[3] = {0.f + (pyc[0] + x_vel_des * str), 0.f + (pyc[1] + y_vel_des * str), posz + (pyc[2] + 0.f * str)};
