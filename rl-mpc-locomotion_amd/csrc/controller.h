@@ -1,4 +1,5 @@
-// controller.h -- the per-tick controller around the contact-force solve, one robot per thread.
+// controller.h -- the per-tick controller around the contact-force solve: one robot per call on the host and in the FSM kernels,
+// one leg per lane in ctrl_pre_kernel / ctrl_post_kernel (the functions take a leg range).
 //
 // Restates, in the reference's own arithmetic types (numpy float32 "f", Python float "d"), what
 //   MPC_Controller/common/LegController.py:89-106,135-171   updateData (leg FK, Jacobian, foot velocity)
@@ -256,11 +257,11 @@ MPC_HD void estimator_update(const float *body, const float *normal, float *est)
 }
 
 // LegController.updateData (LegController.py:89-106): joint state, leg FK / Jacobian, foot velocity
-MPC_HD void leg_update_data(CtrlState &s, const RobotConst &rc, const float *dof) {
+MPC_HD void leg_update_data(CtrlState &s, const RobotConst &rc, const float *dof, int l0 = 0, int l1 = 4) {
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
-  for (int leg = 0; leg < 4; ++leg) {
+  for (int leg = l0; leg < l1; ++leg) {
     for (int j = 0; j < 3; ++j) { s.q[3 * leg + j] = dof[2 * (3 * leg + j)]; s.qd[3 * leg + j] = dof[2 * (3 * leg + j) + 1]; }
     leg_kinematics(rc, leg, s.q + 3 * leg, s.p + 3 * leg, s.J + 9 * leg);
     for (int r = 0; r < 3; ++r) {
@@ -273,13 +274,31 @@ MPC_HD void leg_update_data(CtrlState &s, const RobotConst &rc, const float *dof
 // ---- first half of the tick -----------------------------------------------------------------
 // dof: [12][2] (pos, vel) leg-major; est: kEstLen floats; cmd: 16 floats (vx vy yaw_rate w[13]).
 // rec: solver input record [56 + 4h] (written only when s.do_solve).
-MPC_HD void ctrl_pre(CtrlState &s, const RobotConst &rc, const GaitTable &gt, const CtrlParams &cp, const float *dof,
-                     const float *est, const float *cmd, float *rec) {
+// The tick's first half comes in two parts so that the device can give every leg its own lane (mpc_batch.hip ctrl_pre_kernel): the legs
+// [l0, l1) of this call do their own work, everything that concerns the whole robot is computed by every caller alike (and stored by the
+// one with lead = true).  ctrl_pre_legs: joint data, kinematics, foot positions.  Between the two parts the lanes of a robot exchange
+// foot_positions; ctrl_pre_rest needs those of all four legs.  The host and the FSM path call ctrl_pre, i.e. both parts for all legs.
+MPC_HD void ctrl_pre_legs(CtrlState &s, const RobotConst &rc, const float *dof, int l0 = 0, int l1 = 4) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  leg_update_data(s, rc, dof, l0, l1);
+  // foot positions (ConvexMPCLocomotion.py:248-250)
+  for (int i = l0; i < l1; ++i) {
+    float h[3];
+    hip_location(rc, i, h);
+    for (int c = 0; c < 3; ++c) s.foot_positions[3 * i + c] = h[c] + s.p[3 * i + c];
+    s.pfoot[3 * i] = s.foot_positions[3 * i] + 0.f;
+    s.pfoot[3 * i + 1] = s.foot_positions[3 * i + 1] + 0.f;
+    s.pfoot[3 * i + 2] = s.foot_positions[3 * i + 2] + s.pos_z;
+  }
+}
+MPC_HD void ctrl_pre_rest(CtrlState &s, const RobotConst &rc, const GaitTable &gt, const CtrlParams &cp,
+                          const float *est, const float *cmd, float *rec, int l0 = 0, int l1 = 4, bool lead = true) {
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
   const int nseg = gt.n_seg;
-  leg_update_data(s, rc, dof);
   const float *vBody = est, *omegaBody = est + 3, *rpyBody = est + 6, *gRb = est + 9;
   const float x_vel_des = cmd[0], y_vel_des = cmd[1], yaw_rate = cmd[2];   // ConvexMPCLocomotion.py:119-126
   const float *off = gt.offsets[s.gait_id], *dur = gt.durations[s.gait_id];
@@ -288,22 +307,14 @@ MPC_HD void ctrl_pre(CtrlState &s, const RobotConst &rc, const GaitTable &gt, co
   const double iteration = fmod((double)s.iter / (double)cp.iters_between_mpc, (double)nseg);
   const double phase = (double)(s.iter % per) / (double)per;
 
-  // foot positions (ConvexMPCLocomotion.py:248-250)
-  for (int i = 0; i < 4; ++i) {
-    float h[3];
-    hip_location(rc, i, h);
-    for (int c = 0; c < 3; ++c) s.foot_positions[3 * i + c] = h[c] + s.p[3 * i + c];
-    s.pfoot[3 * i] = s.foot_positions[3 * i] + 0.f;
-    s.pfoot[3 * i + 1] = s.foot_positions[3 * i + 1] + 0.f;
-    s.pfoot[3 * i + 2] = s.foot_positions[3 * i + 2] + s.pos_z;
-  }
   if (s.first_run) {   // :257-263
     s.first_run = 0;
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4; ++i) {      // (the foot history of ALL legs: the ground-normal fit below reads it)
       s.hist[3 * i] = s.foot_positions[3 * i]; s.hist[3 * i + 1] = s.foot_positions[3 * i + 1];
       s.hist[3 * i + 2] = (float)(-rc.body_height);                     // StateEstimator.py:99-101
-      for (int c = 0; c < 3; ++c) { s.p0[3 * i + c] = s.pfoot[3 * i + c]; s.pf[3 * i + c] = s.pfoot[3 * i + c]; }
     }
+    for (int i = l0; i < l1; ++i)
+      for (int c = 0; c < 3; ++c) { s.p0[3 * i + c] = s.pfoot[3 * i + c]; s.pf[3 * i + c] = s.pfoot[3 * i + c]; }
   }
   // StateEstimator._update_com_position_ground_frame (StateEstimator.py:109-118)
   {
@@ -349,13 +360,13 @@ MPC_HD void ctrl_pre(CtrlState &s, const RobotConst &rc, const GaitTable &gt, co
   const float swing_seg = (float)nseg - dur[0], stance_seg = dur[0];        // Gait.py:22-23
   const float swing_time = (float)cp.dt_mpc * swing_seg;                      // getCurrentSwingTime
   const float stance_time = (float)cp.dt_mpc * stance_seg;                    // getCurrentStanceTime
-  for (int l = 0; l < 4; ++l) s.swing_times[l] = swing_time;
+  for (int l = l0; l < l1; ++l) s.swing_times[l] = swing_time;
   const float posz = s.pos_z;
   // coordinateRotation(Z, -yaw_rate * stance_time / 2): float16 matrix (orientation_tools.py:13,20-37) -- the same for the four legs
   const float theta = -yaw_rate * stance_time / 2.f;
   const float cz = round_to_half((float)cos((double)theta)), sz = round_to_half((float)sin((double)theta));
   const float msz = round_to_half((float)(-sin((double)theta)));
-  for (int i = 0; i < 4; ++i) {
+  for (int i = l0; i < l1; ++i) {
     if (s.first_swing[i]) s.swing_time_remaining[i] = (double)s.swing_times[i];
     else s.swing_time_remaining[i] -= cp.dt;
     const float side = (i == 0 || i == 2) ? 1.f : -1.f;
@@ -375,7 +386,7 @@ MPC_HD void ctrl_pre(CtrlState &s, const RobotConst &rc, const GaitTable &gt, co
   s.iter += 1;   // :314
 
   // gait states (Gait.py:30-67) -- phase set before the increment
-  for (int i = 0; i < 4; ++i) {
+  for (int i = l0; i < l1; ++i) {
     const float offf = off[i] / (float)nseg, durf = dur[i] / (float)nseg;
     float pc = (float)phase - offf;
     if (pc < 0.f) pc += 1.0f;
@@ -398,36 +409,45 @@ MPC_HD void ctrl_pre(CtrlState &s, const RobotConst &rc, const GaitTable &gt, co
     // (mpc_weights is None, ConvexMPCLocomotion.py:132-135: the 3-entry commands of the interactive runners) -- here: cmd[3 .. 15] all NaN.
     // The reference asserts w >= 0 (DesiredStateCommand.py:21,27); a negative weight makes this robot's record non-finite, so its
     // solve reports NON_CVX and its previous forces stay in place.
-    {
+    if (lead) {
       bool dflt = true;                      // "no weights" = ALL thirteen entries NaN (what BatchedLocomotion sends for a 3-entry command); a NaN
       for (int k = 0; k < 13; ++k) dflt = dflt && (cmd[3 + k] != cmd[3 + k]);   // among real weights (a diverged policy) poisons the record -> NON_CVX
       bool neg = false;
       for (int k = 0; k < 13; ++k) { const float w = dflt ? rc.weights[k] : cmd[3 + k]; neg = neg || (w < 0.f); rec[IN_W + k] = w; }
       if (neg) for (int k = 0; k < 13; ++k) rec[IN_W + k] = __builtin_nanf("");
     }
-    rec[IN_POS] = 0.f; rec[IN_POS + 1] = 0.f; rec[IN_POS + 2] = s.pos_z;
-    for (int k = 0; k < 3; ++k) {
-      rec[IN_VEL + k] = vBody[k];
-      rec[IN_RPY + k] = rpyBody[k];
-      rec[IN_NRM + k] = cp.flat_ground ? (k == 2 ? 1.f : 0.f) : s.normal[k];
-      rec[IN_ANG + k] = omegaBody[k];
+    if (lead) {
+      rec[IN_POS] = 0.f; rec[IN_POS + 1] = 0.f; rec[IN_POS + 2] = s.pos_z;
+      for (int k = 0; k < 3; ++k) {
+        rec[IN_VEL + k] = vBody[k];
+        rec[IN_RPY + k] = rpyBody[k];
+        rec[IN_NRM + k] = cp.flat_ground ? (k == 2 ? 1.f : 0.f) : s.normal[k];
+        rec[IN_ANG + k] = omegaBody[k];
+      }
     }
     for (int i = 0; i < h; ++i) {                                             // Gait.getMpcTable (Gait.py:69-84)
       const double it = fmod((double)i + iteration + 1.0, (double)nseg);
-      for (int j = 0; j < 4; ++j) {
+      for (int j = l0; j < l1; ++j) {
         float pg = (float)it - off[j];
         if (pg < 0.f) pg += (float)nseg;
         rec[IN_CONTACT + 4 * i + j] = (pg < dur[j]) ? 1.f : 0.f;
       }
     }
     const int o_foot = 28 + 4 * h, o_fric = 40 + 4 * h, o_dpos = 44 + 4 * h, o_dvel = 47 + 4 * h, o_drpy = 50 + 4 * h, o_dang = 53 + 4 * h;
-    for (int k = 0; k < 12; ++k) rec[o_foot + k] = s.foot_positions[k];
-    for (int k = 0; k < 4; ++k) rec[o_fric + k] = rc.mu;
-    rec[o_dpos] = 0.f; rec[o_dpos + 1] = 0.f; rec[o_dpos + 2] = (float)rc.body_height;
-    rec[o_dvel] = x_vel_des; rec[o_dvel + 1] = y_vel_des; rec[o_dvel + 2] = 0.f;
-    rec[o_drpy] = rec[o_drpy + 1] = rec[o_drpy + 2] = 0.f;
-    rec[o_dang] = 0.f; rec[o_dang + 1] = 0.f; rec[o_dang + 2] = yaw_rate;
+    for (int k = 3 * l0; k < 3 * l1; ++k) rec[o_foot + k] = s.foot_positions[k];
+    for (int k = l0; k < l1; ++k) rec[o_fric + k] = rc.mu;
+    if (lead) {
+      rec[o_dpos] = 0.f; rec[o_dpos + 1] = 0.f; rec[o_dpos + 2] = (float)rc.body_height;
+      rec[o_dvel] = x_vel_des; rec[o_dvel + 1] = y_vel_des; rec[o_dvel + 2] = 0.f;
+      rec[o_drpy] = rec[o_drpy + 1] = rec[o_drpy + 2] = 0.f;
+      rec[o_dang] = 0.f; rec[o_dang + 1] = 0.f; rec[o_dang + 2] = yaw_rate;
+    }
   }
+}
+MPC_HD void ctrl_pre(CtrlState &s, const RobotConst &rc, const GaitTable &gt, const CtrlParams &cp, const float *dof,
+                     const float *est, const float *cmd, float *rec) {
+  ctrl_pre_legs(s, rc, dof);
+  ctrl_pre_rest(s, rc, gt, cp, est, cmd, rec);
 }
 
 // interplation.py:4-26
@@ -437,14 +457,14 @@ MPC_HD float bez_d(float x) { return 6.0f * x * (1.0f - x); }
 // ---- second half of the tick ------------------------------------------------------------------
 // forces: this robot's solver output (fp64 [12h], first 12 used) -- read only when the solve ran and
 // reported OSQP_SOLVED.  torques: 12 floats, FL FR RL RR x (hip, thigh, calf).
-MPC_HD void ctrl_post(CtrlState &s, const RobotConst &rc, const double *forces, int solved, float *torques) {
+MPC_HD void ctrl_post(CtrlState &s, const RobotConst &rc, const double *forces, int solved, float *torques, int l0 = 0, int l1 = 4) {
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
   if (s.do_solve && solved)
-    for (int k = 0; k < 12; ++k) s.f_ff[k] = (float)forces[k];                // ConvexMPCLocomotion.py:186-187
+    for (int k = 3 * l0; k < 3 * l1; ++k) s.f_ff[k] = (float)forces[k];      // ConvexMPCLocomotion.py:186-187
   const float height = (float)(rc.body_height / 3.0);                          // :287
-  for (int foot = 0; foot < 4; ++foot) {
+  for (int foot = l0; foot < l1; ++foot) {
     const float swing = s.swing_states[foot];
     float hloc[3];
     hip_location(rc, foot, hloc);
