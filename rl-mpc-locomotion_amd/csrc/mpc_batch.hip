@@ -812,6 +812,7 @@ __global__ void ctrl_set_gait_kernel(int n, CtrlState *st, const int *gait_id) {
 // writes back its leg's fields; what concerns the whole robot every lane computes alike and lane 0 writes.  One lane per robot made
 // the tick's 24 double-precision sines and cosines and its float16-emulating arithmetic one dependent chain (estimator + pre + post:
 // 43 us per tick at 4096 robots, 10 % of a tick).
+static_assert(sizeof(CtrlState) == 888, "CtrlState changed: every field must be stored by store_leg_fields or store_robot_fields");
 __device__ __forceinline__ void store_leg_fields(CtrlState &d, const CtrlState &s, int leg) {
   d.first_swing[leg] = s.first_swing[leg];
   d.swing_time_remaining[leg] = s.swing_time_remaining[leg];
