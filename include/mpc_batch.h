@@ -55,7 +55,7 @@ typedef struct mpc_batch mpc_batch;
 enum {
   MPC_OK = 0,
   MPC_E_ARG = -1,        /* bad argument (null pointer, n <= 0, ...) */
-  MPC_E_HORIZON = -2,    /* planning horizon not compiled in (supported: see mpc_supported_horizons) */
+  MPC_E_HORIZON = -2,    /* planning horizon outside the built range (mpc_supported_horizons: 2 .. 20 in the shipped library) */
   MPC_E_HIP = -3,        /* HIP runtime error */
   MPC_E_NODEVICE = -4    /* no usable GPU */
 };
@@ -86,7 +86,11 @@ void mpc_batch_destroy(mpc_batch *b);
  *                    submodule in the reference; its RESULT is reproduced, by an active-set method of this library's own
  *                    (csrc/mpc_wrench.h active_set: Goldfarb-Idnani's dual method on the problem with the swing feet eliminated,
  *                    like :838-856, then the polish on its set, accepted only if it passes the optimality conditions at 1e-10;
- *                    info[0] = working-set changes).  Eliminated feet return exact 0.0 (:924-927).  That branch returns its
+ *                    info[0] = working-set changes).  Eliminated feet return -0.0, sign bit included: that branch sets them to 0.0f and
+ *                    negates the whole vector on the way out (:924-927, 940-942).  NOT reproduced, because qpOASES' source is an empty
+ *                    submodule of the reference: its own iteration -- the nWSR = 100 working-set cap under setToMPC() tolerances
+ *                    (:906-917), after which qpOASES hands back an unconverged iterate; here every robot ends at the optimum (or on
+ *                    the fall-back route below).  That branch returns its
  *                    vector whatever its solver's status (:906-947): so does this mode -- a robot that the fall-back route (ADMM
  *                    towards 1e-9) leaves unfinished reports SOLVED_INACCURATE / MAX_ITER_REACHED WITH its iterate written; only
  *                    a non-finite / non-convex problem (NON_CVX) writes nothing. */
@@ -105,6 +109,14 @@ int mpc_batch_solve(mpc_batch *b, const float *d_in, double *d_forces, int *d_in
 /* The same with a float64 input record (the reference's pybind11 signature takes std::vector<double>, mpc_osqp.cc:578-591:
  * nothing is narrowed on this entry). */
 int mpc_batch_solve_f64(mpc_batch *b, const double *d_in, double *d_forces, int *d_info, void *stream);
+
+/* The same with a float16 input record (IEEE binary16: torch.float16 / numpy.float16 bits) -- BASELINE.json configs[4], "fp16 state":
+ * the 13 arguments stored in half precision.  Every value is widened to double on load and the arithmetic is the same fp64 as on the
+ * other entries, so the result equals the float64 entry fed the same (fp16-representable) values bit for bit.  (The reference's
+ * own state arguments are partly fp16 already: com_roll_pitch_yaw arrives as numpy.float16, MPC_Controller/common/StateEstimator.py /
+ * math_utils/orientation_tools.py:120-133.  "fp32 accumulate" is NOT offered: fp32 arithmetic does not hold BASELINE's 1e-3 bar against
+ * OSQP on 42-52 % of the robots, profiles/r02_fp32_port_failure_rate.json.) */
+int mpc_batch_solve_f16(mpc_batch *b, const unsigned short *d_in, double *d_forces, int *d_info, void *stream);
 
 /* Cold-start the listed robots (HOST array of indices); ids == NULL resets all. */
 int mpc_batch_reset(mpc_batch *b, const int *ids, int k, void *stream);
@@ -209,6 +221,9 @@ int mpc_ctrl_solver_info(mpc_ctrl *c, int *h_info);                          /* 
 int mpc_ctrl_fsm_init(mpc_ctrl *c, const int *control_mode, int operating_mode, int check_safety, void *stream);
 int mpc_ctrl_run_fsm(mpc_ctrl *c, const float *d_dof, const float *d_body, const float *d_cmd, const int *d_request, float *d_torques, void *stream);
 int mpc_ctrl_fsm_reset(mpc_ctrl *c, const int *ids, int k, const int *control_mode, void *stream);
+/* mpc_ctrl_fsm_reset with a DEVICE array of indices (an env_ids tensor): stream-ordered, no host round trip; the control modes of the last
+ * (re)initialisation are kept. */
+int mpc_ctrl_fsm_reset_device(mpc_ctrl *c, const int *d_ids, int k, void *stream);
 int mpc_ctrl_fsm_state(mpc_ctrl *c, int *h_out);
 
 /* ---- weight policy: observations -> MPC weights (the deployment path of the learned policy) ----------

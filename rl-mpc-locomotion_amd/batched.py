@@ -47,17 +47,19 @@ class BatchedConvexMpc:
             self._handle = None
 
     def solve(self, inputs, forces=None, info=None):
-        """inputs: cuda float32 [N, 56+4h] (layout.py).  Returns (forces f64 [N,12h], info i32 [N,8]).
+        """inputs: cuda [N, 56+4h] (layout.py) -- float32 (what the reference's Python holds), float64 (what pybind11 widens it to) or
+        float16 (BASELINE configs[4]: the state stored in half precision); the arithmetic is fp64 whatever the storage type.
+        Returns (forces f64 [N,12h], info i32 [N,8]).
         Rows whose info[:,1] != 1 (not OSQP_SOLVED) keep their previous forces (the reference returns
         an empty list there, mpc_osqp.cc:781-794)."""
         import torch
-        if inputs.dtype != torch.float32 or not inputs.is_cuda or not inputs.is_contiguous() or tuple(inputs.shape) != (self.n, self.in_len):
-            raise ValueError(f"inputs must be a contiguous cuda float32 tensor of shape {(self.n, self.in_len)}")
+        entry = {torch.float32: "mpc_batch_solve", torch.float64: "mpc_batch_solve_f64", torch.float16: "mpc_batch_solve_f16"}.get(inputs.dtype)
+        if entry is None or not inputs.is_cuda or not inputs.is_contiguous() or tuple(inputs.shape) != (self.n, self.in_len):
+            raise ValueError(f"inputs must be a contiguous cuda float32 / float64 / float16 tensor of shape {(self.n, self.in_len)}")
         forces = self.forces if forces is None else forces
         info = self.info if info is None else info
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        _lib.check(_lib.lib().mpc_batch_solve(self._handle, inputs.data_ptr(), forces.data_ptr(), info.data_ptr(), stream),
-                   "mpc_batch_solve")
+        _lib.check(getattr(_lib.lib(), entry)(self._handle, inputs.data_ptr(), forces.data_ptr(), info.data_ptr(), stream), entry)
         return forces, info
 
     def set_max_iter(self, max_iter):

@@ -1,6 +1,6 @@
-// mpc_batch.hip -- gfx950 kernels + the C ABI of include/mpc_batch.h.
-// One workgroup per robot and kernel: assembly and Ruiz scaling (mpc_core.h, dense P in register tiles), then the OSQP
-// iteration in the wrench space (mpc_wrench.h; one wavefront per robot at h = 10).  All arithmetic fp64.
+// mpc_batch.hip -- the C ABI of include/mpc_batch.h: handles, record buffers, launches; the controller / FSM / policy kernels.
+// The solver kernels are instantiated per planning horizon in mpc_horizon.hip (one translation unit per horizon, mpc_horizon.h) and
+// reached through their HorizonOps entries.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -9,33 +9,18 @@
 #include <string>
 #include <vector>
 
-#define MPC_LOCKSTEP 1   // a single-wavefront workgroup executes its LDS instructions in program order (mpc_wrench.h: Shared::NBUF)
 #include "../../include/mpc_batch.h"
 #include "controller.h"
 #include "mpc_core.h"
+#include "mpc_horizon.h"
 #include "mpc_model.h"
-#include "mpc_wrench.h"
 #include "policy_mlp.h"
 
 using namespace mpc;
 
-// minimum waves per SIMD the register allocator must leave room for in the prep kernel: 3 -> a 256-thread workgroup (h = 10)
-// gets 168 VGPRs and three robots share a CU.  (Four -- 128 VGPRs, 40 KB of LDS each -- were measured slower: 0.278 against
-// 0.235 ms per 4096 robots; the Ruiz passes then spill.)
-#ifndef MPC_SCALE_MIN_WAVES
-#define MPC_SCALE_MIN_WAVES 3
-#endif
-#ifndef MPC_MIN_WAVES_MAX_T
-#define MPC_MIN_WAVES_MAX_T 256   // larger workgroups (h = 16), and the four-tiles-per-thread layout (h = 20), run one per CU
-#endif
-// waves per SIMD of the solve kernel (h = 10: one wave per robot).  1 -> the full 512-register budget (AGPRs as spill space), four
-// robots per CU: measured faster than two waves per SIMD at 256 registers, which spills to scratch memory
-#ifndef MPC_SOLVE_MIN_WAVES
-#define MPC_SOLVE_MIN_WAVES 1
-#endif
-#ifndef MPC_SOLVE_MIN_WAVES_WIDE   // the multi-wave workgroups of the long horizons (128 threads at h = 12, 256 at h = 16 / 20): two waves per
-#define MPC_SOLVE_MIN_WAVES_WIDE 2  // SIMD hide their barriers (measured: h = 16 3.00 -> 2.35 ms, h = 20 3.55 -> 2.83 ms per 4096 robots)
-#endif
+#define MPC_DECL_OPS(HH) extern "C" const mpc::HorizonOps *mpc_horizon_ops_##HH(void);
+MPC_HORIZON_LIST(MPC_DECL_OPS)
+#undef MPC_DECL_OPS
 
 namespace {
 
@@ -59,373 +44,14 @@ struct DeviceGuard {
     if (e_ != hipSuccess) return fail(MPC_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
-// A double moved between the lanes of a quad (lanes 4 q .. 4 q + 3) with DPP quad permutes: two v_mov_b32_dpp, no LDS.
-template <int CTRL>
-__device__ __forceinline__ double quad_perm(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
-  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
-constexpr int quad_ctrl(int a, int b, int c, int d) { return a | (b << 2) | (c << 4) | (d << 6); }
-__device__ __forceinline__ double read_lane(double v, int lane) {   // a lane's value as a wavefront-uniform scalar
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
+constexpr int kWaitVm0 = 0x0F70;   // s_waitcnt vmcnt(0) (gfx9 encoding: vmcnt = simm16[3:0] | [15:14], expcnt [6:4] = 7, lgkmcnt [11:8] = 15: not waited for)
 
-// WAVE: the workgroup is a single wavefront (the h = 10 solve kernel).  Its LDS instructions execute in program order, so a
-// phase boundary needs neither s_barrier nor a wait for the stores to land (the loads of the next phase queue up behind them):
-// only the compiler has to keep the order (wavefront-scope fence).
-template <class TH, bool WAVE = false>
-struct DeviceExec {
-  TH &th;
-  __device__ __forceinline__ TH &first() { return th; }   // (after a workgroup-wide reduction every thread holds the same value)
-  template <class F>
-  __device__ __forceinline__ void par(F &&f) {
-    f(th);
-    if constexpr (WAVE) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    } else __syncthreads();
-  }
-  // a phase that hands nothing over through LDS (its results stay in registers or go to the quad operations below)
-  template <class F>
-  __device__ __forceinline__ void seq(F &&f) { f(th); }
-  // acc(th)[0 .. N) <- the sum over the four lanes of the quad, the same bits in every lane: (l0 + l1) + (l2 + l3)
-  template <int N, class A>
-  __device__ __forceinline__ void quad_allsum(A &&acc) {
-    double *v = acc(th);
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const double a = v[i] + quad_perm<quad_ctrl(1, 0, 3, 2)>(v[i]);
-      v[i] = a + quad_perm<quad_ctrl(2, 3, 0, 1)>(a);
-    }
-  }
-  // Reduce-scatter of six per-lane values over the quad: dst(th)[0] <- the quad's sum of src[j] in lane j, dst(th)[1] <- the sum of
-  // src[4 + (j & 1)], each with the association of quad_allsum, (l_j + l_j^1) + (l_j^2 + l_j^3).  A lane hands its partner what the
-  // partner keeps: three exchanges with lane j ^ 1, two with lane j ^ 2 (the all-sum of all six takes twelve, and a select after it).
-  template <class S, class D>
-  __device__ __forceinline__ void quad_scatter6(S &&src, D &&dst) {
-    const double *w = src(th);
-    double *g = dst(th);
-    const bool odd = threadIdx.x & 1, hi = threadIdx.x & 2;
-    double a[3];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {      // lanes 0, 2 keep the components 0, 2, 4 of their pair; lanes 1, 3 keep 1, 3, 5
-      const double keep = odd ? w[2 * p + 1] : w[2 * p], give = odd ? w[2 * p] : w[2 * p + 1];
-      a[p] = keep + quad_perm<quad_ctrl(1, 0, 3, 2)>(give);
-    }
-    const double keep = hi ? a[1] : a[0], give = hi ? a[0] : a[1];     // lanes 0, 1 end with component 0 / 1, lanes 2, 3 with 2 / 3
-    g[0] = keep + quad_perm<quad_ctrl(2, 3, 0, 1)>(give);
-    g[1] = a[2] + quad_perm<quad_ctrl(2, 3, 0, 1)>(a[2]);
-  }
-  // acc(th)[0] <- the sum, acc(th)[1] <- the maximum (of non-negative values) over the 64 lanes of the wavefront, the same bits in
-  // every lane: four DPP steps leave every lane with its row's (16 lanes) result, v_readlane fetches the four rows
-  template <class A>
-  __device__ __forceinline__ void wave_sum_max(A &&acc) {
-    double *v = acc(th);
-    double a = v[0], m = v[1];
-    a += quad_perm<quad_ctrl(1, 0, 3, 2)>(a);  m = fmax(m, quad_perm<quad_ctrl(1, 0, 3, 2)>(m));
-    a += quad_perm<quad_ctrl(2, 3, 0, 1)>(a);  m = fmax(m, quad_perm<quad_ctrl(2, 3, 0, 1)>(m));
-    a += quad_perm<0x141>(a);                  m = fmax(m, quad_perm<0x141>(m));     // row_half_mirror
-    a += quad_perm<0x140>(a);                  m = fmax(m, quad_perm<0x140>(m));     // row_mirror
-    v[0] = (read_lane(a, 0) + read_lane(a, 16)) + (read_lane(a, 32) + read_lane(a, 48));
-    v[1] = fmax(fmax(read_lane(m, 0), read_lane(m, 16)), fmax(read_lane(m, 32), read_lane(m, 48)));
-  }
-  // val(th)[0] <- the maximum over the workgroup's threads, idx(th) <- the lowest thread holding it (the same in every thread).
-  // One wavefront: DPP row reductions + readlane + a ballot; several: LDS scratch (>= blockDim.x doubles) and two barriers.
-  template <class V, class I>
-  __device__ __forceinline__ void wg_argmax(V &&val, I &&idx, double *scratch) {
-    double *v = val(th);
-    if constexpr (WAVE) {
-      double m = v[0];
-      m = fmax(m, quad_perm<quad_ctrl(1, 0, 3, 2)>(m));
-      m = fmax(m, quad_perm<quad_ctrl(2, 3, 0, 1)>(m));
-      m = fmax(m, quad_perm<0x141>(m));
-      m = fmax(m, quad_perm<0x140>(m));
-      m = fmax(fmax(read_lane(m, 0), read_lane(m, 16)), fmax(read_lane(m, 32), read_lane(m, 48)));
-      const unsigned long long who = __ballot(v[0] == m);
-      idx(th) = who ? __ffsll((long long)who) - 1 : 0;
-      v[0] = m;
-    } else {
-      scratch[threadIdx.x] = v[0];
-      __syncthreads();
-      double m = scratch[0];
-      int ml = 0;
-      for (int i = 1; i < (int)blockDim.x; ++i) { const double x = scratch[i]; if (x > m) { m = x; ml = i; } }
-      __syncthreads();
-      v[0] = m; idx(th) = ml;
-    }
-  }
-  template <class V>
-  __device__ __forceinline__ void wg_sum(V &&val, double *scratch) {
-    double *v = val(th);
-    double a = v[0];
-    a += quad_perm<quad_ctrl(1, 0, 3, 2)>(a);
-    a += quad_perm<quad_ctrl(2, 3, 0, 1)>(a);
-    a += quad_perm<0x141>(a);
-    a += quad_perm<0x140>(a);
-    a = (read_lane(a, 0) + read_lane(a, 16)) + (read_lane(a, 32) + read_lane(a, 48));
-    if constexpr (WAVE) v[0] = a;
-    else {
-      if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = a;
-      __syncthreads();
-      double tot = scratch[0];
-      for (int w = 1; w < (int)(blockDim.x >> 6); ++w) tot += scratch[w];
-      __syncthreads();
-      v[0] = tot;
-    }
-  }
-  // dst(th)[r] <- src(lane r & 3 of the quad)[r >> 2], r = 0 .. 5
-  template <class S, class D>
-  __device__ __forceinline__ void quad_gather6(S &&src, D &&dst) {
-    const double *sv = src(th);
-    double *dv = dst(th);
-    dv[0] = quad_perm<quad_ctrl(0, 0, 0, 0)>(sv[0]);
-    dv[1] = quad_perm<quad_ctrl(1, 1, 1, 1)>(sv[0]);
-    dv[2] = quad_perm<quad_ctrl(2, 2, 2, 2)>(sv[0]);
-    dv[3] = quad_perm<quad_ctrl(3, 3, 3, 3)>(sv[0]);
-    dv[4] = quad_perm<quad_ctrl(0, 0, 0, 0)>(sv[1]);
-    dv[5] = quad_perm<quad_ctrl(1, 1, 1, 1)>(sv[1]);
-  }
-};
-
-// The planning horizons compiled into the library (ConvexMpc accepts any planning_horizon, mpc_osqp.cc:186-190, 508-574; the shipped
-// Python uses 10, ConvexMPCLocomotion.py:27; BASELINE's configurations 10, 16, 20).  Every entry instantiates the prep, solve (job),
-// exact and fall-back kernels for that horizon: -DMPC_HORIZON_LIST to build another set (any h >= 2 whose workgroups fit: h <= 20).
-#ifndef MPC_HORIZON_LIST
-#define MPC_HORIZON_LIST(X) X(8) X(10) X(12) X(16) X(20)
-#endif
-
-constexpr int kSchedNext = 0, kSchedHead = 1, kSchedTail = 2, kSchedJobs = 3, kSchedLen = 4;   // job bookkeeping of a launch (mpc_solve_jobs_kernel)
-
-// Solve kernel (mpc_wrench.h Solver): ADMM + polish of every active robot, from the QP and scale records.  EXACT: the
-// exact-optimum mode (the reference's qpOASES branch) -- a separate instantiation, so that its outer loop does not touch the
-// register allocation of the OSQP mode.
-template <int H, bool EXACT>
-__global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES : MPC_SOLVE_MIN_WAVES_WIDE)) void mpc_solve_kernel(
-    int n, const RobotModel *__restrict__ models, double *__restrict__ state, const double *__restrict__ qp,
-    const double *__restrict__ sc, double *__restrict__ forces, int *__restrict__ info, long long *__restrict__ prof,
-    const int *__restrict__ order, const int *__restrict__ sched, const int *__restrict__ ready, int max_iter) {
-  // static LDS: absolute addresses fold into the ds_* offset fields
-  __shared__ __attribute__((aligned(16))) Shared<H> sh;
-  using C = Cfg<H>;
-  // OSQP mode: the job list holds the launch's active robots (robots whose controller is between two MPC updates have no job), longest
-  // expected solve first (order_block).  Exact mode: this kernel is the second launch -- the robots whose active set mpc_exact_kernel
-  // could not certify, listed in `ready` -- and takes the ADMM route.
-  if ((int)blockIdx.x >= (EXACT ? sched[kSchedTail] : sched[kSchedJobs])) return;
-  const int robot = EXACT ? ready[blockIdx.x] : order[blockIdx.x];
-  WThread<H> th;
-  th.init(threadIdx.x);
-#pragma unroll
-  for (int j = 0; j < C::TE; ++j) th.Mx[j] = 0;
-  using Ex = DeviceExec<WThread<H>, (C::TW <= 64)>;
-  Ex ex{th};
-  const RobotModel &mdl = models[robot];   // (uniform loads; a by-value copy indexed at run time would sit in scratch)
-  Solver<H, Ex> sv{ex,
-                                       sh,
-                                       mdl,
-                                       state + (size_t)robot * state_len<H>(),
-                                       qp + (size_t)robot * C::QP_LEN,
-                                       sc + (size_t)robot * C::SC_LEN,
-                                       forces + (size_t)robot * C::N,
-                                       info + (size_t)robot * kInfoLen,
-                                       prof ? prof + (size_t)robot * kProfLen : nullptr};
-  if constexpr (EXACT) sv.exact();
-  else sv.max_iter = max_iter;
-  sv.template run<EXACT>();
-}
-
-// Exact mode (the reference's qpOASES branch), first launch: the dual active-set method + the polish on its set (mpc_wrench.h
-// active_set / run_active_set), one workgroup per robot.  A robot whose set is not certified (the polished point fails the optimality
-// test, the working set overflows its slots) is appended to `ready` for the second launch, mpc_solve_kernel<H, true>.
-template <int H>
-__global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES : MPC_SOLVE_MIN_WAVES_WIDE)) void mpc_exact_kernel(
-    const RobotModel *__restrict__ models, double *__restrict__ state, const double *__restrict__ qp, const double *__restrict__ sc,
-    double *__restrict__ forces, int *__restrict__ info, long long *__restrict__ prof, const int *__restrict__ order, int *__restrict__ sched,
-    int *__restrict__ ready) {
-  __shared__ __attribute__((aligned(16))) Shared<H> sh;
-  __shared__ __attribute__((aligned(16))) GiShared<H> gsh;
-  using C = Cfg<H>;
-  if ((int)blockIdx.x >= sched[kSchedJobs]) return;
-  const int robot = order[blockIdx.x];
-  WThread<H> th;
-  th.init(threadIdx.x);
-#pragma unroll
-  for (int j = 0; j < C::TE; ++j) th.Mx[j] = 0;
-  using Ex = DeviceExec<WThread<H>, (C::TW <= 64)>;
-  Ex ex{th};
-  Solver<H, Ex> sv{ex, sh, models[robot], state + (size_t)robot * state_len<H>(), qp + (size_t)robot * C::QP_LEN, sc + (size_t)robot * C::SC_LEN,
-                   forces + (size_t)robot * C::N, info + (size_t)robot * kInfoLen, prof ? prof + (size_t)robot * kProfLen : nullptr};
-  sv.exact();
-  sv.gi = &gsh;
-  const bool ok = sv.run_active_set();
-  if (!ok && threadIdx.x == 0) ready[atomicAdd(&sched[kSchedTail], 1)] = robot;
-}
-
-// The OSQP-mode solve as a PERSISTENT kernel: one workgroup per wave slot of the chip, each pulling jobs until none is left.  A solve
-// is two jobs (mpc_wrench.h admm_job / polish_job): the ADMM part, 25 to 250+ iterations long, and the polish, the same ~100 k cycles for
-// every robot and dependent on the ADMM part's result only (x, z, y in the state record, two residuals).  With one job per robot a
-// 4096-robot launch is four jobs of very different length per wave slot, and the launch ends when the unluckiest slot does
-// (measured 0.69 ms against 0.55 ms of work per slot, tools/sched_model.py); with the polishes as uniform filler jobs -- taken only
-// once no ADMM job is left to start -- the tail shrinks to a fraction of one polish.
-//   sched[kSchedNext]  next ADMM job (index into `order`)          sched[kSchedTail]  polish entries published
-//   sched[kSchedHead]  next polish entry to take                   sched[kSchedJobs]  number of jobs (active robots; order_block)
-//   ready[i]           -1 not yet published; robot: polish it; -2: that solve needs no polish (not SOLVED)
-// An ADMM job publishes exactly one entry, in completion order, after a device-scope release of its results; a wave that takes entry
-// i spins until it is there (every job of the launch is then running or done, so the wait is bounded by the longest ADMM part)
-// and acquires before it loads the record.
-template <int H>
-__global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES : MPC_SOLVE_MIN_WAVES_WIDE)) void mpc_solve_jobs_kernel(
-    const RobotModel *__restrict__ models, double *__restrict__ state, const double *__restrict__ qp, double *__restrict__ sc,
-    double *__restrict__ forces, int *__restrict__ info, long long *__restrict__ prof, const int *__restrict__ order, int *__restrict__ sched,
-    int *__restrict__ ready, int max_iter) {
-  __shared__ __attribute__((aligned(16))) Shared<H> sh;
-  __shared__ int job;
-  using C = Cfg<H>;
-  using Ex = DeviceExec<WThread<H>, (C::TW <= 64)>;
-  WThread<H> th;
-  th.init(threadIdx.x);
-  Ex ex{th};
-  const int njobs = sched[kSchedJobs];
-  auto solver = [&](int robot) {
-    return Solver<H, Ex>{ex, sh, models[robot], state + (size_t)robot * state_len<H>(), qp + (size_t)robot * C::QP_LEN, sc + (size_t)robot * C::SC_LEN,
-                         forces + (size_t)robot * C::N, info + (size_t)robot * kInfoLen, prof ? prof + (size_t)robot * kProfLen : nullptr};
-  };
-  for (;;) {     // ---- ADMM jobs, in the dispatch order of order_block
-    [[maybe_unused]] const long long tf0 = MPC_CLOCK();
-    ex.par([&](WThread<H> &t) { if (t.tid == 0) job = atomicAdd(&sched[kSchedNext], 1); });
-    const int idx = job;
-    ex.par([](WThread<H> &) {});     // (everybody has read `job` before thread 0 overwrites it)
-    if (idx >= njobs) break;
-    const int robot = order[idx];
-#pragma unroll
-    for (int j = 0; j < C::TE; ++j) th.Mx[j] = 0;
-    bool pol;
-    {
-      Solver<H, Ex> sv = solver(robot);
-      sv.max_iter = max_iter;
-      sv.jobrec = sc + (size_t)robot * C::SC_LEN + C::SC_JOB;
-      pol = sv.admm_job();
-      if (MPC_PROFILE_SUB == 8 && prof && threadIdx.x == 0) MPC_GST(prof + (size_t)robot * kProfLen + 1, (long long)(sv.t_start - tf0));
-    }
-    // the job's results are device-coherent stores (MPC_GST): once they have completed -- a workgroup-scope release is the wait for
-    // that, with no L2 write-back -- the entry may be published
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    ex.par([&](WThread<H> &t) {
-      if (t.tid == 0) {
-        const int pos = atomicAdd(&sched[kSchedTail], 1);
-        __hip_atomic_store(&ready[pos], pol ? robot : -2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    });
-  }
-  for (;;) {     // ---- polish jobs, in completion order of the ADMM parts
-    [[maybe_unused]] const long long tf0 = MPC_CLOCK();
-    ex.par([&](WThread<H> &t) {
-      if (t.tid == 0) {
-        const int pos = atomicAdd(&sched[kSchedHead], 1);
-        int e = -2;
-        if (pos < njobs) {
-          while ((e = __hip_atomic_load(&ready[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == -1) __builtin_amdgcn_s_sleep(32);
-        } else e = -3;
-        job = e;
-      }
-    });
-    const int e = job;
-    ex.par([](WThread<H> &) {});
-    if (e == -3) break;
-    if (e < 0) continue;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // (the ADMM job's results are read with device-coherent loads, MPC_GLD: no L2 invalidate)
-#pragma unroll
-    for (int j = 0; j < C::TE; ++j) th.Mx[j] = 0;
-    Solver<H, Ex> sv = solver(e);
-    sv.jobrec = sc + (size_t)e * C::SC_LEN + C::SC_JOB;
-    sv.polish_job();
-    if (MPC_PROFILE_SUB == 8 && prof && threadIdx.x == 0) MPC_GST(prof + (size_t)e * kProfLen + 2, (long long)(sv.t_start - tf0));
-  }
-}
-
-// Workgroup -> robot order for the solve kernel of THIS launch: robots sorted by the shader cycles their previous solve took,
-// longest first.  Runs as one extra workgroup of the assembly kernel (blockIdx.x == 0), i.e. hidden behind the assembly.
-// Warm-started robots repeat their iteration counts from step to step, and solve times differ 3x between a 25-iteration
-// and a 75-iteration robot; dispatching the long ones first keeps the tail of the launch short (a counting sort over
-// cycles / 16384 in one workgroup; the order inside a bucket is arbitrary, results do not depend on it).
-// The sort key is the LONGEST of the robot's last kOrderHistory solves (one byte each, cycles / 16384): the reference's gaits
-// have ten segments, so a robot's hard phases (touch-down, lift-off) recur every ten solves, and a solve that is queued as
-// short but runs long is what stretches the tail (tools/tail_model.py: ordering by the previous solve alone 0.717 ms per
-// launch on average, by this key 0.692, clairvoyant 0.650).
-constexpr int kOrderBuckets = 256, kOrderHistory = 10;
-// Also the launch's job bookkeeping: only ACTIVE robots (active == null: all) enter the list, sched[kSchedJobs] = their number, the
-// job counters and the polish entries of mpc_solve_jobs_kernel are reset.
-__device__ void order_block(int n, const long long *__restrict__ prof, unsigned char *__restrict__ hist, int slot, int *__restrict__ order,
-                            const int *__restrict__ active, int *__restrict__ sched, int *__restrict__ ready) {
-  __shared__ int cnt[kOrderBuckets], base[kOrderBuckets];
-  __shared__ int filled;
-  for (int b = threadIdx.x; b < kOrderBuckets; b += blockDim.x) cnt[b] = 0;
-  for (int r = threadIdx.x; r < n; r += blockDim.x) ready[r] = -1;
-  if (threadIdx.x == 0) filled = 0;
-  __syncthreads();
-  constexpr int kPer = 8;                         // robots per thread held in registers (n <= 8192 per pass)
-  for (int r0 = 0; r0 < n; r0 += kPer * blockDim.x) {
-    int bk[kPer], rank[kPer];
-#pragma unroll
-    for (int i = 0; i < kPer; ++i) {
-      const int r = r0 + i * blockDim.x + threadIdx.x;
-      bk[i] = -1;
-      if (r < n && (!active || active[r])) {
-        const long long c = prof[(size_t)r * kProfLen + kProfLen - 1] >> 14;
-        unsigned char *hr = hist + (size_t)r * kOrderHistory;
-        hr[slot] = (unsigned char)(c < 0 ? 0 : (c >= kOrderBuckets ? kOrderBuckets - 1 : c));
-        int mx = 0;
-#pragma unroll
-        for (int k = 0; k < kOrderHistory; ++k) mx = max(mx, (int)hr[k]);
-        bk[i] = mx;
-        rank[i] = atomicAdd(&cnt[bk[i]], 1);      // rank inside the bucket (within this pass)
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int acc = filled;                           // earlier passes fill the front of `order` (only n > 8192 has several)
-      for (int b = kOrderBuckets - 1; b >= 0; --b) { base[b] = acc; acc += cnt[b]; cnt[b] = 0; }
-      filled = acc;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < kPer; ++i)
-      if (bk[i] >= 0) order[base[bk[i]] + rank[i]] = r0 + i * blockDim.x + threadIdx.x;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) { sched[kSchedNext] = 0; sched[kSchedHead] = 0; sched[kSchedTail] = 0; sched[kSchedJobs] = filled; }
-}
-
-// Prep kernel (mpc_core.h Assembler + Scaler): QP record (q, bounds, cone block, wrench form of P) and scale record (OSQP's Ruiz
-// equilibration) of every active robot.  The dense P lives only in this kernel's registers.
-template <int H>
-__global__ __launch_bounds__(Cfg<H>::T, (Cfg<H>::T <= MPC_MIN_WAVES_MAX_T && Cfg<H>::NT == 1 ? MPC_SCALE_MIN_WAVES : 1)) void mpc_prep_kernel(
-    int n, const RobotModel *__restrict__ models, const float *__restrict__ in, const double *__restrict__ in64, const double *__restrict__ state,
-    double *__restrict__ qp, double *__restrict__ sc, long long *__restrict__ prof, const int *__restrict__ active, int *__restrict__ order,
-    unsigned char *__restrict__ hist, int hist_slot, int *__restrict__ sched, int *__restrict__ ready) {
-  __shared__ __attribute__((aligned(16))) PrepShared<H> sh;
-  using C = Cfg<H>;
-  if (blockIdx.x == 0) {      // the extra workgroup (first, so that it starts at once): job list / dispatch order of the solve kernel that follows
-    order_block(n, prof, hist, hist_slot, order, active, sched, ready);
-    return;
-  }
-  const int robot = (int)blockIdx.x - 1;
-  if (robot >= n) return;
-  if (active && !active[robot]) return;
-  Thread<H> th;
-  th.init(threadIdx.x);
-#pragma unroll
-  for (int j = 0; j < C::NT * C::TE; ++j) th.Mx[j] = 0;
-  using Ex = DeviceExec<Thread<H>>;
-  Ex ex{th};
-  const RobotModel &mdl = models[robot];
-  double *qpr = qp + (size_t)robot * C::QP_LEN;
-  Assembler<H, Ex> am{ex, sh.as, mdl, in ? in + (size_t)robot * C::IN_LEN : nullptr, in64 ? in64 + (size_t)robot * C::IN_LEN : nullptr, sh.u12, qpr, prof ? prof + (size_t)robot * kProfLen : nullptr};
-  am.run();
-  Scaler<H, Ex> sk{ex, sh.sc, state + (size_t)robot * state_len<H>(), sh.u12, mdl.alpha, qpr, sc + (size_t)robot * C::SC_LEN, prof ? prof + (size_t)robot * kProfLen : nullptr};
-  sk.run();
+// the kernel set of a planning horizon, or null when the library was built without it (-DMPC_HORIZON_LIST)
+const HorizonOps *horizon_ops(int h) {
+#define MPC_ITEM(HH) if (h == HH) return mpc_horizon_ops_##HH();
+  MPC_HORIZON_LIST(MPC_ITEM)
+#undef MPC_ITEM
+  return nullptr;
 }
 
 __global__ void reset_kernel(double *state, int state_len, const int *ids, int k, int n) {
@@ -435,34 +61,14 @@ __global__ void reset_kernel(double *state, int state_len, const int *ids, int k
   for (int i = threadIdx.x; i < state_len; i += blockDim.x) state[(size_t)robot * state_len + i] = 0.0;
 }
 
-template <int H>
-int launch(int n, const RobotModel *models, const float *in, const double *in64, double *state, double *qp, double *sc, double *forces, int *info,
-           long long *prof, const int *active, int *order, unsigned char *hist, int hist_slot, hipEvent_t *ev, hipStream_t stream, int exact, int max_iter,
-           int *sched, int *ready, int job_slots) {
-  if (ev) (void)hipEventRecord(ev[0], stream);
-  hipLaunchKernelGGL(mpc_prep_kernel<H>, dim3(n + 1), dim3(Cfg<H>::T), 0, stream, n, models, in, in64, state, qp, sc, prof, active, order, hist, hist_slot, sched, ready);
-  if (ev) (void)hipEventRecord(ev[1], stream);
-  if (exact) {
-    hipLaunchKernelGGL((mpc_exact_kernel<H>), dim3(n), dim3(Cfg<H>::TW), 0, stream, models, state, qp, sc, forces, info, prof, order, sched, ready);
-    hipLaunchKernelGGL((mpc_solve_kernel<H, true>), dim3(n), dim3(Cfg<H>::TW), 0, stream, n, models, state, qp, sc, forces, info, prof, order, sched, ready, max_iter);
-  }
-  else if (job_slots > 0) {   // persistent workgroups, ADMM and polish as separate jobs (h = 16: 2.68 -> 2.28 ms, h = 20: 3.36 -> 2.78 ms per 4096 robots)
-    const int slots = Cfg<H>::TW <= 64 ? job_slots : job_slots / 2;         // (multi-wave workgroups: two per CU)
-    hipLaunchKernelGGL((mpc_solve_jobs_kernel<H>), dim3(n < slots ? n : slots), dim3(Cfg<H>::TW), 0, stream, models, state, qp, sc, forces, info, prof, order, sched, ready, max_iter);
-  }
-  else hipLaunchKernelGGL((mpc_solve_kernel<H, false>), dim3(n), dim3(Cfg<H>::TW), 0, stream, n, models, state, qp, sc, forces, info, prof, order, sched, ready, max_iter);
-  if (ev) (void)hipEventRecord(ev[2], stream);
-  HIP_TRY(hipGetLastError());
-  return MPC_OK;
-}
-
-
 }  // namespace
+
 
 constexpr int kTimingRing = 64;
 
 struct mpc_batch {
   int n = 0, h = 0;
+  const HorizonOps *ops = nullptr;   // the kernel set of this planning horizon (mpc_horizon.h)
   int state_len = 0;
   RobotModel *d_models = nullptr;
   double *d_state = nullptr, *d_qp = nullptr, *d_sc = nullptr;   // warm start, QP record (q, l, u, cone, wrench form of P), scale record
@@ -488,78 +94,29 @@ struct mpc_batch {
 
 
 // one solver launch on b's robots (+ the dispatch order for the next one)
-static int launch_solver(mpc_batch *b, const float *d_in, double *d_forces, int *d_info, const int *d_active, hipStream_t st, const double *d_in64 = nullptr) {
+// one solver launch on b's robots (+ the dispatch order for the next one); the input records as float32, float64 or float16
+static int launch_solver(mpc_batch *b, const float *d_in, double *d_forces, int *d_info, const int *d_active, hipStream_t st, const double *d_in64 = nullptr,
+                         const _Float16 *d_in16 = nullptr) {
   DeviceGuard guard_(b->device);
   const int slot = (int)(b->order_launches++ % kOrderHistory);
   if (b->exact) HIP_TRY(hipMemsetAsync(b->d_state, 0, sizeof(double) * (size_t)b->n * b->state_len, st));   // no warm start in that branch (mpc_osqp.cc:906-919)
   hipEvent_t *ev = b->timing ? b->ev[b->launches % kTimingRing] : nullptr;
-  int rc = MPC_E_HORIZON;
-#define MPC_LAUNCH(HH) launch<HH>(b->n, b->d_models, d_in, d_in64, b->d_state, b->d_qp, b->d_sc, d_forces, d_info, b->d_prof, d_active, b->d_order, b->d_hist, slot, ev, st, b->exact, b->max_iter, b->d_sched, b->d_ready, b->job_slots)
-  switch (b->h) {
-#define MPC_CASE(HH) case HH: rc = MPC_LAUNCH(HH); break;
-    MPC_HORIZON_LIST(MPC_CASE)
-#undef MPC_CASE
-  }
-#undef MPC_LAUNCH
-  if (rc == MPC_E_HORIZON) return fail(MPC_E_HORIZON, "solver launch: horizon not compiled in");
-  if (rc != MPC_OK) return rc;
+  const LaunchArgs a{b->n, b->d_models, d_in, d_in64, d_in16, b->d_state, b->d_qp, b->d_sc, d_forces, d_info, b->d_prof, d_active, b->d_order, b->d_hist, slot, ev, st, b->exact,
+                     b->max_iter, b->d_sched, b->d_ready, b->job_slots};
+  const hipError_t e = (hipError_t)b->ops->launch(a);
+  if (e != hipSuccess) return fail(MPC_E_HIP, std::string("solver launch: ") + hipGetErrorString(e));
   b->launches++;
   return MPC_OK;
 }
 
-#define MPC_QP(HH) if (h == HH) return Cfg<HH>::QP_LEN;
-#define MPC_SC(HH) if (h == HH) return Cfg<HH>::SC_LEN;
-#define MPC_XQP(HH) if (h == HH) return Cfg<HH>::XQP_LEN;
-#define MPC_XSC(HH) if (h == HH) return Cfg<HH>::XSC_LEN;
-static size_t qp_len_of(int h) { MPC_HORIZON_LIST(MPC_QP) return 0; }     // (0: horizon not compiled in)
-static size_t sc_len_of(int h) { MPC_HORIZON_LIST(MPC_SC) return 0; }
-static size_t xqp_len_of(int h) { MPC_HORIZON_LIST(MPC_XQP) return 0; }   // the records as the accessors hand them out
-static size_t xsc_len_of(int h) { MPC_HORIZON_LIST(MPC_XSC) return 0; }
-#undef MPC_QP
-#undef MPC_SC
-#undef MPC_XQP
-#undef MPC_XSC
-// The device records keep three bound values and nine cone entries per foot (mpc_core.h); the accessors hand out every bound and the
-// dense cone block, formed here exactly as the solve kernel forms them (E times the bound).
-template <int H>
-static void expand_records(const double *qp, const double *sc, double *xqp, double *xsc) {
-  using C = Cfg<H>;
-  if (xqp) {
-    for (int i = 0; i < C::N; ++i) xqp[i] = qp[C::QP_Q + i];
-    for (int f = 0; f < C::NF; ++f)
-      for (int r = 0; r < 5; ++r) {
-        xqp[C::XQP_L + 5 * f + r] = r < 4 ? 0.0 : qp[C::QP_BND + 3 * f];
-        xqp[C::XQP_U + 5 * f + r] = r < 4 ? qp[C::QP_BND + 3 * f + 1] : qp[C::QP_BND + 3 * f + 2];
-      }
-    for (int i = 0; i < 16 + 72 + 36 + 8; ++i) xqp[C::XQP_CONE + i] = qp[C::QP_CONE + i];
-  }
-  if (xsc) {
-    for (int i = 0; i < 2 * C::N + C::M; ++i) xsc[i] = sc[i];      // D, E, q_s
-    for (int f = 0; f < C::NF; ++f) {
-      for (int k = 0; k < 15; ++k) xsc[C::XSC_AS + 15 * f + k] = 0.0;
-      for (int k = 0; k < 9; ++k) xsc[C::XSC_AS + 15 * f + kAsPos[k]] = sc[C::SC_AS + 9 * f + k];
-      for (int r = 0; r < 5; ++r) {
-        const double e = sc[C::SC_E + 5 * f + r];
-        xsc[C::XSC_LS + 5 * f + r] = e * (r < 4 ? 0.0 : qp[C::QP_BND + 3 * f]);
-        xsc[C::XSC_US + 5 * f + r] = e * (r < 4 ? qp[C::QP_BND + 3 * f + 1] : qp[C::QP_BND + 3 * f + 2]);
-      }
-    }
-    for (int i = 0; i < 4; ++i) xsc[C::XSC_C + i] = sc[C::SC_C + i];
-  }
-}
 static int fetch_records(mpc_batch *b, double *h_qp, double *h_sc) {
-  const size_t ql = qp_len_of(b->h), sl = sc_len_of(b->h), xql = xqp_len_of(b->h), xsl = xsc_len_of(b->h);
+  const size_t ql = b->ops->qp_len, sl = b->ops->sc_len, xql = b->ops->xqp_len, xsl = b->ops->xsc_len;
   std::vector<double> qp((size_t)b->n * ql), sc((size_t)b->n * sl);
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(qp.data(), b->d_qp, sizeof(double) * qp.size(), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(sc.data(), b->d_sc, sizeof(double) * sc.size(), hipMemcpyDeviceToHost));
-  for (int r = 0; r < b->n; ++r) {
-    const double *q = qp.data() + (size_t)r * ql, *c = sc.data() + (size_t)r * sl;
-    double *xq = h_qp ? h_qp + (size_t)r * xql : nullptr, *xs = h_sc ? h_sc + (size_t)r * xsl : nullptr;
-#define MPC_X(HH) if (b->h == HH) expand_records<HH>(q, c, xq, xs);
-    MPC_HORIZON_LIST(MPC_X)
-#undef MPC_X
-  }
+  for (int r = 0; r < b->n; ++r)
+    b->ops->expand(qp.data() + (size_t)r * ql, sc.data() + (size_t)r * sl, h_qp ? h_qp + (size_t)r * xql : nullptr, h_sc ? h_sc + (size_t)r * xsl : nullptr);
   return MPC_OK;
 }
 
@@ -579,14 +136,16 @@ int mpc_supported_horizons(int *out, int cap) {
 int mpc_batch_create(mpc_batch **out, int n, int horizon, double timestep, double alpha, const double *mass,
                      const double *inertia9) {
   if (!out || n <= 0 || !mass || !inertia9) return fail(MPC_E_ARG, "mpc_batch_create: bad argument");
-  if (qp_len_of(horizon) == 0) return fail(MPC_E_HORIZON, "mpc_batch_create: planning horizon not compiled in (see mpc_supported_horizons; -DMPC_HORIZON_LIST builds another set)");
+  const HorizonOps *ops = horizon_ops(horizon);
+  if (!ops) return fail(MPC_E_HORIZON, "mpc_batch_create: planning horizon outside the built range (mpc_supported_horizons: 2 .. 20 in the shipped library)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MPC_E_NODEVICE, "mpc_batch_create: no HIP device");
   mpc_batch *b = new mpc_batch();
   (void)hipGetDevice(&b->device);
   b->n = n;
   b->h = horizon;
-  const size_t qp_len = qp_len_of(horizon), sc_len = sc_len_of(horizon);
+  b->ops = ops;
+  const size_t qp_len = ops->qp_len, sc_len = ops->sc_len;
   b->state_len = (int)(64 * horizon + 2);
   std::vector<RobotModel> models(n);
   for (int i = 0; i < n; ++i) models[i] = make_model(mass[i], inertia9 + 9 * (size_t)i, timestep, alpha);
@@ -613,7 +172,11 @@ int mpc_batch_create(mpc_batch **out, int n, int horizon, double timestep, doubl
     hipDeviceProp_t prop;
     const char *env = getenv("MPC_SOLVE_JOBS");      // tuning hook: 0 = one workgroup per robot (the round-2 launch), N > 0 = that many slots
     if (hipGetDeviceProperties(&prop, b->device) == hipSuccess) b->job_slots = 4 * prop.multiProcessorCount;
-    if (env) b->job_slots = atoi(env);
+    if (env) {   // (anything that is not a number, or negative, is ignored; fewer slots than one multi-wave workgroup needs means "not persistent")
+      char *end = nullptr;
+      const long v = strtol(env, &end, 10);
+      if (end != env && *end == '\0' && v >= 0 && v <= (1 << 20)) b->job_slots = v < 2 ? 0 : (int)v;
+    }
   }
   b->bytes = (long long)(sizeof(RobotModel) * n + sizeof(double) * (size_t)n * (b->state_len + qp_len + sc_len) + sizeof(int) * (size_t)n * kInfoLen);
   *out = b;
@@ -661,6 +224,11 @@ int mpc_batch_set_max_iter(mpc_batch *b, int max_iter) {
 int mpc_batch_solve_f64(mpc_batch *b, const double *d_in, double *d_forces, int *d_info, void *stream) {
   if (!b || !d_in || !d_forces) return fail(MPC_E_ARG, "mpc_batch_solve_f64: bad argument");
   return launch_solver(b, nullptr, d_forces, d_info ? d_info : b->d_info, nullptr, reinterpret_cast<hipStream_t>(stream), d_in);
+}
+
+int mpc_batch_solve_f16(mpc_batch *b, const unsigned short *d_in, double *d_forces, int *d_info, void *stream) {
+  if (!b || !d_in || !d_forces) return fail(MPC_E_ARG, "mpc_batch_solve_f16: bad argument");
+  return launch_solver(b, nullptr, d_forces, d_info ? d_info : b->d_info, nullptr, reinterpret_cast<hipStream_t>(stream), nullptr, reinterpret_cast<const _Float16 *>(d_in));
 }
 
 int mpc_batch_reset(mpc_batch *b, const int *ids, int k, void *stream) {
@@ -758,8 +326,8 @@ int mpc_batch_get_state(mpc_batch *b, double *h_state) {
   return MPC_OK;
 }
 // Test / debugging access to what the prep kernel handed to the solve kernel in the last launch
-int mpc_batch_qp_len(const mpc_batch *b) { return b ? (int)xqp_len_of(b->h) : 0; }
-int mpc_batch_scale_len(const mpc_batch *b) { return b ? (int)xsc_len_of(b->h) : 0; }
+int mpc_batch_qp_len(const mpc_batch *b) { return b ? b->ops->xqp_len : 0; }
+int mpc_batch_scale_len(const mpc_batch *b) { return b ? b->ops->xsc_len : 0; }
 int mpc_batch_get_qp(mpc_batch *b, double *h_qp) {
   if (!b || !h_qp) return fail(MPC_E_ARG, "mpc_batch_get_qp: bad argument");
   DeviceGuard guard_(b->device);
@@ -830,6 +398,16 @@ __device__ __forceinline__ void store_robot_fields(CtrlState &d, const CtrlState
   d.iter = s.iter; d.first_run = s.first_run; d.pos_z = s.pos_z; d.posz_tick = s.posz_tick; d.do_solve = s.do_solve;
   for (int c = 0; c < 3; ++c) { d.normal[c] = s.normal[c]; d.vbody[c] = s.vbody[c]; }
 }
+// The four lanes of a quad each copy the whole st[r] and then store disjoint parts of it back.  Every lane's loads of st[r] must be
+// complete before any lane of the quad stores: the quad sits in one wavefront (whose memory instructions issue in program order), so
+// what is needed is that the COMPILER keeps every load above this point and every store below it, and that the loads' data has arrived
+// (a lane may read a sibling's field late otherwise): wavefront-scope fence + s_waitcnt vmcnt(0) + a scheduling barrier.
+static_assert(kCtrlThreads % 4 == 0, "a robot's four leg lanes must not straddle wavefronts");
+__device__ __forceinline__ void quad_reads_done() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_s_waitcnt(kWaitVm0);
+  __builtin_amdgcn_wave_barrier();
+}
 __global__ __launch_bounds__(kCtrlThreads) void ctrl_pre_kernel(int n, CtrlState *st, const RobotConst *rc, GaitTable gt, CtrlParams cp, const float *dof,
                                 const float *est, const float *cmd, float *rec, int *active) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x, r = t >> 2, leg = t & 3;
@@ -838,18 +416,19 @@ __global__ __launch_bounds__(kCtrlThreads) void ctrl_pre_kernel(int n, CtrlState
   const RobotConst &k = rc[s.robot_type];
   ctrl_pre_legs(s, k, dof + (size_t)r * 24, leg, leg + 1);
   // every lane needs the foot positions of all four legs (centre-of-mass height, ground-normal fit, the solver record)
-  const int q0 = (int)(threadIdx.x & 63u) & ~3;
+  const int q0 = (int)__lane_id() & ~3;      // first lane of my quad (four consecutive lanes of one wavefront: kCtrlThreads % 4 == 0)
   float fp[12];
 #pragma unroll
   for (int l = 0; l < 4; ++l)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float mine = c == 0 ? s.foot_positions[3 * leg] : (c == 1 ? s.foot_positions[3 * leg + 1] : s.foot_positions[3 * leg + 2]);
-      fp[3 * l + c] = __shfl(mine, q0 + l, 64);
+      fp[3 * l + c] = __shfl(mine, q0 + l);
     }
 #pragma unroll
   for (int c = 0; c < 12; ++c) s.foot_positions[c] = fp[c];
   ctrl_pre_rest(s, k, gt, cp, est + (size_t)r * kEstLen, cmd + (size_t)r * 16, rec + (size_t)r * (56 + 4 * cp.horizon), leg, leg + 1, leg == 0);
+  quad_reads_done();
   store_leg_fields(st[r], s, leg);
   if (leg == 0) {
     store_robot_fields(st[r], s);
@@ -899,24 +478,32 @@ __global__ __launch_bounds__(kCtrlThreads) void fsm_pre_kernel(int n, CtrlState 
   active[r] = act;
   st[r] = s; fs[r] = f;
 }
+// Does the controller take the solver's forces?  OSQP branch: only OSQP_SOLVED returns a vector (mpc_osqp.cc:781-794; with the empty list the
+// reference's Python raises at ConvexMPCLocomotion.py:186-187 -- here f_ff keeps its value).  qpOASES branch (exact mode): the vector comes
+// back whatever the solver's status (:906-947) and ConvexMPCLocomotion.py:186-187 adopts it unconditionally: every status for which the
+// library wrote the row (SOLVED, SOLVED_INACCURATE, MAX_ITER_REACHED: mpc_wrench.h store()) -- only NON_CVX writes nothing.
+__device__ __forceinline__ int adopts_forces(int status, int exact) {
+  return exact ? (status == kStSolved || status == kStSolvedInaccurate || status == kStMaxIter) : status == kStSolved;
+}
 __global__ __launch_bounds__(kCtrlThreads) void fsm_post_kernel(int n, CtrlState *st, const FsmState *fs, const RobotConst *rc, int horizon, const double *forces, const int *info,
-                                float *torques) {
+                                int exact, float *torques) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   if (fs[r].run_loco) {
     CtrlState s = st[r];
-    ctrl_post(s, rc[s.robot_type], forces + (size_t)r * 12 * horizon, info[(size_t)r * kInfoLen + 1] == kStSolved, torques + (size_t)r * 12);
+    ctrl_post(s, rc[s.robot_type], forces + (size_t)r * 12 * horizon, adopts_forces(info[(size_t)r * kInfoLen + 1], exact), torques + (size_t)r * 12);
     st[r] = s;
   } else {
     fsm_joint_torques(fs[r], st[r], torques + (size_t)r * 12);
   }
 }
 __global__ __launch_bounds__(kCtrlThreads) void ctrl_post_kernel(int n, CtrlState *st, const RobotConst *rc, int horizon, const double *forces, const int *info,
-                                 float *torques) {
+                                 int exact, float *torques) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x, r = t >> 2, leg = t & 3;      // one lane per leg (see ctrl_pre_kernel)
   if (r >= n) return;
   CtrlState s = st[r];
-  ctrl_post(s, rc[s.robot_type], forces + (size_t)r * 12 * horizon, info[(size_t)r * kInfoLen + 1] == kStSolved, torques + (size_t)r * 12, leg, leg + 1);
+  ctrl_post(s, rc[s.robot_type], forces + (size_t)r * 12 * horizon, adopts_forces(info[(size_t)r * kInfoLen + 1], exact), torques + (size_t)r * 12, leg, leg + 1);
+  quad_reads_done();
   store_leg_fields(st[r], s, leg);
 }
 
@@ -1018,7 +605,7 @@ int mpc_ctrl_step(mpc_ctrl *c, const float *d_dof, const float *d_est, const flo
     int rc = launch_solver(b, c->d_rec, c->d_forces, c->d_info, c->d_active, st);
     if (rc != MPC_OK) return rc;
   }
-  hipLaunchKernelGGL(ctrl_post_kernel, dim3(blocks4), dim3(kCtrlThreads), 0, st, n, c->d_state, c->d_rc, c->cp.horizon, c->d_forces, c->d_info, d_torques);
+  hipLaunchKernelGGL(ctrl_post_kernel, dim3(blocks4), dim3(kCtrlThreads), 0, st, n, c->d_state, c->d_rc, c->cp.horizon, c->d_forces, c->d_info, b->exact, d_torques);
   HIP_TRY(hipGetLastError());
   return MPC_OK;
 }
@@ -1134,6 +721,17 @@ int mpc_ctrl_fsm_reset(mpc_ctrl *c, const int *ids, int k, const int *control_mo
   return MPC_OK;
 }
 
+int mpc_ctrl_fsm_reset_device(mpc_ctrl *c, const int *d_ids, int k, void *stream) {
+  if (!c || !c->d_fsm || !d_ids || k < 0) return fail(MPC_E_ARG, "mpc_ctrl_fsm_reset_device: bad argument (mpc_ctrl_fsm_init first)");
+  DeviceGuard guard_(c->solver->device);
+  if (k == 0) return MPC_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(fsm_init_kernel, dim3((k + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, st, c->n, c->d_state, c->d_fsm, c->d_rc, c->d_fsm_mode, c->fsm_op_mode, d_ids, k, 0,
+                     c->solver->d_state, c->solver->state_len);
+  HIP_TRY(hipGetLastError());
+  return MPC_OK;      // (stream-ordered: no host round trip, no synchronisation)
+}
+
 int mpc_ctrl_run_fsm(mpc_ctrl *c, const float *d_dof, const float *d_body, const float *d_cmd, const int *d_request, float *d_torques, void *stream) {
   if (!c || !d_dof || !d_body || !d_cmd || !d_request || !d_torques) return fail(MPC_E_ARG, "mpc_ctrl_run_fsm: bad argument");
   DeviceGuard guard_(c->solver->device);
@@ -1147,7 +745,7 @@ int mpc_ctrl_run_fsm(mpc_ctrl *c, const float *d_dof, const float *d_body, const
   HIP_TRY(hipGetLastError());
   int rc = launch_solver(b, c->d_rec, c->d_forces, c->d_info, c->d_active, st);
   if (rc != MPC_OK) return rc;
-  hipLaunchKernelGGL(fsm_post_kernel, dim3(blocks), dim3(kCtrlThreads), 0, st, n, c->d_state, c->d_fsm, c->d_rc, c->cp.horizon, c->d_forces, c->d_info, d_torques);
+  hipLaunchKernelGGL(fsm_post_kernel, dim3(blocks), dim3(kCtrlThreads), 0, st, n, c->d_state, c->d_fsm, c->d_rc, c->cp.horizon, c->d_forces, c->d_info, b->exact, d_torques);
   HIP_TRY(hipGetLastError());
   return MPC_OK;
 }

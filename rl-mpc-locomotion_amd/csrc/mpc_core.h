@@ -103,6 +103,23 @@ typedef double mpc_double2 __attribute__((ext_vector_type(2)));
 
 namespace mpc {
 
+// IEEE binary16 input records (mpc_batch_solve_f16: BASELINE configs[4] stores the state in fp16).  The device converts with the hardware
+// instruction; the host emulation (g++ has no _Float16 on x86 before GCC 12) decodes the bits.
+#if defined(__HIPCC__)
+typedef _Float16 mpc_half;
+MPC_HD double half_to_double(mpc_half v) { return (double)v; }
+#else
+typedef unsigned short mpc_half;
+inline double half_to_double(mpc_half b) {
+  const int sgn = b >> 15, ex = (b >> 10) & 31, man = b & 1023;
+  double v;
+  if (ex == 0) v = ldexp((double)man, -24);
+  else if (ex == 31) v = man ? NAN : INFINITY;
+  else v = ldexp((double)(man | 1024), ex - 25);
+  return sgn ? -v : v;
+}
+#endif
+
 // ---- OSQP constants (extern/osqp/include/constants.h:59-88) and the reference's settings -------
 constexpr double kRho0 = 0.1, kSigma = 1e-6, kAlphaRelax = 1.6;
 constexpr double kEpsAbs = 1e-3, kEpsRel = 1e-3;           // mpc_osqp.cc:711-712
@@ -215,7 +232,8 @@ template <int H>
 struct AsmShared {
   using C = Cfg<H>;
   MPC_V in[C::IN_LEN];
-  MPC_V x0[13]; MPC_V xref[13 * H]; MPC_V sdiff[13 * H]; MPC_V xk[13 * H];
+  static constexpr int XK = 13 * H > 74 ? 13 * H : 74;    // (xk / sdiff double as the set-up scratch of Assembler::run: 73 / 62 slots)
+  MPC_V x0[13]; MPC_V xref[13 * H]; MPC_V sdiff[XK]; MPC_V xk[XK];
   MPC_V a_dt[169]; MPC_V b_dt[156]; MPC_V a_exp[169]; MPC_V b_exp[156];
   MPC_V wanb[H * 156];                                  // diag(w) A^k B
   MPC_V B6[72]; MPC_V th1[36]; MPC_V th2[8];            // wrench description of P (mpc_wrench.h), also written to the QP record
@@ -336,7 +354,9 @@ struct Assembler {
   AsmShared<H> &s;
   const RobotModel &mdl;
   const float *in;     // [IN_LEN]   the input record as float32 ...
-  const double *in64;  // [IN_LEN]   ... or as float64 (the reference's std::vector<double> arguments, mpc_osqp.cc:578-591); one of the two is null
+  const double *in64;  // [IN_LEN]   ... or as float64 (the reference's std::vector<double> arguments, mpc_osqp.cc:578-591) ...
+  const mpc_half *in16;  // [IN_LEN] ... or as float16 (BASELINE configs[4]: the state stored in fp16); exactly one of the three is set.  Every
+                       //            value is widened to double on load: the arithmetic is the same fp64 whatever the storage type
   double *u12;         // [288] LDS  out: U1 = B6^T th1 B6, U2 = B6^T diag(th2) B6 (12 x 12 each): P = Sigma2 (x) U1 + N (x) U2 + alpha I
   double *qp;          // [QP_LEN]   out: q, l, u, cone
   long long *prof;     // [kProfLen] slots 1 (dynamics) and 2 (q + P) are written here (may be null)
@@ -354,14 +374,9 @@ struct Assembler {
   }
 
   // ================================ 1. assembly =================================================
+  MPC_HD double in_at(int i) const { return in64 ? in64[i] : (in16 ? half_to_double(in16[i]) : (double)in[i]); }
   MPC_HD void run() {
     tlast = MPC_CLOCK();
-    ex.par([&](Th &t) {
-      for (int i = t.tid; i < C::IN_LEN; i += T) s.in[i] = in64 ? in64[i] : (double)in[i];
-      for (int i = t.tid; i < 169; i += T) s.a_dt[i] = 0;
-      for (int i = t.tid; i < 156; i += T) s.b_dt[i] = 0;
-      for (int i = t.tid; i < 72; i += T) { qp[C::QP_B6 + i] = 0; s.B6[i] = 0; }
-    });
     // ---- A dt, B dt (mpc_osqp.cc:299-336, 606-617, 661-673).  The chain of 3 x 3 products behind them (rotations in both of the
     // reference's conventions, the world-frame feet, the world inertia) is ~250 dependent-free FMAs: ONE thread carries it through
     // registers (static indices) while the others set up x0, x_ref and the bounds -- four barrier phases of one-entry-per-thread
@@ -369,15 +384,15 @@ struct Assembler {
     //   xk: [0..7) cos / sin of roll, pitch, yaw and tan(pitch); [43..55) fw; [64..73) iw        sdiff: [53..62) I^-1 (body)
     double *const trig = s.xk, *const fw = s.xk + 43, *const iw = s.xk + 64;
     double *const iib = s.sdiff + 53;
-    static_assert(13 * H >= 73, "xk / sdiff too small for the set-up scratch");
+    static_assert(AsmShared<H>::XK >= 73, "xk / sdiff too small for the set-up scratch");
     ex.par([&](Th &t) {
-      for (int i = t.tid; i < C::IN_LEN; i += T) s.in[i] = in64 ? in64[i] : (double)in[i];
+      for (int i = t.tid; i < C::IN_LEN; i += T) s.in[i] = in_at(i);
       for (int i = t.tid; i < 169; i += T) s.a_dt[i] = 0;
       for (int i = t.tid; i < 156; i += T) s.b_dt[i] = 0;
       for (int i = t.tid; i < 72; i += T) { qp[C::QP_B6 + i] = 0; s.B6[i] = 0; }
       if (t.tid >= 64 && t.tid < 67) {          // (one wave-front's worth of trigonometry, off the first wavefront)
         const int k = t.tid - 64;
-        const double ang = in64 ? in64[IN_RPY + k] : (double)in[IN_RPY + k];
+        const double ang = in_at(IN_RPY + k);
         trig[2 * k] = cos(ang); trig[2 * k + 1] = sin(ang);
         if (k == 1) trig[6] = tan(ang);
       } else if (t.tid >= 96 && t.tid < 105) {

@@ -121,8 +121,10 @@ struct WThread : RoleRegs<Cfg<H>::TE, (Cfg<H>::FOOT0 != 0 && MPC_SHARE_ROLE_REGS
 // Gram matrix N^T H^-1 N, one slot per working constraint.
 template <int H>
 struct GiShared {
-  static constexpr int NWMAX = H <= 6 ? 40 : H <= 10 ? 56 : (H <= 16 ? 72 : 88);      // slots (the optimum's active stance rows: 24 / 32 / 40 / 51 on
-  static constexpr int NF = 4 * H;                                       //   average for configs 2 / 3 / 4 / 5, up to 34 / 44 / 54 / 67)
+  static constexpr int NF = 4 * H;
+  // slots (the optimum's active stance rows: 24 / 32 / 40 / 51 on average for configs 2 / 3 / 4 / 5, up to 34 / 44 / 54 / 67; a working set
+  // holds linearly independent rows only, so 3 NF bounds it at the shortest horizons)
+  static constexpr int NWMAX = H <= 3 ? 8 * ((3 * NF + 7) / 8) : H <= 6 ? 40 : H <= 10 ? 56 : (H <= 16 ? 72 : 88);
   static constexpr int TL = NWMAX > NF ? NWMAX : NF;
   alignas(16) double ci[NWMAX * (NWMAX + 1) / 2];   // packed lower triangle, (i, j <= i) at i (i + 1) / 2 + j; zero rows / columns at free slots
   // (the method's vectors -- d = N^T H^-1 n_p, the dual direction r, the multipliers, two scratch rows -- live in Shared::fr, which only
@@ -155,7 +157,8 @@ struct Shared {
   using C = Cfg<H>;
   static constexpr int RW = ((C::NF + 1) & ~1);                         // row stride of the residual scratch
   static constexpr int NRED = 21;                                       // residual / certificate reductions (Solver::residuals)
-  static constexpr int PARTLEN_A = C::GW * C::NPW, PARTLEN_B = NRED * RW;
+  static constexpr int PARTLEN_A0 = C::GW * C::NPW, PARTLEN_A1 = C::NW * ((C::GW + 1) & ~1);   // [slot][row] / [row][slot] (even row stride) partials
+  static constexpr int PARTLEN_A = PARTLEN_A0 > PARTLEN_A1 ? PARTLEN_A0 : PARTLEN_A1, PARTLEN_B = NRED * RW;
   static constexpr int PARTLEN = PARTLEN_A > PARTLEN_B ? PARTLEN_A : PARTLEN_B;
   MPC_V B6[72]; MPC_V th1[36]; MPC_V th2[8];
   double c, cinv, rho, calpha;
@@ -164,7 +167,8 @@ struct Shared {
   // per-foot constants in LDS, element k of foot f at [((k >> 1) NF + f) 2 + (k & 1)]: consecutive lanes read consecutive 16-byte
   // pairs (one conflict-free ds_read_b128 per pair)
   MPC_V fa[C::NF * 16];                                 // 0-8: the non-zeros of the scaled cone block, 9: l of row 4, 10-14: u of the five rows
-  MPC_V fr[C::NF * 10];                                 // 0-8: the cone block times rho of its row (factorisation)
+  static constexpr int FR_GI = 3 * GiShared<H>::NWMAX + 2 * GiShared<H>::TL;           // the exact mode's vectors live here too (Solver::active_set)
+  MPC_V fr[C::NF * 10 > FR_GI ? C::NF * 10 : FR_GI];    // 0-8: the cone block times rho of its row (factorisation)
   MPC_V Gf[C::NF * 18];                                 // per foot: G_f = T_k W_f (6 x 3) of the current factorisation
   MPC_V dxy[C::NF * 8];                                 // per foot: delta_x (0-2) and delta_y (3-7) of the last iteration before a check (auxil.c:187-228)
   // the published pivot rows are double buffered -- except where the workgroup is a single wavefront in lock step (MPC_LOCKSTEP:
@@ -1800,7 +1804,7 @@ struct Solver {
   MPC_HD bool active_set() {
     GiShared<H> &g = *gi;
     constexpr int NW = GiShared<H>::NWMAX, TL = GiShared<H>::TL;
-    static_assert(3 * NW + 2 * TL <= NF * 10, "the method's vectors must fit Shared::fr");
+    static_assert(3 * NW + 2 * TL <= (int)(sizeof(s.fr) / sizeof(double)), "the method's vectors must fit Shared::fr");
     double *const gd = s.fr, *const gr = s.fr + NW, *const glam = s.fr + 2 * NW, *const gtmp = s.fr + 3 * NW, *const gtmp2 = s.fr + 3 * NW + TL;
     ex.par([&](Th &t) {
       for (int i = t.tid; i < NW * (NW + 1) / 2; i += T) g.ci[i] = 0.0;
@@ -2071,6 +2075,14 @@ struct Solver {
     }
     return false;
   }
+  // The force the reference returns for variable c of my foot.  OSQP branch: `-x` of the unscaled solution written as 0 - D x
+  // (mpc_osqp.cc:789-790).  qpOASES branch (exact mode): an eliminated foot -- every row an equality with l = u = 0, the swing feet,
+  // mpc_osqp.cc:838-856 -- is `qp_sol = 0.0f`, and the copy-out NEGATES it (:926, 940-942): the sign bit is set, -0.0; every other
+  // variable is the negation of the solver's value.
+  MPC_HD double force_out(const Th &t, int c) const {
+    if (eps_exact > 0) return ((t.tyb & 0x3ff) == 0x2aa) ? -0.0 : -(Dat(t, c) * t.x[c]);
+    return 0.0 - Dat(t, c) * t.x[c];
+  }
   // outputs + persistent state (store_solution, auxil.c:528-561; mpc_osqp.cc:788-790: forces = -x).  A non-convex / non-finite
   // problem has no solution: OSQP cold-starts the iterates (auxil.c:539-563); here the whole record is cleared, so that the
   // robot's next call is the cold "osqp_setup" call on clean data (with NaN inputs the vendored OSQP itself stays poisoned).
@@ -2086,7 +2098,7 @@ struct Solver {
         const int f = t.fid;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          s.part[SL + 3 * f + c] = 0.0 - Dat(t, c) * t.x[c];   // (-x, mpc_osqp.cc:789-790; an eliminated foot's exact zero comes out as +0.0)
+          s.part[SL + 3 * f + c] = force_out(t, c);
           s.part[3 * f + c] = failed ? 0.0 : t.x[c];
           s.part[N + 2 * M + 3 * f + c] = failed ? 0.0 : qp[C::QP_Q + 3 * f + c];
         }
@@ -2185,7 +2197,7 @@ struct Solver {
         const int f = t.fid;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          if (solved) forces[3 * f + c] = 0.0 - Dat(t, c) * t.x[c];
+          if (solved) forces[3 * f + c] = force_out(t, c);
           state[3 * f + c] = failed ? 0.0 : t.x[c];
           state[N + 2 * M + 3 * f + c] = failed ? 0.0 : qp[C::QP_Q + 3 * f + c];
         }

@@ -144,6 +144,10 @@ class BatchedLocomotion:
         if cm is not None and cm.shape != (self.n,):
             raise ValueError(f"fsm_reset: control_mode must have one entry per robot ({self.n}), got shape {cm.shape}")
         ids = None
+        if env_ids is not None and cm is None and hasattr(env_ids, "is_cuda") and env_ids.is_cuda:      # an env_ids tensor on the device: no host round trip
+            d_ids = env_ids.to(device=self.device, dtype=torch.int32).contiguous()
+            _lib.check(_lib.lib().mpc_ctrl_fsm_reset_device(self._handle, d_ids.data_ptr(), d_ids.numel(), stream), "mpc_ctrl_fsm_reset_device")
+            return
         if env_ids is not None:
             ids = np.ascontiguousarray(env_ids.detach().cpu().numpy() if hasattr(env_ids, "detach") else env_ids, dtype=np.int32)
         _lib.check(_lib.lib().mpc_ctrl_fsm_reset(self._handle, None if ids is None else ids.ctypes.data, 0 if ids is None else len(ids),

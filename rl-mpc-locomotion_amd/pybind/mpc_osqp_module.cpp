@@ -57,9 +57,15 @@ class ConvexMpc {
     if (num_legs != 4) throw std::invalid_argument("only quadrupeds (num_legs == 4) are supported");
     if (inertia.size() != 9) throw std::invalid_argument("inertia must have 9 elements");   // assert at mpc_osqp.cc:556
     check(cabi::create(&b_, 1, planning_horizon, timestep, alpha, &mass, inertia.data()), "mpc_batch_create");
-    check(cabi::set_solver(b_, exact_ ? MPC_SOLVER_EXACT : MPC_SOLVER_OSQP), "mpc_batch_set_solver");
-    rec_.assign(cabi::input_len(planning_horizon), 0.0);
-    out_.assign(12 * (size_t)planning_horizon, 0.0);
+    try {      // (a constructor that throws never runs the destructor: the handle is released here)
+      check(cabi::set_solver(b_, exact_ ? MPC_SOLVER_EXACT : MPC_SOLVER_OSQP), "mpc_batch_set_solver");
+      rec_.assign(cabi::input_len(planning_horizon), 0.0);
+      out_.assign(12 * (size_t)planning_horizon, 0.0);
+    } catch (...) {
+      cabi::destroy(b_);
+      b_ = nullptr;
+      throw;
+    }
   }
   ~ConvexMpc() { cabi::destroy(b_); }
   ConvexMpc(const ConvexMpc &) = delete;
@@ -86,10 +92,9 @@ class ConvexMpc {
     put(desired_com_position, 3, "desired_com_position"); put(desired_com_velocity, 3, "desired_com_velocity");
     put(desired_com_roll_pitch_yaw, 3, "desired_com_roll_pitch_yaw"); put(desired_com_angular_velocity, 3, "desired_com_angular_velocity");
     int info[MPC_INFO_LEN] = {0};
-    {
-      py::gil_scoped_release nogil;   // (the reference holds the GIL for the whole call; nothing here needs it)
-      check(cabi::solve_host_f64(b_, rec_.data(), out_.data(), info), "mpc_batch_solve_host_f64");
-    }
+    // The GIL is held for the whole call, as in the reference (mpc_osqp.cc has no gil_scoped_release): two Python threads calling the same
+    // object are serialised -- the call works on the object's record / result buffers and the handle's staging buffers.
+    check(cabi::solve_host_f64(b_, rec_.data(), out_.data(), info), "mpc_batch_solve_host_f64");
     status_ = info[1];
     iterations_ = info[0];
     if (exact_ ? info[1] == MPC_STATUS_NON_CVX : info[1] != MPC_STATUS_SOLVED) return {};

@@ -30,9 +30,11 @@ def test_header_symbols_are_exported():
 def test_input_len_and_horizons():
     L = _lib.lib()
     assert L.mpc_input_len(10) == 96 and L.mpc_input_len(16) == 120
-    buf = (ctypes.c_int * 8)()
-    k = L.mpc_supported_horizons(buf, 8)
-    assert 10 in list(buf[:k])
+    buf = (ctypes.c_int * 32)()
+    k = L.mpc_supported_horizons(buf, 32)
+    assert list(buf[:k]) == list(range(2, 21))      # ConvexMpc takes any planning_horizon (mpc_osqp.cc:186-190): every h up to 20 ships
+    small = (ctypes.c_int * 4)()
+    assert L.mpc_supported_horizons(small, 4) == k and list(small) == [2, 3, 4, 5]      # the count is returned whatever the capacity
 
 
 def test_product_path_fails_loudly_without_gpu():

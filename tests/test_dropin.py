@@ -155,7 +155,8 @@ def _check_exact(solve, name, n, steps=2):
             assert pv < 1e-9 and sr < 1e-8, (name, s, r, pv, sr)
             assert np.abs(f[r] - fx).max() < (1e-6 if h <= 10 else 1e-5) * max(np.abs(fx).max(), 1.0), (name, s, r, np.abs(f[r] - fx).max())
             swing = np.repeat(g[f"inputs_{s}"][r, 28:28 + 4 * h] == 0, 3)
-            assert (f[r][swing] == 0.0).all() and not np.signbit(f[r][swing]).any()       # eliminated feet: exact +0.0 (mpc_osqp.cc:838-856, 924-927)
+            # eliminated feet (mpc_osqp.cc:838-856): `qp_sol = 0.0f` (:926) NEGATED on the way out (:940-942) -- exact zeros with the sign bit set
+            assert (f[r][swing] == 0.0).all() and np.signbit(f[r][swing]).all()
 
 
 @pytest.mark.gpu

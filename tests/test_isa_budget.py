@@ -20,13 +20,31 @@ HIPCC = "/opt/rocm/bin/hipcc"
 def asm(tmp_path_factory):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not installed")
-    out = str(tmp_path_factory.mktemp("isa") / "mpc_batch.s")
-    isa_census.compile_to_asm(os.path.join(ROOT, "rl-mpc-locomotion_amd", "csrc", "mpc_batch.hip"), out, os.path.join(ROOT, "include"))
+    out = str(tmp_path_factory.mktemp("isa") / "mpc_horizons.s")
+    isa_census.compile_to_asm(os.path.join(ROOT, "rl-mpc-locomotion_amd", "csrc"), out, (10, 12, 16, 20))
     return open(out).read()
 
 
-def test_all_horizons_are_instantiated(asm):
-    assert isa_census.horizons(asm) == [8, 10, 12, 16, 20]
+def test_tuned_horizons_are_instantiated(asm):
+    assert isa_census.horizons(asm) == [10, 12, 16, 20]
+
+
+def test_job_results_are_complete_before_they_are_published(asm):
+    """mpc_solve_jobs_kernel hands an ADMM job's results to a polish job in another workgroup (possibly on another XCD) through device-coherent
+    stores and a relaxed flag (`ready[pos]`): every thread must have WAITED for its stores (s_waitcnt vmcnt(0)) before the flag goes out.  The
+    wait is spelled out in the source (__builtin_amdgcn_s_waitcnt), not left to the lowering of a workgroup-scope fence: in every
+    instantiation a full s_waitcnt vmcnt(0) sits between the last result store and the atomic add on `sched[tail]` that opens the publish."""
+    import re
+    for h in (10, 12, 16, 20):
+        body = re.search(isa_census.KERNELS["jobs"] % h, asm, re.S).group(2)
+        lines = [l.strip() for l in body.split("\n") if l.startswith("\t") and not l.startswith("\t.") and not l.startswith("\t;")]
+        # the publish is the atomic add on sched[kSchedTail] (byte offset 8; the job fetches are on offsets 0 and 4)
+        pubs = [i for i, l in enumerate(lines) if l.startswith("global_atomic_add") and "offset:8" in l]
+        assert len(pubs) == 1, (h, pubs)
+        i = pubs[0]
+        prev_store = max(j for j in range(i) if lines[j].startswith("global_store"))
+        assert "sc1" in lines[prev_store], lines[prev_store]          # the results go out as device-coherent (write-through) stores
+        assert any(re.match(r"s_waitcnt\s+vmcnt\(0\)", l) for l in lines[prev_store:i]), (h, lines[prev_store:i])
 
 
 def test_benchmark_horizon_hot_loops_are_scratch_free(asm):

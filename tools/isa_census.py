@@ -4,7 +4,7 @@ The solve kernel keeps a 6x6 fp64 tile per thread in registers for its whole lif
 inside the hot loops decides the kernel's speed by integer factors, and the decision moves with any change
 of the code shape.  This tool reads the assembly and says where the scratch instructions are.
 
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -S --cuda-device-only rl-mpc-locomotion_amd/csrc/mpc_batch.hip -o /tmp/all.s
+  python -c "import sys; sys.path.insert(0, 'tools'); import isa_census as c; c.compile_to_asm('rl-mpc-locomotion_amd/csrc', '/tmp/all.s', (10, 16, 20))"
   python tools/isa_census.py /tmp/all.s                 # per horizon: loops, weighted spill estimate
   python tools/isa_census.py /tmp/all.s --blocks 8      # also every block with >= 8 scratch instructions
 
@@ -24,10 +24,24 @@ KERNEL = "jobs"
 KERNEL_RE = KERNELS[KERNEL]
 
 
-def compile_to_asm(src, out, include_dir, extra=()):
-    """hipcc cross-compiles gfx950 without a GPU."""
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{include_dir}", "-S", "--cuda-device-only", *extra, src, "-o", out]
-    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+def compile_to_asm(csrc_dir, out, horizons=(10, 12, 16, 20), extra=()):
+    """Device assembly of the kernel sets of the given planning horizons, concatenated into `out` (hipcc cross-compiles gfx950 without a
+    GPU; every horizon is its own translation unit, csrc/mpc_horizon.hip -DMPC_H=h: compiled in parallel)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    src = os.path.join(csrc_dir, "mpc_horizon.hip")
+
+    def one(h):
+        o = f"{out}.h{h}.s"
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-DMPC_H={h}", "-S", "--cuda-device-only", *extra, src, "-o", o]
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return o
+    with ThreadPoolExecutor(max_workers=min(len(horizons), len(os.sched_getaffinity(0)))) as pool:
+        parts = list(pool.map(one, horizons))
+    with open(out, "w") as f:
+        for pth in parts:
+            f.write(open(pth).read())
+            f.write("\n")
     return out
 
 
