@@ -150,7 +150,8 @@ struct Cfg {
   static constexpr int NT = H > 16 ? MPC_NT_H20 : (H > 12 ? MPC_NT_H16 : 1);
   static constexpr int MTH = (MT + NT - 1) / NT;         // threads that hold tiles
   static constexpr int TE = TS * TS;                     // tile elements per thread
-  static constexpr int T = (((MTH > N ? MTH : N) + 63) / 64) * 64;   // prep-kernel workgroup: a thread per tile slot and per variable
+  static constexpr int T0 = (((MTH > N ? MTH : N) + 63) / 64) * 64;
+  static constexpr int T = T0 < 128 ? 128 : T0;          // prep-kernel workgroup: a thread per tile slot and per variable (the assembly's set-up phases use threads up to 104)
   static constexpr int MR = (M + T - 1) / T;             // constraint rows per thread (Scaler::for_rows): 1, or 2 at h = 20
   static constexpr int IN_LEN = 56 + 4 * H;
   static_assert(T <= 1024, "workgroup too large");

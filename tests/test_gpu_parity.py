@@ -48,16 +48,17 @@ def test_hip_matches_live_oracle(config, n):
         wl = perturb_workload(wl, 500 + s)
 
 
-@pytest.mark.parametrize("h", [8, 12])
+@pytest.mark.parametrize("h", [2, 3, 5, 7, 8, 9, 11, 12, 13, 14, 15, 17, 18, 19])
 def test_other_planning_horizons_match_live_oracle(h):
-    """planning_horizon beyond BASELINE's 10 / 16 / 20 (mpc_osqp.cc:186-190 accepts any; mpc_supported_horizons lists what is compiled)."""
+    """planning_horizon beyond BASELINE's 10 / 16 / 20: ConvexMpc takes any (mpc_osqp.cc:186-190, 508-574), the library ships 2 .. 20
+    (mpc_supported_horizons).  Cold + two warm-started solves against the vendored OSQP: decisions equal, forces within the tolerance."""
     from oracle.refmpc import RefBatch
     from rl_mpc_locomotion_amd import _lib
     import ctypes as C
-    hs = (C.c_int * 16)()
-    cnt = _lib.lib().mpc_supported_horizons(hs, 16)
-    assert h in list(hs[:cnt]) and {10, 16, 20} <= set(hs[:cnt])
-    n = 96
+    hs = (C.c_int * 32)()
+    cnt = _lib.lib().mpc_supported_horizons(hs, 32)
+    assert list(hs[:cnt]) == list(range(2, 21))
+    n = 64
     wl = make_solver_workload(n, h=h, seed=40 + h, config=2)
     gpu = _gpu(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
     ref = RefBatch(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
@@ -224,6 +225,54 @@ def test_dispatch_order_does_not_change_results():
             fs, infos = _solve(s, w.inputs[i:i + 1])
             assert np.array_equal(fs[0], f[i]) and np.array_equal(infos[0], info[i])
         w = perturb_workload(w, 300 + step)
+
+
+@pytest.mark.parametrize("config,h,n", [(4, 16, 256), (5, 20, 256)])
+def test_warm_started_long_horizons_match_live_oracle(config, h, n):
+    """BASELINE configs[3] / configs[4] (h = 16 with random ground normals, h = 20) over a cold and two WARM-STARTED solves against the
+    vendored OSQP, one workspace per robot: equal iterations / status / polish / rho updates per robot, forces within the tolerance over
+    the whole horizon."""
+    from oracle.refmpc import RefBatch
+    wl = make_solver_workload(n, h=h, seed=700 + config, config=config)
+    gpu = _gpu(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
+    ref = RefBatch(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
+    for s in range(3):
+        f, info = _solve(gpu, wl.inputs)
+        fr = ref.solve(wl.inputs, nthreads=8)
+        assert np.array_equal(info[:, :4], ref.info[:, :4].astype(np.int32)), (h, s)
+        if s:
+            assert (info[:, 5] == 0).all()          # not a first ("osqp_setup") call: warm-started
+        ok = ref.info[:, 1] == 1
+        assert ok.mean() > 0.95 and grf_relerr(f[ok], fr[ok], first_step_only=False).max() < GRF_RTOL, (h, s)
+        wl = perturb_workload(wl, 710 + s)
+
+
+def test_fp16_state_inputs_h20():
+    """BASELINE configs[4]: "65536 Aliengo, horizon = 20, fp16 state".  The input records are ROUNDED TO FLOAT16 (SURVEY 8(d) rounds rpy that
+    way -- the reference's own com_roll_pitch_yaw is numpy.float16 -- here every one of the 13 arguments) and handed to
+    mpc_batch_solve_f16 as a torch.float16 tensor.  The oracle is fed the same rounded record (float16 -> float32 is exact): decisions
+    equal, forces within the tolerance, over a cold and two warm-started solves; and the float64 entry on the widened values gives the
+    same bits (the storage type changes nothing but the load)."""
+    import torch
+    from oracle.refmpc import RefBatch
+    n, h = 256, 20
+    wl = make_solver_workload(n, h=h, seed=905, config=5)
+    gpu = _gpu(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
+    g64 = _gpu(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
+    ref = RefBatch(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
+    for s in range(3):
+        half = wl.inputs.astype(np.float16)
+        assert np.isfinite(half.astype(np.float32)).all()
+        f, info = gpu.solve(torch.from_numpy(half).to("cuda:0"))
+        f2, info2 = g64.solve(torch.from_numpy(half.astype(np.float64)).to("cuda:0"))
+        torch.cuda.synchronize()
+        f, info = f.cpu().numpy().copy(), info.cpu().numpy().copy()
+        assert np.array_equal(f, f2.cpu().numpy()) and np.array_equal(info, info2.cpu().numpy())
+        fr = ref.solve(half.astype(np.float32), nthreads=8)
+        assert np.array_equal(info[:, :4], ref.info[:, :4].astype(np.int32)), s
+        ok = ref.info[:, 1] == 1
+        assert ok.mean() > 0.95 and grf_relerr(f[ok], fr[ok], first_step_only=False).max() < GRF_RTOL, s
+        wl = perturb_workload(wl, 910 + s)
 
 
 @pytest.mark.parametrize("config,h,n", [(4, 16, 4096), (5, 20, 8192)])
