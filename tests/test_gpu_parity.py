@@ -197,13 +197,14 @@ def test_bad_arguments_raise():
     import torch
     from rl_mpc_locomotion_amd import _lib
     from rl_mpc_locomotion_amd.batched import BatchedConvexMpc
-    with pytest.raises(_lib.MpcLibraryError):
-        BatchedConvexMpc([18.0], [[0.03, 0, 0, 0, 0.16, 0, 0, 0, 0.17]], 11, 0.02)       # horizon not compiled in
+    for bad_h in (1, 21, 0, -3):
+        with pytest.raises(_lib.MpcLibraryError):
+            BatchedConvexMpc([18.0], [[0.03, 0, 0, 0, 0.16, 0, 0, 0, 0.17]], bad_h, 0.02)    # outside the shipped range 2 .. 20 (MPC_E_HORIZON)
     g = _gpu(np.array([18.0]), np.array([[0.03, 0.16, 0.17]]), 10, 0.02, 1e-5)
     with pytest.raises(ValueError):
         g.solve(torch.zeros((1, 95), dtype=torch.float32, device="cuda:0"))              # wrong record length
     with pytest.raises(ValueError):
-        g.solve(torch.zeros((1, 96), dtype=torch.float64, device="cuda:0"))              # wrong dtype
+        g.solve(torch.zeros((1, 96), dtype=torch.int32, device="cuda:0"))                # wrong dtype (float32 / float64 / float16 records only)
 
 
 @pytest.mark.gpu
