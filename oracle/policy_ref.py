@@ -10,7 +10,9 @@ The network itself is third-party code that is absent from /root/reference: rsl_
 num_actions))`` and ``act_inference(obs) = actor(obs)``; hidden sizes and activation from
 RL_Environment/tasks/legged_config_ppo.py:5-9 ([512, 256, 128], 'elu').  Its state_dict keys are ``actor.0.weight``,
 ``actor.0.bias``, ``actor.2.weight``, ... (every second index is the parameter-free activation).
-Pinned by tests/golden/policy_mlp.npz, minted with torch.nn.Sequential of the same structure
+Pinned by (i) tests/golden/runner_policy_h10.npz -- minted by executing the REFERENCE'S OWN `compute_observations` / `step` and
+`RobotRunnerPolicy.run` (taken from the source files by AST, tests/golden/make_golden_runner_policy.py; only the rsl_rl network and the
+hydra config are stand-ins) -- and (ii) tests/golden/policy_mlp.npz, minted with torch.nn.Sequential of the same structure
 (tests/golden/make_golden_policy.py).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import this.
 """
 import numpy as np

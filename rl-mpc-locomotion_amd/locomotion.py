@@ -10,7 +10,7 @@ import ctypes as C
 
 import numpy as np
 
-from . import _lib
+from . import _lib, gym_states
 from .gait import gait_arrays
 from .quadruped import ROBOT_TABLE64
 
@@ -63,8 +63,11 @@ class BatchedLocomotion:
     def run(self, dof_states, body_states, commands, torques=None):
         """The batched ``controller.run(dof_states, body_states, commands)`` of the reference loop
         (RL_Environment/tasks/aliengo.py:252-256): dof_states [N,12,2], body_states [N,13] (pos3, quat xyzw,
-        lin vel3, ang vel3, world frame), commands [N,16]; returns torques [N,12]."""
+        lin vel3, ang vel3, world frame), commands [N,16]; returns torques [N,12].  Also takes the interactive runners'
+        container (RL_MPC_Locomotion.py:96-101): Isaac Gym's structured host arrays `dof_states["pos" / "vel"]`,
+        `body_states["pose"]["r"]` ... and a [3] / [N,3] command (gym_states.py)."""
         import torch
+        dof_states, body_states, commands = self._inputs(dof_states, body_states, commands)
         commands = self._full_commands(commands)
         for name, t, numel in (("dof_states", dof_states, self.n * 24), ("body_states", body_states, self.n * 13), ("commands", commands, self.n * 16)):
             if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or t.numel() != numel:
@@ -74,6 +77,21 @@ class BatchedLocomotion:
         _lib.check(_lib.lib().mpc_ctrl_run(self._handle, dof_states.data_ptr(), body_states.data_ptr(), commands.data_ptr(),
                                            torques.data_ptr(), stream), "mpc_ctrl_run")
         return torques
+
+    def _inputs(self, dof_states, body_states, commands):
+        """The reference's two input containers (gym_states.py): device tensors in the RL-bridge layout pass through; Isaac Gym's structured
+        host arrays (`dof_states["pos"]`, `body_states["pose"]["r"]` ..., the interactive runners) and host float arrays are converted and
+        uploaded."""
+        import torch
+        if gym_states.is_structured(dof_states):
+            dof_states = gym_states.dof_states_to_array(dof_states)
+        if body_states is not None and gym_states.is_structured(body_states):
+            body_states = gym_states.body_states_to_array(body_states)
+        up = lambda x: x if (x is None or hasattr(x, "is_cuda")) else torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self.device)
+        commands = up(commands)
+        if commands.dim() == 1:
+            commands = commands.reshape(1, -1).expand(self.n, -1).contiguous()      # one command for every robot (the viewer loop's `commands`)
+        return up(dof_states), up(body_states), commands
 
     def _full_commands(self, commands):
         """[N, 3] commands (vx, vy, yaw rate: the interactive runners, mpc_weights None) -> [N, 16] with NaN weights, which the
@@ -124,6 +142,7 @@ class BatchedLocomotion:
         """The batched ``RobotRunnerFSM.run(dof_states, body_states, commands)`` (robot_runner/RobotRunnerFSM.py:44-71);
         ``request`` [N] cuda int32 is the control mode requested for each robot this tick."""
         import torch
+        dof_states, body_states, commands = self._inputs(dof_states, body_states, commands)
         commands = self._full_commands(commands)
         for name, t, numel in (("dof_states", dof_states, self.n * 24), ("body_states", body_states, self.n * 13), ("commands", commands, self.n * 16)):
             if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or t.numel() != numel:
@@ -166,6 +185,9 @@ class BatchedLocomotion:
         ``policy`` is a ``weight_policy.WeightPolicy``; returns (torques [N,12], weights [N,12])."""
         import torch
         stream = torch.cuda.current_stream(self.device).cuda_stream
+        dof_states, body_states, commands3 = self._inputs(dof_states, body_states, commands3)
+        if prev_weights is not None and not hasattr(prev_weights, "is_cuda"):
+            prev_weights = torch.from_numpy(np.ascontiguousarray(prev_weights, dtype=np.float32)).to(self.device)
         if body_states.dtype != torch.float32 or not body_states.is_cuda or not body_states.is_contiguous() or body_states.numel() != self.n * 13:
             raise ValueError("body_states must be a contiguous cuda float32 tensor with %d elements" % (self.n * 13))
         _lib.check(_lib.lib().mpc_ctrl_update_estimate(self._handle, body_states.data_ptr(), stream), "mpc_ctrl_update_estimate")

@@ -35,14 +35,17 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from make_golden_controller import inputs_for  # noqa: E402  (the same smooth seeded signals)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = "/root/reference/RL_Environment/tasks/aliengo.py"
+# the three task files carry the same glue for their robot type (aliengo.py / a1.py / go1.py :201, :213-216, :227-263, :321-349)
+TASKS = {"aliengo": ("/root/reference/RL_Environment/tasks/aliengo.py", "Aliengo", RobotType.ALIENGO, 11),
+         "a1": ("/root/reference/RL_Environment/tasks/a1.py", "A1Task", RobotType.A1, 12),
+         "go1": ("/root/reference/RL_Environment/tasks/go1.py", "Go1", RobotType.GO1, 13)}
 
 
-def reference_methods():
-    """`pre_physics_step` and `reset_idx` of class Aliengo, compiled from the reference's source text (the module itself cannot be
+def reference_methods(SRC, cls_name):
+    """`pre_physics_step` and `reset_idx` of the task class, compiled from the reference's source text (the module itself cannot be
     imported without Isaac Gym)."""
     tree = ast.parse(open(SRC).read())
-    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "Aliengo"][0]
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls_name][0]
     fns = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in ("pre_physics_step", "reset_idx")]
     mod = ast.Module(body=fns, type_ignores=[])
     gymtorch = types.SimpleNamespace(unwrap_tensor=lambda t: t)
@@ -58,8 +61,9 @@ class StubGym:
     def set_dof_state_tensor_indexed(self, *a): pass
 
 
-def main(n=4, ticks=40, reset_at=20, reset_ids=(1, 3), seed=11):
-    pre_physics_step, reset_idx = reference_methods()
+def main(task_name="aliengo", n=4, ticks=40, reset_at=20, reset_ids=(1, 3)):
+    SRC, cls_name, robot, seed = TASKS[task_name]
+    pre_physics_step, reset_idx = reference_methods(SRC, cls_name)
     rng = np.random.default_rng(seed)
     Parameters.flat_ground = False
     Parameters.cmpc_gait = GaitType.TROT
@@ -69,7 +73,7 @@ def main(n=4, ticks=40, reset_at=20, reset_ids=(1, 3), seed=11):
     task.controllers = []
     for _ in range(n):                       # aliengo.py:213-216
         r = RobotRunnerMin()
-        r.init(RobotType.ALIENGO)
+        r.init(robot)
         task.controllers.append(r)
     task.default_dof_pos = torch.zeros((n, 12)); task.dof_pos = torch.zeros((n, 12)); task.dof_vel = torch.zeros((n, 12))
     task.initial_root_states = torch.zeros((n, 13)); task.commands_x = torch.zeros(n); task.commands_y = torch.zeros(n); task.commands_yaw = torch.zeros(n)
@@ -78,7 +82,8 @@ def main(n=4, ticks=40, reset_at=20, reset_ids=(1, 3), seed=11):
     st = [dict(phase=rng.uniform(0, 2 * np.pi, 21), amp=rng.uniform(0.02, 0.15, 21), yaw0=rng.uniform(-3, 3), H=float(rng.uniform(0.28, 0.36)),
                v0=rng.uniform(-0.5, 0.5, 3) * np.array([1, 0.4, 0.1]), cmd=np.zeros(3), w=np.zeros(12)) for _ in range(n)]
     out = dict(actions=np.zeros((ticks, n, 12), np.float32), dof_state=np.zeros((ticks, n * 12, 2), np.float32), root_states=np.zeros((ticks, n, 13), np.float32),
-               commands=np.zeros((ticks, n, 3), np.float32), torques=np.zeros((ticks, n, 12), np.float32), reset_at=reset_at, reset_ids=np.array(reset_ids))
+               commands=np.zeros((ticks, n, 3), np.float32), torques=np.zeros((ticks, n, 12), np.float32), reset_at=reset_at, reset_ids=np.array(reset_ids),
+               robot_type=np.full(n, {"aliengo": 0, "a1": 1, "go1": 2}[task_name], np.int32))
     for k in range(ticks):
         if k == reset_at:
             task.dof_state = torch.zeros((n * 12, 2))
@@ -94,9 +99,10 @@ def main(n=4, ticks=40, reset_at=20, reset_ids=(1, 3), seed=11):
         pre_physics_step(task, actions)                                         # aliengo.py:227-263, unmodified
         out["actions"][k], out["dof_state"][k], out["root_states"][k] = actions.numpy(), task.dof_state.numpy(), task.root_states.numpy()
         out["commands"][k], out["torques"][k] = task.commands.numpy(), task.torques.numpy()
-    np.savez_compressed(os.path.join(HERE, "bridge_h10_aliengo.npz"), **out)
-    print("bridge_h10_aliengo written: max |tau|", float(np.abs(out["torques"]).max()))
+    np.savez_compressed(os.path.join(HERE, f"bridge_h10_{task_name}.npz"), **out)
+    print(f"bridge_h10_{task_name} written: max |tau|", float(np.abs(out["torques"]).max()))
 
 
 if __name__ == "__main__":
-    main()
+    for name in (sys.argv[1:] or list(TASKS)):
+        main(name)

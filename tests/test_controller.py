@@ -179,16 +179,18 @@ def test_hip_controller_reset_and_gait_switch():
 
 
 @pytest.mark.gpu
-def test_env_bridge_matches_reference_glue():
-    """MpcEnvBridge against the reference's own pre_physics_step / reset_idx (RL_Environment/tasks/aliengo.py:227-263, :321-349),
-    executed unmodified by tests/golden/make_golden_bridge.py: rescaled actions, command record, controller.run for every env,
-    device env_ids in reset_idx."""
+@pytest.mark.parametrize("task", ["aliengo", "a1", "go1"])
+def test_env_bridge_matches_reference_glue(task):
+    """MpcEnvBridge against the reference's own pre_physics_step / reset_idx of all three task files (RL_Environment/tasks/aliengo.py,
+    a1.py, go1.py :227-263, :321-349 -- the same glue around another RobotType, :201), executed unmodified by
+    tests/golden/make_golden_bridge.py: rescaled actions, command record, controller.run for every env, device env_ids in reset_idx."""
     import torch
     import rl_mpc_locomotion_amd  # noqa: F401
     from rl_mpc_locomotion_amd.env_bridge import MpcEnvBridge
-    g = load_golden("bridge_h10_aliengo")
+    g = load_golden("bridge_h10_" + task)
     T, n = g["actions"].shape[:2]
-    br = MpcEnvBridge(np.zeros(n, np.int32), np.zeros(n, np.int32), horizon=10, flat_ground=False)        # four Aliengo, trot
+    assert (g["robot_type"] == {"aliengo": 0, "a1": 1, "go1": 2}[task]).all()
+    br = MpcEnvBridge(g["robot_type"], np.zeros(n, np.int32), horizon=10, flat_ground=False)              # four robots of the task's type, trot
     worst = 0.0
     for k in range(T):
         if k == int(g["reset_at"]):

@@ -177,3 +177,114 @@ def test_gpu_runner_policy_loop():
         assert torch.isfinite(tau).all()
         w_prev = w.cpu().numpy()
     assert (loco.fsm_state()[:, 0] == BatchedLocomotion.LOCOMOTION).all()
+
+
+# ------------------------------------------------------------------- pinned by the reference's own code
+RUNNER_GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "runner_policy_h10.npz")
+
+
+def test_oracle_matches_the_reference_weight_policy_code():
+    """tests/golden/runner_policy_h10.npz was minted by executing the reference's OWN `WeightPolicy.compute_observations` / `step`
+    (WeightPolicy.py:94-139) and `RobotRunnerPolicy.run` (RobotRunnerPolicy.py:62-92), taken from the source by AST
+    (tests/golden/make_golden_runner_policy.py).  The oracle restatement against it: the observation layout entry by entry (the estimator
+    part through the host restatement of StateEstimator.update, bit-exact), and the weights of `step` on the recorded observations."""
+    from tests.emu.emu import estimator_update
+    g = np.load(RUNNER_GOLD)
+    _, sd = _gold()
+    params = policy_ref.actor_params_from_state_dict(sd)
+    T, n = g["obs"].shape[:2]
+    w_prev = g["weights0"].copy()
+    for k in range(T):
+        nrm = -g["obs"][k, :, 6:9]                                        # projected_gravity = -ground_normal_yaw (WeightPolicy.py:124-125)
+        est = estimator_update(g["body"][k], nrm)
+        obs = policy_ref.observations(g["dof"][k], est[:, 0:3], est[:, 3:6], nrm, g["commands"][k], w_prev)
+        np.testing.assert_array_equal(obs, g["obs"][k])                  # float32 products of the same values: exact
+        _, w = policy_ref.step(params, g["obs"][k])
+        np.testing.assert_allclose(w, g["weights"][k], rtol=ACT_RTOL, atol=20 * ACT_ATOL)
+        w_prev = g["weights"][k]                                          # `self.weights` feeds the next tick's observation (RobotRunnerPolicy.py:76-80)
+    assert (g["weights"] >= 0).all() and (g["state"] == 4).all()
+
+
+def test_runner_policy_torques_on_the_emulation():
+    """The FSM half of RobotRunnerPolicy.run (updateCommand(commands, weights) -> ControlFSM.runFSM -> LegController.updateCommand,
+    RobotRunnerPolicy.py:83-92) on the host emulation, fed the weights the reference's policy produced: torques within the controller
+    tolerance on every tick."""
+    from tests.emu.emu import fsm_replay
+    g = np.load(RUNNER_GOLD)
+    T, n = g["obs"].shape[:2]
+    cmd = np.concatenate((g["commands"], g["weights"], np.zeros((T, n, 1), np.float32)), axis=2)
+    tau, fsm = fsm_replay(g["robot_type"], np.zeros(n, np.int32), np.full(n, 4, np.int32), g["dof"], g["body"], cmd, np.full((T, n), 4, np.int32))
+    assert (fsm[:, :, 0] == g["state"]).all()
+    scale = np.maximum(np.abs(g["torque"]).max(axis=2, keepdims=True), 1.0)
+    assert (np.abs(tau - g["torque"]) / scale).max() < 5e-5
+
+
+@pytest.mark.gpu
+def test_gpu_runner_policy_matches_the_reference_runner():
+    """BatchedLocomotion.run_policy against the unmodified RobotRunnerPolicy.run (golden above), through the reference's INTERACTIVE input
+    container -- Isaac Gym's structured `dof_states["pos" / "vel"]` and `body_states["pose"]["r"]`, `["vel"]["linear" / "angular"]`
+    (RL_MPC_Locomotion.py:96-101), which is the only form WeightPolicy.compute_observations reads: observations exact, weights within the
+    fp32 MLP tolerance, torques within the controller tolerance."""
+    import torch
+    import rl_mpc_locomotion_amd  # noqa: F401
+    from rl_mpc_locomotion_amd import gym_states
+    from rl_mpc_locomotion_amd.locomotion import BatchedLocomotion
+    g = np.load(RUNNER_GOLD)
+    _, sd = _gold()
+    pol = _policy(sd)
+    T, n = g["obs"].shape[:2]
+    loco = BatchedLocomotion(g["robot_type"], np.zeros(n, np.int32), horizon=10)
+    loco.fsm_init(np.full(n, BatchedLocomotion.LOCOMOTION), operating_mode=1, check_safety=True)
+    req = torch.full((n,), BatchedLocomotion.LOCOMOTION, dtype=torch.int32, device="cuda")
+    w_prev = g["weights0"].copy()
+    errs = []
+    for k in range(T):
+        d, b = gym_states.to_structured(g["dof"][k], g["body"][k])
+        assert d.dtype == gym_states.DOF_STATE and b.dtype == gym_states.BODY_STATE
+        # the observation the policy will see: the fresh estimate + the controller's ground normal of the previous tick
+        tau, w = loco.run_policy(pol, [d[i] for i in range(n)], [b[i] for i in range(n)], g["commands"][k], w_prev, req)
+        torch.cuda.synchronize()
+        w = w.cpu().numpy()
+        np.testing.assert_allclose(w, g["weights"][k], rtol=ACT_RTOL, atol=20 * ACT_ATOL)
+        scale = np.maximum(np.abs(g["torque"][k]).max(axis=1, keepdims=True), 1.0)
+        errs.append((np.abs(tau.cpu().numpy() - g["torque"][k]) / scale).max(axis=1))
+        w_prev = g["weights"][k]             # (the reference's own previous weights: keeps the two loops on the same inputs tick by tick)
+    assert (loco.fsm_state()[:, 0] == BatchedLocomotion.LOCOMOTION).all()
+    # The weights here come out of the MFMA chain and differ from torch's CPU sgemm in the last bits (<= 2e-4 on a weight of 50); they
+    # enter the QP, so the torques of this END-TO-END loop carry that difference: BASELINE's 1e-3 bar for every (tick, robot), the
+    # controller's own 5e-5 for nine in ten.  (With the reference's weights fed in, the controller meets 5e-5 everywhere:
+    # test_runner_policy_torques_on_the_emulation.)
+    errs = np.stack(errs)
+    assert errs.max() < 1e-3 and (errs < 5e-5).mean() > 0.9, (errs.max(), (errs < 5e-5).mean())
+
+
+@pytest.mark.gpu
+def test_gpu_observations_match_the_reference_code():
+    """mpc_policy_observations on the estimate of mpc_ctrl_update_estimate against the observation vectors the reference's own
+    compute_observations built (runner_policy_h10.npz): bit-exact but for the ground normal (see below)."""
+    import torch
+    import rl_mpc_locomotion_amd  # noqa: F401
+    from rl_mpc_locomotion_amd.locomotion import BatchedLocomotion
+    g = np.load(RUNNER_GOLD)
+    _, sd = _gold()
+    pol = _policy(sd)
+    T, n = g["obs"].shape[:2]
+    loco = BatchedLocomotion(g["robot_type"], np.zeros(n, np.int32), horizon=10)
+    loco.fsm_init(np.full(n, BatchedLocomotion.LOCOMOTION), operating_mode=1, check_safety=True)
+    req = torch.full((n,), BatchedLocomotion.LOCOMOTION, dtype=torch.int32, device="cuda")
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    w_prev = g["weights0"].copy()
+    for k in range(T):
+        from rl_mpc_locomotion_amd import _lib
+        _lib.check(_lib.lib().mpc_ctrl_update_estimate(loco._handle, t(g["body"][k]).data_ptr(), None), "mpc_ctrl_update_estimate")
+        est, nrm = loco.estimate()
+        obs = pol.compute_observations(t(g["dof"][k]), est, nrm, t(g["commands"][k]), t(w_prev))
+        o = obs.cpu().numpy()
+        keep = np.r_[0:6, 9:48]
+        np.testing.assert_array_equal(o[:, keep], g["obs"][k][:, keep])
+        # entries 6-8 = -ground_normal_yaw: the reference's least squares is LAPACK's single-precision sgelsd (scipy.linalg.lstsq on float32,
+        # StateEstimator.py:132), here fp64 normal equations -- on exactly coplanar feet that is (3e-8, 2e-7, 1) there and (0, 0, 1) here
+        np.testing.assert_allclose(o[:, 6:9], g["obs"][k][:, 6:9], rtol=0, atol=2e-6)
+        cmd16 = np.concatenate((g["commands"][k], g["weights"][k], np.zeros((n, 1), np.float32)), axis=1)
+        loco.run_fsm(t(g["dof"][k]), t(g["body"][k]), t(cmd16), req)     # advances the controller (its ground normal enters the next observation)
+        w_prev = g["weights"][k]
