@@ -199,6 +199,10 @@ int mpc_ctrl_set_gait(mpc_ctrl *c, const int *gait_id, void *stream);       /* H
  * MPC_SOLVER_OSQP (default here: BASELINE's comparator) or MPC_SOLVER_EXACT, see mpc_batch_set_solver. */
 int mpc_ctrl_set_solver(mpc_ctrl *c, int solver);
 int mpc_ctrl_solver_info(mpc_ctrl *c, int *h_info);                          /* [n, 8] of the last solves */
+/* What solveDenseMPC marshalled (ConvexMPCLocomotion.py:128-185): the 13 arguments of each robot's LAST compute_contact_forces call as the
+ * controller built them, HOST [n, 56 + 4 h] float32 in the layout of mpc_batch_solve (parity tests of the controller against the
+ * reference's recorded calls). */
+int mpc_ctrl_solver_record(mpc_ctrl *c, float *h_rec);
 
 /* ---- control FSM around the controller (RobotRunnerFSM) -------------------------------------------
  *

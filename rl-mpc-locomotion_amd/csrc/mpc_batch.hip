@@ -760,6 +760,14 @@ int mpc_ctrl_fsm_state(mpc_ctrl *c, int *h_out) {
   return MPC_OK;
 }
 
+int mpc_ctrl_solver_record(mpc_ctrl *c, float *h_rec) {
+  if (!c || !h_rec) return fail(MPC_E_ARG, "mpc_ctrl_solver_record: bad argument");
+  DeviceGuard guard_(c->solver->device);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(h_rec, c->d_rec, sizeof(float) * (size_t)c->n * (56 + 4 * (size_t)c->cp.horizon), hipMemcpyDeviceToHost));
+  return MPC_OK;
+}
+
 int mpc_ctrl_solver_info(mpc_ctrl *c, int *h_info) {
   if (!c || !h_info) return fail(MPC_E_ARG, "mpc_ctrl_solver_info: bad argument");
   DeviceGuard guard_(c->solver->device);

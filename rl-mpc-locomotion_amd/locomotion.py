@@ -206,6 +206,12 @@ class BatchedLocomotion:
         _lib.check(_lib.lib().mpc_ctrl_estimate(self._handle, est.data_ptr(), nrm.data_ptr(), stream), "mpc_ctrl_estimate")
         return est, nrm
 
+    def solver_record(self):
+        """[N, 56+4h] float32: the 13 arguments of each robot's last compute_contact_forces call as the controller marshalled them."""
+        out = np.zeros((self.n, 56 + 4 * self.h), dtype=np.float32)
+        _lib.check(_lib.lib().mpc_ctrl_solver_record(self._handle, out.ctypes.data), "mpc_ctrl_solver_record")
+        return out
+
     def solver_info(self):
         out = np.zeros((self.n, 8), dtype=np.int32)
         _lib.check(_lib.lib().mpc_ctrl_solver_info(self._handle, out.ctypes.data), "mpc_ctrl_solver_info")

@@ -6,8 +6,11 @@ RobotRunnerMin objects (their `mpc_osqp` module served by the oracle), exactly w
     python tests/golden/make_golden_bridge.py        (build container only: needs /root/reference)
 
 Recorded per tick: actions, dof_state, root_states, commands -> the torques the reference hands to the simulator; env ids 1 and 3
-go through reset_idx before tick 20.  tests/test_controller.py::test_env_bridge_matches_reference_glue replays it through
-rl_mpc_locomotion_amd.env_bridge.MpcEnvBridge on the GPU."""
+go through reset_idx before tick 20; and OSQP's decisions (iterations, status, polish status, rho updates) of every solve, because they are
+what the torques hinge on: a polish accepted there and rejected here is a 1e-2 difference in the forces, and it takes a 1e-7 difference
+in one solver argument (the ground normal: LAPACK's single-precision sgelsd there, StateEstimator.py:132) to flip one.
+tests/test_controller.py::test_env_bridge_matches_reference_glue replays it through rl_mpc_locomotion_amd.env_bridge.MpcEnvBridge on
+the GPU."""
 import ast
 import os
 import sys
@@ -22,8 +25,18 @@ sys.path.insert(0, "/root/reference")
 import rl_mpc_locomotion_amd  # noqa: E402,F401
 from oracle.refmpc import RefConvexMpc  # noqa: E402
 
+class Recording(RefConvexMpc):
+    """The oracle behind the seam, keeping OSQP's decisions of the last call (iterations, status, polish status, rho updates)."""
+    last = None
+
+    def compute_contact_forces(self, *args):
+        out = super().compute_contact_forces(*args)
+        self.last = self.info[:4].copy()
+        return out
+
+
 m = types.ModuleType("mpc_osqp")
-m.ConvexMpc = RefConvexMpc
+m.ConvexMpc = Recording
 m.OSQP, m.QPOASES = 0, 1
 sys.modules["mpc_osqp"] = m
 from MPC_Controller.Parameters import Parameters  # noqa: E402
@@ -83,7 +96,8 @@ def main(task_name="aliengo", n=4, ticks=40, reset_at=20, reset_ids=(1, 3)):
                v0=rng.uniform(-0.5, 0.5, 3) * np.array([1, 0.4, 0.1]), cmd=np.zeros(3), w=np.zeros(12)) for _ in range(n)]
     out = dict(actions=np.zeros((ticks, n, 12), np.float32), dof_state=np.zeros((ticks, n * 12, 2), np.float32), root_states=np.zeros((ticks, n, 13), np.float32),
                commands=np.zeros((ticks, n, 3), np.float32), torques=np.zeros((ticks, n, 12), np.float32), reset_at=reset_at, reset_ids=np.array(reset_ids),
-               robot_type=np.full(n, {"aliengo": 0, "a1": 1, "go1": 2}[task_name], np.int32))
+               robot_type=np.full(n, {"aliengo": 0, "a1": 1, "go1": 2}[task_name], np.int32),
+               decisions=np.zeros((ticks, n, 4), np.int32))      # OSQP's (iter, status, polish, rho updates) of the tick's solve; zeros: no solve
     for k in range(ticks):
         if k == reset_at:
             task.dof_state = torch.zeros((n * 12, 2))
@@ -96,7 +110,12 @@ def main(task_name="aliengo", n=4, ticks=40, reset_at=20, reset_ids=(1, 3)):
         task.dof_state = torch.from_numpy(np.concatenate(dofs, 0))             # (num_envs * num_dofs, 2)
         task.root_states = torch.from_numpy(np.stack(roots))
         task.commands = torch.from_numpy(rng.uniform(-1, 1, (n, 3)).astype(np.float32) * np.array([1.5, 0.5, 1.0], np.float32))
+        for c in task.controllers:
+            c.cMPC._cpp_mpc.last = None
         pre_physics_step(task, actions)                                         # aliengo.py:227-263, unmodified
+        for r, c in enumerate(task.controllers):
+            if c.cMPC._cpp_mpc.last is not None:
+                out["decisions"][k, r] = c.cMPC._cpp_mpc.last
         out["actions"][k], out["dof_state"][k], out["root_states"][k] = actions.numpy(), task.dof_state.numpy(), task.root_states.numpy()
         out["commands"][k], out["torques"][k] = task.commands.numpy(), task.torques.numpy()
     np.savez_compressed(os.path.join(HERE, f"bridge_h10_{task_name}.npz"), **out)

