@@ -203,6 +203,15 @@ int mpc_ctrl_solver_info(mpc_ctrl *c, int *h_info);                          /* 
  * controller built them, HOST [n, 56 + 4 h] float32 in the layout of mpc_batch_solve (parity tests of the controller against the
  * reference's recorded calls). */
 int mpc_ctrl_solver_record(mpc_ctrl *c, float *h_rec);
+/* ... and what came back: each robot's force vector of its LAST solve, HOST [n, 12 h] float64 (rows of robots that never solved: zeros). */
+int mpc_ctrl_solver_forces(mpc_ctrl *c, double *h_forces);
+/* The controllers' ConvexMpc objects (ConvexMPCLocomotion.solver, ConvexMPCLocomotion.py:102-108) as the batch handle that mpc_ctrl_create
+ * built: BORROWED (mpc_ctrl_destroy frees it) -- for the accessors of the first section on a controller's solver (mpc_batch_enable_timing /
+ * _kernel_times, _get_state, _get_profile, _set_max_iter ...). */
+mpc_batch *mpc_ctrl_solver(mpc_ctrl *c);
+/* ConvexMPCLocomotion.iterationCounter (ConvexMPCLocomotion.py:62, a plain attribute there) of every robot, HOST [n]: the gait phase and
+ * which tick is the next MPC update follow from it (benchmarks: SURVEY.md 8(d) samples the counter per robot). */
+int mpc_ctrl_set_iteration(mpc_ctrl *c, const int *iteration, void *stream);
 
 /* ---- control FSM around the controller (RobotRunnerFSM) -------------------------------------------
  *
@@ -267,6 +276,11 @@ int mpc_policy_observations(int n, const float *d_dof, const float *d_est, const
 int mpc_ctrl_update_estimate(mpc_ctrl *c, const float *d_body, void *stream);
 int mpc_ctrl_estimate(mpc_ctrl *c, float *d_est, float *d_ground_normal, void *stream);
 int mpc_pack_commands(int n, const float *d_cmd3, const float *d_weights12, float *d_cmd16, void *stream);
+
+/* Shader clock of `device` under the solve kernel's own regime (one wave of dependent fp64 FMAs per SIMD on every CU) for about busy_ms
+ * milliseconds: *ghz = shader cycles of one workgroup / HIP-event time of the launch, *ms (may be NULL) = that time.  Benchmarks record it next
+ * to their numbers: boxes of one pool differ by 10 % in the clock they sustain. */
+int mpc_device_clock(int device, int busy_ms, double *ghz, double *ms);
 
 const char *mpc_last_error(void);
 

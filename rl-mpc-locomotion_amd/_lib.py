@@ -14,7 +14,7 @@ SYMBOLS = [
     "mpc_batch_set_solver", "mpc_batch_set_max_iter", "mpc_batch_solve_f64", "mpc_batch_solve_f16", "mpc_batch_reset", "mpc_batch_reset_device", "mpc_batch_solve_host", "mpc_batch_solve_host_f64", "mpc_batch_size", "mpc_batch_horizon", "mpc_batch_device_bytes",
     "mpc_batch_state_len", "mpc_batch_get_state", "mpc_batch_set_state", "mpc_batch_qp_len", "mpc_batch_scale_len", "mpc_batch_get_qp", "mpc_batch_get_scale", "mpc_batch_get_profile", "mpc_batch_enable_timing",
     "mpc_batch_kernel_times", "mpc_last_error",
-    "mpc_ctrl_create", "mpc_ctrl_destroy", "mpc_ctrl_step", "mpc_ctrl_run", "mpc_ctrl_reset", "mpc_ctrl_reset_device", "mpc_ctrl_set_gait", "mpc_ctrl_set_solver", "mpc_ctrl_solver_info", "mpc_ctrl_solver_record",
+    "mpc_ctrl_create", "mpc_ctrl_destroy", "mpc_ctrl_step", "mpc_ctrl_run", "mpc_ctrl_reset", "mpc_ctrl_reset_device", "mpc_ctrl_set_gait", "mpc_ctrl_set_solver", "mpc_ctrl_solver_info", "mpc_ctrl_solver_record", "mpc_ctrl_solver_forces", "mpc_ctrl_solver", "mpc_ctrl_set_iteration", "mpc_device_clock",
     "mpc_ctrl_fsm_init", "mpc_ctrl_run_fsm", "mpc_ctrl_fsm_reset", "mpc_ctrl_fsm_reset_device", "mpc_ctrl_fsm_state",
     "mpc_policy_create", "mpc_policy_destroy", "mpc_policy_step", "mpc_policy_observations", "mpc_ctrl_estimate", "mpc_ctrl_update_estimate", "mpc_pack_commands",
 ]
@@ -73,6 +73,10 @@ def lib():
         L.mpc_ctrl_set_solver.argtypes = [vp, ci]; L.mpc_ctrl_set_solver.restype = ci
         L.mpc_ctrl_solver_info.argtypes = [vp, vp]; L.mpc_ctrl_solver_info.restype = ci
         L.mpc_ctrl_solver_record.argtypes = [vp, vp]; L.mpc_ctrl_solver_record.restype = ci
+        L.mpc_ctrl_solver_forces.argtypes = [vp, vp]; L.mpc_ctrl_solver_forces.restype = ci
+        L.mpc_ctrl_solver.argtypes = [vp]; L.mpc_ctrl_solver.restype = vp
+        L.mpc_ctrl_set_iteration.argtypes = [vp, vp, vp]; L.mpc_ctrl_set_iteration.restype = ci
+        L.mpc_device_clock.argtypes = [ci, ci, vp, vp]; L.mpc_device_clock.restype = ci
         L.mpc_ctrl_fsm_init.argtypes = [vp, vp, ci, ci, vp]; L.mpc_ctrl_fsm_init.restype = ci
         L.mpc_ctrl_run_fsm.argtypes = [vp, vp, vp, vp, vp, vp, vp]; L.mpc_ctrl_run_fsm.restype = ci
         L.mpc_ctrl_fsm_reset.argtypes = [vp, vp, ci, vp, vp]; L.mpc_ctrl_fsm_reset.restype = ci
@@ -88,6 +92,13 @@ def lib():
         L.mpc_last_error.argtypes = []; L.mpc_last_error.restype = C.c_char_p
         _LIB = L
     return _LIB
+
+
+def device_clock(device=0, busy_ms=20):
+    """(GHz, ms): the shader clock `device` sustains under one wave of dependent fp64 FMAs per SIMD (mpc_device_clock)."""
+    ghz, ms = C.c_double(0.0), C.c_double(0.0)
+    check(lib().mpc_device_clock(int(device), int(busy_ms), C.addressof(ghz), C.addressof(ms)), "mpc_device_clock")
+    return ghz.value, ms.value
 
 
 def check(rc, what):

@@ -375,6 +375,22 @@ __global__ void ctrl_set_gait_kernel(int n, CtrlState *st, const int *gait_id) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r < n) st[r].gait_id = gait_id[r];
 }
+__global__ void ctrl_set_iter_kernel(int n, CtrlState *st, const int *iter) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) st[r].iter = iter[r];
+}
+// mpc_device_clock: one dependent v_fma_f64 chain per lane, one wave per SIMD on every CU (the solve kernel's own regime);
+// shader cycles (s_memtime) of workgroup 0 over the HIP-event time of the launch = the shader clock the device grants under that load.
+__global__ __launch_bounds__(64) void clock_probe_kernel(long long *out, int iters) {
+  double a = threadIdx.x * 1e-3 + 1.0, b = 1.0000001, c = 1e-9;
+  const long long t0 = __builtin_readcyclecounter();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 32; ++k) a = a * b + c;
+  }
+  const long long t1 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0 + (a == 0.5 ? 1 : 0);
+}
 // The controller's two halves of a tick with ONE LANE PER LEG (four lanes per robot, a hardware quad): a lane works on a private copy of
 // the robot's state, does its own leg's part (controller.h ctrl_pre_legs / ctrl_pre_rest / ctrl_post with the leg range [leg, leg + 1)) and
 // writes back its leg's fields; what concerns the whole robot every lane computes alike and lane 0 writes.  One lane per robot made
@@ -668,6 +684,57 @@ int mpc_ctrl_set_gait(mpc_ctrl *c, const int *gait_id, void *stream) {
   HIP_TRY(hipMemcpyAsync(c->d_gait, gait_id, sizeof(int) * c->n, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(ctrl_set_gait_kernel, dim3((c->n + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, st, c->n, c->d_state, c->d_gait);
   HIP_TRY(hipGetLastError());
+  return MPC_OK;
+}
+
+int mpc_ctrl_set_iteration(mpc_ctrl *c, const int *iteration, void *stream) {
+  if (!c || !iteration) return fail(MPC_E_ARG, "mpc_ctrl_set_iteration: bad argument");
+  DeviceGuard guard_(c->solver->device);
+  for (int r = 0; r < c->n; ++r) if (iteration[r] < 0) return fail(MPC_E_ARG, "mpc_ctrl_set_iteration: negative counter");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  HIP_TRY(hipMemcpyAsync(c->d_active, iteration, sizeof(int) * c->n, hipMemcpyHostToDevice, st));   // (d_active is rewritten by the next tick's ctrl_pre)
+  hipLaunchKernelGGL(ctrl_set_iter_kernel, dim3((c->n + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, st, c->n, c->d_state, c->d_active);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(st));      // `iteration` is a host buffer
+  c->h_iter.assign(iteration, iteration + c->n);
+  return MPC_OK;
+}
+
+mpc_batch *mpc_ctrl_solver(mpc_ctrl *c) { return c ? c->solver : nullptr; }
+
+int mpc_ctrl_solver_forces(mpc_ctrl *c, double *h_forces) {
+  if (!c || !h_forces) return fail(MPC_E_ARG, "mpc_ctrl_solver_forces: bad argument");
+  DeviceGuard guard_(c->solver->device);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(h_forces, c->d_forces, sizeof(double) * (size_t)c->n * 12 * c->cp.horizon, hipMemcpyDeviceToHost));
+  return MPC_OK;
+}
+
+int mpc_device_clock(int device, int busy_ms, double *ghz, double *ms) {
+  if (!ghz || busy_ms <= 0 || busy_ms > 1000) return fail(MPC_E_ARG, "mpc_device_clock: bad argument (1 .. 1000 ms)");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(MPC_E_NODEVICE, "mpc_device_clock: no such HIP device");
+  DeviceGuard guard_(device);
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  const int blocks = 4 * prop.multiProcessorCount;       // one single-wave workgroup per SIMD
+  long long *d_out = nullptr;
+  HIP_TRY(hipMalloc(&d_out, sizeof(long long) * blocks));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  // ~6.3 shader cycles per dependent fp64 FMA, 32 per trip: ~10 k trips per ms at 2.1 GHz
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(64), 0, nullptr, d_out, 2000);
+  HIP_TRY(hipEventRecord(e0, nullptr));
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(64), 0, nullptr, d_out, 10000 * busy_ms);
+  HIP_TRY(hipEventRecord(e1, nullptr));
+  HIP_TRY(hipEventSynchronize(e1));
+  float t = 0.f;
+  HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+  long long cyc = 0;
+  HIP_TRY(hipMemcpy(&cyc, d_out, sizeof cyc, hipMemcpyDeviceToHost));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d_out);
+  *ghz = t > 0.f ? (double)cyc / ((double)t * 1e6) : 0.0;
+  if (ms) *ms = t;
   return MPC_OK;
 }
 

@@ -16,9 +16,12 @@ from .quadruped import ROBOT_TABLE64
 
 
 class BatchedLocomotion:
-    def __init__(self, robot_type, gait_id, horizon=10, controller_dt=0.01, alpha=1e-5, flat_ground=False, device=None, solver="osqp"):
+    def __init__(self, robot_type, gait_id, horizon=10, controller_dt=0.01, alpha=1e-5, flat_ground=False, device=None, solver="osqp",
+                 iterations_between_mpc=None):
         """solver: "osqp" (the reference's OSQP branch, BASELINE's comparator) or "exact" (its qpOASES branch -- what the shipped
-        Python passes, ConvexMPCLocomotion.py:108 -- the QP's optimum, cold every call); see BatchedConvexMpc."""
+        Python passes, ConvexMPCLocomotion.py:108 -- the QP's optimum, cold every call); see BatchedConvexMpc.
+        iterations_between_mpc: the second constructor argument of ConvexMPCLocomotion (ConvexMPCLocomotion.py:58); None = what
+        RobotRunnerMin passes, int(27 / (1000 controller_dt)) (RobotRunnerMin.py:21-22: 2 at the reference's controller_dt = 0.01)."""
         import torch
         if not torch.cuda.is_available():
             raise _lib.MpcLibraryError("BatchedLocomotion needs a GPU (torch.cuda.is_available() is False); no CPU fallback")
@@ -27,7 +30,8 @@ class BatchedLocomotion:
         rt = np.ascontiguousarray(robot_type, dtype=np.int32)
         gi = np.ascontiguousarray(gait_id, dtype=np.int32)
         self.n, self.h = len(rt), int(horizon)
-        iters = int(27 / (1000.0 * controller_dt))                    # RobotRunnerMin.py:21-22
+        iters = int(27 / (1000.0 * controller_dt)) if iterations_between_mpc is None else int(iterations_between_mpc)   # RobotRunnerMin.py:21-22
+        self.iterations_between_mpc = iters
         off, dur = gait_arrays(self.h)
         off = np.ascontiguousarray(off, dtype=np.int32); dur = np.ascontiguousarray(dur, dtype=np.int32)
         tab = np.ascontiguousarray(ROBOT_TABLE64, dtype=np.float64)
@@ -211,6 +215,31 @@ class BatchedLocomotion:
         out = np.zeros((self.n, 56 + 4 * self.h), dtype=np.float32)
         _lib.check(_lib.lib().mpc_ctrl_solver_record(self._handle, out.ctypes.data), "mpc_ctrl_solver_record")
         return out
+
+    def solver_forces(self):
+        """[N, 12h] float64: each robot's force vector of its last solve (what compute_contact_forces returned)."""
+        out = np.zeros((self.n, 12 * self.h), dtype=np.float64)
+        _lib.check(_lib.lib().mpc_ctrl_solver_forces(self._handle, out.ctypes.data), "mpc_ctrl_solver_forces")
+        return out
+
+    def set_iteration(self, iteration):
+        """``cMPC.iterationCounter = iteration[r]`` for every robot (ConvexMPCLocomotion.py:62): gait phase and MPC cadence follow from it."""
+        import torch
+        it = np.ascontiguousarray(iteration, dtype=np.int32)
+        if it.shape != (self.n,):
+            raise ValueError("iteration must have one entry per robot")
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.lib().mpc_ctrl_set_iteration(self._handle, it.ctypes.data, stream), "mpc_ctrl_set_iteration")
+
+    def enable_timing(self):
+        """HIP events around the two solver kernels of every launch of this controller's solver (mpc_batch_enable_timing)."""
+        _lib.check(_lib.lib().mpc_batch_enable_timing(_lib.lib().mpc_ctrl_solver(self._handle)), "mpc_batch_enable_timing")
+
+    def kernel_times(self, last_k):
+        """(prep_ms [k], solve_ms [k]) of the last k solver launches of this controller."""
+        a = np.zeros(last_k, dtype=np.float32); b = np.zeros(last_k, dtype=np.float32)
+        _lib.check(_lib.lib().mpc_batch_kernel_times(_lib.lib().mpc_ctrl_solver(self._handle), int(last_k), a.ctypes.data, b.ctypes.data), "mpc_batch_kernel_times")
+        return a, b
 
     def solver_info(self):
         out = np.zeros((self.n, 8), dtype=np.int32)

@@ -4,6 +4,7 @@
 // exposes intra-phase races).  Lets the CPU test-suite check the kernel's algorithm against the
 // oracle without a GPU.
 #define MPC_EMU_DEBUG 1
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -274,6 +275,37 @@ int emu_sc_len(int h) {
 }
 }
 
+// ---- the controller as a stepping object: mpc_ctrl_create / mpc_ctrl_run / mpc_ctrl_reset of the library, robot by robot on the host ----
+// (closed-loop tests drive it tick by tick: the next inputs depend on the torques it returned; bench.py --emulate runs its control flow on it)
+struct EmuCtrl {
+  int n, h;
+  GaitTable gt;
+  CtrlParams cp;
+  std::vector<CtrlState> st;
+  std::vector<RobotConst> rc;
+  std::vector<RobotModel> mdl;
+  std::vector<double> state, forces;
+  std::vector<int> info;
+  std::vector<float> rec;
+};
+template <int H>
+static void emu_ctrl_tick(EmuCtrl &c, int r0, int r1, const float *dof, const float *body, const float *cmd, float *torques, int exact) {
+  const int inlen = 56 + 4 * H, sl = 64 * H + 2;
+  for (int r = r0; r < r1; ++r) {
+    float est[kEstLen];
+    estimator_update(body + (size_t)r * 13, c.st[r].normal, est);
+    float *rec = c.rec.data() + (size_t)r * inlen;
+    ctrl_pre(c.st[r], c.rc[r], c.gt, c.cp, dof + (size_t)r * 24, est, cmd + (size_t)r * 16, rec);
+    int *info = c.info.data() + (size_t)r * kInfoLen;
+    if (c.st[r].do_solve) {
+      if (exact) std::fill(c.state.begin() + (size_t)r * sl, c.state.begin() + (size_t)(r + 1) * sl, 0.0);
+      solve_one<H>(c.mdl[r], rec, c.state.data() + (size_t)r * sl, c.forces.data() + (size_t)r * 12 * H, info, false, nullptr, nullptr, exact != 0);
+    }
+    const int st_ = info[1];
+    const int adopt = exact ? (st_ == kStSolved || st_ == kStSolvedInaccurate || st_ == kStMaxIter) : st_ == kStSolved;
+    ctrl_post(c.st[r], c.rc[r], c.forces.data() + (size_t)r * 12 * H, adopt, torques + (size_t)r * 12);
+  }
+}
 extern "C" {
 
 // ---- controller replay (ctrl_pre -> emulated solve -> ctrl_post), horizon 10 ---------------------------
@@ -315,6 +347,68 @@ int emu_ctrl_replay(int n, int ticks, const double *robot_table, const int *robo
     }
   return 0;
 }
+
+void *emu_ctrl_open(int n, int h, const double *robot_table, const int *robot_type, const int *gait_id, const int *gait_off, const int *gait_dur,
+                    int flat_ground, double dt, int iters_between_mpc, double alpha) {
+  EmuCtrl *c = new EmuCtrl();
+  c->n = n; c->h = h;
+  c->gt.n_seg = h;
+  for (int g = 0; g < kNumGaitIds; ++g) for (int j = 0; j < 4; ++j) { c->gt.offsets[g][j] = (float)gait_off[4 * g + j]; c->gt.durations[g][j] = (float)gait_dur[4 * g + j]; }
+  c->cp = CtrlParams{dt, iters_between_mpc, dt * iters_between_mpc, h, flat_ground};
+  c->st.resize(n); c->rc.resize(n); c->mdl.resize(n);
+  c->state.assign((size_t)n * (64 * h + 2), 0.0); c->forces.assign((size_t)n * 12 * h, 0.0); c->info.assign((size_t)n * kInfoLen, 0);
+  c->rec.assign((size_t)n * (56 + 4 * h), 0.f);
+  for (int r = 0; r < n; ++r) {
+    const double *row = robot_table + 25 * robot_type[r];
+    RobotConst &k = c->rc[r];
+    k.abad = row[0]; k.hip = row[1]; k.knee = row[2];
+    for (int i = 0; i < 3; ++i) k.hiploc[i] = (float)row[3 + i];
+    k.body_height = row[10]; k.mu = (float)row[11];
+    for (int i = 0; i < 13; ++i) k.weights[i] = (float)row[12 + i];
+    const double inertia9[9] = {row[7], 0, 0, 0, row[8], 0, 0, 0, row[9]};
+    c->mdl[r] = make_model(row[6], inertia9, c->cp.dt_mpc, alpha);
+    ctrl_init(c->st[r], k, robot_type[r], gait_id[r]);
+  }
+  return c;
+}
+int emu_ctrl_run(void *hnd, const float *dof, const float *body, const float *cmd, float *torques, int exact, int nthreads) {
+  EmuCtrl &c = *static_cast<EmuCtrl *>(hnd);
+  auto work = [&](int r0, int r1) {
+    switch (c.h) {
+#define EMU_CASE(HH) case HH: emu_ctrl_tick<HH>(c, r0, r1, dof, body, cmd, torques, exact); break;
+      EMU_HORIZONS(EMU_CASE)
+#undef EMU_CASE
+      default: break;
+    }
+  };
+  if (nthreads <= 1 || c.n < 2) { work(0, c.n); return 0; }
+  std::vector<std::thread> pool;
+  const int per = (c.n + nthreads - 1) / nthreads;
+  for (int t = 0; t < nthreads; ++t) {
+    const int r0 = t * per, r1 = std::min(c.n, r0 + per);
+    if (r0 < r1) pool.emplace_back(work, r0, r1);
+  }
+  for (auto &t : pool) t.join();
+  return 0;
+}
+void emu_ctrl_reset(void *hnd, const int *ids, int k) {     // mpc_ctrl_reset: RobotRunnerMin.reset + a new ConvexMpc object
+  EmuCtrl &c = *static_cast<EmuCtrl *>(hnd);
+  const int sl = 64 * c.h + 2;
+  for (int i = 0; i < (ids ? k : c.n); ++i) {
+    const int r = ids ? ids[i] : i;
+    if (r < 0 || r >= c.n) continue;
+    ctrl_reset(c.st[r], c.rc[r]);
+    std::fill(c.state.begin() + (size_t)r * sl, c.state.begin() + (size_t)(r + 1) * sl, 0.0);
+  }
+}
+void emu_ctrl_set_iteration(void *hnd, const int *it) { EmuCtrl &c = *static_cast<EmuCtrl *>(hnd); for (int r = 0; r < c.n; ++r) c.st[r].iter = it[r]; }
+void emu_ctrl_get(void *hnd, int *info, double *forces, float *rec) {
+  EmuCtrl &c = *static_cast<EmuCtrl *>(hnd);
+  if (info) std::memcpy(info, c.info.data(), sizeof(int) * c.info.size());
+  if (forces) std::memcpy(forces, c.forces.data(), sizeof(double) * c.forces.size());
+  if (rec) std::memcpy(rec, c.rec.data(), sizeof(float) * c.rec.size());
+}
+void emu_ctrl_close(void *hnd) { delete static_cast<EmuCtrl *>(hnd); }
 
 // ---- RobotRunnerFSM.run replay (estimator -> fsm_tick -> [ctrl_pre -> emulated solve -> ctrl_post] | joint PD), horizon 10 ----
 // init_mode [n], request [T][n]: FSM_StateName values; fsm_out [T][n][3] = (state, operating mode, recovery flag) after the tick.

@@ -65,6 +65,71 @@ def ctrl_replay(robot_type, gait_id, flat_ground, dof, est, cmd, dt=0.01, iters_
     return tau, rec, fff
 
 
+class EmuLocomotion:
+    """The library's per-tick controller (mpc_ctrl_create / _run / _reset: BatchedLocomotion) on the host emulation, as a stepping object:
+    run(dof [n,12,2], body [n,13], cmd [n,16]) -> torques [n,12] (numpy float32)."""
+
+    def __init__(self, robot_type, gait_id, horizon=10, controller_dt=0.01, alpha=1e-5, flat_ground=False, solver="osqp", iterations_between_mpc=None, nthreads=8):
+        import rl_mpc_locomotion_amd  # noqa: F401
+        from rl_mpc_locomotion_amd.gait import gait_arrays
+        from rl_mpc_locomotion_amd.quadruped import ROBOT_TABLE64
+        L = lib()
+        self.n, self.h, self.exact, self.nthreads = len(robot_type), int(horizon), int(solver == "exact"), nthreads
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        off, dur = gait_arrays(self.h)
+        off = np.ascontiguousarray(off, dtype=np.int32); dur = np.ascontiguousarray(dur, dtype=np.int32)
+        tab = np.ascontiguousarray(ROBOT_TABLE64, dtype=np.float64)
+        rt = np.ascontiguousarray(robot_type, dtype=np.int32); gi = np.ascontiguousarray(gait_id, dtype=np.int32)
+        iters = int(27 / (1000.0 * controller_dt)) if iterations_between_mpc is None else int(iterations_between_mpc)
+        L.emu_ctrl_open.restype = C.c_void_p
+        L.emu_ctrl_open.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_double, C.c_int, C.c_double]
+        L.emu_ctrl_run.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int]
+        L.emu_ctrl_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.emu_ctrl_set_iteration.argtypes = [C.c_void_p, C.c_void_p]
+        L.emu_ctrl_get.argtypes = [C.c_void_p] * 4
+        L.emu_ctrl_close.argtypes = [C.c_void_p]
+        self._h = L.emu_ctrl_open(self.n, self.h, p(tab), p(rt), p(gi), p(off), p(dur), int(bool(flat_ground)), float(controller_dt), iters, float(alpha))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().emu_ctrl_close(self._h)
+            self._h = None
+
+    def run(self, dof, body, cmd):
+        dof = np.ascontiguousarray(dof, dtype=np.float32); body = np.ascontiguousarray(body, dtype=np.float32); cmd = np.ascontiguousarray(cmd, dtype=np.float32)
+        assert dof.size == self.n * 24 and body.size == self.n * 13 and cmd.size == self.n * 16
+        tau = np.zeros((self.n, 12), np.float32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        assert lib().emu_ctrl_run(self._h, p(dof), p(body), p(cmd), p(tau), self.exact, self.nthreads) == 0
+        return tau
+
+    def reset(self, env_ids=None):
+        if env_ids is None:
+            lib().emu_ctrl_reset(self._h, None, 0)
+        else:
+            ids = np.ascontiguousarray(env_ids, dtype=np.int32)
+            lib().emu_ctrl_reset(self._h, ids.ctypes.data_as(C.c_void_p), len(ids))
+
+    def set_iteration(self, it):
+        it = np.ascontiguousarray(it, dtype=np.int32)
+        lib().emu_ctrl_set_iteration(self._h, it.ctypes.data_as(C.c_void_p))
+
+    def solver_info(self):
+        out = np.zeros((self.n, 8), np.int32)
+        lib().emu_ctrl_get(self._h, out.ctypes.data_as(C.c_void_p), None, None)
+        return out
+
+    def solver_forces(self):
+        out = np.zeros((self.n, 12 * self.h))
+        lib().emu_ctrl_get(self._h, None, out.ctypes.data_as(C.c_void_p), None)
+        return out
+
+    def solver_record(self):
+        out = np.zeros((self.n, 56 + 4 * self.h), np.float32)
+        lib().emu_ctrl_get(self._h, None, None, out.ctypes.data_as(C.c_void_p))
+        return out
+
+
 def estimator_update(body, normal):
     L = lib()
     body = np.ascontiguousarray(body, dtype=np.float32); normal = np.ascontiguousarray(normal, dtype=np.float32)
