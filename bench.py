@@ -3,10 +3,13 @@
 
     python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5]
 
-A "step" = one pass of the hot path over one batch of synthetic input: every robot of the batch does one
-``compute_contact_forces`` (QP build + OSQP-equivalent solve, mpc_osqp.cc:578-796) on the GPU.  The leg-torque map
-(LegController.updateCommand) is NOT inside `value`; the whole ``controller.run`` seam including it is the
-secondary ``control_loop`` leg.
+A "step" = one pass of the hot path over one batch of synthetic input = SURVEY.md 8(d)'s unit of work for every robot of the batch: one
+``controller.run(dof_states, body_states, commands) -> torques`` call (the reference's batch seam, RL_Environment/tasks/aliengo.py:246-256) on
+which EVERY robot is due for its MPC update -- state estimator, leg kinematics, gait / foot placement, one ``compute_contact_forces``
+(QP build + OSQP-equivalent solve, mpc_osqp.cc:578-796), swing / stance commands and the leg-torque map (LegController.updateCommand, a22).
+(`--seam ctrl`, the default for configs 2 and 3.  `--seam solver` times the bare ``compute_contact_forces`` batch, a2-a13 without the
+controller around it: the `secondary.solver_seam` line, and the only seam of configs 4 / 5, whose terrain normals are a solver-input
+specification.)
 
 Workloads (BASELINE.json configs):
   --config 2 (default, the configuration the metric is quoted on): 4096 Aliengo per GPU, trot, horizon 10, flat terrain; weak scaling.
@@ -90,6 +93,8 @@ def parse_args():
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--robots", type=int, default=None, help="robots per GPU (overrides the configuration's size)")
     ap.add_argument("--horizon", type=int, default=None, help="(overrides the configuration's horizon)")
+    ap.add_argument("--seam", default=None, choices=["ctrl", "solver"], help="ctrl: controller.run with every robot due (SURVEY 8(d)'s unit incl. the torque map; default for "
+                                                                             "configs 2, 3); solver: the bare compute_contact_forces batch (default for configs 4, 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-control-loop", action="store_true", help="skip the secondary legs (profiling runs)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary single-GPU lines of the other configurations")
@@ -125,6 +130,120 @@ class _EmulatedSolver:
 
     def kernel_times(self, k):
         return np.full(k, 1e-3, np.float32), np.full(k, 1e-3, np.float32)
+
+
+class _EmulatedLocomotion:
+    """--emulate: the host emulation of the controller kernels behind BatchedLocomotion's interface (CPU tensors)."""
+
+    def __init__(self, cs, h, controller_dt):
+        from tests.emu.emu import EmuLocomotion
+        self.e = EmuLocomotion(cs.robot_type, cs.gait_id, horizon=h, controller_dt=controller_dt, nthreads=2)
+
+    def enable_timing(self):
+        pass
+
+    def reset(self):
+        self.e.reset()
+
+    def set_iteration(self, it):
+        self.e.set_iteration(it)
+
+    def run(self, dof, body, cmd):
+        import torch
+        return torch.from_numpy(self.e.run(dof.numpy(), body.numpy(), cmd.numpy()))
+
+    def kernel_times(self, k):
+        return np.full(k, 1e-3, np.float32), np.full(k, 1e-3, np.float32)
+
+    def solver_info(self):
+        return self.e.solver_info()
+
+    def solver_record(self):
+        return self.e.solver_record()
+
+    def solver_forces(self):
+        return np.nan_to_num(self.e.solver_forces())
+
+
+class _Model:
+    """what cpu_baseline / exact_leg need to know about the robots of a leg"""
+
+    def __init__(self, robot_type, dt_mpc, alpha):
+        from rl_mpc_locomotion_amd.quadruped import ROBOT_TABLE64, COL_MASS, COL_INERTIA
+        self.mass = ROBOT_TABLE64[robot_type, COL_MASS]
+        self.inertia_diag = ROBOT_TABLE64[robot_type, COL_INERTIA:COL_INERTIA + 3]
+        self.dt_mpc, self.alpha = dt_mpc, alpha
+
+
+CTRL_DT = 0.02      # controller.run period of the ctrl seam: iterationsBetweenMPC = int(27 / (1000 * 0.02)) = 1 (RobotRunnerMin.py:21-22), so EVERY call is
+                    # an MPC update of every robot, with the reference's dtMPC = 0.02 (its own 0.01 x 2, ConvexMPCLocomotion.py:58)
+
+
+def run_leg_ctrl(cfg_id, n, h, K, W, dev, rank, world, dist, repeats=1, emulate=False):
+    """`value`'s leg: K timed controller.run calls (every robot due on every call) after W warm-up calls, `repeats` blocks, each bracketed by
+    barrier + synchronize; then ONE untimed replay of the same block that fetches, per step, what the solver was handed and what it did
+    (records, info) -- the solves are deterministic, so the replay's are the timed block's."""
+    import torch
+    from rl_mpc_locomotion_amd import layout as L
+    from rl_mpc_locomotion_amd.synthetic import ControlStepStream
+
+    R = max(1, repeats)
+    cs = ControlStepStream(n, h=h, seed=1000 + rank, config=cfg_id)            # this rank's shard: its own seeded robots
+    host = [cs.step(s) for s in range(W + K)]
+    ins = [tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in t) for t in host]     # resident in HBM before timing
+    if emulate:
+        ctl = _EmulatedLocomotion(cs, h, CTRL_DT)
+        sync = lambda: None
+    else:
+        from rl_mpc_locomotion_amd.locomotion import BatchedLocomotion
+        ctl = BatchedLocomotion(cs.robot_type, cs.gait_id, horizon=h, controller_dt=CTRL_DT, device=dev)
+        assert ctl.iterations_between_mpc == 1
+        sync = lambda: torch.cuda.synchronize(dev)
+    ctl.enable_timing()
+    block_s, prep_ms, solve_ms = [], [], []
+    for r in range(R + 1):                       # block R is the untimed replay
+        replay = r == R
+        ctl.reset()
+        ctl.set_iteration(cs.iteration0)
+        recs, infos, first_forces = [], [], None
+        for s in range(W):
+            ctl.run(*ins[s])
+            if replay:
+                recs.append(ctl.solver_record())
+        sync()
+        if dist is not None:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for s in range(K):
+            ctl.run(*ins[W + s])
+            if replay:
+                recs.append(ctl.solver_record()); infos.append(ctl.solver_info())
+                if s == 0:
+                    first_forces = ctl.solver_forces()
+        sync()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if replay:
+            break
+        if dist is not None:
+            from rl_mpc_locomotion_amd.sharding import max_over_ranks
+            elapsed = max_over_ranks(elapsed, dev)
+        block_s.append(elapsed)
+        a, b = ctl.kernel_times(min(K, 64))
+        prep_ms.append(a.astype(np.float64)); solve_ms.append(b.astype(np.float64))
+    prep_ms, solve_ms = np.concatenate(prep_ms), np.concatenate(solve_ms)
+    info = np.stack(infos)                                           # [K, n, 8]
+    flops = asm_flops = exec_flops = 0.0
+    for j in range(K):
+        contact = recs[W + j][:, L.IN_CONTACT:L.IN_CONTACT + 4 * h]
+        it, nf = info[j, :, 0].astype(np.float64), info[j, :, 4].astype(np.float64)
+        fa, fs = algorithmic_flops(h, contact, it, nf)
+        flops += fs; asm_flops += fa
+        exec_flops += executed_flops(h, it, nf)
+    return dict(wl=_Model(cs.robot_type, CTRL_DT, 1e-5), batches=recs, solver=ctl, block_s=np.array(block_s), elapsed=float(np.median(block_s)), prep_ms=prep_ms,
+                solve_ms=solve_ms, info=info, first_forces=first_forces, flops_per_launch=flops / K, prep_flops_per_launch=asm_flops / K, exec_flops=exec_flops / K)
 
 
 def run_leg(cfg_id, n, h, K, W, dev, rank, world, dist, repeats=1, emulate=False):
@@ -240,8 +359,16 @@ def main():
         n = hi - lo
     n_total = n * world if (args.robots or cfg["robots_per_gpu"]) else robots_total
 
-    m = run_leg(args.config, n, h, K, W, dev, rank, world, dist, repeats=args.repeats, emulate=args.emulate)
+    seam = args.seam or ("ctrl" if args.config in (2, 3) else "solver")
+    if seam == "ctrl" and args.config in (4, 5):
+        raise SystemExit("bench.py: configs 4 / 5 specify the solver's terrain-normal argument directly (SURVEY 8(d)): --seam solver only")
+    clock0 = device_state(local_rank) if not args.emulate and rank == 0 else None
+    leg = run_leg_ctrl if seam == "ctrl" else run_leg
+    m = leg(args.config, n, h, K, W, dev, rank, world, dist, repeats=args.repeats, emulate=args.emulate)
+    clock1 = device_state(local_rank, smi=False) if not args.emulate and rank == 0 else None
     gather = all_gather_leg(n, n_total, dev, dist) if dist is not None else None
+    if dist is not None and seam == "ctrl":
+        gather["sharded_loop"] = sharded_loop_leg(args.config, n_total, h, dev, dist, emulate=args.emulate)
 
     if rank != 0:
         dist.destroy_process_group()
@@ -249,19 +376,12 @@ def main():
 
     info, solve_ms, prep_ms = m["info"], m["solve_ms"], m["prep_ms"]
     achieved_tflops = m["flops_per_launch"] / (solve_ms.mean() * 1e-3) / 1e12
-    # HBM-side traffic is a rocprofv3 PMC measurement taken offline on this same command (tools/pmc_passes.sh ->
-    # profiles/rNN_pmc_summary[_prep]_h10.json); bench.py cannot run the profiler on itself.  Both kernels of a step are counted.
+    # HBM-side traffic is a rocprofv3 PMC measurement of THIS command, taken in separate --pmc passes (tools/pmc_passes.sh ->
+    # profiles/<TRAFFIC_PROFILE>_pmc_summary[_prep]_h10.json; bench.py cannot run the profiler on itself).  The files are named here, not
+    # searched for, and quoted only if they were measured on the kernel sources of this tree (their kernel_source_sha256).
     traffic, traffic_parts = None, None
-    try:
-        import glob
-        ps = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary_h10.json")))
-        pp = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary_prep_h10.json")))
-        if ps and pp and n == 4096 and h == 10 and args.config == 2:
-            t_solve = float(json.load(open(ps[-1]))["hbm_traffic_bytes_per_launch"])
-            t_prep = float(json.load(open(pp[-1]))["hbm_traffic_bytes_per_launch"])
-            traffic, traffic_parts = t_solve + t_prep, {"solve_kernel": t_solve, "prep_kernel": t_prep, "from": [os.path.basename(ps[-1]), os.path.basename(pp[-1])]}
-    except (OSError, ValueError, KeyError):
-        traffic = None
+    if n == 4096 and h == 10 and args.config == 2 and not args.emulate:
+        traffic, traffic_parts = traffic_from_profile()
     value = n_total * K / m["elapsed"]
     out = {
         "metric": f"MPC control steps/sec (whole node) @ horizon={h}, {n} robots; max |GRF| err vs OSQP",   # BASELINE.json's metric at the default configuration
@@ -280,9 +400,13 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"config {args.config}: {n} robots/GPU x {world} GPU(s), {cfg['what']}; one compute_contact_forces (QP build + solve) per robot "
-                               "per step, warm-started seeded sequence, SURVEY.md 8(d); the leg-torque map (a22) is outside `value` (see control_loop)",
-                   "robots_per_gpu": n, "robots_total": n_total, "horizon": h, "parallelism": f"robot-sharded x{world}"},
+        "config": {"workload": f"config {args.config}: {n} robots/GPU x {world} GPU(s), {cfg['what']}; " + (
+                       "one controller.run(dof_states, body_states, commands) -> torques call per step with EVERY robot due for its MPC update: state estimator, leg "
+                       "kinematics, gait / foot placement, compute_contact_forces (QP build + solve), swing / stance commands, leg-torque map a22 = SURVEY.md 8(d)'s "
+                       "unit of work; warm-started seeded sequence at 8(d)'s input distributions" if seam == "ctrl" else
+                       "one compute_contact_forces (QP build + solve) per robot per step, warm-started seeded sequence, SURVEY.md 8(d); the bare solver batch "
+                       "(a2-a13), no controller around it"),
+                   "seam": seam, "robots_per_gpu": n, "robots_total": n_total, "horizon": h, "parallelism": f"robot-sharded x{world}"},
         "solved_fraction": float((info[..., 1] == 1).mean()),
         "mean_admm_iters": float(info[..., 0].mean()),
         "mean_factorisations": float(info[..., 4].mean()),
@@ -295,7 +419,8 @@ def main():
                              "mean duration of the solve kernel (mpc_solve_jobs_kernel) from HIP events on the launch stream; `peak` is the FP32 vector rate SURVEY 8(d) "
                              "prescribes, the kernel's arithmetic is fp64 (frac_fp64_peak, peak 78.6 TF)",
                      "kernel": "mpc_solve_jobs_kernel<10> (persistent: ADMM and polish jobs of every robot)", "kernel_ms": float(solve_ms.mean()), "prep_kernel_ms": float(prep_ms.mean()),
-                     "step_ms_all_kernels": float((prep_ms + solve_ms).mean()), "flops_per_launch": m["flops_per_launch"],
+                     "step_ms_all_kernels": float((prep_ms + solve_ms).mean()), "step_ms_outside_the_two_solver_kernels": float(m["elapsed"] / K * 1e3 - (prep_ms + solve_ms).mean()),
+                     "flops_per_launch": m["flops_per_launch"],
                      "prep_kernel_flops_per_launch": m["prep_flops_per_launch"],
                      "frac_fp64_peak": achieved_tflops / FP64_VECTOR_PEAK_TFLOPS,
                      "executed": {"flops_per_launch": m["exec_flops"], "tflops": m["exec_flops"] / (solve_ms.mean() * 1e-3) / 1e12,
@@ -303,6 +428,10 @@ def main():
                                   "note": "operations the solve kernel executes (bench.py executed_flops: OSQP on all 12 h variables through the 6 h x 6 h "
                                           "wrench-space core), for orientation only -- `achieved` / `frac` use the SURVEY 8(d) minimal-algorithm count"}},
     }
+    if clock0 is not None:
+        out["device_state"] = {"before": clock0, "after": clock1,
+                               "note": "shader_clock_ghz: mpc_device_clock -- shader cycles / HIP-event time of ~20 ms of dependent fp64 FMAs, one wave per SIMD on every CU "
+                                       "(the solve kernel's regime); boxes of the pool that sustain ~10 % less run every kernel of this line ~10 % slower"}
     if args.emulate:
         out["data"] = "synthetic; EMULATED kernels on the CPU (control-flow dry run: the numbers mean nothing)"
     if gather is not None:
@@ -316,11 +445,18 @@ def main():
         out["secondary"] = secondary_lines(dev)          # the other BASELINE configurations at their per-GPU sizes (N = 1 only)
     if world == 1 and not args.no_secondary and args.config == 2 and not args.robots:
         out["secondary"]["exact"] = exact_leg(m["wl"], m["batches"], W, h, dev)
+        if seam == "ctrl":      # the bare compute_contact_forces batch on the same configuration (what `value` was before round 4)
+            ms = run_leg(args.config, n, h, K, W, dev, 0, 1, None, repeats=3)
+            out["secondary"]["solver_seam"] = {"robots": n, "horizon": h, "steps": K, "control_steps_per_s": n * K / ms["elapsed"], "ms_per_step": ms["elapsed"] / K * 1e3,
+                                               "prep_kernel_ms": float(ms["prep_ms"].mean()), "solve_kernel_ms": float(ms["solve_ms"].mean()),
+                                               "solved_fraction": float((ms["info"][..., 1] == 1).mean()), "mean_admm_iters": float(ms["info"][..., 0].mean()),
+                                               "what": "config 2 through the bare solver seam: one compute_contact_forces batch per step (a2-a13), no estimator / controller / torque map"}
+            del ms
     if not args.no_control_loop and world == 1:      # secondary legs: single-GPU runs only
         out["control_loop"] = control_loop_leg(n, h, dev)
         out["control_loop_with_resets"] = control_loop_leg(n, h, dev, reset_every=37)
         out["policy"] = policy_leg(n, dev)
-        # the SURVEY 8(d) unit of work includes the leg-torque map (a22), which `value` does not: the same robots through the whole controller.run seam
+        # the same unit at the reference's own cadence (controller.run every 10 ms, MPC update on every 2nd call): two controller ticks per control step
         out["control_steps_per_s_incl_torque_map"] = out["control_loop"]["control_steps_per_s_incl_torque_map"]
     if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
         out["cpu_baseline"] = cpu_baseline(m["wl"], m["batches"], W, h, gpu_first_forces=m["first_forces"])
@@ -328,6 +464,48 @@ def main():
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+TRAFFIC_PROFILE = "r04"      # profiles/r04_pmc_summary_h10.json + ..._prep_h10.json: the PMC passes that `roofline.traffic` quotes
+
+
+def traffic_from_profile():
+    """(bytes per step, parts) from the named PMC summaries, or (None, why): refused when a file is missing or was measured on other kernel sources."""
+    from rl_mpc_locomotion_amd import _lib
+    files = [os.path.join(ROOT, "profiles", f"{TRAFFIC_PROFILE}_pmc_summary_h10.json"), os.path.join(ROOT, "profiles", f"{TRAFFIC_PROFILE}_pmc_summary_prep_h10.json")]
+    try:
+        ds = [json.load(open(f)) for f in files]
+    except (OSError, ValueError) as e:
+        return None, {"refused": f"no PMC summary for this round ({e.__class__.__name__}: {files[0]})"}
+    here = _lib.kernel_source_hash()
+    if any(d.get("kernel_source_sha256") != here for d in ds):
+        return None, {"refused": "the PMC summaries were measured on other kernel sources than this tree's (kernel_source_sha256 differs): re-run tools/pmc_passes.sh",
+                      "from": [os.path.basename(f) for f in files]}
+    t_solve, t_prep = (float(d["hbm_traffic_bytes_per_launch"]) for d in ds)
+    return t_solve + t_prep, {"solve_kernel": t_solve, "prep_kernel": t_prep, "from": [os.path.basename(f) for f in files], "round": TRAFFIC_PROFILE,
+                              "kernel_source_sha256": here}
+
+
+def device_state(device, smi=True):
+    """Shader clock under the solve kernel's regime (mpc_device_clock) and, best effort, what rocm-smi says about clocks / power / temperature."""
+    from rl_mpc_locomotion_amd import _lib
+    out = {}
+    try:
+        ghz, ms = _lib.device_clock(device, 20)
+        out["shader_clock_ghz"] = ghz
+        out["probe_ms"] = ms
+    except Exception as e:      # never fail the bench line on the probe
+        out["error"] = repr(e)
+    if smi:
+        try:
+            r = subprocess.run(["rocm-smi", "-d", str(device), "--showclocks", "--showpower", "--showtemp", "--showperflevel", "--json"], capture_output=True, text=True, timeout=20)
+            j = json.loads(r.stdout)
+            card = next(iter(j.values()))
+            keep = {k: v for k, v in card.items() if any(t in k.lower() for t in ("sclk", "mclk", "power", "temperature (sensor junction)", "performance level"))}
+            out["rocm_smi"] = keep
+        except Exception as e:
+            out["rocm_smi"] = {"unavailable": repr(e)[:120]}
+    return out
 
 
 def secondary_lines(dev, steps=5, warm=2):
@@ -418,6 +596,49 @@ def all_gather_leg(n, n_total, dev, dist, reps=50, warm=5):
     ok = bool(tuple(out.shape) == (n_total, 12))
     return {"ms": ms, "bytes_per_rank": n * 48, "robots_total": n_total, "shape_ok": ok,
             "note": "one all_gather_into_tensor of [n_local, 12] float32 per rank over RCCL / xGMI on a side stream; latency-bound"}
+
+
+def sharded_loop_leg(cfg_id, n_total, h, dev, dist, ticks=8, warm=3, emulate=False):
+    """N > 1 only, NOT `value`: the product-level sharded stepper (sharding.ShardedLocomotion: per-rank controller on its block of ONE env batch,
+    asynchronous all-gather of the torques on a side stream, read one tick later) -- ms per controller.run tick without and with the exchange,
+    max over ranks.  The difference is what the all-gather costs when it overlaps the next tick's estimator / ctrl_pre / prep kernels."""
+    import torch
+    from rl_mpc_locomotion_amd.sharding import ShardedLocomotion, max_over_ranks
+    from rl_mpc_locomotion_amd.synthetic import ControlStepStream
+    cs = ControlStepStream(n_total, h=h, seed=2000, config=cfg_id)             # the WHOLE batch, identical on every rank; each rank runs its block
+    kw = dict(controller_dt=CTRL_DT)
+    if emulate:
+        class Emu(_EmulatedLocomotion):
+            def __init__(self, robot_type, gait_id, horizon=10, controller_dt=CTRL_DT):
+                from tests.emu.emu import EmuLocomotion
+                self.e = EmuLocomotion(robot_type, gait_id, horizon=horizon, controller_dt=controller_dt, nthreads=2)
+                self.device = "cpu"
+        kw["controller_factory"] = Emu
+    else:
+        kw["device"] = dev
+    sl = ShardedLocomotion(cs.robot_type, cs.gait_id, horizon=h, **kw)
+    ins = [tuple(torch.from_numpy(np.ascontiguousarray(a[sl.lo:sl.hi] if a.shape[0] == n_total else a)).to(dev) for a in cs.step(k)) for k in range(warm + ticks)]
+    sync = (lambda: torch.cuda.synchronize(dev)) if dev.type == "cuda" else (lambda: None)
+    out = {}
+    for label, with_gather in (("ms_per_tick_no_exchange", False), ("ms_per_tick_with_exchange", True)):
+        sl.reset()
+        got = None
+        for k in range(warm + ticks):
+            if k == warm:
+                sync(); dist.barrier(); sync()
+                t0 = time.perf_counter()
+            if with_gather and k > 0:
+                got = sl.torques_all()                      # last tick's exchange, read while this tick is being launched
+            sl.run(*ins[k])
+            if with_gather:
+                sl.start_gather()
+        sync(); dist.barrier()
+        out[label] = max_over_ranks(time.perf_counter() - t0, dev) / ticks * 1e3
+        if with_gather:
+            out["shape_ok"] = bool(got is not None and tuple(got.shape) == (n_total, 12))
+    out["robots_total"], out["ticks"] = n_total, ticks
+    out["note"] = "ShardedLocomotion: one env batch over the ranks, all-gather of [n_local, 12] float32 on a side stream overlapped with the next tick; every robot due on every tick"
+    return out
 
 
 def control_loop_leg(n, h, dev, ticks=40, warm=10, reset_every=0):

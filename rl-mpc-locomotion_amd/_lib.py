@@ -94,6 +94,19 @@ def lib():
     return _LIB
 
 
+def kernel_source_hash():
+    """sha256 over the kernel sources (csrc/*.h, *.hip, the Makefile): what a measurement of the library is a measurement OF.  Profiles record
+    it (tools/pmc_passes.sh) and bench.py quotes a profile's numbers only when it equals the tree's."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(_HERE, "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")) or f == "Makefile":
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
 def device_clock(device=0, busy_ms=20):
     """(GHz, ms): the shader clock `device` sustains under one wave of dependent fp64 FMAs per SIMD (mpc_device_clock)."""
     ghz, ms = C.c_double(0.0), C.c_double(0.0)

@@ -180,3 +180,60 @@ class TickStream:
         cmd[:, 0:3] = self.cmd
         cmd[:, 3:15] = self.w
         return dof, body, cmd
+
+
+class ControlStepStream:
+    """SURVEY.md 8(d)'s synthetic robot states at the BATCH seam -- (dof_states, body_states, commands) of ``controller.run``
+    (RL_Environment/tasks/aliengo.py:246-256) instead of the 13 solver arguments: the same distributions as make_solver_workload
+    (roll / pitch U(-0.15, 0.15), yaw U(-pi, pi), height H U(0.9, 1.05), omega U(-0.5, 0.5)^3, v (U(-1.5, 1.5), U(-0.5, 0.5), U(-0.1, 0.1)),
+    joints = stand pose + U(-0.2, 0.2), commands (U(-2.5, 2.5), U(-1, 1), U(-2.5, 2.5)), weights = MPC_param_const + U(-1, 1) MPC_param_scale,
+    gait counter U{0 .. h-1} MPC steps), and from step to step the random walk of perturb_workload.  The controller derives the solver's
+    arguments itself (state estimator, leg kinematics, gait table), as the reference's does.  step(s) must be called for s = 0, 1, 2 ... in
+    order (or rewind() first)."""
+
+    def __init__(self, n, h=10, seed=0, config=2):
+        rng = np.random.default_rng(seed)
+        idx = np.arange(n)
+        if config == 3:
+            self.robot_type = np.array([RobotType.GO1, RobotType.A1, RobotType.ALIENGO], dtype=np.int32)[idx % 3]
+            self.gait_id = np.array([0, 6, 1], dtype=np.int32)[(idx // 3) % 3]
+        else:
+            self.robot_type = np.full(n, int(RobotType.ALIENGO), dtype=np.int32)
+            self.gait_id = np.zeros(n, dtype=np.int32)
+        self.n, self.h, self.seed = n, h, seed
+        H = ROBOT_TABLE[self.robot_type, COL_HEIGHT]
+        self.rpy0 = np.stack([rng.uniform(-0.15, 0.15, n), rng.uniform(-0.15, 0.15, n), rng.uniform(-np.pi, np.pi, n)], -1)
+        self.z = H * rng.uniform(0.9, 1.05, n)
+        self.omega0 = rng.uniform(-0.5, 0.5, (n, 3))
+        self.vel0 = np.stack([rng.uniform(-1.5, 1.5, n), rng.uniform(-0.5, 0.5, n), rng.uniform(-0.1, 0.1, n)], -1)
+        self.q0 = np.tile([0.0, 0.8, -1.6], 4)[None] + rng.uniform(-0.2, 0.2, (n, 12))
+        self.cmd = np.zeros((n, 16), dtype=np.float32)
+        self.cmd[:, 0:3] = np.stack([rng.uniform(-2.5, 2.5, n), rng.uniform(-1, 1, n), rng.uniform(-2.5, 2.5, n)], -1)
+        self.cmd[:, 3:15] = MPC_PARAM_CONST + rng.uniform(-1, 1, (n, 12)).astype(np.float32) * MPC_PARAM_SCALE
+        self.iteration0 = rng.integers(0, h, n).astype(np.int32)      # ConvexMPCLocomotion.iterationCounter at the first step (one MPC step per tick)
+        self.rewind()
+
+    def rewind(self):
+        self._s = 0
+        self._rpy, self._omega, self._vel, self._q = self.rpy0.copy(), self.omega0.copy(), self.vel0.copy(), self.q0.copy()
+
+    def step(self, s):
+        assert s == self._s, "ControlStepStream.step: steps in order (rewind() to start again)"
+        n = self.n
+        if s > 0:
+            rng = np.random.default_rng((self.seed + 1) * 100003 + s)
+            self._vel += rng.standard_normal((n, 3)) * 0.1
+            self._omega += rng.standard_normal((n, 3)) * 0.05
+            self._q += rng.standard_normal((n, 12)) * 0.03
+            self._rpy += rng.standard_normal((n, 3)) * 0.01
+        self._s += 1
+        rng2 = np.random.default_rng((self.seed + 7) * 7919 + s)
+        dof = np.stack([self._q, rng2.standard_normal((n, 12)) * 0.5], axis=2).astype(np.float32)
+        r, p, y = self._rpy[:, 0], self._rpy[:, 1], self._rpy[:, 2]
+        cy, sy, cp, sp, cr, sr = np.cos(y / 2), np.sin(y / 2), np.cos(p / 2), np.sin(p / 2), np.cos(r / 2), np.sin(r / 2)
+        body = np.zeros((n, 13), dtype=np.float32)
+        body[:, 2] = self.z
+        body[:, 3:7] = np.stack([sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy], -1)
+        body[:, 7:10] = self._vel
+        body[:, 10:13] = self._omega
+        return dof, body, self.cmd

@@ -29,6 +29,18 @@ def test_two_ranks_weak_scaling_line():
     assert b["value"] > 0 and abs(b["value"] - 10 * 2 / (b["ms_per_step"] * 2e-3)) < 1e-6 * b["value"]
     assert b["all_gather_torques"]["shape_ok"] and b["all_gather_torques"]["robots_total"] == 10
     assert b["solved_fraction"] == 1.0 and "EMULATED" in b["data"]
+    assert b["config"]["seam"] == "ctrl"                 # `value` goes through controller.run (SURVEY 8(d)'s unit incl. the torque map)
+    sl = b["all_gather_torques"]["sharded_loop"]           # the product-level sharded stepper with its overlapped exchange
+    assert sl["shape_ok"] and sl["robots_total"] == 10 and sl["ms_per_tick_with_exchange"] > 0
+
+
+@pytest.mark.parametrize("flags,total", [(("--robots", "2"), 16), (("--config", "4", "--robots-total", "19"), 19), (("--config", "5", "--robots-total", "17"), 17)])
+def test_eight_ranks_dry_run(flags, total):
+    """The full node: `bench.py --gpus 8` exactly as the driver launches it, on the CPU (gloo, emulated kernels) for configs 2 / 4 / 5 --
+    even and uneven shards, barriers, max-over-ranks, gather leg, JSON from rank 0 only.  Unmeasured on hardware until a SCALE record exists."""
+    b = _run(*flags, gpus=8)
+    assert b["n_gpus"] == 8 and b["config"]["robots_total"] == total and b["value"] > 0
+    assert b["all_gather_torques"]["shape_ok"] and b["all_gather_torques"]["robots_total"] == total
 
 
 @pytest.mark.parametrize("config,h", [(4, 16), (5, 20)])

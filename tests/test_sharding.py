@@ -101,3 +101,128 @@ def test_two_gpu_shards_match_one_gpu(tmp_path):
     for r in range(world):
         z = np.load(tmp_path / f"rank{r}.npz")
         assert np.array_equal(z["a"], ref[0]) and np.array_equal(z["b"], ref[1])
+
+
+# ---- ShardedLocomotion: one env batch over the ranks of a node ------------------------------------------------------------
+class _EmuController:
+    """the host emulation of the controller kernels behind BatchedLocomotion's interface (CPU tensors), for the gloo tests"""
+
+    def __init__(self, robot_type, gait_id, horizon=10, **kw):
+        from tests.emu.emu import EmuLocomotion
+        self.e = EmuLocomotion(robot_type, gait_id, horizon=horizon, nthreads=1, **kw)
+        self.device = "cpu"
+
+    def run(self, dof, body, cmd):
+        return torch.from_numpy(self.e.run(dof.numpy(), body.numpy(), cmd.numpy()))
+
+    def reset(self, env_ids=None):
+        self.e.reset(env_ids)
+
+
+def _tick_inputs(n_total, ticks):
+    from rl_mpc_locomotion_amd.synthetic import TickStream
+    ts = TickStream(n_total, seed=77, config=3)
+    return ts, [tuple(torch.from_numpy(np.ascontiguousarray(a)) for a in ts.tick(k)) for k in range(ticks)]
+
+
+def _sharded_worker(rank, world, port, n_total, ticks, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rl_mpc_locomotion_amd.sharding import ShardedLocomotion
+    ts, ins = _tick_inputs(n_total, ticks)
+    sl = ShardedLocomotion(ts.robot_type, ts.gait_id, horizon=10, controller_factory=_EmuController)
+    assert (sl.lo, sl.hi) == shard_bounds(n_total, rank, world)
+    outs = []
+    for k in range(ticks):
+        if k == 3:
+            sl.reset(np.array([0, n_total - 1, n_total // 2]))       # global ids: every rank resets what it owns
+        local = sl.run(*ins[k])                                       # whole-batch tensors: sliced to this rank's block
+        assert tuple(local.shape) == (sl.n_local, 12)
+        sl.start_gather()
+        outs.append(sl.torques_all().numpy().copy())
+    np.save(os.path.join(out_dir, f"sharded{rank}.npy"), np.stack(outs))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_total", [(2, 7), (8, 20)])
+def test_sharded_locomotion_matches_single_process(tmp_path, world, n_total):
+    """ShardedLocomotion on `world` gloo ranks (uneven shards, global-id resets, the asynchronous all-gather) returns, on every rank, the
+    torques of the same batch run in one process -- bit for bit.  world = 8: the dry run of a full node."""
+    ticks, port = 6, _free_port()
+    mp.spawn(_sharded_worker, args=(world, port, n_total, ticks, str(tmp_path)), nprocs=world, join=True)
+    ts, ins = _tick_inputs(n_total, ticks)
+    one = _EmuController(ts.robot_type, ts.gait_id)
+    ref = []
+    for k in range(ticks):
+        if k == 3:
+            one.reset(np.array([0, n_total - 1, n_total // 2], dtype=np.int32))
+        ref.append(one.run(*ins[k]).numpy().copy())
+    ref = np.stack(ref)
+    assert np.abs(ref).max() > 1.0
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"sharded{r}.npy"), ref), f"rank {r}"
+
+
+@pytest.mark.gpu
+def test_sharded_locomotion_single_gpu_equals_batched():
+    """world = 1 (no process group): ShardedLocomotion is BatchedLocomotion plus a no-op exchange; device-side global-id reset included."""
+    from rl_mpc_locomotion_amd.locomotion import BatchedLocomotion
+    from rl_mpc_locomotion_amd.sharding import ShardedLocomotion
+    n, ticks = 33, 6
+    ts, ins = _tick_inputs(n, ticks)
+    sl = ShardedLocomotion(ts.robot_type, ts.gait_id, horizon=10, device="cuda:0")
+    one = BatchedLocomotion(ts.robot_type, ts.gait_id, horizon=10, device="cuda:0")
+    ids = torch.tensor([0, n - 1, n // 2], dtype=torch.int32, device="cuda:0")
+    for k in range(ticks):
+        d = tuple(a.cuda() for a in ins[k])
+        if k == 3:
+            sl.reset(ids); one.reset(ids)
+        a = sl.run(*d); sl.start_gather()
+        b = one.run(*d)
+        assert torch.equal(sl.torques_all(), b) and torch.equal(a, b)
+    assert float(b.abs().max()) > 1.0
+
+
+def _sharded_nccl_worker(rank, world, port, n_total, ticks, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dev = torch.device(f"cuda:{rank}")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)     # RCCL
+    from rl_mpc_locomotion_amd.sharding import ShardedLocomotion
+    ts, ins = _tick_inputs(n_total, ticks)
+    sl = ShardedLocomotion(ts.robot_type, ts.gait_id, horizon=10, device=dev)
+    outs, prev = [], None
+    for k in range(ticks):
+        if k == 3:
+            sl.reset(torch.tensor([0, n_total - 1, n_total // 2], dtype=torch.int32, device=dev))    # global ids on the device
+        if prev is not None:
+            outs.append(sl.torques_all().cpu().numpy().copy())        # last tick's exchange, read after this tick's inputs were staged
+        sl.run(*(a.to(dev) for a in ins[k]))
+        sl.start_gather()
+        prev = k
+    outs.append(sl.torques_all().cpu().numpy().copy())
+    np.save(os.path.join(out_dir, f"sharded{rank}.npy"), np.stack(outs))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_locomotion_two_gpus_match_one(tmp_path):
+    """ShardedLocomotion over RCCL on two GPUs (uneven shards, overlapped exchange) against one GPU's batch: bit-identical torques on both ranks.
+    Needs two visible devices (1-GPU boxes skip)."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from rl_mpc_locomotion_amd.locomotion import BatchedLocomotion
+    n_total, world, ticks, port = 13, 2, 6, _free_port()
+    mp.spawn(_sharded_nccl_worker, args=(world, port, n_total, ticks, str(tmp_path)), nprocs=world, join=True)
+    ts, ins = _tick_inputs(n_total, ticks)
+    one = BatchedLocomotion(ts.robot_type, ts.gait_id, horizon=10, device="cuda:0")
+    ref = []
+    for k in range(ticks):
+        if k == 3:
+            one.reset(np.array([0, n_total - 1, n_total // 2], dtype=np.int32))
+        ref.append(one.run(*(a.cuda() for a in ins[k])).cpu().numpy().copy())
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"sharded{r}.npy"), np.stack(ref)), f"rank {r}"

@@ -9,7 +9,7 @@
 set -u
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
-TAG=${TAG:-r03}
+TAG=${TAG:-r04}
 MODE=${1:-full}
 mkdir -p $ROOT/gpurun_out
 cd $ROOT

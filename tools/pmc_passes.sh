@@ -9,6 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$PWD}
 PMC_TAG=${PMC_TAG:-pmc}          # output prefix: gpurun_out/${PMC_TAG}_<pass>.csv
 PMC_FLAGS=${PMC_FLAGS:-}          # extra bench.py flags (e.g. "--config 4 --robots 4096")
 CMD="python $ROOT/bench.py --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline --no-control-loop --no-secondary $PMC_FLAGS"
+python -c "import sys; sys.path.insert(0, '$ROOT'); import rl_mpc_locomotion_amd; from rl_mpc_locomotion_amd import _lib; print(_lib.kernel_source_hash())" > $ROOT/gpurun_out/${PMC_TAG}_source.sha256
 cd /tmp
 for spec in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq1:SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU" "sq2:SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_ANY SQ_WAVES"; do
   name=${spec%%:*}; ctrs=${spec#*:}

@@ -22,7 +22,11 @@ N, M = 12 * h, 20 * h
 alg = n * ((56 + 4 * h) * 4 + (2 * N + 2 * M + 2) * 8 * 2 + N * 8 + 8 * 4)   # path level: input record, warm-start state r+w, forces, info
 rec = n * ((2 * N + M + 36 * h + 4) + (2 * N + 16 + 116)) * 8 * 2                     # scale + QP records handed from the prep kernel to the solve kernel (written once, read once; csrc/mpc_core.h: SC_LEN, QP_LEN)
 c = counters
+sha = None
+for f in glob.glob(os.path.join(src, "*source.sha256")):
+    sha = open(f).read().strip()
 summary = {
+    "kernel_source_sha256": sha,    # rl_mpc_locomotion_amd._lib.kernel_source_hash() on the box that measured (bench.py quotes this file only when the tree still matches)
     "command": "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-control-loop --no-secondary (tools/pmc_passes.sh: one rocprofv3 --pmc pass per counter group, --kernel-trace only)",
     "kernel": f"{kname}<{h}>, {n} robots per launch, mean of the 5 timed (warm-started) dispatches",
     "counters_per_launch": counters,
