@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 for round in 1 2 3; do
   for v in "$@"; do
-    MPC_LIB_PATH=$GRAFT_REPO_ROOT/rl-mpc-locomotion_amd/csrc/variants/libmpc_batch_$v.so python bench.py $AB_FLAGS --no-secondary --no-cpu-baseline --no-control-loop 2>/dev/null | python -c "
+    MPC_LIB_PATH=$GRAFT_REPO_ROOT/rl-mpc-locomotion_amd/csrc/variants/libmpc_batch_$v.so python bench.py --seam solver $AB_FLAGS --no-secondary --no-cpu-baseline --no-control-loop 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('$v round $round', round(d['value']), 'solve', round(d['roofline']['kernel_ms'],4), 'prep', round(d['roofline']['prep_kernel_ms'],4), 'err', d.get('max_grf_err_vs_osqp'))"
   done
 done
