@@ -108,8 +108,11 @@ struct WThread : RoleRegs<Cfg<H>::TE, (Cfg<H>::FOOT0 != 0 && MPC_SHARE_ROLE_REGS
 #ifndef MPC_EXACT_DIRECT          // exact mode: the active-set method's iterate is tested for optimality before any polish refinement
 #define MPC_EXACT_DIRECT 1
 #endif
-#ifndef MPC_PAIR_SWEEP          // which workgroup sizes sweep two pivots per phase (see sweep_all)
-#define MPC_PAIR_SWEEP(T) ((T) <= 64)
+#ifndef MPC_PAIR_SWEEP_MAXT     // the largest workgroup that sweeps two pivots per phase (see sweep_all)
+#define MPC_PAIR_SWEEP_MAXT 64
+#endif
+#ifndef MPC_PAIR_SWEEP
+#define MPC_PAIR_SWEEP(T) ((T) <= MPC_PAIR_SWEEP_MAXT)
 #endif
 #ifndef MPC_LOCKSTEP
 #define MPC_LOCKSTEP 0
