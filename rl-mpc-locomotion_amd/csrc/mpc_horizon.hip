@@ -106,12 +106,10 @@ __global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES
 // once no ADMM job is left to start -- the tail shrinks to a fraction of one polish.
 //   sched[kSchedNext]  next ADMM job (index into `order`)          sched[kSchedTail]  polish entries published
 //   sched[kSchedHead]  next polish entry to take                   sched[kSchedJobs]  number of jobs (active robots; order_block)
-//   ready[i]           -1 not yet published; robot: polish it; -2: nothing to do (that solve needs no polish: not SOLVED -- or the entry is taken)
-// An ADMM job publishes exactly one entry, in completion order, after a device-scope release of its results.  Once no ADMM job is left a
-// workgroup polishes the entries it published itself (same XCD: the problem's records are still in its L2), then takes the rest in
-// publication order; an entry is claimed by an atomic swap, so each is polished once.  A wave that reaches an unpublished entry spins until
-// it is there (every job of the launch is then running or done, so the wait is bounded by the longest ADMM part) and acquires before it
-// loads the record.
+//   ready[i]           -1 not yet published; robot: polish it; -2: that solve needs no polish (not SOLVED)
+// An ADMM job publishes exactly one entry, in completion order, after a device-scope release of its results; a wave that takes entry
+// i spins until it is there (every job of the launch is then running or done, so the wait is bounded by the longest ADMM part)
+// and acquires before it loads the record.
 template <int H>
 __global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES : MPC_SOLVE_MIN_WAVES_WIDE)) void mpc_solve_jobs_kernel(
     const RobotModel *__restrict__ models, double *__restrict__ state, const double *__restrict__ qp, double *__restrict__ sc,
@@ -119,10 +117,6 @@ __global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES
     int *__restrict__ ready, int max_iter) {
   __shared__ __attribute__((aligned(16))) Shared<H> sh;
   __shared__ int job;
-  // the polish entries this workgroup published itself: it polishes them first (their QP and scale records are still in this XCD's L2 from the
-  // ADMM job's loads -- a polish job on another XCD fetches the 9.4 KB again over the fabric: 2 x 61 MB per 4096-robot launch before, r03 PMC)
-  constexpr int kMine = 12;
-  __shared__ int mine_pos[kMine], mine_robot[kMine], n_mine;
   using C = Cfg<H>;
   using Ex = DeviceExec<WThread<H>, (C::TW <= 64)>;
   WThread<H> th;
@@ -133,7 +127,6 @@ __global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES
     return Solver<H, Ex>{ex, sh, models[robot], state + (size_t)robot * state_len<H>(), qp + (size_t)robot * C::QP_LEN, sc + (size_t)robot * C::SC_LEN,
                          forces + (size_t)robot * C::N, info + (size_t)robot * kInfoLen, prof ? prof + (size_t)robot * kProfLen : nullptr};
   };
-  if (threadIdx.x == 0) n_mine = 0;
   for (;;) {     // ---- ADMM jobs, in the dispatch order of order_block
     [[maybe_unused]] const long long tf0 = MPC_CLOCK();
     ex.par([&](WThread<H> &t) { if (t.tid == 0) job = atomicAdd(&sched[kSchedNext], 1); });
@@ -163,33 +156,22 @@ __global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES
       if (t.tid == 0) {
         const int pos = atomicAdd(&sched[kSchedTail], 1);
         __hip_atomic_store(&ready[pos], pol ? robot : -2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (pol && n_mine < kMine) { mine_pos[n_mine] = pos; mine_robot[n_mine] = robot; ++n_mine; }
       }
     });
   }
-  // ---- polish jobs.  An entry is CLAIMED by swapping its robot for -2 (exactly one taker): first this workgroup's own entries, then
-  // whatever is left, in publication order (the entries of workgroups that are still inside a long ADMM part: the tail's filler jobs).
-  int own = 0;
-  for (;;) {
+  for (;;) {     // ---- polish jobs, in completion order of the ADMM parts
     [[maybe_unused]] const long long tf0 = MPC_CLOCK();
     ex.par([&](WThread<H> &t) {
       if (t.tid == 0) {
+        const int pos = atomicAdd(&sched[kSchedHead], 1);
         int e = -2;
-        if (own < n_mine) {
-          const int r = mine_robot[own];
-          e = atomicCAS(&ready[mine_pos[own]], r, -2) == r ? r : -2;      // (a free workgroup may have taken it meanwhile)
-        } else {
-          const int pos = atomicAdd(&sched[kSchedHead], 1);
-          if (pos < njobs) {
-            while ((e = __hip_atomic_load(&ready[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == -1) __builtin_amdgcn_s_sleep(32);
-            if (e >= 0 && atomicCAS(&ready[pos], e, -2) != e) e = -2;
-          } else e = -3;
-        }
+        if (pos < njobs) {
+          while ((e = __hip_atomic_load(&ready[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == -1) __builtin_amdgcn_s_sleep(32);
+        } else e = -3;
         job = e;
       }
     });
     const int e = job;
-    ++own;                                  // (uniform: every thread counts the same passes)
     ex.par([](WThread<H> &) {});
     if (e == -3) break;
     if (e < 0) continue;
