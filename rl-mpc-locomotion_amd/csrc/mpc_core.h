@@ -90,7 +90,7 @@ typedef double mpc_double2 __attribute__((ext_vector_type(2)));
 #define MPC_PROW_SKEW 0
 #endif
 #ifndef MPC_NT_H20
-#define MPC_NT_H20 4
+#define MPC_NT_H20 2
 #endif
 #ifndef MPC_NT_H16
 #define MPC_NT_H16 1
@@ -145,8 +145,10 @@ struct Cfg {
   static constexpr int G = N / TS;                       // tile grid G x G, lower triangle stored
   static constexpr int MT = G * (G + 1) / 2;             // lower-triangle tiles
   // Dense-P tiles per thread of the prep kernel (the only user of the dense 2H x 2H tile grid: the Ruiz norms).  Up to h = 16
-  // every thread holds one tile.  The longest horizon has 820 tiles: four per thread make it a 256-thread workgroup with one
-  // wave per SIMD and the full 512-register budget (one or two per thread spill the tiles in the pass loop).
+  // every thread holds one tile.  The longest horizon has 820 tiles: two per thread make it a 448-thread workgroup, seven waves at the
+  // 256-register cap (34 registers spilled, outside the pass loop): measured 3 % faster than four per thread (256 threads, one wave per
+  // SIMD with the full 512-register budget: 1.163 -> 1.127 ms per 4096 robots, profiles/r04_ab_prep_h20.txt); three per thread spill in the
+  // pass loop (3.1 ms).
   static constexpr int NT = H > 16 ? MPC_NT_H20 : (H > 12 ? MPC_NT_H16 : 1);
   static constexpr int MTH = (MT + NT - 1) / NT;         // threads that hold tiles
   static constexpr int TE = TS * TS;                     // tile elements per thread
