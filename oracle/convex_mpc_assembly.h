@@ -13,7 +13,7 @@
  *   - P is built with the reference's block recursion, in the reference's order (mpc_osqp.cc:387-434)
  * The matrix exponential (mpc_osqp.cc:338-351, Eigen Pade) is replaced by its exact closed form:
  * the 25x25 augmented matrix M is nilpotent of index 3, so exp(M) = I + M + M^2/2 exactly
- * (tests/test_oracle_assembly.py checks this against scipy.linalg.expm to 1e-15).
+ * (tests/test_oracle.py::test_exponential_closed_form_matches_expm checks this against scipy.linalg.expm to 1e-15).
  *
  * The arithmetic type is AREAL (double unless overridden).  The reference computes in double; the
  * float instantiation exists only so the CPU can predict what an fp32 device assembly does.

@@ -24,7 +24,7 @@
  * regularisation selects).
  *
  * This file is the CPU model of the HIP kernel (same algorithm, scalar).  It is validated against the
- * real library (oracle/_ref/libconvex_mpc_ref.so) by tests/test_oracle_port.py.  Built twice:
+ * real library (oracle/_ref/libconvex_mpc_ref.so) by tests/test_oracle.py::test_dense_port_tracks_vendored_osqp.  Built twice:
  * -DREAL=double (checker) and -DREAL=float (predicts the effect of fp32 device arithmetic).
  */
 #include <math.h>
