@@ -3,10 +3,10 @@
 set -e
 cd "$(dirname "$0")/.."
 TAG=${TAG:-r04}
-for f in bench_n1.json kernel_stats_bench_steps10.csv kernel_stats_config4_4096xh16.csv kernel_stats_config5_4096xh20.csv exact_mode_sweep.json parity_sweep.json parity_sweep_seeds0_24.json; do cp gpurun_out/${TAG}_$f profiles/${TAG}_$f; done
+for f in bench_n1.json kernel_stats_bench_steps10.csv kernel_stats_config4_4096xh16.csv kernel_stats_config5_4096xh20.csv exact_mode_sweep.json parity_sweep.json; do cp gpurun_out/${TAG}_$f profiles/${TAG}_$f; done
 for h in 10 16 20; do
   d=$(mktemp -d)
-  for p in fetch write sq1 sq2; do cp gpurun_out/${TAG}_pmc_h${h}_$p.csv profiles/; cp gpurun_out/${TAG}_pmc_h${h}_$p.csv $d/; done
+  for p in fetch write sq1 sq2; do cp gpurun_out/${TAG}_pmc_h${h}_$p.csv profiles/; cp gpurun_out/${TAG}_pmc_h${h}_$p.csv $d/; done; cp gpurun_out/${TAG}_pmc_h${h}_source.sha256 $d/
   python tools/pmc_summary.py $d profiles/${TAG}_pmc_summary_h$h.json 4096 $h mpc_solve_jobs_kernel > /dev/null
   python tools/pmc_summary.py $d profiles/${TAG}_pmc_summary_prep_h$h.json 4096 $h mpc_prep_kernel > /dev/null
   rm -rf $d
@@ -14,7 +14,7 @@ done
 python - <<'PY'
 import json, os
 TAG = os.environ.get("TAG", "r03")
-d = json.load(open(f"profiles/{TAG}_parity_sweep_seeds0_24.json"))
+d = json.load(open(f"profiles/{TAG}_parity_sweep.json"))
 print("parity", sum(v["solves"] for v in d.values()), "solves, mismatches", sum(v["decision_mismatch"] for v in d.values()), "max rel err", max(v["max_rel_err"] for v in d.values()))
 d = json.load(open(f"profiles/{TAG}_bench_n1.json")); r = d["roofline"]
 print("value", round(d["value"]), "ms/step", round(d["ms_per_step"], 4), "solve", round(r["kernel_ms"], 4), "prep", round(r["prep_kernel_ms"], 4), "frac", round(r["frac"], 5), "traffic MB", round(r["traffic"] / 1e6, 1))
