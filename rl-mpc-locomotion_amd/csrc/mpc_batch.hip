@@ -54,11 +54,12 @@ const HorizonOps *horizon_ops(int h) {
   return nullptr;
 }
 
-__global__ void reset_kernel(double *state, int state_len, const int *ids, int k, int n) {
+__global__ void reset_kernel(double *state, int state_len, const int *ids, int k, int n, int *seed, int seed_len) {
   const int r = blockIdx.x;
   const int robot = ids ? ids[r] : r;
   if (r >= k || robot < 0 || robot >= n) return;
   for (int i = threadIdx.x; i < state_len; i += blockDim.x) state[(size_t)robot * state_len + i] = 0.0;
+  for (int i = threadIdx.x; i < seed_len; i += blockDim.x) seed[(size_t)robot * seed_len + i] = 0;      // (a new ConvexMpc object knows no working set either)
 }
 
 }  // namespace
@@ -77,6 +78,8 @@ struct mpc_batch {
   int *d_order = nullptr;        // job list of the solve kernel: the launch's active robots, longest expected solve first (order_block, written by the prep launch)
   int *d_sched = nullptr;        // [kSchedLen] job counters of the launch; d_ready [n]: polish entries (mpc_solve_jobs_kernel)
   int *d_ready = nullptr;
+  int *d_seed = nullptr;         // [n, 4 h] exact mode: the working set each robot's previous call ended on (seeds the active-set method; MPC_EXACT_WARM=0: never)
+  bool warm_sets = true;
   int job_slots = 0;             // wave slots of the device for the persistent job kernel (0: one workgroup per robot)
   bool timing = false;           // mpc_batch_enable_timing: HIP events around the two kernels of each launch
   hipEvent_t ev[kTimingRing][3];
@@ -102,7 +105,7 @@ static int launch_solver(mpc_batch *b, const float *d_in, double *d_forces, int 
   if (b->exact) HIP_TRY(hipMemsetAsync(b->d_state, 0, sizeof(double) * (size_t)b->n * b->state_len, st));   // no warm start in that branch (mpc_osqp.cc:906-919)
   hipEvent_t *ev = b->timing ? b->ev[b->launches % kTimingRing] : nullptr;
   const LaunchArgs a{b->n, b->d_models, d_in, d_in64, d_in16, b->d_state, b->d_qp, b->d_sc, d_forces, d_info, b->d_prof, d_active, b->d_order, b->d_hist, slot, ev, st, b->exact,
-                     b->max_iter, b->d_sched, b->d_ready, b->job_slots};
+                     b->max_iter, b->d_sched, b->d_ready, b->job_slots, b->warm_sets ? b->d_seed : nullptr};
   const hipError_t e = (hipError_t)b->ops->launch(a);
   if (e != hipSuccess) return fail(MPC_E_HIP, std::string("solver launch: ") + hipGetErrorString(e));
   b->launches++;
@@ -161,6 +164,8 @@ int mpc_batch_create(mpc_batch **out, int n, int horizon, double timestep, doubl
       (e = hipMalloc(&b->d_hist, (size_t)n * kOrderHistory)) != hipSuccess ||
       (e = hipMalloc(&b->d_sched, sizeof(int) * kSchedLen)) != hipSuccess ||
       (e = hipMalloc(&b->d_ready, sizeof(int) * (size_t)n)) != hipSuccess ||
+      (e = hipMalloc(&b->d_seed, sizeof(int) * (size_t)n * 4 * horizon)) != hipSuccess ||
+      (e = hipMemset(b->d_seed, 0, sizeof(int) * (size_t)n * 4 * horizon)) != hipSuccess ||
       (e = hipMemset(b->d_prof, 0, sizeof(long long) * (size_t)n * kProfLen)) != hipSuccess ||
       (e = hipMemcpy(b->d_models, models.data(), sizeof(RobotModel) * n, hipMemcpyHostToDevice)) != hipSuccess ||
       (e = hipMemset(b->d_hist, 0, (size_t)n * kOrderHistory)) != hipSuccess ||
@@ -178,6 +183,7 @@ int mpc_batch_create(mpc_batch **out, int n, int horizon, double timestep, doubl
       if (end != env && *end == '\0' && v >= 0 && v <= (1 << 20)) b->job_slots = v < 2 ? 0 : (int)v;
     }
   }
+  if (const char *ew = getenv("MPC_EXACT_WARM")) b->warm_sets = !(ew[0] == '0' && ew[1] == '\0');      // tuning hook: 0 = the exact mode's active-set method starts empty on every call
   b->bytes = (long long)(sizeof(RobotModel) * n + sizeof(double) * (size_t)n * (b->state_len + qp_len + sc_len) + sizeof(int) * (size_t)n * kInfoLen);
   *out = b;
   return MPC_OK;
@@ -195,6 +201,7 @@ void mpc_batch_destroy(mpc_batch *b) {
   if (b->d_hist) (void)hipFree(b->d_hist);
   if (b->d_sched) (void)hipFree(b->d_sched);
   if (b->d_ready) (void)hipFree(b->d_ready);
+  if (b->d_seed) (void)hipFree(b->d_seed);
   if (b->timing) for (auto &e3 : b->ev) for (auto &e : e3) (void)hipEventDestroy(e);
   if (b->d_host_in) (void)hipFree(b->d_host_in);
   if (b->d_host_in64) (void)hipFree(b->d_host_in64);
@@ -237,13 +244,14 @@ int mpc_batch_reset(mpc_batch *b, const int *ids, int k, void *stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!ids) {
     HIP_TRY(hipMemsetAsync(b->d_state, 0, sizeof(double) * (size_t)b->n * b->state_len, st));
+    HIP_TRY(hipMemsetAsync(b->d_seed, 0, sizeof(int) * (size_t)b->n * 4 * b->h, st));
     return MPC_OK;
   }
   if (k <= 0) return MPC_OK;
   int *d_ids = nullptr;
   HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&d_ids), sizeof(int) * k, st));
   HIP_TRY(hipMemcpyAsync(d_ids, ids, sizeof(int) * k, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(reset_kernel, dim3(k), dim3(256), 0, st, b->d_state, b->state_len, d_ids, k, b->n);
+  hipLaunchKernelGGL(reset_kernel, dim3(k), dim3(256), 0, st, b->d_state, b->state_len, d_ids, k, b->n, b->d_seed, 4 * b->h);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipFreeAsync(d_ids, st));
   return MPC_OK;
@@ -254,7 +262,7 @@ int mpc_batch_reset_device(mpc_batch *b, const int *d_ids, int k, void *stream) 
   DeviceGuard guard_(b->device);
   if (k == 0) return MPC_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(reset_kernel, dim3(k), dim3(256), 0, st, b->d_state, b->state_len, d_ids, k, b->n);
+  hipLaunchKernelGGL(reset_kernel, dim3(k), dim3(256), 0, st, b->d_state, b->state_len, d_ids, k, b->n, b->d_seed, 4 * b->h);
   HIP_TRY(hipGetLastError());
   return MPC_OK;
 }

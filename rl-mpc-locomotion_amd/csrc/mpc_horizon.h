@@ -38,6 +38,7 @@ struct LaunchArgs {        // one solver launch on n robots: the prep kernel, th
   int exact, max_iter;
   int *sched, *ready;
   int job_slots;
+  int *seed;               // [n, 4 h] exact mode: the working set each robot's previous call ended on (mpc_wrench.h seed_working_set), or null: every call starts empty
 };
 
 struct HorizonOps {

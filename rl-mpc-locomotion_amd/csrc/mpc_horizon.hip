@@ -78,7 +78,7 @@ template <int H>
 __global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES : MPC_SOLVE_MIN_WAVES_WIDE)) void mpc_exact_kernel(
     const RobotModel *__restrict__ models, double *__restrict__ state, const double *__restrict__ qp, const double *__restrict__ sc,
     double *__restrict__ forces, int *__restrict__ info, long long *__restrict__ prof, const int *__restrict__ order, int *__restrict__ sched,
-    int *__restrict__ ready) {
+    int *__restrict__ ready, int *__restrict__ seed) {
   __shared__ __attribute__((aligned(16))) Shared<H> sh;
   __shared__ __attribute__((aligned(16))) GiShared<H> gsh;
   using C = Cfg<H>;
@@ -94,6 +94,7 @@ __global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES
                    forces + (size_t)robot * C::N, info + (size_t)robot * kInfoLen, prof ? prof + (size_t)robot * kProfLen : nullptr};
   sv.exact();
   sv.gi = &gsh;
+  sv.seedrec = seed ? seed + (size_t)robot * C::NF : nullptr;
   const bool ok = sv.run_active_set();
   if (!ok && threadIdx.x == 0) ready[atomicAdd(&sched[kSchedTail], 1)] = robot;
 }
@@ -274,7 +275,7 @@ int launch(const LaunchArgs &a) {
                      a.hist_slot, a.sched, a.ready);
   if (a.ev) (void)hipEventRecord(a.ev[1], a.stream);
   if (a.exact) {
-    hipLaunchKernelGGL((mpc_exact_kernel<H>), dim3(a.n), dim3(Cfg<H>::TW), 0, a.stream, a.models, a.state, a.qp, a.sc, a.forces, a.info, a.prof, a.order, a.sched, a.ready);
+    hipLaunchKernelGGL((mpc_exact_kernel<H>), dim3(a.n), dim3(Cfg<H>::TW), 0, a.stream, a.models, a.state, a.qp, a.sc, a.forces, a.info, a.prof, a.order, a.sched, a.ready, a.seed);
     hipLaunchKernelGGL((mpc_solve_kernel<H, true>), dim3(a.n), dim3(Cfg<H>::TW), 0, a.stream, a.n, a.models, a.state, a.qp, a.sc, a.forces, a.info, a.prof, a.order, a.sched, a.ready,
                        a.max_iter);
   }

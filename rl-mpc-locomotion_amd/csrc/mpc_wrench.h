@@ -135,6 +135,7 @@ struct GiShared {
   int owner[NWMAX];                                 // foot * 8 + row of the slot's constraint, -1: free
   unsigned long long freem[2];                      // bit i: slot i is free
   int hi, p_foot, p_row, p_side, p_slot, k1, converged, fail, passes, adds, drops;
+  int seed_shift, seed_same, seed_k, seeded;        // seeding (Solver::seed_working_set): which of the previous call's sets fits, its size, rows kept
   double p_viol, gamma, zeta, t1, lam_p, tstep;
 };
 
@@ -150,6 +151,12 @@ struct GiShared {
 #endif
 #ifndef MPC_GI_DELTA
 #define MPC_GI_DELTA 0.0
+#endif
+#ifndef MPC_SEED_PIVOT            // exact mode, seeding: a seeded row whose pivot in the Gram matrix falls below this fraction of its diagonal entry is dropped as dependent
+#define MPC_SEED_PIVOT 1e-8
+#endif
+#ifndef MPC_SEED_LAMBDA           // ... and one whose multiplier is below this fraction of the largest is dropped as not (clearly) active
+#define MPC_SEED_LAMBDA 1e-6
 #endif
 #ifndef MPC_SPLIT_RANGES
 #define MPC_SPLIT_RANGES 0   // (measured on the ISA: no help at present)
@@ -227,6 +234,7 @@ struct Solver {
   bool act_given = false;            // polish(): the active set is in t.act already (active_set) instead of OSQP's guess from (z, y)
   bool xn_given = false;             // polish<true>(): Shared::dxy holds the candidate optimum of that set (active_set's iterate): checked first, refined only if the check fails
   GiShared<H> *gi = nullptr;         // LDS of the exact mode's active-set phase (null in the OSQP mode)
+  int *seedrec = nullptr;            // [NF] exact mode: the working set the previous call of this robot ended on (one code per foot, seed_code), or null: start empty
   static constexpr int kStableChecks = MPC_STABLE_CHECKS;
   MPC_HD void exact() { eps_exact = MPC_EPS_EXACT; eps_abs = eps_rel = kEpsAdmmFloor; max_iter = 5 * kMaxIter; polish_refine = H > 10 ? MPC_EXACT_REFINE + MPC_EXACT_REFINE / 2 : MPC_EXACT_REFINE; max_rho_updates = MPC_EXACT_RHO_UPDATES; }   // then run<true>()
 #ifdef MPC_EMU_DEBUG
@@ -1804,11 +1812,11 @@ struct Solver {
         }
       }
   }
-  MPC_HD bool active_set() {
+  // the empty working set (first: also what a foot lane derives once per call -- row norms, tolerances, the C of H^-1)
+  MPC_HD void gi_clear(bool first) {
     GiShared<H> &g = *gi;
-    constexpr int NW = GiShared<H>::NWMAX, TL = GiShared<H>::TL;
-    static_assert(3 * NW + 2 * TL <= (int)(sizeof(s.fr) / sizeof(double)), "the method's vectors must fit Shared::fr");
-    double *const gd = s.fr, *const gr = s.fr + NW, *const glam = s.fr + 2 * NW, *const gtmp = s.fr + 3 * NW, *const gtmp2 = s.fr + 3 * NW + TL;
+    constexpr int NW = GiShared<H>::NWMAX;
+    double *const gd = s.fr, *const gr = s.fr + NW, *const glam = s.fr + 2 * NW;
     ex.par([&](Th &t) {
       for (int i = t.tid; i < NW * (NW + 1) / 2; i += T) g.ci[i] = 0.0;
       if (t.tid < NW) { g.owner[t.tid] = -1; glam[t.tid] = 0.0; gd[t.tid] = 0.0; gr[t.tid] = 0.0; }
@@ -1819,6 +1827,10 @@ struct Solver {
       if (t.foot) {
         const int fixed = ((t.tyb & 0x3ff) == 0x2aa);                 // all five rows are equalities (set_rho_vec's test: u - l < 1e-4)
         t.gfix = fixed;
+        if (!first) {
+#pragma unroll
+          for (int r = 0; r < 5; ++r) { t.act[r] = fixed ? -1 : 0; t.gslot[r] = -1; }
+        } else {
         double a[9], lo[5], up[5];
         foot_a(t, a);
         foot_bounds(t, lo, up);
@@ -1836,8 +1848,237 @@ struct Solver {
 #pragma unroll
           for (int c = 0; c < 3; ++c) t.pC[4 * c] = fast_rsqrt(s.calpha * Dat(t, c) * Dat(t, c) + MPC_GI_DELTA);
         }
+        }
       }
     });
+  }
+  // ---- a warm start of the working set.  The branch this mode stands for is cold on every call (mpc_osqp.cc:906-919), and so is the RESULT here
+  // -- the optimum is unique, whatever set the method starts from --, but consecutive calls of a controller end on working sets that share most
+  // of their rows once the previous one is moved by one horizon step (23 of 24 rows seeded, 3 of them dropped again, 5 passes left of 31:
+  // profiles/r04_active_set_persistence.txt).  seedrec holds, per foot, the set the previous call ended on (seed_code); the start is
+  //   x = x0 + H^-1 N lam,  lam = (N^T H^-1 N)^-1 (b - N^T x0) >= 0  on the seeded rows N  (x0 = -H^-1 q):
+  // one application of H^-1 per seeded row (its column of the Gram matrix N^T H^-1 N, which is also what a regular pass computes for its
+  // row: step B), the Gram matrix inverted in place by symmetric sweeps, rows with a negative multiplier dropped one at a time (the rank-one
+  // downdate of a regular drop) -- then every invariant of the dual method holds (x optimal on its rows, multipliers >= 0) and the regular
+  // passes take over.  A dependent seed (tiny pivot) abandons the warm start: the method starts empty, as before.
+  // x += H^-1 N v  (v: one number per slot), A x with it
+  MPC_HD void gi_move(int hi, const double *v) {
+    (void)hi;
+    gi_apply([&](Th &t, double *r3) {
+      double a[9], w[5];
+      foot_a(t, a);
+#pragma unroll
+      for (int r = 0; r < 5; ++r) w[r] = t.gslot[r] >= 0 ? (t.act[r] < 0 ? 1.0 : -1.0) * v[t.gslot[r]] : 0.0;
+      at_mul(a, w, r3);
+    });
+    ex.par([&](Th &t) {
+      if (t.foot) {
+        double a[9];
+        foot_a(t, a);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) t.gx[c] += t.pw[c];
+        a_mul(a, t.gx, t.gax);
+      }
+    });
+  }
+  // Put the iterate back ON its working rows:  d lam = G^-1 (b - N^T x),  x += H^-1 N d lam,  lam += d lam.  The seeded inverse comes out of up to 50 sweeps
+  // of a matrix whose condition reaches 1e8, so steps taken with it leave the rows by ~1e-9 -- and an iterate that is off its rows stays there: the passes move
+  // along the rows, and the polish that tests the final point refines inside their null space only (it reports a dual residual of |A| x 1e-9 for ever).
+  MPC_HD void gi_on_rows(int hi, double *gd, double *gr, double *glam) {
+    GiShared<H> &g = *gi;
+    constexpr int NW = GiShared<H>::NWMAX;
+    ex.par([&](Th &t) {
+      if (t.foot && !t.gfix) {
+        double lo[5], up[5];
+        foot_bounds(t, lo, up);
+#pragma unroll
+        for (int r = 0; r < 5; ++r)
+          if (t.gslot[r] >= 0) gd[t.gslot[r]] = t.act[r] < 0 ? lo[r] - t.gax[r] : t.gax[r] - up[r];
+      }
+    });
+    ex.par([&](Th &t) {
+      if (t.tid < NW && t.tid < hi) {
+        double acc = 0.0;
+        for (int j = 0; j < hi; ++j) acc += gi_ci(t.tid, j) * gd[j];
+        gr[t.tid] = g.owner[t.tid] >= 0 ? acc : 0.0;
+      }
+    });
+    gi_move(hi, gr);
+    ex.par([&](Th &t) {
+      if (t.tid < NW && t.tid < hi) {
+        if (g.owner[t.tid] >= 0) glam[t.tid] = dmax(glam[t.tid] + gr[t.tid], 0.0);
+        gd[t.tid] = 0.0; gr[t.tid] = 0.0;
+      }
+    });
+  }
+  static MPC_HD int seed_code(const int *act, int fixed) {      // rows: 2 bits each (0 free, 1 at its lower, 2 at its upper bound); bit 10: fixed foot; bit 11: valid
+    int c = (1 << 11) | (fixed ? 1 << 10 : 0);
+#pragma unroll
+    for (int r = 0; r < 5; ++r) c |= (act[r] < 0 ? 1 : (act[r] > 0 ? 2 : 0)) << (2 * r);
+    return c;
+  }
+  // returns the number of slots in use (0: nothing seeded); hi / free masks / adds are the caller's loop variables
+  MPC_HD int seed_working_set(int &hi, unsigned long long &free0, unsigned long long &free1, double *gd, double *gr, double *glam, double *gtmp, double *gtmp2) {
+    GiShared<H> &g = *gi;
+    constexpr int NW = GiShared<H>::NWMAX;
+    ex.par([&](Th &t) { if (t.tid == 0) { g.seed_shift = 1; g.seed_same = 1; g.seed_k = 0; g.seeded = 0; } });
+    ex.par([&](Th &t) {      // does the previous call's set fit this call's contact pattern -- moved by one horizon step, or as it is?
+      if (t.foot) {
+        const int k = t.fid >> 2, leg = t.fid & 3, last = k + 1 >= H;
+        const int cs = seedrec[(last ? k : k + 1) * 4 + leg], cu = seedrec[t.fid];
+        if (!((cs >> 11) & 1) || (!last && ((cs >> 10) & 1) != t.gfix)) g.seed_shift = 0;
+        if (!((cu >> 11) & 1) || ((cu >> 10) & 1) != t.gfix) g.seed_same = 0;
+        t.gbrow = cs; t.gbside = cu;
+      }
+    });
+    const int mode = g.seed_shift ? 1 : (g.seed_same ? 2 : 0);
+    if (!mode) return 0;
+    ex.par([&](Th &t) {      // my seeded rows (at most three per foot: its three variables), their number
+      if (t.foot) {
+        const int code = mode == 1 ? t.gbrow : t.gbside;
+        double lo[5], up[5];
+        foot_bounds(t, lo, up);
+        int cnt = 0;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+          const int c = t.gfix ? 0 : (code >> (2 * r)) & 3;
+          const bool take = c != 0 && cnt < 3 && (c == 1 ? lo[r] > -kInfty * kMinScaling : up[r] < kInfty * kMinScaling);
+          t.act[r] = take ? (c == 1 ? -1 : 1) : (t.gfix ? -1 : 0);
+          cnt += take ? 1 : 0;
+        }
+        gtmp[t.fid] = (double)cnt;
+      }
+    });
+    ex.par([&](Th &t) {      // slots in foot order
+      if (t.foot) {
+        int base = 0, total = 0;
+        for (int j = 0; j < NF; ++j) { const int c = (int)gtmp[j]; base += j < t.fid ? c : 0; total += c; }
+        if (!t.gfix) {
+#pragma unroll
+          for (int r = 0; r < 5; ++r)
+            if (t.act[r] != 0) {
+              if (base < NW) { t.gslot[r] = base; g.owner[base] = t.fid * 8 + r; } else t.act[r] = 0;
+              ++base;
+            }
+        }
+        if (t.fid == 0) g.seed_k = total < NW ? total : NW;
+      }
+    });
+    const int K = g.seed_k;
+    if (K == 0) return 0;
+    // the Gram matrix, a column per seeded row:  y = H^-1 n_j,  G_ij = n_i^T y
+    for (int j = 0; j < K; ++j) {
+      const int pf = g.owner[j] >> 3, pr = g.owner[j] & 7;
+      gi_apply([&](Th &t, double *r3) {
+        double a[9];
+        foot_a(t, a);
+        gi_row(a, pr, r3);
+        int side = 0;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) side += r == pr ? t.act[r] : 0;
+        const double sg = (t.foot && t.fid == pf) ? (side < 0 ? 1.0 : -1.0) : 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) r3[c] *= sg;
+      });
+      ex.par([&](Th &t) {
+        if (t.foot && !t.gfix) {
+          double a[9], av[5];
+          foot_a(t, a);
+          a_mul(a, t.pw, av);
+#pragma unroll
+          for (int r = 0; r < 5; ++r)
+            if (t.gslot[r] >= j) g.ci[t.gslot[r] * (t.gslot[r] + 1) / 2 + j] = (t.act[r] < 0 ? 1.0 : -1.0) * av[r];
+        }
+      });
+    }
+    // its inverse, in place: a symmetric sweep per pivot (a -> -a^-1 after all of them), then the sign
+    ex.par([&](Th &t) { if (t.tid < K) gr[t.tid] = gi_ci(t.tid, t.tid); });      // the diagonal as it was: the scale of the pivot test
+    int live = K;
+    for (int p = 0; p < K; ++p) {
+      ex.par([&](Th &t) { if (t.tid < K) gtmp[t.tid] = gi_ci(t.tid, p); });
+      const double piv = gtmp[p];
+      if (!(piv > MPC_SEED_PIVOT * gr[p])) {      // row p is (nearly) a combination of the rows before it: it leaves the seed -- its row and column
+        ex.par([&](Th &t) {                        // become a free slot's zeros, which is the matrix without it (the sweeps so far never used it as a pivot)
+          if (t.tid < K) g.ci[t.tid >= p ? t.tid * (t.tid + 1) / 2 + p : p * (p + 1) / 2 + t.tid] = 0.0;
+          if (t.tid == 0) g.owner[p] = -1;
+          if (t.foot) {
+#pragma unroll
+            for (int r = 0; r < 5; ++r) if (t.gslot[r] == p) { t.act[r] = 0; t.gslot[r] = -1; }
+          }
+        });
+        if (p < 64) free0 |= 1ull << p; else free1 |= 1ull << (p - 64);
+        --live;
+        continue;
+      }
+      const double rp = fast_recip(piv);
+      ex.par([&](Th &t) {
+        gi_rank1(t, gtmp, -rp, K, p);
+        if (t.tid < K) g.ci[t.tid >= p ? t.tid * (t.tid + 1) / 2 + p : p * (p + 1) / 2 + t.tid] = t.tid == p ? -rp : gtmp[t.tid] * rp;
+      });
+    }
+    ex.par([&](Th &t) {
+      for (int i = t.tid; i < K * (K + 1) / 2; i += T) g.ci[i] = -g.ci[i];
+      if (t.foot && !t.gfix) {      // b - N^T x0: what each seeded row is violated by at x0
+        double lo[5], up[5];
+        foot_bounds(t, lo, up);
+#pragma unroll
+        for (int r = 0; r < 5; ++r)
+          if (t.gslot[r] >= 0) gd[t.gslot[r]] = t.act[r] < 0 ? lo[r] - t.gax[r] : t.gax[r] - up[r];
+      }
+    });
+    ex.par([&](Th &t) {      // lam = G^-1 (b - N^T x0)
+      if (t.tid < K) {
+        double acc = 0.0;
+        for (int j = 0; j < K; ++j) acc += gi_ci(t.tid, j) * gd[j];
+        glam[t.tid] = acc;
+      }
+    });
+    hi = K;
+    // Rows the new problem does not hold at this point leave: the smallest multiplier goes, the rest follow it (the rank-one downdate of a
+    // regular drop), until every multiplier is CLEARLY positive -- a seeded row is only as good as its computed multiplier, and one whose true
+    // multiplier is -1e-8 of the largest would stay in the set for good (the regular passes only ever add violated rows and drop rows whose
+    // multiplier they drive to zero); a row dropped here that the optimum does hold is violated again and comes back by a regular pass.
+    ex.seq([&](Th &t) { t.gred[0] = (t.tid < K && g.owner[t.tid < NW ? t.tid : 0] >= 0) ? glam[t.tid < NW ? t.tid : 0] : 0.0; });
+    ex.wg_argmax([](Th &t) { return t.gred; }, [](Th &t) -> int & { return t.gidx; }, gtmp);
+    const double lam_floor = MPC_SEED_LAMBDA * ex.first().gred[0];
+    for (int rep = 0; rep < K; ++rep) {
+      ex.seq([&](Th &t) { t.gred[0] = (t.tid < K && g.owner[t.tid < NW ? t.tid : 0] >= 0) ? -glam[t.tid < NW ? t.tid : 0] : -kInfty; });
+      ex.wg_argmax([](Th &t) { return t.gred; }, [](Th &t) -> int & { return t.gidx; }, gtmp);
+      if (!(ex.first().gred[0] > -lam_floor)) break;
+      const int k1 = ex.first().gidx;
+      ex.par([&](Th &t) {
+        if (t.tid < K) gtmp[t.tid] = t.tid == k1 ? 0.0 : gi_ci(t.tid, k1);
+        if (t.tid == 0) { gtmp2[0] = fast_recip(gi_ci(k1, k1)); gtmp2[1] = glam[k1]; }
+      });
+      ex.par([&](Th &t) {
+        gi_rank1(t, gtmp, -gtmp2[0], K, k1);
+        if (t.tid < K) {
+          const int i = t.tid;
+          if (g.owner[i] >= 0 && i != k1) glam[i] -= gtmp2[1] * gtmp2[0] * gtmp[i];
+          g.ci[i >= k1 ? i * (i + 1) / 2 + k1 : k1 * (k1 + 1) / 2 + i] = 0.0;
+          if (i == k1) { g.owner[k1] = -1; glam[k1] = 0.0; gd[k1] = 0.0; }
+        }
+        if (t.foot) {
+#pragma unroll
+          for (int r = 0; r < 5; ++r) if (t.gslot[r] == k1) { t.act[r] = 0; t.gslot[r] = -1; }
+        }
+      });
+      if (k1 < 64) free0 |= 1ull << k1; else free1 |= 1ull << (k1 - 64);
+      --live;
+    }
+    // x = x0 + H^-1 N lam, then once more with the correction for what that left on the seeded rows (gi_on_rows)
+    gi_move(K, glam);
+    gi_on_rows(K, gd, gr, glam);
+    ex.par([&](Th &t) { if (t.tid == 0) g.seeded = live; });
+    ex.par([&](Th &t) { if (t.tid < K) { gd[t.tid] = 0.0; gr[t.tid] = 0.0; } });
+    return K;
+  }
+  MPC_HD bool active_set() {
+    GiShared<H> &g = *gi;
+    constexpr int NW = GiShared<H>::NWMAX, TL = GiShared<H>::TL;
+    static_assert(3 * NW + 2 * TL <= (int)(sizeof(s.fr) / sizeof(double)), "the method's vectors must fit Shared::fr");
+    double *const gd = s.fr, *const gr = s.fr + NW, *const glam = s.fr + 2 * NW, *const gtmp = s.fr + 3 * NW, *const gtmp2 = s.fr + 3 * NW + TL;
+    gi_clear(true);
     polish_factor();
     if (s.bad) return false;
     gi_apply([&](Th &t, double *r3) {
@@ -1860,6 +2101,15 @@ struct Solver {
     int hi = 0, passes = 0, adds = 0, drops = 0;
     unsigned long long free0 = NW >= 64 ? ~0ull : ((1ull << (NW & 63)) - 1), free1 = NW > 64 ? ((1ull << (NW - 64)) - 1) : 0ull;
     double lam_p = 0.0;
+    int seeded_k = 0;
+    if (seedrec) {
+      unsigned long long rel0 = 0, rel1 = 0;      // slots the seeding took and released again
+      const int K = seeded_k = seed_working_set(hi, rel0, rel1, gd, gr, glam, gtmp, gtmp2);
+      if (K > 0) {      // slots 0 .. K - 1 are in use, except the released ones
+        const unsigned long long low0 = K >= 64 ? ~0ull : ((1ull << K) - 1), low1 = K > 64 ? ((1ull << (K - 64)) - 1) : 0ull;
+        free0 = (free0 & ~low0) | rel0; free1 = (free1 & ~low1) | rel1;
+      }
+    }
     for (int pass = 0; pass < kGiMaxPass; ++pass) {
       if (new_p) {
         // ---- A. the most violated row outside the working set (violation over the row's norm)
@@ -2025,7 +2275,15 @@ struct Solver {
       new_p = add;
       MPC_SUBLAP(7, 5);
     }
+    if (seeded_k > 0 && converged && !fail) gi_on_rows(hi, gd, gr, glam);      // (see there; a cold start keeps its rows to rounding by itself)
     ex.par([&](Th &t) { if (t.tid == 0) { g.passes = passes; g.adds = adds; g.drops = drops; g.hi = hi; g.converged = converged; g.fail = fail; } });
+#ifdef MPC_EMU_DEBUG
+    if (getenv("EMU_GI_TRACE")) {
+      double mn = kInfty, mx = 0; int cnt = 0;
+      for (int i = 0; i < hi; ++i) if (g.owner[i] >= 0) { ++cnt; mn = dmin(mn, glam[i]); mx = dmax(mx, glam[i]); }
+      fprintf(stderr, "  working set %d rows, multipliers min %.3e max %.3e\n", cnt, mn, mx);
+    }
+#endif
     return converged && !fail && !s.bad;
   }
 
@@ -2226,6 +2484,9 @@ struct Solver {
     load();
     lap(9);
     const bool found = active_set();
+    if (seedrec) ex.par([&](Th &t) {      // what the next call of this robot may start from (before the polish, which re-uses t.act)
+      if (t.foot) seedrec[t.fid] = found ? seed_code(t.act, t.gfix) : 0;
+    });
     lap(8);
     bool ok = false;
     if (found) {

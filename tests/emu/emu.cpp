@@ -29,6 +29,8 @@ static inline int fill_byte() { return g_poison ? 0xFF : 0; }
 static int g_exact_route = 0;   // emu_set_exact_route: 0 = active set, then ADMM if it fails (the product); 1 = ADMM route only; 2 = active set only
 static int g_split = 0;      // emu_set_split: the OSQP-mode solve as ADMM job + polish job (the persistent kernel's path)
 static int g_max_iter = 0;   // emu_set_max_iter: OSQP's max_iter setting (0 = the default, kMaxIter)
+static int *g_seed = nullptr;   // emu_set_seed_buffer: [n][4 h] working-set seeds of the exact mode (mpc_batch's d_seed), or null
+static int g_seed_stride = 0;
 
 template <class TH, int NTHREADS>
 struct HostExec {
@@ -142,7 +144,8 @@ static long prep_one(const RobotModel &mdl, const float *in, const double *state
 }
 // prep kernel -> solve kernel of one robot
 template <int H>
-static void solve_one(const RobotModel &mdl, const float *in, double *state, double *forces, int *info, bool reverse, long *phases, double *dbg = nullptr, bool exact = false) {
+static void solve_one(const RobotModel &mdl, const float *in, double *state, double *forces, int *info, bool reverse, long *phases, double *dbg = nullptr, bool exact = false,
+                      int *seed = nullptr) {
   using C = Cfg<H>;
   std::vector<double> qp(C::QP_LEN, 0.0), sc(C::SC_LEN, 0.0);
   long ph = prep_one<H>(mdl, in, state, qp.data(), sc.data(), reverse);
@@ -159,8 +162,9 @@ static void solve_one(const RobotModel &mdl, const float *in, double *state, dou
       std::memset((void *)gs, fill_byte(), sizeof(GiShared<H>));
       sv.exact();
       sv.gi = gs;
+      sv.seedrec = seed;          // the working set of this robot's previous call (emu_set_seed_buffer), or null: start empty
       const bool ok = g_exact_route == 1 ? false : sv.run_active_set();          // first launch: the active-set method
-      if (getenv("EMU_GI_TRACE")) fprintf(stderr, "active_set ok=%d passes=%d adds=%d drops=%d conv=%d fail=%d hi=%d\n", (int)ok, gs->passes, gs->adds, gs->drops, gs->converged, gs->fail, gs->hi);
+      if (getenv("EMU_GI_TRACE")) fprintf(stderr, "active_set ok=%d passes=%d adds=%d drops=%d conv=%d fail=%d hi=%d seed_k=%d seeded=%d\n", (int)ok, gs->passes, gs->adds, gs->drops, gs->converged, gs->fail, gs->hi, seed ? gs->seed_k : -1, seed ? gs->seeded : -1);
       ph += ex.phases;
       delete gs;
       if (!ok && g_exact_route != 2) {   // second launch: the ADMM route on a fresh workgroup
@@ -466,6 +470,7 @@ int emu_estimator_update(int n, const float *body, const float *normal, float *e
 
 void emu_set_poison(int on) { g_poison = on; }
 void emu_set_max_iter(int it) { g_max_iter = it; }
+void emu_set_seed_buffer(int *buf, int stride) { g_seed = buf; g_seed_stride = stride; }
 void emu_set_split(int on) { g_split = on; }
 void emu_set_exact_route(int r) { g_exact_route = r; }
 void emu_check_counts(long *out) { out[0] = g_checks; out[1] = g_dual_cands; }
@@ -494,7 +499,7 @@ int emu_batch_solve(int h, int n, const double *model, double dt, double alpha, 
       double *rs = state + (size_t)r * sl, *rf = forces + (size_t)r * N;
       int *rinfo = info + (size_t)r * kInfoLen;
       switch (h) {
-#define EMU_CASE(HH) case HH: solve_one<HH>(mdl, ri, rs, rf, rinfo, reverse, &ph, nullptr, exact); break;
+#define EMU_CASE(HH) case HH: solve_one<HH>(mdl, ri, rs, rf, rinfo, reverse, &ph, nullptr, exact, exact && g_seed ? g_seed + (size_t)r * g_seed_stride : nullptr); break;
         EMU_HORIZONS(EMU_CASE)
 #undef EMU_CASE
       }

@@ -31,11 +31,16 @@ class EmuBatch:
         self.state = np.zeros((n, lib().emu_state_len(h)))
         self.info = np.zeros((n, 8), dtype=np.int32)
         self.phases = np.zeros(n, dtype=np.int64)
+        self.seed = np.zeros((n, 4 * h), dtype=np.int32)      # exact mode: the working sets the previous call ended on (mpc_batch's d_seed)
+        self.warm_sets = True
 
     def solve(self, records, reverse=False, nthreads=8, exact=False):
-        """exact: the exact-optimum mode (mpc_batch_set_solver(MPC_SOLVER_EXACT)): cold on every call."""
+        """exact: the exact-optimum mode (mpc_batch_set_solver(MPC_SOLVER_EXACT)): cold on every call (its RESULT; the working set of the
+        previous call seeds the active-set method unless warm_sets is False)."""
         if exact:
             self.state[:] = 0.0
+            lib().emu_set_seed_buffer.argtypes = [C.c_void_p, C.c_int]
+            lib().emu_set_seed_buffer(self.seed.ctypes.data_as(C.c_void_p) if self.warm_sets else None, 4 * self.h)
         rec = np.ascontiguousarray(records, dtype=np.float32)
         out = np.full((self.n, 12 * self.h), np.nan)
         p = lambda a: a.ctypes.data_as(C.c_void_p)
