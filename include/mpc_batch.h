@@ -82,7 +82,8 @@ void mpc_batch_destroy(mpc_batch *b);
  *   MPC_SOLVER_OSQP  (default) the OSQP branch (mpc_osqp.cc:690-796): OSQP 0.6.0's iterates at eps 1e-3 with polish, warm-started
  *                    from the previous call -- BASELINE.json's comparator;
  *   MPC_SOLVER_EXACT the qpOASES branch (:797-947, what the shipped Python selects, ConvexMPCLocomotion.py:108): the QP's optimum
- *                    (unique: the Hessian is 2 B^T Q B + alpha I), cold on every call like that branch.  qpOASES itself is an empty
+ *                    (unique: the Hessian is 2 B^T Q B + alpha I), cold on every call like that branch (the RESULT: the active-set method behind it
+ *                    starts from the working set of the robot's previous call, which changes how fast it gets there, not where).  qpOASES itself is an empty
  *                    submodule in the reference; its RESULT is reproduced, by an active-set method of this library's own
  *                    (csrc/mpc_wrench.h active_set: Goldfarb-Idnani's dual method on the problem with the swing feet eliminated,
  *                    like :838-856, then the polish on its set, accepted only if it passes the optimality conditions at 1e-10;

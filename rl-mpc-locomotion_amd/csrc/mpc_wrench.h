@@ -1933,6 +1933,7 @@ struct Solver {
     });
     const int mode = g.seed_shift ? 1 : (g.seed_same ? 2 : 0);
     if (!mode) return 0;
+    MPC_SUBLAP(9, 9);      // (-DMPC_PROFILE_SUB=9: the seeding's parts in slots 1 .. 5, what came before it in slot 9)
     ex.par([&](Th &t) {      // my seeded rows (at most three per foot: its three variables), their number
       if (t.foot) {
         const int code = mode == 1 ? t.gbrow : t.gbside;
@@ -1966,6 +1967,7 @@ struct Solver {
     });
     const int K = g.seed_k;
     if (K == 0) return 0;
+    MPC_SUBLAP(9, 1);
     // the Gram matrix, a column per seeded row:  y = H^-1 n_j,  G_ij = n_i^T y
     for (int j = 0; j < K; ++j) {
       const int pf = g.owner[j] >> 3, pr = g.owner[j] & 7;
@@ -1991,6 +1993,7 @@ struct Solver {
         }
       });
     }
+    MPC_SUBLAP(9, 2);
     // its inverse, in place: a symmetric sweep per pivot (a -> -a^-1 after all of them), then the sign
     ex.par([&](Th &t) { if (t.tid < K) gr[t.tid] = gi_ci(t.tid, t.tid); });      // the diagonal as it was: the scale of the pivot test
     int live = K;
@@ -2016,6 +2019,7 @@ struct Solver {
         if (t.tid < K) g.ci[t.tid >= p ? t.tid * (t.tid + 1) / 2 + p : p * (p + 1) / 2 + t.tid] = t.tid == p ? -rp : gtmp[t.tid] * rp;
       });
     }
+    MPC_SUBLAP(9, 3);
     ex.par([&](Th &t) {
       for (int i = t.tid; i < K * (K + 1) / 2; i += T) g.ci[i] = -g.ci[i];
       if (t.foot && !t.gfix) {      // b - N^T x0: what each seeded row is violated by at x0
@@ -2066,10 +2070,12 @@ struct Solver {
       if (k1 < 64) free0 |= 1ull << k1; else free1 |= 1ull << (k1 - 64);
       --live;
     }
+    MPC_SUBLAP(9, 4);
     // x = x0 + H^-1 N lam, then once more with the correction for what that left on the seeded rows (gi_on_rows)
     gi_move(K, glam);
     gi_on_rows(K, gd, gr, glam);
     ex.par([&](Th &t) { if (t.tid == 0) g.seeded = live; });
+    MPC_SUBLAP(9, 5);
     ex.par([&](Th &t) { if (t.tid < K) { gd[t.tid] = 0.0; gr[t.tid] = 0.0; } });
     return K;
   }

@@ -19,6 +19,7 @@ inertia9 = np.zeros((n, 9)); inertia9[:, 0], inertia9[:, 4], inertia9[:, 8] = wl
 solver = sys.argv[3] if len(sys.argv) > 3 else "osqp"      # or "exact"
 sv = BatchedConvexMpc(wl.mass, inertia9, h, wl.dt_mpc, wl.alpha, solver=solver)
 names = ["load", "dyn", "qP", "sc-load", "sc-loop", "sc-store", "Kform", "sweep", "admm", "r-mulP", "r-rest", "p-setup", "p-H", "p-refine", "p-fin", "total"]
+if os.environ.get("PROF_NAMES"): names = os.environ["PROF_NAMES"].split(",")
 w = wl
 for step in range(4):
     d = torch.from_numpy(w.inputs).cuda()
