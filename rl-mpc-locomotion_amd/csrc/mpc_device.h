@@ -125,6 +125,18 @@ struct DeviceExec {
       v[0] = tot;
     }
   }
+  // acc(th)[0 .. 4) += A B for the 16 x 4 matrix A and the 4 x 16 matrix B that the wavefront's lanes hold one element each of (v_mfma_f64_16x16x4_f64:
+  // lane l holds A[l & 15][l >> 4] and B[l >> 4][l & 15]; of the 16 x 16 result, element (row (l >> 4) + 4 r, column l & 15) in acc[r]).  The one place of the
+  // solver where a matrix instruction pays: the blocked inverse of the seeded Gram matrix (mpc_wrench.h seed_inverse_mfma), one instruction per 16 x 16 tile
+  // and four pivots where the scalar sweep spends ~500.
+  template <class FA, class FB, class FC>
+  __device__ __forceinline__ void mfma16(FA &&fa, FB &&fb, FC &&fc) {
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    double *c = fc(th);
+    v4d acc = {c[0], c[1], c[2], c[3]};
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa(th), fb(th), acc, 0, 0, 0);
+    c[0] = acc[0]; c[1] = acc[1]; c[2] = acc[2]; c[3] = acc[3];
+  }
   // dst(th)[r] <- src(lane r & 3 of the quad)[r >> 2], r = 0 .. 5
   template <class S, class D>
   __device__ __forceinline__ void quad_gather6(S &&src, D &&dst) {

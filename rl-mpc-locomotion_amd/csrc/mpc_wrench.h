@@ -32,7 +32,9 @@
 #pragma once
 
 #include "mpc_core.h"
+#include <type_traits>
 #ifdef MPC_EMU_DEBUG
+#include <vector>
 #include <cstdio>
 #include <cstdlib>
 #endif
@@ -82,6 +84,8 @@ struct WThread : RoleRegs<Cfg<H>::TE, (Cfg<H>::FOOT0 != 0 && MPC_SHARE_ROLE_REGS
   double gx[3], gv[3], gbviol;                   //   the dual method's primal iterate, H^-1 n_p of my variables, my best candidate's violation
   double grn[5], gtol[5], gax[5], gred[1];       //   1 / |row|, violation tolerance and A x of my rows; operand of the workgroup reductions
   int gidx;                                      //   their index result
+  static constexpr int kGaccT = C::TW <= 64 ? 3 : 0;      //   seed_inverse_mfma: up to 3 x 3 tiles of 16 x 16 (single-wavefront workgroups only)
+  double gacc[kGaccT ? 4 * kGaccT * kGaccT : 1], gz[kGaccT ? kGaccT : 1], gnr[kGaccT ? kGaccT : 1];      //   my four elements of each tile; my element of L^-1 A_K,J / B^-1 A_K,J per tile column
   double pG[9], pC[9], pu0[3], pg[3], pr[3], pt[3], pxN[3], pPu[3], pw[3];
   double pQ[18], pR[21], pv[3], pn[6];           // orthogonalisation of the step's wrench columns (polish)
   double xp[3], zp[5], yp[5];
@@ -1917,6 +1921,150 @@ struct Solver {
     for (int r = 0; r < 5; ++r) c |= (act[r] < 0 ? 1 : (act[r] > 0 ? 2 : 0)) << (2 * r);
     return c;
   }
+  // ---- the seeded Gram matrix inverted on the matrix pipe (single-wavefront workgroups, K <= 48).  The symmetric sweep of seed_working_set in blocks of
+  // FOUR pivots:  A_ij -= A_iK B A_Kj,  A_Kj -> B A_Kj (and its mirror),  A_KK -> -B,  B = A_KK^-1 (4 x 4, by Cholesky) -- after all blocks A = -G^-1.  The matrix is held
+  // as TT x TT tiles of 16 x 16 in the accumulator layout of v_mfma_f64_16x16x4_f64 (lane l: rows (l >> 4) + 4 r, r = 0 .. 3, column l & 15; padded with the
+  // identity), and that layout makes the update ONE instruction per tile and block: the four pivot rows 4 q + (l >> 4) of a tile row are register q of every
+  // lane, which is exactly the B-operand layout (B[k = l >> 4][col = l & 15]) -- and, the matrix being symmetric, also the A-operand layout of the transposed
+  // block A_iK (A[row = l & 15][k = l >> 4]) of the tile in the mirrored position.  With B = L^-T L^-1 both operands are Z = L^-1 A_K,: , so
+  //     acc(I, J) += (-Z_I)^T-as-A x Z_J-as-B.
+  // Per block: the pivot rows go through LDS once (every lane needs the four rows of its column to form its element of Z and of B A_K,:), the 4 x 4
+  // Cholesky is done redundantly by every lane, the new pivot rows go through LDS once more to be mirrored into the pivot columns.  ~200 instructions per four
+  // pivots against ~500 per pivot of the scalar sweep (profiles/r04_exact_warm_start.txt).  A pivot below MPC_SEED_PIVOT of its original diagonal entry gives the
+  // matrix back untouched (false): the scalar path, which can drop a dependent row, takes over.
+  template <int N, int I = 0, class F>
+  static MPC_HD void static_for(F &&f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<N, I + 1>(f); }
+  }
+  template <int TT, int GQ>
+  MPC_HD bool mfma_groups(int K, double *rowsA, double *rowsB, double *coef) {
+    if constexpr (GQ >= 4 * TT) return true;
+    else {
+      GiShared<H> &g = *gi;
+      constexpr int G = GQ / 4, q = GQ % 4, base = 4 * GQ;
+      if (base >= K) return true;      // (the rest is the identity padding)
+      ex.par([&](Th &t) {      // the four pivot rows of every tile column
+        const int gl = t.tid >> 4, c = t.tid & 15;
+        static_for<TT>([&](auto J) { rowsA[(J.value * 4 + gl) * 16 + c] = t.gacc[(G * TT + J.value) * 4 + q]; });
+      });
+      ex.par([&](Th &t) {      // B = P^-1 of the 4 x 4 pivot block P = L L^T (every lane the same arithmetic; lane 0 hands out L^-1 and B)
+        double P[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b <= a; ++b) P[a][b] = rowsA[(G * 4 + a) * 16 + 4 * q + b];
+        bool ok = true;
+        double L[4][4], m[4][4], ri[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          double d = P[a][a];
+#pragma unroll
+          for (int k = 0; k < a; ++k) d -= L[a][k] * L[a][k];
+          const double d0 = base + a < K ? gi_ci(base + a, base + a) : 1.0;      // the diagonal as it was: the scale of the pivot test
+          ok = ok && d > MPC_SEED_PIVOT * d0;
+          ri[a] = fast_rsqrt(ok ? d : 1.0);
+          L[a][a] = d * ri[a];
+#pragma unroll
+          for (int b = a + 1; b < 4; ++b) {
+            double v = P[b][a];
+#pragma unroll
+            for (int k = 0; k < a; ++k) v -= L[b][k] * L[a][k];
+            L[b][a] = v * ri[a];
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {      // m = L^-1 (lower)
+          m[a][a] = ri[a];
+#pragma unroll
+          for (int b = 0; b < a; ++b) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = b; k < a; ++k) v += L[a][k] * m[k][b];
+            m[a][b] = -v * ri[a];
+          }
+        }
+        if (t.tid == 0) {
+          g.fail = ok ? 0 : 1;
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+              coef[4 * a + b] = b <= a ? m[a][b] : 0.0;
+              double v = 0.0;      // B = m^T m
+#pragma unroll
+              for (int k = (a > b ? a : b); k < 4; ++k) v += m[k][a] * m[k][b];
+              coef[16 + 4 * a + b] = v;
+            }
+        }
+      });
+      if (g.fail) return false;
+      ex.par([&](Th &t) {      // my element of Z_J = L^-1 A_K,J and of the new pivot rows B A_K,J
+        const int gl = t.tid >> 4, c = t.tid & 15;
+        double lin[4], bin[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { lin[k] = coef[4 * gl + k]; bin[k] = coef[16 + 4 * gl + k]; }
+        static_for<TT>([&](auto J) {
+          double z = 0.0, nr = 0.0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { const double v = rowsA[(J.value * 4 + k) * 16 + c]; z += lin[k] * v; nr += bin[k] * v; }
+          if (J.value == G && (c >> 2) == q) nr = -((c & 3) == 0 ? bin[0] : ((c & 3) == 1 ? bin[1] : ((c & 3) == 2 ? bin[2] : bin[3])));      // the pivot block: -B
+          t.gz[J.value] = z; t.gnr[J.value] = nr;
+          rowsB[(J.value * 4 + gl) * 16 + c] = nr;
+        });
+      });
+      static_for<TT * TT>([&](auto IJ) {
+        constexpr int I = IJ.value / TT, J = IJ.value % TT;
+        ex.mfma16([](Th &t) { return -t.gz[I]; }, [](Th &t) { return t.gz[J]; }, [](Th &t) { return t.gacc + 4 * (I * TT + J); });
+      });
+      ex.seq([&](Th &t) {      // the pivot rows and, mirrored, the pivot columns
+        const int gl = t.tid >> 4, c = t.tid & 15;
+        static_for<TT>([&](auto J) { t.gacc[(G * TT + J.value) * 4 + q] = t.gnr[J.value]; });
+        if ((c >> 2) == q) {
+          static_for<TT>([&](auto I) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (!(I.value == G && r == q)) t.gacc[(I.value * TT + G) * 4 + r] = rowsB[(I.value * 4 + (c & 3)) * 16 + gl + 4 * r];
+          });
+        }
+      });
+      ex.par([](Th &) {});      // (rowsA / rowsB are rewritten by the next block)
+      return mfma_groups<TT, GQ + 1>(K, rowsA, rowsB, coef);
+    }
+  }
+  template <int TT>
+  MPC_HD bool seed_inverse_mfma(int K) {
+    if constexpr (Th::kGaccT < TT || (int)(sizeof(s.part) / sizeof(double)) < 2 * 64 * TT + 32) return false;
+    else {
+      GiShared<H> &g = *gi;
+      double *rowsA = s.part, *rowsB = s.part + 64 * TT, *coef = s.part + 128 * TT;      // (the tile product's partials: free between two applications of H^-1)
+      ex.seq([&](Th &t) {
+        const int gl = t.tid >> 4, c = t.tid & 15;
+        static_for<TT * TT>([&](auto IJ) {
+          constexpr int I = IJ.value / TT, J = IJ.value % TT;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int R = 16 * I + gl + 4 * r, Cc = 16 * J + c;
+            t.gacc[4 * IJ.value + r] = (R < K && Cc < K) ? gi_ci(R, Cc) : (R == Cc ? 1.0 : 0.0);
+          }
+        });
+      });
+      if (!mfma_groups<TT, 0>(K, rowsA, rowsB, coef)) return false;
+      ex.par([&](Th &t) {      // G^-1 = -(the swept matrix): the packed lower triangle for the passes that follow
+        const int gl = t.tid >> 4, c = t.tid & 15;
+        static_for<TT * TT>([&](auto IJ) {
+          constexpr int I = IJ.value / TT, J = IJ.value % TT;
+          if constexpr (J <= I) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int R = 16 * I + gl + 4 * r, Cc = 16 * J + c;
+              if (Cc <= R && R < K) g.ci[R * (R + 1) / 2 + Cc] = -t.gacc[4 * IJ.value + r];
+            }
+          }
+        });
+      });
+      return true;
+    }
+  }
   // returns the number of slots in use (0: nothing seeded); hi / free masks / adds are the caller's loop variables
   MPC_HD int seed_working_set(int &hi, unsigned long long &free0, unsigned long long &free1, double *gd, double *gr, double *glam, double *gtmp, double *gtmp2) {
     GiShared<H> &g = *gi;
@@ -1995,9 +2143,29 @@ struct Solver {
     }
     MPC_SUBLAP(9, 2);
     // its inverse, in place: a symmetric sweep per pivot (a -> -a^-1 after all of them), then the sign
+#ifdef MPC_EMU_DEBUG
+    std::vector<double> dbgG((size_t)K * K);
+    for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) dbgG[(size_t)i * K + j] = gi_ci(i, j);
+#endif
+    bool inverted = false;
+    if constexpr (T <= 64) {      // on the matrix pipe where the workgroup is one wavefront; false: a dependent row, or a seed beyond 48 rows -- the scalar sweep below
+      inverted = K <= 16 ? seed_inverse_mfma<1>(K) : (K <= 32 ? seed_inverse_mfma<2>(K) : (K <= 48 ? seed_inverse_mfma<3>(K) : false));
+      ex.par([&](Th &t) { if (t.tid == 0) g.fail = 0; });
+    }
+#ifdef MPC_EMU_DEBUG
+    if (getenv("EMU_GI_TRACE") && inverted) {
+      double worst = 0;
+      for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) {
+        double acc = 0;
+        for (int k = 0; k < K; ++k) acc += dbgG[(size_t)i * K + k] * gi_ci(k, j);
+        worst = dmax(worst, fabs(acc - (i == j ? 1.0 : 0.0)));
+      }
+      fprintf(stderr, "  seeded inverse on the matrix pipe: K %d |G Ginv - I| %.3e\n", K, worst);
+    }
+#endif
     ex.par([&](Th &t) { if (t.tid < K) gr[t.tid] = gi_ci(t.tid, t.tid); });      // the diagonal as it was: the scale of the pivot test
     int live = K;
-    for (int p = 0; p < K; ++p) {
+    for (int p = 0; p < K && !inverted; ++p) {
       ex.par([&](Th &t) { if (t.tid < K) gtmp[t.tid] = gi_ci(t.tid, p); });
       const double piv = gtmp[p];
       if (!(piv > MPC_SEED_PIVOT * gr[p])) {      // row p is (nearly) a combination of the rows before it: it leaves the seed -- its row and column
@@ -2021,7 +2189,7 @@ struct Solver {
     }
     MPC_SUBLAP(9, 3);
     ex.par([&](Th &t) {
-      for (int i = t.tid; i < K * (K + 1) / 2; i += T) g.ci[i] = -g.ci[i];
+      if (!inverted) for (int i = t.tid; i < K * (K + 1) / 2; i += T) g.ci[i] = -g.ci[i];
       if (t.foot && !t.gfix) {      // b - N^T x0: what each seeded row is violated by at x0
         double lo[5], up[5];
         foot_bounds(t, lo, up);

@@ -5,6 +5,7 @@
 // oracle without a GPU.
 #define MPC_EMU_DEBUG 1
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -116,6 +117,20 @@ struct HostExec {
       tot = w == 0 ? ws : tot + ws;
     }
     for (int i = 0; i < NTHREADS; ++i) val(th[i])[0] = tot;
+  }
+  // the device's v_mfma_f64_16x16x4_f64 (mpc_device.h mfma16), wavefront by wavefront: lane l holds A[l & 15][l >> 4], B[l >> 4][l & 15] and the
+  // result elements (row (l >> 4) + 4 r, column l & 15), r = 0 .. 3; the sum over k in the instruction's order (k = 0 first, fused multiply-adds)
+  template <class FA, class FB, class FC> void mfma16(FA &&fa, FB &&fb, FC &&fc) {
+    for (int w = 0; w + 63 < NTHREADS; w += 64) {
+      double A[16][4], B[4][16];
+      for (int l = 0; l < 64; ++l) { A[l & 15][l >> 4] = fa(th[w + l]); B[l >> 4][l & 15] = fb(th[w + l]); }
+      for (int l = 0; l < 64; ++l)
+        for (int r = 0; r < 4; ++r) {
+          double acc = fc(th[w + l])[r];
+          for (int k = 0; k < 4; ++k) acc = std::fma(A[(l >> 4) + 4 * r][k], B[k][l & 15], acc);
+          fc(th[w + l])[r] = acc;
+        }
+    }
   }
   template <class S, class D> void quad_gather6(S &&src, D &&dst) {
     for (int q = 0; q + 3 < NTHREADS; q += 4) {
