@@ -78,7 +78,10 @@ typedef double mpc_double2 __attribute__((ext_vector_type(2)));
 #define MPC_SHARE_ROLE_REGS 1
 #endif
 #ifndef MPC_FOOT0                 // first foot lane of the solve kernel's workgroup for horizon H with MTW tile lanes
-#define MPC_FOOT0(H, MTW) (((H) == 12 || (H) == 16) ? (((MTW) + 3) / 4) * 4 : 0)
+#ifndef MPC_SPLIT_H10             // 1: also at h = 10 tile lanes and foot lanes are different threads (a 128-thread workgroup: a tile wave and a foot wave; experiment)
+#define MPC_SPLIT_H10 0
+#endif
+#define MPC_FOOT0(H, MTW) (((H) == 12 || (H) == 16 || ((H) == 10 && MPC_SPLIT_H10)) ? (((MTW) + 3) / 4) * 4 : 0)
 #endif
 #ifndef MPC_PART_ROWMAJOR
 #define MPC_PART_ROWMAJOR 1

@@ -280,7 +280,7 @@ int launch(const LaunchArgs &a) {
                        a.max_iter);
   }
   else if (a.job_slots > 0) {   // persistent workgroups, ADMM and polish as separate jobs (h = 16: 2.68 -> 2.28 ms, h = 20: 3.36 -> 2.78 ms per 4096 robots)
-    int slots = Cfg<H>::TW <= 64 ? a.job_slots : a.job_slots / 2;         // (multi-wave workgroups: two per CU)
+    int slots = Cfg<H>::TW <= 64 || (H == 10 && MPC_SPLIT_H10) ? a.job_slots : a.job_slots / 2;         // (multi-wave workgroups: two per CU; the two-wave split of h = 10: four)
     if (slots < 1) slots = 1;
     hipLaunchKernelGGL((mpc_solve_jobs_kernel<H>), dim3(a.n < slots ? a.n : slots), dim3(Cfg<H>::TW), 0, a.stream, a.models, a.state, a.qp, a.sc, a.forces, a.info, a.prof, a.order,
                        a.sched, a.ready, a.max_iter);
