@@ -2149,7 +2149,11 @@ struct Solver {
 #endif
     bool inverted = false;
     if constexpr (T <= 64) {      // on the matrix pipe where the workgroup is one wavefront; false: a dependent row, or a seed beyond 48 rows -- the scalar sweep below
-      inverted = K <= 16 ? seed_inverse_mfma<1>(K) : (K <= 32 ? seed_inverse_mfma<2>(K) : (K <= 48 ? seed_inverse_mfma<3>(K) : false));
+      bool try_mfma = true;
+#ifdef MPC_EMU_DEBUG
+      if (getenv("EMU_SEED_SCALAR")) try_mfma = false;      // (tests: the scalar sweep, which the single-wavefront workgroups otherwise reach only through a dependent row)
+#endif
+      if (try_mfma) inverted = K <= 16 ? seed_inverse_mfma<1>(K) : (K <= 32 ? seed_inverse_mfma<2>(K) : (K <= 48 ? seed_inverse_mfma<3>(K) : false));
       ex.par([&](Th &t) { if (t.tid == 0) g.fail = 0; });
     }
 #ifdef MPC_EMU_DEBUG

@@ -250,9 +250,13 @@ def _warm_sequence(make, h, cfg, n, steps=4):
     return passes
 
 
-@pytest.mark.parametrize("h,cfg,n", [(10, 2, 16), (10, 3, 12), (16, 4, 4), (20, 5, 3)])
-def test_exact_mode_warm_working_set_on_the_host_emulation(h, cfg, n):
+@pytest.mark.parametrize("h,cfg,n,scalar", [(10, 2, 16, False), (10, 3, 12, False), (16, 4, 4, False), (20, 5, 3, False), (10, 3, 8, True), (8, 2, 6, False), (3, 2, 4, False)])
+def test_exact_mode_warm_working_set_on_the_host_emulation(h, cfg, n, scalar, monkeypatch):
+    """scalar: the seeded Gram matrix inverted by the scalar sweep also where the workgroup is one wavefront (h <= 10: otherwise the blocked inverse on the
+    matrix pipe, seed_inverse_mfma, which hands over to the scalar sweep only for a dependent row)."""
     from tests.emu.emu import EmuBatch
+    if scalar:
+        monkeypatch.setenv("EMU_SEED_SCALAR", "1")
 
     def make(wl):
         e = EmuBatch(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
