@@ -2527,7 +2527,9 @@ struct Solver {
   // robot's next call is the cold "osqp_setup" call on clean data (with NaN inputs the vendored OSQP itself stays poisoned).
   MPC_HD void store(long long t0) {
     tc[15] = MPC_CLOCK() - t0;
-    if (s.first) tc[15] = -tc[15];   // a cold solve is no predictor of the robot's next (warm) one: negative = ignored by the dispatch order (order_block)
+    if (s.first && eps_exact == 0.0) tc[15] = -tc[15];   // a cold solve is no predictor of the robot's next (warm) one: negative = ignored by the dispatch order (order_block).
+                                                         // (The exact mode clears the record on every call, so every solve is "first": there the last solves do order the launch --
+                                                         //  with a seeded working set a robot that needed 30 passes last time tends to need them again.)
     const bool failed = s.bad || s.status == kStNonCvx;
     // (the reference's qpOASES branch returns its vector whatever the solver's status, mpc_osqp.cc:906-947: in the exact mode an iterate that
     // ran out of iterations is written too, with its status)
@@ -2625,7 +2627,9 @@ struct Solver {
     }
     lap(14);
     tc[15] = MPC_CLOCK() - t0;
-    if (s.first) tc[15] = -tc[15];   // a cold solve is no predictor of the robot's next (warm) one: negative = ignored by the dispatch order (order_block)
+    if (s.first && eps_exact == 0.0) tc[15] = -tc[15];   // a cold solve is no predictor of the robot's next (warm) one: negative = ignored by the dispatch order (order_block).
+                                                         // (The exact mode clears the record on every call, so every solve is "first": there the last solves do order the launch --
+                                                         //  with a seeded working set a robot that needed 30 passes last time tends to need them again.)
     // outputs + persistent state (store_solution, auxil.c:528-561; mpc_osqp.cc:788-790: forces = -x): see store()
     ex.par([&](Th &t) {
       const bool failed = s.bad || s.status == kStNonCvx;
