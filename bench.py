@@ -455,6 +455,8 @@ def main():
     if not args.no_control_loop and world == 1:      # secondary legs: single-GPU runs only
         out["control_loop"] = control_loop_leg(n, h, dev)
         out["control_loop_with_resets"] = control_loop_leg(n, h, dev, reset_every=37)
+        out["control_loop_exact"] = control_loop_leg(n, h, dev, solver="exact")      # the reference AS SHIPPED passes mpc.QPOASES (ConvexMPCLocomotion.py:108)
+        out["control_loop_exact"]["note"] = "the same loop with the controllers' ConvexMpc objects in the exact-optimum mode (the reference's qpOASES branch, what its Python selects)"
         out["policy"] = policy_leg(n, dev)
         # the same unit at the reference's own cadence (controller.run every 10 ms, MPC update on every 2nd call): two controller ticks per control step
         out["control_steps_per_s_incl_torque_map"] = out["control_loop"]["control_steps_per_s_incl_torque_map"]
@@ -643,7 +645,7 @@ def sharded_loop_leg(cfg_id, n_total, h, dev, dist, ticks=8, warm=3, emulate=Fal
     return out
 
 
-def control_loop_leg(n, h, dev, ticks=40, warm=10, reset_every=0):
+def control_loop_leg(n, h, dev, ticks=40, warm=10, reset_every=0, solver="osqp"):
     """Secondary figure (NOT `value`): robot-ticks/s of the whole controller.run seam on device tensors --
     state estimator + leg kinematics + gait / foot placement + the MPC solve on every second tick (the
     reference's cadence, RobotRunnerMin.py:21-22) + swing / stance commands + joint torques.
@@ -653,7 +655,7 @@ def control_loop_leg(n, h, dev, ticks=40, warm=10, reset_every=0):
     from rl_mpc_locomotion_amd.locomotion import BatchedLocomotion
     from rl_mpc_locomotion_amd.synthetic import TickStream
     ts = TickStream(n, seed=4242, config=2)
-    ctl = BatchedLocomotion(ts.robot_type, ts.gait_id, horizon=h, device=dev)
+    ctl = BatchedLocomotion(ts.robot_type, ts.gait_id, horizon=h, device=dev, solver=solver)
     ins = [tuple(torch.from_numpy(a).to(dev) for a in ts.tick(k)) for k in range(warm + ticks)]
     rng = np.random.default_rng(5)
     ids = [torch.from_numpy(rng.choice(n, max(1, n // 64), replace=False).astype(np.int32)).to(dev) for _ in range(warm + ticks)]
