@@ -268,3 +268,41 @@ def test_long_run_with_random_resets_stays_healthy():
             worst = max(worst, float(tau.abs().max()))
             assert (ctl.solver_info()[:, 1] == 1).all()
     assert worst < 1e4
+
+
+@pytest.mark.gpu
+def test_controller_solver_accessors_and_iteration_counter():
+    """mpc_ctrl_set_iteration / mpc_ctrl_solver / mpc_ctrl_solver_forces / mpc_device_clock (the accessors bench.py's `value` leg uses): with
+    controller_dt = 0.02 every robot is due on every run (iterationsBetweenMPC = 1); the counter sets the gait phase; the solver's forces and record are
+    those of the launch; the solver handle's kernel timing works through the controller."""
+    import torch
+    from rl_mpc_locomotion_amd import _lib
+    from rl_mpc_locomotion_amd.locomotion import BatchedLocomotion
+    from rl_mpc_locomotion_amd.synthetic import ControlStepStream
+    n, h = 64, 10
+    cs = ControlStepStream(n, h=h, seed=3, config=3)
+    ctl = BatchedLocomotion(cs.robot_type, cs.gait_id, horizon=h, controller_dt=0.02, device="cuda:0")
+    assert ctl.iterations_between_mpc == 1
+    ctl.enable_timing()
+    ctl.set_iteration(cs.iteration0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    for s in range(3):
+        tau = ctl.run(*(up(a) for a in cs.step(s)))
+    torch.cuda.synchronize()
+    info, rec, f = ctl.solver_info(), ctl.solver_record(), ctl.solver_forces()
+    assert (info[:, 1] == 1).all() and np.isfinite(tau.cpu().numpy()).all()
+    # the contact table of the record is the gait table at the counter the robots were given (+ the three runs)
+    from rl_mpc_locomotion_amd.gait import mpc_table
+    from rl_mpc_locomotion_amd import layout as L
+    tables = [mpc_table(cs.gait_id, cs.iteration0 + k, 1, h) for k in (2, 3)]      # (the counter is read before / after its increment: ConvexMPCLocomotion.py:217-231)
+    got = rec[:, L.IN_CONTACT:L.IN_CONTACT + 4 * h]
+    assert any(np.array_equal(got, w) for w in tables)
+    want = tables[0] if np.array_equal(got, tables[0]) else tables[1]
+    swing = np.repeat(want == 0, 3, axis=1)
+    assert (f[swing] == 0).all() and (np.abs(f).max(1) > 1.0).all()          # forces of the last solve: zero on swing feet, something on the others
+    prep, solve = ctl.kernel_times(3)
+    assert (prep > 0).all() and (solve > 0).all()
+    ghz, ms = _lib.device_clock(0, 5)
+    assert 0.5 < ghz < 3.5 and ms > 1.0
+    with pytest.raises(_lib.MpcLibraryError):
+        _lib.check(_lib.lib().mpc_ctrl_set_iteration(ctl._handle, np.full(n, -1, np.int32).ctypes.data, None), "mpc_ctrl_set_iteration")
