@@ -299,7 +299,7 @@ def test_controller_solver_accessors_and_iteration_counter():
     assert any(np.array_equal(got, w) for w in tables)
     want = tables[0] if np.array_equal(got, tables[0]) else tables[1]
     swing = np.repeat(want == 0, 3, axis=1)
-    assert (np.abs(f[swing]) < 1e-3).all() and (np.abs(f).max(1) > 1.0).all()      # forces of the last solve: (ADMM-)zero on swing feet, something on the others
+    assert np.abs(f[swing]).max() < 1e-2 * np.abs(f).max() and (np.abs(f).max(1) > 1.0).all()      # forces of the last solve: zero to ADMM accuracy (eps 1e-3) on swing feet
     prep, solve = ctl.kernel_times(3)
     assert (prep > 0).all() and (solve > 0).all()
     ghz, ms = _lib.device_clock(0, 5)
