@@ -423,6 +423,10 @@ def main():
                      "flops_per_launch": m["flops_per_launch"],
                      "prep_kernel_flops_per_launch": m["prep_flops_per_launch"],
                      "frac_fp64_peak": achieved_tflops / FP64_VECTOR_PEAK_TFLOPS,
+                     "mfma": {"utilisation_of_this_kernel": 0.0,
+                              "note": "by design: the one GEMM-shaped contraction of the reference's assembly (B_qp^T Q B_qp) is removed algebraically (P = alpha I + BB^T Theta BB, "
+                                      "DESIGN.md 3.1) and fp64 MFMA issues at the vector rate on gfx950; the matrix pipe is used where it cuts INSTRUCTIONS: the weight policy's "
+                                      "actor (v_mfma_f32_32x32x2_f32, `policy`) and the exact mode's seeded Gram inverse (v_mfma_f64_16x16x4_f64, `secondary.exact`)"},
                      "executed": {"flops_per_launch": m["exec_flops"], "tflops": m["exec_flops"] / (solve_ms.mean() * 1e-3) / 1e12,
                                   "frac_fp64_peak": m["exec_flops"] / (solve_ms.mean() * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                                   "note": "operations the solve kernel executes (bench.py executed_flops: OSQP on all 12 h variables through the 6 h x 6 h "
