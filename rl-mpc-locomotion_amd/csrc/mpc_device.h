@@ -96,14 +96,22 @@ struct DeviceExec {
       const unsigned long long who = __ballot(v[0] == m);
       idx(th) = who ? __ffsll((long long)who) - 1 : 0;
       v[0] = m;
-    } else {
-      scratch[threadIdx.x] = v[0];
+    } else {      // every wavefront as above, then the few wavefront results through LDS (a serial scan of blockDim.x entries by every thread cost 5-8 k cycles
+      double m = v[0];      //  per call: three of them per pass of the exact mode's active-set method)
+      m = fmax(m, quad_perm<quad_ctrl(1, 0, 3, 2)>(m));
+      m = fmax(m, quad_perm<quad_ctrl(2, 3, 0, 1)>(m));
+      m = fmax(m, quad_perm<0x141>(m));
+      m = fmax(m, quad_perm<0x140>(m));
+      m = fmax(fmax(read_lane(m, 0), read_lane(m, 16)), fmax(read_lane(m, 32), read_lane(m, 48)));
+      const unsigned long long who = __ballot(v[0] == m);
+      const int w = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
+      if ((threadIdx.x & 63) == 0) { scratch[2 * w] = m; scratch[2 * w + 1] = (double)(64 * w + (who ? __ffsll((long long)who) - 1 : 0)); }
       __syncthreads();
-      double m = scratch[0];
-      int ml = 0;
-      for (int i = 1; i < (int)blockDim.x; ++i) { const double x = scratch[i]; if (x > m) { m = x; ml = i; } }
+      double best = scratch[0];
+      int bl = (int)scratch[1];
+      for (int k = 1; k < nw; ++k) { const double x = scratch[2 * k]; if (x > best) { best = x; bl = (int)scratch[2 * k + 1]; } }
       __syncthreads();
-      v[0] = m; idx(th) = ml;
+      v[0] = best; idx(th) = bl;
     }
   }
   template <class V>

@@ -37,8 +37,10 @@ namespace {
 // Solve kernel (mpc_wrench.h Solver): ADMM + polish of every active robot, from the QP and scale records.  EXACT: the
 // exact-optimum mode (the reference's qpOASES branch) -- a separate instantiation, so that its outer loop does not touch the
 // register allocation of the OSQP mode.
+// (EXACT, multi-wave: the full register budget -- this instantiation is the exact mode's rarely used second launch; at two waves per SIMD it
+// keeps 2.2 KB of scratch per lane, at one 1.1 KB.)
 template <int H, bool EXACT>
-__global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES : MPC_SOLVE_MIN_WAVES_WIDE)) void mpc_solve_kernel(
+__global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES : (EXACT ? 1 : MPC_SOLVE_MIN_WAVES_WIDE))) void mpc_solve_kernel(
     int n, const RobotModel *__restrict__ models, double *__restrict__ state, const double *__restrict__ qp,
     const double *__restrict__ sc, double *__restrict__ forces, int *__restrict__ info, long long *__restrict__ prof,
     const int *__restrict__ order, const int *__restrict__ sched, const int *__restrict__ ready, int max_iter) {
