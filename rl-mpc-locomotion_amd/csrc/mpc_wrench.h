@@ -159,6 +159,9 @@ struct GiShared {
 #ifndef MPC_SEED_PIVOT            // exact mode, seeding: a seeded row whose pivot in the Gram matrix falls below this fraction of its diagonal entry is dropped as dependent
 #define MPC_SEED_PIVOT 1e-8
 #endif
+#ifndef MPC_SEED_DIRECT_GRAM      // ... the seed's Gram matrix entry by entry from the held tiles (0: a column per seeded row, K applications of H^-1)
+#define MPC_SEED_DIRECT_GRAM 1
+#endif
 #ifndef MPC_SEED_LAMBDA           // ... and one whose multiplier is below this fraction of the largest is dropped as not (clearly) active
 #define MPC_SEED_LAMBDA 1e-6
 #endif
@@ -1771,6 +1774,9 @@ struct Solver {
   //   downdate drops one, free slots keep zero rows -- no triangular solves, nothing to compact.
   // Lane roles: foot lanes own x, their rows' status (t.act: -1 lower, +1 upper) and slots; lane i < NWMAX also serves slot i.
   static constexpr int kGiMaxPass = 8 * NF;        // adds + drops (observed: <= 1.3 x the final set)
+  static constexpr int kSeedStep0 = 8;             // seed_working_set: the first slot of every step, in the second scratch row from here on
+  static constexpr bool kSeedDirectGram = MPC_SEED_DIRECT_GRAM && 12 * GiShared<H>::NWMAX <= Sh::PARTLEN && 3 * GiShared<H>::NWMAX <= (int)(sizeof(Sh::dxy) / sizeof(double)) &&
+                                          kSeedStep0 + H + 1 <= GiShared<H>::TL;
   MPC_HD double gi_ci(int i, int j) const { return i >= j ? gi->ci[i * (i + 1) / 2 + j] : gi->ci[j * (j + 1) / 2 + i]; }
   // t.pw <- H^-1 r for the per-foot vector r given by rv(t) (zero on fixed feet whatever rv says: C = 0 there)
   template <class RV>
@@ -2102,6 +2108,8 @@ struct Solver {
       if (t.foot) {
         int base = 0, total = 0;
         for (int j = 0; j < NF; ++j) { const int c = (int)gtmp[j]; base += j < t.fid ? c : 0; total += c; }
+        if ((t.fid & 3) == 0) gtmp2[kSeedStep0 + (t.fid >> 2)] = (double)(base < NW ? base : NW);      // first slot of my step (slots are in foot order)
+        if (t.fid == 0) gtmp2[kSeedStep0 + H] = (double)(total < NW ? total : NW);
         if (!t.gfix) {
 #pragma unroll
           for (int r = 0; r < 5; ++r)
@@ -2116,7 +2124,91 @@ struct Solver {
     const int K = g.seed_k;
     if (K == 0) return 0;
     MPC_SUBLAP(9, 1);
-    // the Gram matrix, a column per seeded row:  y = H^-1 n_j,  G_ij = n_i^T y
+    // The Gram matrix G = N^T H^-1 N.  H^-1 = C (I - V (I - M^-1) V^T) C^T (omega_apply) and a normal touches one foot, so with u_i = C^T n_i
+    // (three numbers), v_i = V_f^T u_i (six, in the wrench space of the row's step k_i) and vt_i = dl o v_i
+    //     G_ij = [same foot] u_i^T u_j  -  [same step] (v_i^T v_j - 2 vt_i^T vt_j)  -  vt_i^T Mx(k_i, k_j) vt_j
+    // with Mx the held tile (2 I - Mh^-1, see product<kHeld>): every entry is a 6 x 6 quadratic form of ONE tile, formed by the lane that holds
+    // it -- no application of H^-1 at all, where a column per seeded row costs K of them (71 k of a seeded solve's 311 k cycles at h = 10).
+    if constexpr (kSeedDirectGram) {
+      double *const rvt = s.part, *const rv = s.part + 6 * NW, *const ru = s.dxy;      // per slot: vt, v, u
+      ex.par([&](Th &t) {
+        if (t.foot && !t.gfix) {
+          double a[9], gf[18];
+          foot_a(t, a);
+          load_g(t, gf);
+          const double *dl = s.dl + 6 * (t.fid >> 2);
+#pragma unroll
+          for (int r = 0; r < 5; ++r)
+            if (t.gslot[r] >= 0) {
+              double n[3], u[3];
+              gi_row(a, r, n);
+              const double sg = t.act[r] < 0 ? 1.0 : -1.0;
+#pragma unroll
+              for (int c = 0; c < 3; ++c) n[c] *= sg;
+              ct_mul(t.pC, n, u);
+              double *ov = rv + 6 * t.gslot[r], *ovt = rvt + 6 * t.gslot[r], *ou = ru + 3 * t.gslot[r];
+#pragma unroll
+              for (int q = 0; q < 6; ++q) {
+                const double v = gf[3 * q] * u[0] + gf[3 * q + 1] * u[1] + gf[3 * q + 2] * u[2];
+                ov[q] = v;
+                ovt[q] = dl[q] * v;
+              }
+#pragma unroll
+              for (int c = 0; c < 3; ++c) ou[c] = u[c];
+            }
+        }
+      });
+      ex.par([&](Th &t) {
+        if (t.mact) {
+          const int i0 = (int)gtmp2[kSeedStep0 + t.ti], i1 = (int)gtmp2[kSeedStep0 + 1 + t.ti], j0 = (int)gtmp2[kSeedStep0 + t.tj], j1 = (int)gtmp2[kSeedStep0 + 1 + t.tj];
+          for (int j = j0; j < j1; ++j) {
+            double vj[6], w[6], vrj[6], uj[3];
+#pragma unroll
+            for (int q = 0; q < 6; q += 2) MPC_LDS_LOAD128(rvt + 6 * j + q, vj[q], vj[q + 1]);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { vrj[q] = 0.0; if (q < 3) uj[q] = 0.0; }
+            if (t.dia) {
+#pragma unroll
+              for (int q = 0; q < 6; q += 2) MPC_LDS_LOAD128(rv + 6 * j + q, vrj[q], vrj[q + 1]);
+#pragma unroll
+              for (int c = 0; c < 3; ++c) uj[c] = ru[3 * j + c];
+            }
+#pragma unroll
+            for (int aa = 0; aa < TS; ++aa) {
+              double acc = t.dia ? -2.0 * vj[aa] : 0.0;      // (Mx - 2 I) vt_j on the diagonal tile: -Mh^-1 vt_j
+#pragma unroll
+              for (int bb = 0; bb < TS; ++bb) acc += t.Mx[aa * TS + bb] * vj[bb];
+              w[aa] = acc;
+            }
+            const int fj = g.owner[j] >> 3;
+            for (int i = t.dia ? j : i0; i < i1; ++i) {
+              double vi[6];
+#pragma unroll
+              for (int q = 0; q < 6; q += 2) MPC_LDS_LOAD128(rvt + 6 * i + q, vi[q], vi[q + 1]);
+              double acc = 0.0;
+#pragma unroll
+              for (int q = 0; q < 6; ++q) acc -= vi[q] * w[q];
+              if (t.dia) {
+                double vri[6];
+#pragma unroll
+                for (int q = 0; q < 6; q += 2) MPC_LDS_LOAD128(rv + 6 * i + q, vri[q], vri[q + 1]);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) acc -= vri[q] * vrj[q];
+                if ((g.owner[i] >> 3) == fj) acc += (ru[3 * i] * uj[0] + ru[3 * i + 1] * uj[1]) + ru[3 * i + 2] * uj[2];
+              }
+              g.ci[i * (i + 1) / 2 + j] = acc;
+            }
+          }
+        }
+      });
+    }
+    bool by_columns = !kSeedDirectGram;
+#ifdef MPC_EMU_DEBUG
+    std::vector<double> dbgDirect;
+    if (kSeedDirectGram && getenv("EMU_GRAM_CHECK")) { dbgDirect.assign(g.ci, g.ci + K * (K + 1) / 2); by_columns = true; }
+#endif
+    // (horizons whose LDS stages are too small for the slot records: a column per seeded row,  y = H^-1 n_j,  G_ij = n_i^T y)
+    if (by_columns)
     for (int j = 0; j < K; ++j) {
       const int pf = g.owner[j] >> 3, pr = g.owner[j] & 7;
       gi_apply([&](Th &t, double *r3) {
@@ -2141,6 +2233,14 @@ struct Solver {
         }
       });
     }
+#ifdef MPC_EMU_DEBUG
+    if (!dbgDirect.empty()) {
+      double worst = 0, big = 0;
+      for (int i = 0; i < K; ++i) big = dmax(big, fabs(gi_ci(i, i)));
+      for (int i = 0; i < K * (K + 1) / 2; ++i) worst = dmax(worst, fabs(dbgDirect[i] - g.ci[i]));
+      fprintf(stderr, "  seed Gram matrix: K %d direct vs by columns: max |diff| %.3e (largest diagonal entry %.3e)\n", K, worst, big);
+    }
+#endif
     MPC_SUBLAP(9, 2);
     // its inverse, in place: a symmetric sweep per pivot (a -> -a^-1 after all of them), then the sign
 #ifdef MPC_EMU_DEBUG
