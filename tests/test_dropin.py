@@ -275,6 +275,25 @@ def test_exact_mode_warm_working_set_on_the_host_emulation(h, cfg, n, scalar, mo
     _warm_sequence(make, h, cfg, n)
 
 
+@pytest.mark.parametrize("h,cfg,n", [(10, 3, 8), (16, 4, 3), (20, 5, 2), (8, 2, 4)])
+def test_exact_mode_seed_gram_matrix_entry_by_entry_equals_the_one_by_columns(h, cfg, n, monkeypatch, capfd):
+    """The seed's Gram matrix N^T H^-1 N is formed entry by entry from the held tiles of the factorisation (mpc_wrench.h seed_working_set); the debug build
+    of the emulation also forms it the long way -- one application of H^-1 per seeded row -- and reports the largest difference."""
+    import re
+    from tests.emu.emu import EmuBatch
+    from rl_mpc_locomotion_amd.synthetic import make_solver_workload, perturb_workload
+    monkeypatch.setenv("EMU_GRAM_CHECK", "1")
+    wl = make_solver_workload(n, h=h, seed=77, config=cfg)
+    e = EmuBatch(wl.mass, wl.inertia_diag, h, wl.dt_mpc, wl.alpha)
+    w = wl
+    for s in range(3):
+        e.solve(w.inputs, exact=True)
+        w = perturb_workload(w, 300 + s)
+    lines = re.findall(r"seed Gram matrix: K (\d+) direct vs by columns: max \|diff\| (\S+) \(largest diagonal entry (\S+)\)", capfd.readouterr().err)
+    assert len(lines) >= n, lines                                   # the seeded calls (the second and third of every robot) report
+    assert all(int(k) > 0 and float(d) <= 1e-12 * float(big) for k, d, big in lines), lines
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("h,cfg,n", [(10, 2, 512), (10, 3, 96), (16, 4, 64), (20, 5, 32)])
 def test_exact_mode_warm_working_set(h, cfg, n):
