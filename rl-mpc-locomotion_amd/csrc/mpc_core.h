@@ -176,10 +176,17 @@ struct Cfg {
   // three numbers stand for the foot's ten bounds, and E times them is bit for bit what scaling.c:152-153 computes.
   static constexpr int QP_Q = 0, QP_BND = N, QP_CONE = N + 3 * NF, QP_B6 = QP_CONE + 16, QP_TH1 = QP_B6 + 72,
                        QP_TH2 = QP_TH1 + 36, QP_LEN = QP_TH2 + 8;
-  // The scale record the scaling kernel hands to the solve kernel: D[N] E[M] q_s[N] A_s[9 NF] c 1/c | job[2]
-  // (A_s: the nine structural nonzeros of a foot's 5 x 3 cone block, kAsPos; the scaled bounds are E times the QP record's;
+  // The scale record the scaling kernel hands to the solve kernel: D[N] E[M] q_s[N] c 1/c | job[2]
+  // (the scaled cone block is not in it: every foot's block is the QP record's 5 x 3 cone block times E of its rows and D of its columns, nine
+  // structural nonzeros (kAsPos) that the solve kernel forms as (a E) D -- scaled_cone_entry below; the ten passes of scaling.c round (a e) d ten times,
+  // a difference of a few ulp.  The scaled bounds are E times the QP record's;
   // job: primal / dual residual of the ADMM part's result, from the ADMM job of a solve to its polish job, mpc_wrench.h)
-  static constexpr int SC_D = 0, SC_E = N, SC_QS = N + M, SC_AS = 2 * N + M, SC_C = SC_AS + 9 * NF, SC_JOB = SC_C + 2, SC_LEN = SC_C + 4;
+  static constexpr int SC_D = 0, SC_E = N, SC_QS = N + M, SC_C = 2 * N + M, SC_JOB = SC_C + 2, SC_LEN = SC_C + 4;
+  // structural nonzero k (0 .. 8) of foot f's scaled cone block
+  static MPC_HD double scaled_cone_entry(const double *qp, const double *sc, int f, int k) {
+    const int pos = kAsPos[k];
+    return (qp[QP_CONE + pos] * sc[SC_E + 5 * f + pos / 3]) * sc[SC_D + 3 * f + pos % 3];
+  }
   // The same two records as mpc_batch_get_qp / mpc_batch_get_scale hand them out (include/mpc_batch.h: every bound, the dense cone
   // block): q[N] l[M] u[M] cone[15] pad | B6 th1 th2 pad2   and   D[N] E[M] q_s[N] A_s[15 NF] l_s[M] u_s[M] c 1/c | job[2]
   static constexpr int XQP_L = N, XQP_U = N + M, XQP_CONE = N + 2 * M, XQP_LEN = XQP_CONE + 16 + 72 + 36 + 8;
@@ -634,7 +641,7 @@ struct Scaler {
   const double *u12;   // [288] LDS  U1, U2 of the assembly part
   double alpha;
   const double *qp;    // [QP_LEN]  q, l, u, cone from the assembly kernel
-  double *sc;          // [SC_LEN]  out: D, E, q_s, A_s, l_s, u_s, c, 1/c
+  double *sc;          // [SC_LEN]  out: D, E, q_s, c, 1/c
   long long *prof = nullptr;   // [kProfLen] slots 3 (tile build + first norms), 4 (the ten passes), 5 (record store) under MPC_SECTION_PROFILE
   long long tc[6] = {0, 0, 0, 0, 0, 0};
   long long tlast = 0;
@@ -862,7 +869,6 @@ struct Scaler {
         sc[C::SC_D + t.tid] = s.D[t.tid];
       }
       for_rows(t, [&](int i) { sc[C::SC_E + i] = s.E[i]; });
-      for (int k = t.tid; k < NF * 9; k += T) { const int f = k / 9; sc[C::SC_AS + k] = s.As[15 * f + kAsPos[k - 9 * f]]; }
     });
     lap(5);
     if (prof) {

@@ -311,7 +311,7 @@ void expand_records(const double *qp, const double *sc, double *xqp, double *xsc
     for (int i = 0; i < 2 * C::N + C::M; ++i) xsc[i] = sc[i];      // D, E, q_s
     for (int f = 0; f < C::NF; ++f) {
       for (int k = 0; k < 15; ++k) xsc[C::XSC_AS + 15 * f + k] = 0.0;
-      for (int k = 0; k < 9; ++k) xsc[C::XSC_AS + 15 * f + kAsPos[k]] = sc[C::SC_AS + 9 * f + k];
+      for (int k = 0; k < 9; ++k) xsc[C::XSC_AS + 15 * f + kAsPos[k]] = C::scaled_cone_entry(qp, sc, f, k);
       for (int r = 0; r < 5; ++r) {
         const double e = sc[C::SC_E + 5 * f + r];
         xsc[C::XSC_LS + 5 * f + r] = e * (r < 4 ? 0.0 : qp[C::QP_BND + 3 * f]);

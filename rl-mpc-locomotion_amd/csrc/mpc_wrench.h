@@ -239,7 +239,7 @@ struct Solver {
   const RobotModel &mdl;
   double *state;       // [state_len<H>()]
   const double *qp;    // [QP_LEN]  q, bounds, cone, wrench description from the assembly kernel
-  const double *sc;    // [SC_LEN]  D, E, q_s, A_s, c from the scaling kernel
+  const double *sc;    // [SC_LEN]  D, E, q_s, c from the scaling kernel
   double *forces;      // [N]   out: -D x (all horizon steps), untouched on failure
   int *info;           // [kInfoLen]
   long long *prof;     // [kProfLen] shader-clock cycles per section (may be null)
@@ -531,9 +531,8 @@ struct Solver {
         const int f = t.fid;
 #pragma unroll
         for (int c = 0; c < 3; ++c) t.q[c] = sc[C::SC_QS + 3 * f + c];
-        const double *as = sc + C::SC_AS + 9 * f;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) s.fa[pidx(k, f)] = as[k];
+        for (int k = 0; k < 9; ++k) s.fa[pidx(k, f)] = C::scaled_cone_entry(qp, sc, f, k);
         s.fa[pidx(15, f)] = 0.0;
         const double *bnd = qp + C::QP_BND + 3 * f;
         int tyb = 0;
