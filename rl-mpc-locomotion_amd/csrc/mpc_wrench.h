@@ -523,7 +523,8 @@ struct Solver {
   static_assert(SL + N <= Sh::PARTLEN, "the state / force stage must fit Shared::part");
   MPC_HD void load() {
     ex.par([&](Th &t) {
-      for (int i = t.tid; i < SL; i += T) s.part[i] = MPC_GLD(state + i);
+      for (int i = t.tid; i < N + 2 * M; i += T) s.part[i] = MPC_GLD(state + i);      // x, z, y (the previous q in between is the prep kernel's business)
+      if (t.tid < 2) s.part[2 * N + 2 * M + t.tid] = MPC_GLD(state + 2 * N + 2 * M + t.tid);      // rho, flag
       for (int i = t.tid; i < 72; i += T) s.B6[i] = qp[C::QP_B6 + i];
       for (int i = t.tid; i < 36; i += T) s.th1[i] = qp[C::QP_TH1 + i];
       for (int i = t.tid; i < 6; i += T) s.th2[i] = qp[C::QP_TH2 + i];
