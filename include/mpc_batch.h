@@ -143,8 +143,9 @@ int mpc_batch_set_state(mpc_batch *b, const double *h_state);
  *                mpc_osqp.cc:606-688 with its Hessian in the wrench form P = BB^T Theta BB + alpha I (csrc/mpc_wrench.h);
  *   scale record [n, mpc_batch_scale_len] D[12h] E[20h] q_s[12h] A_s[15*4h] l_s[20h] u_s[20h] c 1/c -- OSQP's scaling.c output -- and two
  *                doubles of job hand-over (the ADMM part's residuals, read by the solve's polish job).
- * (On the device the records are shorter -- three bound values and the nine structural cone entries per foot, csrc/mpc_core.h -- and
- * the accessors expand them with the solve kernel's own arithmetic: l_s = E l, u_s = E u.) */
+ * (On the device the records are shorter -- three bound values per foot, no scaled cone block, csrc/mpc_core.h -- and the accessors
+ * expand them with the solve kernel's own arithmetic: l_s = E l, u_s = E u, a foot's scaled cone block = (cone block x E of its rows) x D
+ * of its columns.) */
 int mpc_batch_qp_len(const mpc_batch *b);
 int mpc_batch_scale_len(const mpc_batch *b);
 int mpc_batch_get_qp(mpc_batch *b, double *h_qp);
