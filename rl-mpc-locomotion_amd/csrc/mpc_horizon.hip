@@ -13,11 +13,12 @@
 
 using namespace mpc;
 
-// minimum waves per SIMD the register allocator must leave room for in the prep kernel: 3 -> a 256-thread workgroup gets 168 VGPRs and
-// three robots share a CU.  h = 10: four (128 VGPRs, 88 B of scratch, 36 KB of LDS each) -- 0.205 -> 0.201 ms per 4096 robots with the
-// kernel as it is now (round 2's kernel lost with four: 0.278 against 0.235 ms, its Ruiz passes spilled).
+// minimum waves per SIMD the register allocator must leave room for in the prep kernel: 3 -> a 256-thread workgroup (h = 10)
+// gets 168 VGPRs and three robots share a CU.  Four (128 VGPRs, 88 B of scratch, 36 KB of LDS each): round 2's kernel lost with them
+// (0.278 against 0.235 ms per 4096 robots); this round's gains 2 % (0.205 -> 0.201 ms) and pays with 96 MB of spill traffic per launch
+// (fabric side 38 -> 133 MB, profiles/r04_ab_prep_h20.txt): not taken.
 #ifndef MPC_SCALE_MIN_WAVES
-#define MPC_SCALE_MIN_WAVES (MPC_H == 10 ? 4 : 3)
+#define MPC_SCALE_MIN_WAVES 3
 #endif
 #ifndef MPC_MIN_WAVES_MAX_T
 #define MPC_MIN_WAVES_MAX_T 256   // larger workgroups (h = 16), and the four-tiles-per-thread layout (h = 20), run one per CU
