@@ -75,7 +75,7 @@ struct MfmaSweepCfg {
   static constexpr int NW = 6 * H, T = Cfg<H>::TW, MT = (NW + 15) / 16, MP = 16 * MT, W = T / 64;
   static constexpr int WC = W >= 4 ? 2 : 1, WR = W / WC;
   static constexpr int TR = (MT + WR - 1) / WR, TC = (MT + WC - 1) / WC, TPW = TR * TC;
-  static constexpr bool on = MPC_MFMA_SWEEP(H) && T > 64 && T % 64 == 0 && WR * WC == W;
+  static constexpr bool on = MPC_MFMA_SWEEP(H) && T % 64 == 0 && WR * WC == W;
 };
 
 template <int H>
@@ -193,7 +193,8 @@ struct Shared {
   static constexpr int NRED = 21;                                       // residual / certificate reductions (Solver::residuals)
   static constexpr int PARTLEN_A0 = C::GW * C::NPW, PARTLEN_A1 = C::NW * ((C::GW + 1) & ~1);   // [slot][row] / [row][slot] (even row stride) partials
   static constexpr int PARTLEN_A = PARTLEN_A0 > PARTLEN_A1 ? PARTLEN_A0 : PARTLEN_A1, PARTLEN_B = NRED * RW;
-  static constexpr int PARTLEN = PARTLEN_A > PARTLEN_B ? PARTLEN_A : PARTLEN_B;
+  static constexpr int PARTLEN_AB = PARTLEN_A > PARTLEN_B ? PARTLEN_A : PARTLEN_B, PARTLEN_C = MfmaSweepCfg<H>::on ? 16 * MfmaSweepCfg<H>::MP : 0;   // (C: sweep_all_mfma's stage, a tile row of the matrix)
+  static constexpr int PARTLEN = PARTLEN_AB > PARTLEN_C ? PARTLEN_AB : PARTLEN_C;
   MPC_V B6[72]; MPC_V th1[36]; MPC_V th2[8];
   double c, cinv, rho, calpha;
   double rho3[4], rinv3[4];                             // rho and 1 / rho of a loose / inequality / equality row (index type + 1)
@@ -1083,14 +1084,15 @@ struct Solver {
         });
       });
       ex.par([&](Th &t) {
-        if (t.mact) {
+        // (every thread, whether it holds a tile or not: an unconditional definition, so that the tiles are dead registers during the blocks)
+        const int ti = t.mact ? t.ti : 0, tj = t.mact ? t.tj : 0;
 #pragma unroll
-          for (int a = 0; a < TS; ++a) {
-            const int r = TS * t.ti + a;
-            if ((r >> 4) == c) {
+        for (int a = 0; a < TS; ++a) {
+          const int r = TS * ti + a;
 #pragma unroll
-              for (int b = 0; b < TS; ++b) t.Mx[a * TS + b] = chunk[(r & 15) * MS::MP + TS * t.tj + b];
-            }
+          for (int b = 0; b < TS; ++b) {
+            const double v = chunk[(r & 15) * MS::MP + TS * tj + b];
+            t.Mx[a * TS + b] = (r >> 4) == c ? v : (c == 0 ? 0.0 : t.Mx[a * TS + b]);
           }
         }
       });
