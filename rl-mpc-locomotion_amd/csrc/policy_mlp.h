@@ -35,6 +35,51 @@ __device__ __forceinline__ void layer(const float *in, int in_stride, float *out
                                       const float *__restrict__ b, int K, int NOUT, bool elu) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, h = lane >> 5;
   const int nblocks = (NOUT + 31) / 32;
+  if (nblocks >= 2 * (kThreads / 64) && nblocks % 2 == 0) {
+    // wide layers: TWO column blocks per wave and trip -- one read of the activations feeds both, and the matrix pipe has two independent accumulation chains,
+    // so one block's weight loads travel while the other block's products run (policy step 0.070 -> 0.061 ms per 4096 robots; the products alone
+    // are ~24 us).  Every output is still the same chain of fused multiply-adds in the same order: the results do not change by a bit.
+    for (int pb = wave; pb < nblocks / 2; pb += kThreads / 64) {
+      const int n0 = pb * 64 + col, n1 = n0 + 32;      // (NOUT may end inside the second block)
+      const bool live0 = n0 < NOUT, live1 = n1 < NOUT;
+      const float *w0 = W + (size_t)(live0 ? n0 : 0) * K + 4 * h, *w1 = W + (size_t)(live1 ? n1 : 0) * K + 4 * h;
+      const float *ar = in + col * in_stride + 4 * h;
+      f32x16 acc0, acc1;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+      float4 x0 = *reinterpret_cast<const float4 *>(w0), x1 = *reinterpret_cast<const float4 *>(w1);
+      for (int k0 = 0; k0 < K; k0 += 8) {
+        const float4 a4 = *reinterpret_cast<const float4 *>(ar + k0);
+        float4 u0 = x0, u1 = x1;
+        if (k0 + 8 < K) { x0 = *reinterpret_cast<const float4 *>(w0 + k0 + 8); x1 = *reinterpret_cast<const float4 *>(w1 + k0 + 8); }      // the next trip's weights (two trips ahead: no faster)
+        if (!live0) u0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!live1) u1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, u0.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, u1.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, u0.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, u1.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, u0.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, u1.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, u0.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, u1.w, acc1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        const int n = blk ? n1 : n0;
+        if (blk ? live1 : live0) {
+          const float bias = b[n];
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            float v = (blk ? acc1[reg] : acc0[reg]) + bias;
+            if (elu) v = v > 0.f ? v : expm1f(v);
+            out[row * out_stride + n] = v;
+          }
+        }
+      }
+    }
+    return;
+  }
   for (int nb = wave; nb < nblocks; nb += kThreads / 64) {
     const int n = nb * 32 + col;
     const bool live = n < NOUT;
@@ -43,9 +88,11 @@ __device__ __forceinline__ void layer(const float *in, int in_stride, float *out
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float4 wn = *reinterpret_cast<const float4 *>(wr);
     for (int k0 = 0; k0 < K; k0 += 8) {
       const float4 a4 = *reinterpret_cast<const float4 *>(ar + k0);
-      float4 w4 = *reinterpret_cast<const float4 *>(wr + k0);
+      float4 w4 = wn;
+      if (k0 + 8 < K) wn = *reinterpret_cast<const float4 *>(wr + k0 + 8);      // the next trip's weights
       if (!live) w4 = make_float4(0.f, 0.f, 0.f, 0.f);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, w4.x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, w4.y, acc, 0, 0, 0);
