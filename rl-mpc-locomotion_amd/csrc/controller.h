@@ -7,7 +7,7 @@
 //                                                            MPC marshalling, swing / stance leg commands)
 //   MPC_Controller/convex_MPC/Gait.py:26-93                   OffsetDurationGait
 //   MPC_Controller/common/FootSwingTrajectory.py:54-70, math_utils/interplation.py:4-26   swing Bezier
-//   MPC_Controller/common/StateEstimator.py:99-143            contact history, CoM height, ground normal
+//   MPC_Controller/common/StateEstimator.py:99-143            contact history, CoM height, ground normal (gelsd43.h)
 //   MPC_Controller/common/LegController.py:108-132            updateCommand (12 joint torques)
 // do for one robot and one control tick.  Split in two halves around the solver launch:
 //   ctrl_pre  : everything up to the call of compute_contact_forces (writes the solver input record)
@@ -19,6 +19,7 @@
 #include <math.h>
 
 #include "mpc_core.h"
+#include "gelsd43.h"
 
 namespace mpc {
 
@@ -324,7 +325,7 @@ MPC_HD void ctrl_pre_rest(CtrlState &s, const RobotConst &rc, const GaitTable &g
       float acc = 0.f;
       for (int i = 0; i < 4; ++i) {
         const float *fp = s.foot_positions + 3 * i;
-        const float z = fp[0] * gRb[6] + fp[1] * gRb[7] + fp[2] * gRb[8];   // (foot . gRb^T)[:, 2]
+        const float z = fmaf(fp[2], gRb[8], fmaf(fp[1], gRb[7], fp[0] * gRb[6]));   // (foot . gRb^T)[:, 2]: numpy's (4,3) x (3,3) float32 product is OpenBLAS sgemm, which fuses the k = 1, 2 terms
         acc = (i == 0) ? (-z) * cph[0] : acc + (-z) * cph[i];
       }
       s.pos_z = acc / csum;
@@ -334,22 +335,13 @@ MPC_HD void ctrl_pre_rest(CtrlState &s, const RobotConst &rc, const GaitTable &g
     for (int i = 0; i < 4; ++i)
       if (s.contact_phase[i] != 0.f)
         for (int c = 0; c < 3; ++c) s.hist[3 * i + c] = s.foot_positions[3 * i + c];
-    // least squares H n = 1 (scipy lstsq / LAPACK sgelsd there; normal equations in double here)
-    double AtA[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Atb[3] = {0, 0, 0};
-    for (int i = 0; i < 4; ++i)
-      for (int r = 0; r < 3; ++r) {
-        Atb[r] += (double)s.hist[3 * i + r];
-        for (int c = 0; c < 3; ++c) AtA[3 * r + c] += (double)s.hist[3 * i + r] * (double)s.hist[3 * i + c];
-      }
-    const double c00 = AtA[4] * AtA[8] - AtA[5] * AtA[7], c01 = AtA[5] * AtA[6] - AtA[3] * AtA[8], c02 = AtA[3] * AtA[7] - AtA[4] * AtA[6];
-    const double det = AtA[0] * c00 + AtA[1] * c01 + AtA[2] * c02;
-    double nv[3];
-    nv[0] = (c00 * Atb[0] + (AtA[2] * AtA[7] - AtA[1] * AtA[8]) * Atb[1] + (AtA[1] * AtA[5] - AtA[2] * AtA[4]) * Atb[2]) / det;
-    nv[1] = (c01 * Atb[0] + (AtA[0] * AtA[8] - AtA[2] * AtA[6]) * Atb[1] + (AtA[2] * AtA[3] - AtA[0] * AtA[5]) * Atb[2]) / det;
-    nv[2] = (c02 * Atb[0] + (AtA[1] * AtA[6] - AtA[0] * AtA[7]) * Atb[1] + (AtA[0] * AtA[4] - AtA[1] * AtA[3]) * Atb[2]) / det;
-    float n[3] = {(float)nv[0], (float)nv[1], (float)nv[2]};
+    // least squares H n = 1: scipy.linalg.lstsq on float32 = LAPACK SGELSD there, walked operation by operation here (gelsd43.h) --
+    // bit-identical to the reference's normal on every tick of the goldens
+    float n[3];
+    gelsd43::solve_ones(s.hist, n);
     for (int pass = 0; pass < 2; ++pass) {           // normalised twice (StateEstimator.py:134,140)
-      const float nn = sqrtf((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2]);
+      // np.linalg.norm = sqrt(x.dot(x)); OpenBLAS' sdot rounds each product to float32, sums them in double and rounds once
+      const float nn = sqrtf((float)(((double)(n[0] * n[0]) + (double)(n[1] * n[1])) + (double)(n[2] * n[2])));
       n[0] /= nn; n[1] /= nn; n[2] /= nn;
       if (pass == 0 && n[2] < 0.f) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
     }
