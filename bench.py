@@ -8,7 +8,7 @@ A "step" = one pass of the hot path over one batch of synthetic input = SURVEY.m
 which EVERY robot is due for its MPC update -- state estimator, leg kinematics, gait / foot placement, one ``compute_contact_forces``
 (QP build + OSQP-equivalent solve, mpc_osqp.cc:578-796), swing / stance commands and the leg-torque map (LegController.updateCommand, a22).
 (`--seam ctrl`, the default for configs 2 and 3.  `--seam solver` times the bare ``compute_contact_forces`` batch, a2-a13 without the
-controller around it: the `secondary.solver_seam` line, and the only seam of configs 4 / 5, whose terrain normals are a solver-input
+controller around it: the `secondary.solver_seam` line, and the default seam of configs 4 / 5, whose terrain normals are a solver-input
 specification.)
 
 Workloads (BASELINE.json configs):
@@ -359,9 +359,9 @@ def main():
         n = hi - lo
     n_total = n * world if (args.robots or cfg["robots_per_gpu"]) else robots_total
 
+    # configs 4 / 5 specify the solver's terrain-normal argument directly, so their default seam is the solver's; `--seam ctrl` runs them
+    # through controller.run as well (16- / 20-segment gaits, the ground normal from the estimator's foot-contact fit: `secondary.config4_ctrl` / `config5_ctrl`)
     seam = args.seam or ("ctrl" if args.config in (2, 3) else "solver")
-    if seam == "ctrl" and args.config in (4, 5):
-        raise SystemExit("bench.py: configs 4 / 5 specify the solver's terrain-normal argument directly (SURVEY 8(d)): --seam solver only")
     clock0 = device_state(local_rank) if not args.emulate and rank == 0 else None
     leg = run_leg_ctrl if seam == "ctrl" else run_leg
     m = leg(args.config, n, h, K, W, dev, rank, world, dist, repeats=args.repeats, emulate=args.emulate)
@@ -526,6 +526,18 @@ def secondary_lines(dev, steps=5, warm=2):
                                "solve_kernel_ms": float(m["solve_ms"].mean()), "solved_fraction": float((m["info"][..., 1] == 1).mean()),
                                "mean_admm_iters": float(m["info"][..., 0].mean()), "what": CONFIGS[cid]["what"]}
         del m
+    # configs 4 / 5 through the controller.run seam too (a15-a23 with 16- / 20-segment gaits, ground normal from the estimator's fit, a22 included);
+    # parity of that path: tests/test_controller.py on the controller_h16_* / controller_h20_* goldens
+    for cid, n in ((4, 4096), (5, 8192)):
+        h = CONFIGS[cid]["h"]
+        m = run_leg_ctrl(cid, n, h, steps, warm, dev, 0, 1, None)
+        out[f"config{cid}_ctrl"] = {"robots": n, "horizon": h, "steps": steps, "control_steps_per_s": n * steps / m["elapsed"],
+                                    "ms_per_step": m["elapsed"] / steps * 1e3, "prep_kernel_ms": float(m["prep_ms"].mean()),
+                                    "solve_kernel_ms": float(m["solve_ms"].mean()), "solved_fraction": float((m["info"][..., 1] == 1).mean()),
+                                    "mean_admm_iters": float(m["info"][..., 0].mean()),
+                                    "what": f"config {cid}'s robots and horizon through controller.run (every robot due): estimator, {h}-segment trot, foot placement, "
+                                            "compute_contact_forces with the ground normal of the estimator's foot-contact fit, swing / stance commands, torque map"}
+        del m
     return out
 
 
@@ -644,6 +656,39 @@ def sharded_loop_leg(cfg_id, n_total, h, dev, dist, ticks=8, warm=3, emulate=Fal
         out[label] = max_over_ranks(time.perf_counter() - t0, dev) / ticks * 1e3
         if with_gather:
             out["shape_ok"] = bool(got is not None and tuple(got.shape) == (n_total, 12))
+    # SURVEY 8(e)'s scaling check: the N-rank torques of the last tick, gathered over the collective, against the SAME env batch run by one
+    # process on rank 0's device -- bit for bit; and what every rank held (a hash of its block, its device) so a record shows N devices took part
+    import hashlib
+    last = sl.torques_all()                                 # the exchange started after the last tick
+    mine = last[sl.lo:sl.hi].contiguous().cpu().numpy()
+    report = {"rank": sl.rank, "robots": [sl.lo, sl.hi], "torque_block_sha256": hashlib.sha256(mine.tobytes()).hexdigest()[:16],
+              "device": (torch.cuda.get_device_name(dev) + f" #{dev.index}") if dev.type == "cuda" else "cpu (emulated kernels)"}
+    if dev.type == "cuda":
+        try:
+            from rl_mpc_locomotion_amd import _lib
+            report["shader_clock_ghz"] = _lib.device_clock(dev.index, 5)[0]
+        except Exception as e:
+            report["shader_clock_ghz"] = repr(e)[:80]
+    reports = [None] * dist.get_world_size()
+    dist.all_gather_object(reports, report)
+    out["ranks"] = reports
+    out["collective"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size()}
+    if sl.rank == 0:
+        if emulate:
+            one = kw["controller_factory"](cs.robot_type, cs.gait_id, horizon=h, controller_dt=CTRL_DT)
+        else:
+            from rl_mpc_locomotion_amd.locomotion import BatchedLocomotion
+            one = BatchedLocomotion(cs.robot_type, cs.gait_id, horizon=h, controller_dt=CTRL_DT, device=dev)
+        cs.rewind()
+        for k in range(warm + ticks):
+            ref = one.run(*(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in cs.step(k)))
+        same = bool(torch.equal(ref.to(last.device), last))
+        out["bit_identical_to_single_process"] = same
+        out["torque_blocks_sha256_single_process"] = [hashlib.sha256(ref[lo:hi].contiguous().cpu().numpy().tobytes()).hexdigest()[:16]
+                                                       for lo, hi in ((r["robots"][0], r["robots"][1]) for r in reports)]
+        if not same:
+            raise SystemExit(f"bench.py: the {dist.get_world_size()}-rank torques differ from the single-process batch (SURVEY 8(e) demands bit identity): {json.dumps(out)}")
+    dist.barrier()
     out["robots_total"], out["ticks"] = n_total, ticks
     out["note"] = "ShardedLocomotion: one env batch over the ranks, all-gather of [n_local, 12] float32 on a side stream overlapped with the next tick; every robot due on every tick"
     return out

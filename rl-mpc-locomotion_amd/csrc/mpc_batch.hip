@@ -218,7 +218,12 @@ int mpc_batch_solve(mpc_batch *b, const float *d_in, double *d_forces, int *d_in
 
 int mpc_batch_set_solver(mpc_batch *b, int solver) {
   if (!b || (solver != MPC_SOLVER_OSQP && solver != MPC_SOLVER_EXACT)) return fail(MPC_E_ARG, "mpc_batch_set_solver: MPC_SOLVER_OSQP (0) or MPC_SOLVER_EXACT (1)");
-  b->exact = solver == MPC_SOLVER_EXACT;
+  const bool exact = solver == MPC_SOLVER_EXACT;
+  if (exact != b->exact && b->d_seed) {      // a working set left by an earlier stretch in the exact mode is not this stretch's
+    DeviceGuard guard_(b->device);
+    HIP_TRY(hipMemset(b->d_seed, 0, sizeof(int) * (size_t)b->n * 4 * b->h));
+  }
+  b->exact = exact;
   return MPC_OK;
 }
 
@@ -357,6 +362,7 @@ int mpc_batch_set_state(mpc_batch *b, const double *h_state) {
   if (!b || !h_state) return fail(MPC_E_ARG, "mpc_batch_set_state: bad argument");
   DeviceGuard guard_(b->device);
   HIP_TRY(hipMemcpy(b->d_state, h_state, sizeof(double) * (size_t)b->n * b->state_len, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(b->d_seed, 0, sizeof(int) * (size_t)b->n * 4 * b->h));      // the working sets belonged to the state that was replaced
   return MPC_OK;
 }
 
@@ -468,7 +474,7 @@ __global__ __launch_bounds__(kCtrlThreads) void estimator_kernel(int n, const Ct
   for (int k = 0; k < kEstLen; ++k) est[(size_t)r * kEstLen + k] = e[k];
 }
 __global__ __launch_bounds__(kCtrlThreads) void fsm_init_kernel(int n, CtrlState *st, FsmState *fs, const RobotConst *rc, const int *mode, int op_mode, const int *ids, int k, int fresh,
-                                                                double *solver_state, int state_len) {
+                                                                double *solver_state, int state_len, int *seed, int seed_len) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= k) return;
   const int r = ids ? ids[i] : i;
@@ -479,21 +485,25 @@ __global__ __launch_bounds__(kCtrlThreads) void fsm_init_kernel(int n, CtrlState
   else fsm_reinit(f, mode[r], op_mode, s, rc[s.robot_type], f.last_rb22);
   // entering LOCOMOTION runs cMPC.initialize (FSM_State_Locomotion.py:32-42 -> ConvexMPCLocomotion.py:102-108): a NEW ConvexMpc object,
   // i.e. x = y = z = 0, rho = 0.1 and an "osqp_setup" first call.  (fsm_tick clears entered_loco at its top, so it is consumed here.)
-  if (f.entered_loco && solver_state)
+  if (f.entered_loco && solver_state) {
     for (int q = 0; q < state_len; ++q) solver_state[(size_t)r * state_len + q] = 0.0;
+    for (int q = 0; q < seed_len; ++q) seed[(size_t)r * seed_len + q] = 0;           // ... which knows no working set either (exact mode)
+  }
   st[r] = s; fs[r] = f;
 }
 // RobotRunnerFSM.run up to the solver launch: fsm_tick, then ctrl_pre for the robots whose state runs the locomotion controller
 __global__ __launch_bounds__(kCtrlThreads) void fsm_pre_kernel(int n, CtrlState *st, FsmState *fs, const RobotConst *rc, GaitTable gt, CtrlParams cp, FsmParams fp,
                                const float *dof, const float *body, const float *est, const float *cmd, const int *request, float *rec,
-                               int *active, double *solver_state, int state_len) {
+                               int *active, double *solver_state, int state_len, int *seed, int seed_len) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   CtrlState s = st[r];
   FsmState f = fs[r];
   fsm_tick(f, s, rc[s.robot_type], fp, dof + (size_t)r * 24, body + (size_t)r * 13, request[r]);
-  if (f.entered_loco)    // cMPC.initialize built a new ConvexMpc (ConvexMPCLocomotion.py:102-108): the next solve is a cold one
+  if (f.entered_loco) {  // cMPC.initialize built a new ConvexMpc (ConvexMPCLocomotion.py:102-108): the next solve is a cold one, from the empty working set
     for (int k = 0; k < state_len; ++k) solver_state[(size_t)r * state_len + k] = 0.0;
+    for (int k = 0; k < seed_len; ++k) seed[(size_t)r * seed_len + k] = 0;
+  }
   int act = 0;
   if (f.run_loco) {
     ctrl_pre(s, rc[s.robot_type], gt, cp, dof + (size_t)r * 24, est + (size_t)r * kEstLen, cmd + (size_t)r * 16, rec + (size_t)r * (56 + 4 * cp.horizon));
@@ -726,21 +736,31 @@ int mpc_device_clock(int device, int busy_ms, double *ghz, double *ms) {
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   const int blocks = 4 * prop.multiProcessorCount;       // one single-wave workgroup per SIMD
-  long long *d_out = nullptr;
-  HIP_TRY(hipMalloc(&d_out, sizeof(long long) * blocks));
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  struct Probe {      // released on every path out
+    long long *d_out = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t st = nullptr;
+    ~Probe() {
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+      if (d_out) (void)hipFree(d_out);
+      if (st) (void)hipStreamDestroy(st);
+    }
+  } pr;
+  HIP_TRY(hipMalloc(&pr.d_out, sizeof(long long) * blocks));
+  HIP_TRY(hipStreamCreateWithFlags(&pr.st, hipStreamNonBlocking));      // a stream of its own: the null stream would serialise with the caller's work
+  HIP_TRY(hipEventCreate(&pr.e0)); HIP_TRY(hipEventCreate(&pr.e1));
   // ~6.3 shader cycles per dependent fp64 FMA, 32 per trip: ~10 k trips per ms at 2.1 GHz
-  hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(64), 0, nullptr, d_out, 2000);
-  HIP_TRY(hipEventRecord(e0, nullptr));
-  hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(64), 0, nullptr, d_out, 10000 * busy_ms);
-  HIP_TRY(hipEventRecord(e1, nullptr));
-  HIP_TRY(hipEventSynchronize(e1));
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(64), 0, pr.st, pr.d_out, 2000);
+  HIP_TRY(hipEventRecord(pr.e0, pr.st));
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(64), 0, pr.st, pr.d_out, 10000 * busy_ms);
+  HIP_TRY(hipEventRecord(pr.e1, pr.st));
+  HIP_TRY(hipEventSynchronize(pr.e1));
   float t = 0.f;
-  HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+  HIP_TRY(hipEventElapsedTime(&t, pr.e0, pr.e1));
   long long cyc = 0;
-  HIP_TRY(hipMemcpy(&cyc, d_out, sizeof cyc, hipMemcpyDeviceToHost));
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d_out);
+  HIP_TRY(hipMemcpyAsync(&cyc, pr.d_out, sizeof cyc, hipMemcpyDeviceToHost, pr.st));
+  HIP_TRY(hipStreamSynchronize(pr.st));
   *ghz = t > 0.f ? (double)cyc / ((double)t * 1e6) : 0.0;
   if (ms) *ms = t;
   return MPC_OK;
@@ -765,7 +785,7 @@ int mpc_ctrl_fsm_init(mpc_ctrl *c, const int *control_mode, int operating_mode, 
   if (rc != MPC_OK) return rc;
   hipLaunchKernelGGL(ctrl_init_kernel, dim3((c->n + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, st, c->n, c->d_state, c->d_rc, c->d_robot_type, c->d_gait);
   hipLaunchKernelGGL(fsm_init_kernel, dim3((c->n + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, st, c->n, c->d_state, c->d_fsm, c->d_rc, c->d_fsm_mode, operating_mode,
-                     (const int *)nullptr, c->n, 1, (double *)nullptr, 0);   // (the whole solver was reset above)
+                     (const int *)nullptr, c->n, 1, (double *)nullptr, 0, (int *)nullptr, 0);   // (the whole solver was reset above)
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(st));                          // control_mode is a host buffer
   return MPC_OK;
@@ -789,7 +809,7 @@ int mpc_ctrl_fsm_reset(mpc_ctrl *c, const int *ids, int k, const int *control_mo
     HIP_TRY(hipMemcpyAsync(d_ids, ids, sizeof(int) * k, hipMemcpyHostToDevice, st));
   }
   hipLaunchKernelGGL(fsm_init_kernel, dim3((cnt + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, st, c->n, c->d_state, c->d_fsm, c->d_rc, c->d_fsm_mode, c->fsm_op_mode, d_ids, cnt, 0,
-                     c->solver->d_state, c->solver->state_len);
+                     c->solver->d_state, c->solver->state_len, c->solver->d_seed, 4 * c->solver->h);
   HIP_TRY(hipGetLastError());
   if (d_ids) HIP_TRY(hipFreeAsync(d_ids, st));
   HIP_TRY(hipStreamSynchronize(st));
@@ -802,7 +822,7 @@ int mpc_ctrl_fsm_reset_device(mpc_ctrl *c, const int *d_ids, int k, void *stream
   if (k == 0) return MPC_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(fsm_init_kernel, dim3((k + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, st, c->n, c->d_state, c->d_fsm, c->d_rc, c->d_fsm_mode, c->fsm_op_mode, d_ids, k, 0,
-                     c->solver->d_state, c->solver->state_len);
+                     c->solver->d_state, c->solver->state_len, c->solver->d_seed, 4 * c->solver->h);
   HIP_TRY(hipGetLastError());
   return MPC_OK;      // (stream-ordered: no host round trip, no synchronisation)
 }
@@ -816,7 +836,7 @@ int mpc_ctrl_run_fsm(mpc_ctrl *c, const float *d_dof, const float *d_body, const
   mpc_batch *b = c->solver;
   hipLaunchKernelGGL(estimator_kernel, dim3(blocks), dim3(kCtrlThreads), 0, st, n, c->d_state, d_body, c->d_est);
   hipLaunchKernelGGL(fsm_pre_kernel, dim3(blocks), dim3(kCtrlThreads), 0, st, n, c->d_state, c->d_fsm, c->d_rc, c->gt, c->cp, c->fp, d_dof, d_body, c->d_est, d_cmd,
-                     d_request, c->d_rec, c->d_active, b->d_state, b->state_len);
+                     d_request, c->d_rec, c->d_active, b->d_state, b->state_len, b->d_seed, 4 * b->h);
   HIP_TRY(hipGetLastError());
   int rc = launch_solver(b, c->d_rec, c->d_forces, c->d_info, c->d_active, st);
   if (rc != MPC_OK) return rc;
@@ -879,8 +899,8 @@ int mpc_policy_create(mpc_policy **out, int n_layers, const int *dims, const flo
     return fail(MPC_E_ARG, "mpc_policy_create: bad argument");
   size_t total = 0;
   for (int l = 0; l < n_layers; ++l) {
-    if (dims[l] <= 0 || dims[l + 1] <= 0 || dims[l] % 8 != 0 || !weights[l] || !biases[l])
-      return fail(MPC_E_ARG, "mpc_policy_create: layer input widths must be positive multiples of 8");
+    if (dims[l] <= 0 || dims[l + 1] <= 0 || dims[l] % 16 != 0 || !weights[l] || !biases[l])
+      return fail(MPC_E_ARG, "mpc_policy_create: layer input widths must be positive multiples of 16");
     total += (size_t)dims[l] * dims[l + 1] + (((size_t)dims[l + 1] + 7) / 8) * 8;   // keeps every array 32-byte aligned
   }
   if (dims[n_layers] > 16) return fail(MPC_E_ARG, "mpc_policy_create: at most 16 outputs");

@@ -4,20 +4,25 @@
 //   RL_Environment/tasks/legged_config_ppo.py:5-9)  ->  clamp to [-1, 1] and the affine map to MPC weights
 //   (WeightPolicy.step, :94-118; Parameters.MPC_param_scale / MPC_param_const, MPC_Controller/Parameters.py:25-33).
 //
-// One fused kernel: a 256-thread workgroup carries 32 robots through every layer; activations stay in LDS,
-// weights stream from HBM/L2 (760 KB, shared by all workgroups) as 16-byte loads, the products run on the fp32
-// MFMA pipe (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains, so the result differs from a CPU sgemm only by the
-// summation order).  Rows of the MFMA tile are robots, columns are output neurons; a wave owns output column
-// blocks nb = wave, wave + 4, ...  Inside a chunk of 8 inputs, lane half h = lane / 32 takes inputs 4h .. 4h+3
-// over four MFMAs, so both operands are single 16-byte loads.
+// One fused kernel: a workgroup carries 16 robots through every layer -- 4096 robots are 256 workgroups, one per CU of the chip (32 robots
+// per workgroup left half the CUs idle); activations stay in LDS, weights stream from L2 (760 KB, shared by all workgroups) as 16-byte
+// loads, the products run on the fp32 MFMA pipe (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains, so the result differs from a CPU sgemm
+// only by the summation order).  Rows of the MFMA tile are robots, columns are output neurons; a wave owns groups of up to four
+// 16-column blocks -- four independent accumulation chains (4 VGPRs each) fed by ONE read of the activations, so three blocks' weight
+// loads travel while the fourth's products run.  Inside a chunk of 16 inputs, lane quarter q = lane / 16 takes inputs 4q .. 4q+3 over
+// four MFMAs, so both operands are single 16-byte loads.
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace policy {
 
 constexpr int kMaxLayers = 8;
-constexpr int kRows = 32;            // robots per workgroup (MFMA M)
-constexpr int kThreads = 256;
+constexpr int kRows = 16;            // robots per workgroup (MFMA M)
+#ifndef POLICY_THREADS
+#define POLICY_THREADS 512
+#endif
+constexpr int kThreads = POLICY_THREADS;
+constexpr int kWaves = kThreads / 64;
 constexpr int kPad = 4;              // floats of row padding in LDS (keeps the 16-byte row reads off one bank)
 
 struct Net {
@@ -28,87 +33,69 @@ struct Net {
   float scale[16], shift[16];        // action -> weight map (first dims[n_layers] entries used)
 };
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// out[r][n] = act( sum_k in[r][k] W[n][k] + b[n] ), r < 32.  K % 8 == 0.
+// NB column blocks (16 outputs each) starting at block nb0: out[r][n] = act( sum_k in[r][k] W[n][k] + b[n] ), r < 16.  K % 16 == 0.
+template <int NB>
+__device__ __forceinline__ void blocks(const float *in, int in_stride, float *out, int out_stride, const float *__restrict__ W,
+                                       const float *__restrict__ b, int K, int NOUT, bool elu, int nb0) {
+  const int lane = threadIdx.x & 63, col = lane & 15, q = lane >> 4;
+  const float *wr[NB];
+  bool live[NB];
+  f32x4 acc[NB];
+  float4 wn[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int n = (nb0 + j) * 16 + col;
+    live[j] = n < NOUT;
+    wr[j] = W + (size_t)(live[j] ? n : 0) * K + 4 * q;
+    acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    wn[j] = *reinterpret_cast<const float4 *>(wr[j]);
+  }
+  const float *ar = in + col * in_stride + 4 * q;     // A operand: row = lane & 15, k = 4 (lane >> 4) + i in MFMA i of the chunk
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    const float4 a4 = *reinterpret_cast<const float4 *>(ar + k0);
+    float4 w4[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      w4[j] = wn[j];
+      if (k0 + 16 < K) wn[j] = *reinterpret_cast<const float4 *>(wr[j] + k0 + 16);      // the next trip's weights
+      if (!live[j]) w4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, w4[j].x, acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, w4[j].y, acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, w4[j].z, acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, w4[j].w, acc[j], 0, 0, 0);
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    if (!live[j]) continue;
+    const int n = (nb0 + j) * 16 + col;
+    const float bias = b[n];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {   // C layout of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg
+      float v = acc[j][reg] + bias;
+      if (elu) v = v > 0.f ? v : expm1f(v);            // torch.nn.ELU, alpha = 1
+      out[(4 * q + reg) * out_stride + n] = v;
+    }
+  }
+}
+
 __device__ __forceinline__ void layer(const float *in, int in_stride, float *out, int out_stride, const float *__restrict__ W,
                                       const float *__restrict__ b, int K, int NOUT, bool elu) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, h = lane >> 5;
-  const int nblocks = (NOUT + 31) / 32;
-  if (nblocks >= 2 * (kThreads / 64) && nblocks % 2 == 0) {
-    // wide layers: TWO column blocks per wave and trip -- one read of the activations feeds both, and the matrix pipe has two independent accumulation chains,
-    // so one block's weight loads travel while the other block's products run (policy step 0.070 -> 0.061 ms per 4096 robots; the products alone
-    // are ~24 us).  Every output is still the same chain of fused multiply-adds in the same order: the results do not change by a bit.
-    for (int pb = wave; pb < nblocks / 2; pb += kThreads / 64) {
-      const int n0 = pb * 64 + col, n1 = n0 + 32;      // (NOUT may end inside the second block)
-      const bool live0 = n0 < NOUT, live1 = n1 < NOUT;
-      const float *w0 = W + (size_t)(live0 ? n0 : 0) * K + 4 * h, *w1 = W + (size_t)(live1 ? n1 : 0) * K + 4 * h;
-      const float *ar = in + col * in_stride + 4 * h;
-      f32x16 acc0, acc1;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-      float4 x0 = *reinterpret_cast<const float4 *>(w0), x1 = *reinterpret_cast<const float4 *>(w1);
-      for (int k0 = 0; k0 < K; k0 += 8) {
-        const float4 a4 = *reinterpret_cast<const float4 *>(ar + k0);
-        float4 u0 = x0, u1 = x1;
-        if (k0 + 8 < K) { x0 = *reinterpret_cast<const float4 *>(w0 + k0 + 8); x1 = *reinterpret_cast<const float4 *>(w1 + k0 + 8); }      // the next trip's weights (two trips ahead: no faster)
-        if (!live0) u0 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!live1) u1 = make_float4(0.f, 0.f, 0.f, 0.f);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, u0.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, u1.x, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, u0.y, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, u1.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, u0.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, u1.z, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, u0.w, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, u1.w, acc1, 0, 0, 0);
-      }
-#pragma unroll
-      for (int blk = 0; blk < 2; ++blk) {
-        const int n = blk ? n1 : n0;
-        if (blk ? live1 : live0) {
-          const float bias = b[n];
-#pragma unroll
-          for (int reg = 0; reg < 16; ++reg) {
-            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            float v = (blk ? acc1[reg] : acc0[reg]) + bias;
-            if (elu) v = v > 0.f ? v : expm1f(v);
-            out[row * out_stride + n] = v;
-          }
-        }
-      }
-    }
-    return;
-  }
-  for (int nb = wave; nb < nblocks; nb += kThreads / 64) {
-    const int n = nb * 32 + col;
-    const bool live = n < NOUT;
-    const float *wr = W + (size_t)(live ? n : 0) * K + 4 * h;
-    const float *ar = in + col * in_stride + 4 * h;     // A operand: row = lane & 31
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    float4 wn = *reinterpret_cast<const float4 *>(wr);
-    for (int k0 = 0; k0 < K; k0 += 8) {
-      const float4 a4 = *reinterpret_cast<const float4 *>(ar + k0);
-      float4 w4 = wn;
-      if (k0 + 8 < K) wn = *reinterpret_cast<const float4 *>(wr + k0 + 8);      // the next trip's weights
-      if (!live) w4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, w4.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, w4.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, w4.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, w4.w, acc, 0, 0, 0);
-    }
-    if (live) {
-      const float bias = b[n];
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {   // C layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        float v = acc[reg] + bias;
-        if (elu) v = v > 0.f ? v : expm1f(v);            // torch.nn.ELU, alpha = 1
-        out[row * out_stride + n] = v;
-      }
-    }
+  const int wave = threadIdx.x >> 6;
+  const int nblocks = (NOUT + 15) / 16;
+  // as many blocks per wave and trip as leaves every wave of the workgroup something to do
+  if (nblocks >= 4 * kWaves) {
+    for (int g = wave; 4 * g < nblocks; g += kWaves) blocks<4>(in, in_stride, out, out_stride, W, b, K, NOUT, elu, 4 * g);
+  } else if (nblocks >= 2 * kWaves) {
+    for (int g = wave; 2 * g < nblocks; g += kWaves) blocks<2>(in, in_stride, out, out_stride, W, b, K, NOUT, elu, 2 * g);
+  } else {
+    for (int g = wave; g < nblocks; g += kWaves) blocks<1>(in, in_stride, out, out_stride, W, b, K, NOUT, elu, g);
   }
 }
 

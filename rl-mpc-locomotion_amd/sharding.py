@@ -63,7 +63,7 @@ class ShardedLocomotion:
         tau_all = sl.torques_all()                                           #   (the next tick's estimator / ctrl_pre / prep kernels) -> [n_total, 12]
 
     The exchange is one RCCL all-gather of 48 B per robot (24.6 KB per GPU at 4096 robots: latency-bound on xGMI), so it is issued once per tick,
-    in place, from a snapshot of the local block taken on the side stream, and waited for only when its result is read.  Uneven shards (the
+    from a snapshot of the local block taken on the current stream, and waited for only when its result is read.  Uneven shards (the
     first n_total % world ranks hold one robot more) are padded to the largest block for the collective.
     `controller_factory(robot_type, gait_id, **kw)` builds the per-rank controller (default BatchedLocomotion on this rank's GPU; the CPU tests pass
     the host emulation and run over gloo)."""
@@ -104,25 +104,30 @@ class ShardedLocomotion:
         return self._tau
 
     def start_gather(self):
-        """Issue the all-gather of the last run's torques (asynchronously: on the side stream on a GPU, as an async collective on the CPU)."""
+        """Issue the all-gather of the last run's torques (asynchronously: on the side stream on a GPU, as an async collective on the CPU).
+        The local block is snapshot ON THE CURRENT STREAM first -- `run` hands out the controller's persistent torque buffer, which the next
+        tick's ctrl_post overwrites on that stream -- so run(k) -> start_gather() -> run(k + 1) -> torques_all() returns tick k's torques.
+        A process group of ONE rank (a 1-GPU box) takes the same path: the collective still runs on the side stream."""
         import torch
         import torch.distributed as dist
         if self._tau is None:
             raise RuntimeError("ShardedLocomotion.start_gather: run() first")
-        if self.world == 1:
+        if self.world == 1 and not dist.is_initialized():
             self._all[: self.n_local].copy_(self._tau)
             return
+        if self._side is not None and self._work is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._side)        # a gather nobody read yet still sends from the staging buffer
+        self._stage[: self.n_local].copy_(self._tau)                             # ordered before the next run() by the stream itself
         if self._side is not None:
-            self._side.wait_stream(torch.cuda.current_stream(self.device))      # the torques of this tick are complete
+            self._side.wait_stream(torch.cuda.current_stream(self.device))      # the snapshot is complete
             with torch.cuda.stream(self._side):
-                self._stage[: self.n_local].copy_(self._tau)
                 self._work = dist.all_gather_into_tensor(self._all, self._stage, group=self.group, async_op=True)
         else:
-            self._stage[: self.n_local].copy_(self._tau)
             self._work = dist.all_gather_into_tensor(self._all, self._stage, group=self.group, async_op=True)
 
     def torques_all(self):
-        """[n_total, 12] on this rank's device: waits for the gather started last (the current stream waits; the host does not block on a GPU)."""
+        """[n_total, 12] on this rank's device, a fresh tensor (the next gather reuses the receive buffer): waits for the gather started last
+        (the current stream waits; the host does not block on a GPU)."""
         import torch
         if self._work is not None:
             self._work.wait()
@@ -131,7 +136,7 @@ class ShardedLocomotion:
             torch.cuda.current_stream(self.device).wait_stream(self._side)
         mx = max(self.sizes)
         if len(set(self.sizes)) == 1:
-            return self._all[: self.n_total]
+            return self._all[: self.n_total].clone()
         return torch.cat([self._all[r * mx: r * mx + self.sizes[r]] for r in range(self.world)], dim=0)
 
     def reset(self, env_ids=None):

@@ -32,6 +32,10 @@ def test_two_ranks_weak_scaling_line():
     assert b["config"]["seam"] == "ctrl"                 # `value` goes through controller.run (SURVEY 8(d)'s unit incl. the torque map)
     sl = b["all_gather_torques"]["sharded_loop"]           # the product-level sharded stepper with its overlapped exchange
     assert sl["shape_ok"] and sl["robots_total"] == 10 and sl["ms_per_tick_with_exchange"] > 0
+    # SURVEY 8(e)'s scaling check inside the bench: the 2-rank torques equal the single-process batch bit for bit; one report per rank
+    assert sl["bit_identical_to_single_process"] is True and sl["collective"] == {"backend": "gloo", "ranks": 2}
+    assert [r["rank"] for r in sl["ranks"]] == [0, 1] and [r["robots"] for r in sl["ranks"]] == [[0, 5], [5, 10]]
+    assert [r["torque_block_sha256"] for r in sl["ranks"]] == sl["torque_blocks_sha256_single_process"]
 
 
 @pytest.mark.parametrize("flags,total", [(("--robots", "2"), 16), (("--config", "4", "--robots-total", "19"), 19), (("--config", "5", "--robots-total", "17"), 17)])

@@ -113,7 +113,11 @@ class _EmuController:
         self.device = "cpu"
 
     def run(self, dof, body, cmd):
-        return torch.from_numpy(self.e.run(dof.numpy(), body.numpy(), cmd.numpy()))
+        tau = torch.from_numpy(self.e.run(dof.numpy(), body.numpy(), cmd.numpy()))
+        if getattr(self, "torques", None) is None:
+            self.torques = torch.zeros_like(tau)
+        self.torques.copy_(tau)            # one persistent output buffer, overwritten by every tick -- like BatchedLocomotion.torques
+        return self.torques
 
     def reset(self, env_ids=None):
         self.e.reset(env_ids)
@@ -162,6 +166,77 @@ def test_sharded_locomotion_matches_single_process(tmp_path, world, n_total):
     assert np.abs(ref).max() > 1.0
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"sharded{r}.npy"), ref), f"rank {r}"
+
+
+def _overlap_worker(rank, world, port, n_total, ticks, out_dir):
+    """the documented overlap: run(k) -> start_gather() -> run(k + 1) -> torques_all() must return tick k's torques"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rl_mpc_locomotion_amd.sharding import ShardedLocomotion
+    ts, ins = _tick_inputs(n_total, ticks)
+    sl = ShardedLocomotion(ts.robot_type, ts.gait_id, horizon=10, controller_factory=_EmuController)
+    outs = []
+    sl.run(*ins[0]); sl.start_gather()
+    for k in range(1, ticks):
+        sl.run(*ins[k])                        # overwrites the controller's torque buffer while tick k - 1's exchange is in flight
+        got = sl.torques_all()                 # tick k - 1
+        sl.start_gather()                      # tick k; must not disturb what was just returned
+        outs.append(got.numpy().copy())
+        assert np.array_equal(outs[-1], got.numpy())
+    outs.append(sl.torques_all().numpy().copy())
+    np.save(os.path.join(out_dir, f"overlap{rank}.npy"), np.stack(outs))
+    dist.destroy_process_group()
+
+
+def test_overlapped_gather_returns_the_tick_it_was_started_for(tmp_path):
+    world, n_total, ticks, port = 2, 7, 5, _free_port()
+    mp.spawn(_overlap_worker, args=(world, port, n_total, ticks, str(tmp_path)), nprocs=world, join=True)
+    ts, ins = _tick_inputs(n_total, ticks)
+    one = _EmuController(ts.robot_type, ts.gait_id)
+    ref = np.stack([one.run(*ins[k]).numpy().copy() for k in range(ticks)])
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"overlap{r}.npy"), ref), f"rank {r}"
+
+
+def _one_rank_rccl_worker(rank, world, port, n_total, ticks, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)               # RCCL, a communicator of one rank
+    from rl_mpc_locomotion_amd.sharding import ShardedLocomotion, all_gather_torques, max_over_ranks
+    ts, ins = _tick_inputs(n_total, ticks)
+    sl = ShardedLocomotion(ts.robot_type, ts.gait_id, horizon=10, device=dev)
+    assert sl.world == 1 and dist.is_initialized()
+    outs = []
+    sl.run(*(a.to(dev) for a in ins[0])); sl.start_gather()
+    for k in range(1, ticks):
+        sl.run(*(a.to(dev) for a in ins[k]))
+        got = sl.torques_all()
+        sl.start_gather()
+        outs.append(got.cpu().numpy().copy())
+    outs.append(sl.torques_all().cpu().numpy().copy())
+    direct = all_gather_torques(torch.from_numpy(outs[-1]).to(dev), n_total).cpu().numpy()
+    assert np.array_equal(direct, outs[-1]) and max_over_ranks(1.5, dev) == 1.5
+    np.save(os.path.join(out_dir, "rccl1.npy"), np.stack(outs))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_exchange_runs_on_one_gpu(tmp_path):
+    """What a 1-GPU box can execute of the N > 1 path: a torch.distributed process group over RCCL (backend "nccl") with ONE rank,
+    ShardedLocomotion's asynchronous all_gather_into_tensor on its side stream in the documented overlap (run(k) -> start_gather() ->
+    run(k + 1) -> torques_all()), all_gather_torques and max_over_ranks -- against BatchedLocomotion, bit for bit.  Communicators of two
+    and eight ranks stay unmeasured on hardware until a multi-GPU node runs the two tests below."""
+    from rl_mpc_locomotion_amd.locomotion import BatchedLocomotion
+    n_total, ticks, port = 33, 5, _free_port()
+    mp.spawn(_one_rank_rccl_worker, args=(1, port, n_total, ticks, str(tmp_path)), nprocs=1, join=True)
+    ts, ins = _tick_inputs(n_total, ticks)
+    one = BatchedLocomotion(ts.robot_type, ts.gait_id, horizon=10, device="cuda:0")
+    ref = np.stack([one.run(*(a.cuda() for a in ins[k])).cpu().numpy().copy() for k in range(ticks)])
+    assert np.array_equal(np.load(tmp_path / "rccl1.npy"), ref)
 
 
 @pytest.mark.gpu
