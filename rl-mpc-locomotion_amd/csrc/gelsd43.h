@@ -33,10 +33,12 @@ namespace gelsd43 {
 MPC_HD float sgn(float a, float b) { return b >= 0.f ? fabsf(a) : -fabsf(a); }      // Fortran SIGN(a, b)  (b = -0.0 does not occur on this path)
 
 // SNRM2 (OpenBLAS nrm2_sse: squares and sum in double, one rounding at the end)
-MPC_HD float nrm2(int n, const float *x, int inc) {
+template <int N>
+MPC_HD float nrm2(const float *x, int inc) {
   GELSD_NO_CONTRACT
   double s = 0.0;
-  for (int i = 0; i < n; ++i) s += (double)x[i * inc] * (double)x[i * inc];
+#pragma unroll
+  for (int i = 0; i < N; ++i) s += (double)x[i * inc] * (double)x[i * inc];
   return (float)sqrt(s);
 }
 // SLAPY2 (LAPACK 3.10+)
@@ -47,86 +49,106 @@ MPC_HD float lapy2(float x, float y) {
   const float q = z / w;
   return w * sqrtf(1.f + q * q);
 }
-// SLARFG: n = 1 + number of entries of x
-MPC_HD void larfg(int n, float &alpha, float *x, int incx, float &tau) {
+// SLARFG on a vector of N entries: alpha and the N - 1 entries of x
+template <int N>
+MPC_HD void larfg(float &alpha, float *x, int incx, float &tau) {
   GELSD_NO_CONTRACT
   tau = 0.f;
-  if (n <= 1) return;
-  const float xnorm = nrm2(n - 1, x, incx);
+  if (N <= 1) return;
+  const float xnorm = nrm2<(N > 1 ? N - 1 : 1)>(x, incx);
   if (xnorm == 0.f) return;
   const float beta = -sgn(lapy2(alpha, xnorm), alpha);
   tau = (beta - alpha) / beta;
   const float sc = 1.f / (alpha - beta);
-  for (int i = 0; i < n - 1; ++i) x[i * incx] = x[i * incx] * sc;      // SSCAL
+#pragma unroll
+  for (int i = 0; i < N - 1; ++i) x[i * incx] = x[i * incx] * sc;      // SSCAL
   alpha = beta;
 }
-// SGEMV('T'), beta = 0: w[j] = sum_i C(i, j) v[i], i < m (C column-major, leading dimension ldc; v with stride incv)
-MPC_HD void gemv_t(int m, int n, const float *C, int ldc, const float *v, int incv, float *w) {
+// Everything below is written with compile-time loop bounds and constant array indices (template maxima, run-time extents as predicates):
+// after inlining, the 4 x 3 matrix, the right-hand side and the 3 x 3 VT live in registers on the device -- no scratch memory.
+
+// one column of SGEMV('T'), beta = 0: sum_{i < m} c[i] v[i * incv] in the order OpenBLAS' kernel uses for that m (header comment)
+template <int M>
+MPC_HD float gemv_t_col(int m, bool one_column, const float *c, const float *v, int incv) {
   GELSD_NO_CONTRACT
-  for (int j = 0; j < n; ++j) {
-    const float *c = C + j * ldc;
-    if (m == 1) w[j] = c[0] * v[0];
-    else if (m == 2) w[j] = fmaf(c[0], v[0], c[1] * v[incv]);
-    else if (m == 3) w[j] = fmaf(c[2], v[2 * incv], fmaf(c[0], v[0], c[1] * v[incv]));
-    else if (n == 1) w[j] = ((c[0] * v[0] + c[1] * v[incv]) + c[2] * v[2 * incv]) + c[3] * v[3 * incv];
-    else w[j] = (c[0] * v[0] + c[1] * v[incv]) + (c[2] * v[2 * incv] + c[3] * v[3 * incv]);
+  if (m == 1) return c[0] * v[0];
+  if (M >= 2 && m == 2) return fmaf(c[0], v[0], c[M >= 2 ? 1 : 0] * v[(M >= 2 ? 1 : 0) * incv]);
+  if (M >= 3 && m == 3) return fmaf(c[M >= 3 ? 2 : 0], v[(M >= 3 ? 2 : 0) * incv], fmaf(c[0], v[0], c[M >= 2 ? 1 : 0] * v[(M >= 2 ? 1 : 0) * incv]));
+  if (M >= 4) {
+    const float p0 = c[0] * v[0], p1 = c[M >= 2 ? 1 : 0] * v[(M >= 2 ? 1 : 0) * incv], p2 = c[M >= 3 ? 2 : 0] * v[(M >= 3 ? 2 : 0) * incv],
+                p3 = c[M >= 4 ? 3 : 0] * v[(M >= 4 ? 3 : 0) * incv];
+    return one_column ? ((p0 + p1) + p2) + p3 : (p0 + p1) + (p2 + p3);
+  }
+  return 0.f;
+}
+// SLARF('Left'): C (m x n, m <= M, n <= N) <- (I - tau v v^T) C, with the library's scan for trailing zeros of v and zero columns of C;
+// SGEMV('T') then SGER (a += (alpha y_j) x_i as one fma)
+template <int M, int N>
+MPC_HD void larf_left(const float *v, int incv, float tau, float *C, int ldc) {
+  GELSD_NO_CONTRACT
+  if (tau == 0.f) return;
+  int lastv = M;
+#pragma unroll
+  for (int i = M - 1; i >= 0; --i)
+    if (lastv == i + 1 && v[i * incv] == 0.f) lastv = i;
+  if (lastv == 0) return;
+  // ILASLC(lastv, N, C): the last column with a non-zero among its first lastv rows
+  int lastc = 0;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    bool nz = false;
+#pragma unroll
+    for (int i = 0; i < M; ++i) nz = nz || (i < lastv && C[i + j * ldc] != 0.f);
+    if (nz) lastc = j + 1;
+  }
+  if (lastc == 0) return;
+  float w[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) w[j] = j < lastc ? gemv_t_col<M>(lastv, lastc == 1, C + j * ldc, v, incv) : 0.f;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const float t = -tau * w[j];
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+      if (j < lastc && i < lastv) C[i + j * ldc] = fmaf(t, v[i * incv], C[i + j * ldc]);
   }
 }
-// SGEMV('N'), beta = 0: w[i] = sum_j C(i, j) v[j], i < m, j < n
-MPC_HD void gemv_n(int m, int n, const float *C, int ldc, const float *v, int incv, float *w) {
+// SLARF('Right'): C (m x n) <- C (I - tau v v^T); SGEMV('N') (a sequential fma chain per row) then SGER
+template <int M, int N>
+MPC_HD void larf_right(const float *v, int incv, float tau, float *C, int ldc) {
   GELSD_NO_CONTRACT
-  for (int i = 0; i < m; ++i) {
+  if (tau == 0.f) return;
+  int lastv = N;
+#pragma unroll
+  for (int j = N - 1; j >= 0; --j)
+    if (lastv == j + 1 && v[j * incv] == 0.f) lastv = j;
+  if (lastv == 0) return;
+  // ILASLR(M, lastv, C): the last row with a non-zero among its first lastv columns
+  int lastc = 0;
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    bool nz = false;
+#pragma unroll
+    for (int j = 0; j < N; ++j) nz = nz || (j < lastv && C[i + j * ldc] != 0.f);
+    if (nz) lastc = i + 1;
+  }
+  if (lastc == 0) return;
+  float w[M];
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
     float acc = 0.f;
-    for (int j = 0; j < n; ++j) acc = fmaf(C[i + j * ldc], v[j * incv], acc);
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+      if (j < lastv) acc = fmaf(C[i + j * ldc], v[j * incv], acc);
     w[i] = acc;
   }
-}
-// SGER: C(i, j) += alpha x[i] y[j]
-MPC_HD void ger(int m, int n, float alpha, const float *x, int incx, const float *y, int incy, float *C, int ldc) {
-  GELSD_NO_CONTRACT
-  for (int j = 0; j < n; ++j) {
-    const float t = alpha * y[j * incy];
-    for (int i = 0; i < m; ++i) C[i + j * ldc] = fmaf(t, x[i * incx], C[i + j * ldc]);
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const float t = -tau * v[j * incv];
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+      if (j < lastv && i < lastc) C[i + j * ldc] = fmaf(t, w[i], C[i + j * ldc]);
   }
-}
-// SLARF('Left'): C (m x n) <- (I - tau v v^T) C, with the library's scan for trailing zeros of v and zero columns of C
-MPC_HD void larf_left(int m, int n, const float *v, int incv, float tau, float *C, int ldc) {
-  if (tau == 0.f) return;
-  int lastv = m;
-  while (lastv > 0 && v[(lastv - 1) * incv] == 0.f) --lastv;
-  if (lastv == 0) return;
-  int lastc = n;                                                     // ILASLC
-  if (!(n == 0 || C[(n - 1) * ldc] != 0.f || C[lastv - 1 + (n - 1) * ldc] != 0.f)) {
-    for (lastc = n; lastc >= 1; --lastc) {
-      bool nz = false;
-      for (int i = 0; i < lastv; ++i) nz = nz || C[i + (lastc - 1) * ldc] != 0.f;
-      if (nz) break;
-    }
-  }
-  if (lastc == 0) return;
-  float w[3];
-  gemv_t(lastv, lastc, C, ldc, v, incv, w);
-  ger(lastv, lastc, -tau, v, incv, w, 1, C, ldc);
-}
-// SLARF('Right'): C (m x n) <- C (I - tau v v^T)
-MPC_HD void larf_right(int m, int n, const float *v, int incv, float tau, float *C, int ldc) {
-  if (tau == 0.f) return;
-  int lastv = n;
-  while (lastv > 0 && v[(lastv - 1) * incv] == 0.f) --lastv;
-  if (lastv == 0) return;
-  int lastc = m;                                                     // ILASLR
-  if (!(m == 0 || C[m - 1] != 0.f || C[m - 1 + (lastv - 1) * ldc] != 0.f)) {
-    lastc = 0;
-    for (int j = 0; j < lastv; ++j) {
-      int i = m;
-      while (i >= 1 && C[(i > 1 ? i : 1) - 1 + j * ldc] == 0.f) --i;
-      lastc = lastc > i ? lastc : i;
-    }
-  }
-  if (lastc == 0) return;
-  float w[3];
-  gemv_n(lastc, lastv, C, ldc, v, incv, w);
-  ger(lastc, lastv, -tau, w, 1, v, incv, C, ldc);
 }
 // SLARTG (LAPACK 3.10+, la_xisnan-free branch; the scaled branch serves |f| or |g| outside (rtmin, rtmax))
 MPC_HD void lartg(float f, float g, float &c, float &s, float &r) {
@@ -231,214 +253,230 @@ MPC_HD void lasv2(float f, float g, float h, float &ssmin, float &ssmax, float &
   ssmax = sgn(ssmax, tsign);
   ssmin = sgn(ssmin, tsign * sgn(1.f, f) * sgn(1.f, h));
 }
-// SROT on n entries: x <- c x + s y, y <- c y - s x
-MPC_HD void rot(int n, float *x, int incx, float *y, int incy, float c, float s) {
+// SROT on the entries i < N of two strided vectors: x <- c x + s y, y <- c y - s x
+template <int N>
+MPC_HD void rot(float *x, int incx, float *y, int incy, float c, float s) {
   GELSD_NO_CONTRACT
-  for (int i = 0; i < n; ++i) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
     const float xv = x[i * incx], yv = y[i * incy];
     x[i * incx] = fmaf(c, xv, s * yv);
     y[i * incy] = fmaf(c, yv, -(s * xv));
   }
 }
-// SLASR('L', 'V', dir): plane rotations (cs[j], sn[j]) between rows j and j + 1 of A (rows x ncol, leading dimension lda), forward or backward
-MPC_HD void lasr_lv(bool forward, int rows, int ncol, const float *cs, const float *sn, float *A, int lda) {
+// SLASR('L', 'V', dir) on all three rows: plane rotations (cs[j], sn[j]) between rows j and j + 1 of A (3 x NCOL, leading dimension lda)
+template <int NCOL, bool FORWARD>
+MPC_HD void lasr3(const float *cs, const float *sn, float *A, int lda) {
   GELSD_NO_CONTRACT
-  for (int jj = 0; jj < rows - 1; ++jj) {
-    const int j = forward ? jj : rows - 2 - jj;
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int j = FORWARD ? jj : 1 - jj;
     const float ct = cs[j], st = sn[j];
-    if (ct != 1.f || st != 0.f)
-      for (int i = 0; i < ncol; ++i) {
+    if (ct != 1.f || st != 0.f) {
+#pragma unroll
+      for (int i = 0; i < NCOL; ++i) {
         const float temp = A[j + 1 + i * lda];
         A[j + 1 + i * lda] = ct * temp - st * A[j + i * lda];
         A[j + i * lda] = st * temp + ct * A[j + i * lda];
       }
+    }
   }
+}
+// the 2 x 2 block (d[R], e[R], d[R + 1]) of SBDSQR: SLASV2, the rotations on rows R, R + 1 of VT and c
+template <int R>
+MPC_HD void block2(float *d, float *e, float *vt, float *c) {
+  float sigmn, sigmx, sinr, cosr, sinl, cosl;
+  lasv2(d[R], e[R], d[R + 1], sigmn, sigmx, sinr, cosr, sinl, cosl);
+  d[R] = sigmx; e[R] = 0.f; d[R + 1] = sigmn;
+  rot<3>(vt + R, 3, vt + R + 1, 3, cosr, sinr);
+  rot<1>(c + R, 1, c + R + 1, 1, cosl, sinl);
 }
 // SBDSQR('U', 3, ncvt = 3, nru = 0, ncc = 1): singular values of the upper bidiagonal (d, e), VT <- rotations applied to the rows of
 // the 3 x 3 identity, c <- left rotations applied to c.  Returns 0 (LAPACK info; > 0: no convergence within 6 n^2 sweeps).
+// n = 3 leaves the general routine three situations: the unreduced 3 x 3 (ll = 1, m = 3: implicit-shift or zero-shift QR sweeps, chased
+// from the larger end), a 2 x 2 block at rows (2, 3) or (1, 2) (SLASV2), and a deflated last value.
 MPC_HD int bdsqr3(float *d, float *e, float *vt /* 3 x 3 column-major */, float *c) {
   GELSD_NO_CONTRACT
   const int n = 3, maxitr = 6;
   const float eps = 5.96046448e-08f, unfl = 1.17549435e-38f;
   const float tolmul = 10.f;                                               // max(10, min(100, eps^(-1/8))) with eps^(-1/8) = 2^3
   const float tol = tolmul * eps;
-  float smax = 0.f;
-  for (int i = 0; i < n; ++i) smax = fmaxf(smax, fabsf(d[i]));
-  for (int i = 0; i < n - 1; ++i) smax = fmaxf(smax, fabsf(e[i]));
+  float smax = fmaxf(fmaxf(fmaxf(fabsf(d[0]), fabsf(d[1])), fabsf(d[2])), fmaxf(fabsf(e[0]), fabsf(e[1])));
   float smin = 0.f;
   float sminoa = fabsf(d[0]);
   if (sminoa != 0.f) {
     float mu = sminoa;
-    for (int i = 1; i < n; ++i) {
-      mu = fabsf(d[i]) * (mu / (mu + fabsf(e[i - 1])));
+    mu = fabsf(d[1]) * (mu / (mu + fabsf(e[0])));
+    sminoa = fminf(sminoa, mu);
+    if (sminoa != 0.f) {
+      mu = fabsf(d[2]) * (mu / (mu + fabsf(e[1])));
       sminoa = fminf(sminoa, mu);
-      if (sminoa == 0.f) break;
     }
   }
   sminoa = sminoa / sqrtf((float)n);
   const float thresh = fmaxf(tol * sminoa, (float)maxitr * ((float)n * ((float)n * unfl)));
   const int maxitdivn = maxitr * n;
   int iterdivn = 0, iter = -1, oldll = -1, oldm = -1, m = n, idir = 0;       // m, ll: 1-based as in the Fortran
-  float work[4 * 2];                                                           // cs / sn / oldcs / oldsn of a sweep (n - 1 = 2 each)
-  float *w1 = work, *w2 = work + 2, *w3 = work + 4, *w4 = work + 6;
-#define D(i) d[(i) - 1]
-#define E(i) e[(i) - 1]
   for (;;) {
     if (m <= 1) break;
     if (iter >= n) { iter -= n; ++iterdivn; if (iterdivn >= maxitdivn) return 1; }
-    smax = fabsf(D(m));
-    int ll = 0;
-    bool split = false;
-    for (int lll = 1; lll <= m - 1; ++lll) {
-      ll = m - lll;
-      const float abss = fabsf(D(ll)), abse = fabsf(E(ll));
-      if (abse <= thresh) { split = true; break; }
-      smax = fmaxf(smax, fmaxf(abss, abse));
-    }
-    if (split) {
-      E(ll) = 0.f;
-      if (ll == m - 1) { m = m - 1; continue; }
-    } else ll = 0;
-    ll = ll + 1;
-    if (ll == m - 1) {        // 2 x 2 block
-      float sigmn, sigmx, sinr, cosr, sinl, cosl;
-      lasv2(D(m - 1), E(m - 1), D(m), sigmn, sigmx, sinr, cosr, sinl, cosl);
-      D(m - 1) = sigmx; E(m - 1) = 0.f; D(m) = sigmn;
-      rot(3, vt + (m - 2), 3, vt + (m - 1), 3, cosr, sinr);
-      rot(1, c + (m - 2), 1, c + (m - 1), 1, cosl, sinl);
-      m = m - 2;
+    if (m == 2) {        // rows 1, 2: a negligible e(1) deflates, otherwise the 2 x 2 block
+      if (fabsf(e[0]) <= thresh) { e[0] = 0.f; m = 1; continue; }
+      block2<0>(d, e, vt, c);
+      m = 0;
       continue;
     }
-    if (ll > oldm || m < oldll) idir = (fabsf(D(ll)) >= fabsf(D(m))) ? 1 : 2;
-    bool again = false;
-    if (idir == 1) {
-      if (fabsf(E(m - 1)) <= fabsf(tol) * fabsf(D(m))) { E(m - 1) = 0.f; continue; }
-      float mu = fabsf(D(ll));
-      smin = mu;
-      for (int lll = ll; lll <= m - 1; ++lll) {
-        if (fabsf(E(lll)) <= tol * mu) { E(lll) = 0.f; again = true; break; }
-        mu = fabsf(D(lll + 1)) * (mu / (mu + fabsf(E(lll))));
-        smin = fminf(smin, mu);
-      }
-    } else {
-      if (fabsf(E(ll)) <= fabsf(tol) * fabsf(D(ll))) { E(ll) = 0.f; continue; }
-      float mu = fabsf(D(m));
-      smin = mu;
-      for (int lll = m - 1; lll >= ll; --lll) {
-        if (fabsf(E(lll)) <= tol * mu) { E(lll) = 0.f; again = true; break; }
-        mu = fabsf(D(lll)) * (mu / (mu + fabsf(E(lll))));
-        smin = fminf(smin, mu);
-      }
+    // m == 3: look for a split from the bottom
+    smax = fabsf(d[2]);
+    if (fabsf(e[1]) <= thresh) { e[1] = 0.f; m = 2; continue; }
+    smax = fmaxf(smax, fmaxf(fabsf(d[1]), fabsf(e[1])));
+    if (fabsf(e[0]) <= thresh) {        // split at the top: the 2 x 2 block of rows 2, 3
+      e[0] = 0.f;
+      block2<1>(d, e, vt, c);
+      m = 1;
+      continue;
     }
-    if (again) continue;
+    smax = fmaxf(smax, fmaxf(fabsf(d[0]), fabsf(e[0])));
+    const int ll = 1;
+    if (ll > oldm || m < oldll) idir = (fabsf(d[0]) >= fabsf(d[2])) ? 1 : 2;
+    if (idir == 1) {
+      if (fabsf(e[1]) <= fabsf(tol) * fabsf(d[2])) { e[1] = 0.f; continue; }
+      float mu = fabsf(d[0]);
+      smin = mu;
+      if (fabsf(e[0]) <= tol * mu) { e[0] = 0.f; continue; }
+      mu = fabsf(d[1]) * (mu / (mu + fabsf(e[0])));
+      smin = fminf(smin, mu);
+      if (fabsf(e[1]) <= tol * mu) { e[1] = 0.f; continue; }
+      mu = fabsf(d[2]) * (mu / (mu + fabsf(e[1])));
+      smin = fminf(smin, mu);
+    } else {
+      if (fabsf(e[0]) <= fabsf(tol) * fabsf(d[0])) { e[0] = 0.f; continue; }
+      float mu = fabsf(d[2]);
+      smin = mu;
+      if (fabsf(e[1]) <= tol * mu) { e[1] = 0.f; continue; }
+      mu = fabsf(d[1]) * (mu / (mu + fabsf(e[1])));
+      smin = fminf(smin, mu);
+      if (fabsf(e[0]) <= tol * mu) { e[0] = 0.f; continue; }
+      mu = fabsf(d[0]) * (mu / (mu + fabsf(e[0])));
+      smin = fminf(smin, mu);
+    }
     oldll = ll; oldm = m;
     float shift, r;
     if ((float)n * tol * (smin / smax) <= fmaxf(eps, 0.01f * tol)) shift = 0.f;
     else {
       float sll;
-      if (idir == 1) { sll = fabsf(D(ll)); las2(D(m - 1), E(m - 1), D(m), shift, r); }
-      else { sll = fabsf(D(m)); las2(D(ll), E(ll), D(ll + 1), shift, r); }
+      if (idir == 1) { sll = fabsf(d[0]); las2(d[1], e[1], d[2], shift, r); }
+      else { sll = fabsf(d[2]); las2(d[0], e[0], d[1], shift, r); }
       if (sll > 0.f) { const float q = shift / sll; if (q * q < eps) shift = 0.f; }
     }
     iter = iter + m - ll;
-    const int rows = m - ll + 1;
+    float w1[2], w2[2], w3[2], w4[2];      // cs / sn of the right rotations, of the left rotations
     if (shift == 0.f) {
       if (idir == 1) {
         float cs = 1.f, oldcs = 1.f, sn = 0.f, oldsn = 0.f;
-        for (int i = ll; i <= m - 1; ++i) {
-          lartg(D(i) * cs, E(i), cs, sn, r);
-          if (i > ll) E(i - 1) = oldsn * r;
-          lartg(oldcs * r, D(i + 1) * sn, oldcs, oldsn, D(i));
-          w1[i - ll] = cs; w2[i - ll] = sn; w3[i - ll] = oldcs; w4[i - ll] = oldsn;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          lartg(d[i] * cs, e[i], cs, sn, r);
+          if (i > 0) e[i - (i > 0 ? 1 : 0)] = oldsn * r;
+          lartg(oldcs * r, d[i + 1] * sn, oldcs, oldsn, d[i]);
+          w1[i] = cs; w2[i] = sn; w3[i] = oldcs; w4[i] = oldsn;
         }
-        const float h = D(m) * cs;
-        D(m) = h * oldcs;
-        E(m - 1) = h * oldsn;
-        lasr_lv(true, rows, 3, w1, w2, vt + (ll - 1), 3);
-        lasr_lv(true, rows, 1, w3, w4, c + (ll - 1), 3);
-        if (fabsf(E(m - 1)) <= thresh) E(m - 1) = 0.f;
+        const float h = d[2] * cs;
+        d[2] = h * oldcs;
+        e[1] = h * oldsn;
+        lasr3<3, true>(w1, w2, vt, 3);
+        lasr3<1, true>(w3, w4, c, 3);
+        if (fabsf(e[1]) <= thresh) e[1] = 0.f;
       } else {
         float cs = 1.f, oldcs = 1.f, sn = 0.f, oldsn = 0.f;
-        for (int i = m; i >= ll + 1; --i) {
-          lartg(D(i) * cs, E(i - 1), cs, sn, r);
-          if (i < m) E(i) = oldsn * r;
-          lartg(oldcs * r, D(i - 1) * sn, oldcs, oldsn, D(i));
-          w1[i - ll - 1] = cs; w2[i - ll - 1] = -sn; w3[i - ll - 1] = oldcs; w4[i - ll - 1] = -oldsn;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int i = 2 - k;                  // 0-based row of D(I), I = M .. LL + 1
+          lartg(d[i] * cs, e[i - 1], cs, sn, r);
+          if (k > 0) e[i] = oldsn * r;
+          lartg(oldcs * r, d[i - 1] * sn, oldcs, oldsn, d[i]);
+          w1[i - 1] = cs; w2[i - 1] = -sn; w3[i - 1] = oldcs; w4[i - 1] = -oldsn;
         }
-        const float h = D(ll) * cs;
-        D(ll) = h * oldcs;
-        E(ll) = h * oldsn;
-        lasr_lv(false, rows, 3, w3, w4, vt + (ll - 1), 3);
-        lasr_lv(false, rows, 1, w1, w2, c + (ll - 1), 3);
-        if (fabsf(E(ll)) <= thresh) E(ll) = 0.f;
+        const float h = d[0] * cs;
+        d[0] = h * oldcs;
+        e[0] = h * oldsn;
+        lasr3<3, false>(w3, w4, vt, 3);
+        lasr3<1, false>(w1, w2, c, 3);
+        if (fabsf(e[0]) <= thresh) e[0] = 0.f;
       }
     } else {
       if (idir == 1) {
-        float f = (fabsf(D(ll)) - shift) * (sgn(1.f, D(ll)) + shift / D(ll));
-        float g = E(ll);
-        for (int i = ll; i <= m - 1; ++i) {
+        float f = (fabsf(d[0]) - shift) * (sgn(1.f, d[0]) + shift / d[0]);
+        float g = e[0];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
           float cosr, sinr, cosl, sinl;
           lartg(f, g, cosr, sinr, r);
-          if (i > ll) E(i - 1) = r;
-          f = cosr * D(i) + sinr * E(i);
-          E(i) = cosr * E(i) - sinr * D(i);
-          g = sinr * D(i + 1);
-          D(i + 1) = cosr * D(i + 1);
+          if (i > 0) e[i - (i > 0 ? 1 : 0)] = r;
+          f = cosr * d[i] + sinr * e[i];
+          e[i] = cosr * e[i] - sinr * d[i];
+          g = sinr * d[i + 1];
+          d[i + 1] = cosr * d[i + 1];
           lartg(f, g, cosl, sinl, r);
-          D(i) = r;
-          f = cosl * E(i) + sinl * D(i + 1);
-          D(i + 1) = cosl * D(i + 1) - sinl * E(i);
-          if (i < m - 1) { g = sinl * E(i + 1); E(i + 1) = cosl * E(i + 1); }
-          w1[i - ll] = cosr; w2[i - ll] = sinr; w3[i - ll] = cosl; w4[i - ll] = sinl;
+          d[i] = r;
+          f = cosl * e[i] + sinl * d[i + 1];
+          d[i + 1] = cosl * d[i + 1] - sinl * e[i];
+          if (i < 1) { g = sinl * e[i + (i < 1 ? 1 : 0)]; e[i + (i < 1 ? 1 : 0)] = cosl * e[i + (i < 1 ? 1 : 0)]; }
+          w1[i] = cosr; w2[i] = sinr; w3[i] = cosl; w4[i] = sinl;
         }
-        E(m - 1) = f;
-        lasr_lv(true, rows, 3, w1, w2, vt + (ll - 1), 3);
-        lasr_lv(true, rows, 1, w3, w4, c + (ll - 1), 3);
-        if (fabsf(E(m - 1)) <= thresh) E(m - 1) = 0.f;
+        e[1] = f;
+        lasr3<3, true>(w1, w2, vt, 3);
+        lasr3<1, true>(w3, w4, c, 3);
+        if (fabsf(e[1]) <= thresh) e[1] = 0.f;
       } else {
-        float f = (fabsf(D(m)) - shift) * (sgn(1.f, D(m)) + shift / D(m));
-        float g = E(m - 1);
-        for (int i = m; i >= ll + 1; --i) {
+        float f = (fabsf(d[2]) - shift) * (sgn(1.f, d[2]) + shift / d[2]);
+        float g = e[1];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int i = 2 - k;
           float cosr, sinr, cosl, sinl;
           lartg(f, g, cosr, sinr, r);
-          if (i < m) E(i) = r;
-          f = cosr * D(i) + sinr * E(i - 1);
-          E(i - 1) = cosr * E(i - 1) - sinr * D(i);
-          g = sinr * D(i - 1);
-          D(i - 1) = cosr * D(i - 1);
+          if (k > 0) e[i] = r;
+          f = cosr * d[i] + sinr * e[i - 1];
+          e[i - 1] = cosr * e[i - 1] - sinr * d[i];
+          g = sinr * d[i - 1];
+          d[i - 1] = cosr * d[i - 1];
           lartg(f, g, cosl, sinl, r);
-          D(i) = r;
-          f = cosl * E(i - 1) + sinl * D(i - 1);
-          D(i - 1) = cosl * D(i - 1) - sinl * E(i - 1);
-          if (i > ll + 1) { g = sinl * E(i - 2); E(i - 2) = cosl * E(i - 2); }
-          w1[i - ll - 1] = cosr; w2[i - ll - 1] = -sinr; w3[i - ll - 1] = cosl; w4[i - ll - 1] = -sinl;
+          d[i] = r;
+          f = cosl * e[i - 1] + sinl * d[i - 1];
+          d[i - 1] = cosl * d[i - 1] - sinl * e[i - 1];
+          if (k < 1) { g = sinl * e[i - (k < 1 ? 2 : 1)]; e[i - (k < 1 ? 2 : 1)] = cosl * e[i - (k < 1 ? 2 : 1)]; }
+          w1[i - 1] = cosr; w2[i - 1] = -sinr; w3[i - 1] = cosl; w4[i - 1] = -sinl;
         }
-        E(ll) = f;
-        if (fabsf(E(ll)) <= thresh) E(ll) = 0.f;
-        lasr_lv(false, rows, 3, w3, w4, vt + (ll - 1), 3);
-        lasr_lv(false, rows, 1, w1, w2, c + (ll - 1), 3);
+        e[0] = f;
+        if (fabsf(e[0]) <= thresh) e[0] = 0.f;
+        lasr3<3, false>(w3, w4, vt, 3);
+        lasr3<1, false>(w1, w2, c, 3);
       }
     }
   }
-  for (int i = 1; i <= n; ++i)
-    if (D(i) < 0.f) {
-      D(i) = -D(i);
-      for (int k = 0; k < 3; ++k) vt[(i - 1) + 3 * k] = -1.f * vt[(i - 1) + 3 * k];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    if (d[i] < 0.f) {
+      d[i] = -d[i];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) vt[i + 3 * k] = -1.f * vt[i + 3 * k];
     }
-  for (int i = 1; i <= n - 1; ++i) {      // decreasing order
-    int isub = 1;
-    float sm = D(1);
-    for (int j = 2; j <= n + 1 - i; ++j)
-      if (D(j) <= sm) { isub = j; sm = D(j); }
-    if (isub != n + 1 - i) {
-      D(isub) = D(n + 1 - i);
-      D(n + 1 - i) = sm;
-      for (int k = 0; k < 3; ++k) { const float t = vt[(isub - 1) + 3 * k]; vt[(isub - 1) + 3 * k] = vt[(n - i) + 3 * k]; vt[(n - i) + 3 * k] = t; }
-      const float t = c[isub - 1]; c[isub - 1] = c[n - i]; c[n - i] = t;
-    }
+  // decreasing order (SBDSQR's selection sort: the smallest of the first n + 1 - i goes to place n + 1 - i; ties take the later one)
+  auto swap_rows = [&](int p, int q) {      // constant arguments at every call
+    const float td = d[p]; d[p] = d[q]; d[q] = td;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const float t = vt[p + 3 * k]; vt[p + 3 * k] = vt[q + 3 * k]; vt[q + 3 * k] = t; }
+    const float tc = c[p]; c[p] = c[q]; c[q] = tc;
+  };
+  {
+    int isub = 0;
+    float sm = d[0];
+    if (d[1] <= sm) { isub = 1; sm = d[1]; }
+    if (d[2] <= sm) { isub = 2; sm = d[2]; }
+    if (isub == 0) swap_rows(0, 2); else if (isub == 1) swap_rows(1, 2);
+    if (!(d[1] <= d[0])) swap_rows(0, 1);
   }
-#undef D
-#undef E
   return 0;
 }
 // SLASCL('G') for values in the normal range: one rounded quotient, then one product per entry
@@ -447,95 +485,113 @@ MPC_HD float lascl_mul(float cfrom, float cto) { return cto / cfrom; }
 // x (3) = argmin |A x - 1|, A = 4 x 3 row-major float32 (the foot-contact history).  Returns LAPACK's rank.
 MPC_HD int solve_ones(const float *A_rowmajor, float *x, float *dbg = nullptr) {
   GELSD_NO_CONTRACT
-  const int lda = 4;
+  constexpr int lda = 4;
   float a[12], b[4] = {1.f, 1.f, 1.f, 1.f}, tau[3];
+#pragma unroll
   for (int i = 0; i < 4; ++i)
+#pragma unroll
     for (int j = 0; j < 3; ++j) a[i + lda * j] = A_rowmajor[3 * i + j];
-  // SGEQR2 + SORM2R('L', 'T')
-  for (int i = 0; i < 3; ++i) {
-    larfg(4 - i, a[i + lda * i], a + (i + 1) + lda * i, 1, tau[i]);
-    const float aii = a[i + lda * i];
-    a[i + lda * i] = 1.f;
-    if (i < 2) larf_left(4 - i, 2 - i, a + i + lda * i, 1, tau[i], a + i + lda * (i + 1), lda);
-    a[i + lda * i] = aii;
+  // SGEQR2
+  {
+    larfg<4>(a[0], a + 1, 1, tau[0]);
+    float aii = a[0]; a[0] = 1.f;
+    larf_left<4, 2>(a, 1, tau[0], a + lda, lda);
+    a[0] = aii;
+    larfg<3>(a[1 + lda], a + 2 + lda, 1, tau[1]);
+    aii = a[1 + lda]; a[1 + lda] = 1.f;
+    larf_left<3, 1>(a + 1 + lda, 1, tau[1], a + 1 + 2 * lda, lda);
+    a[1 + lda] = aii;
+    larfg<2>(a[2 + 2 * lda], a + 3 + 2 * lda, 1, tau[2]);
   }
-  for (int i = 0; i < 3; ++i) {
-    const float aii = a[i + lda * i];
-    a[i + lda * i] = 1.f;
-    larf_left(4 - i, 1, a + i + lda * i, 1, tau[i], b + i, 4);
-    a[i + lda * i] = aii;
+  // SORM2R('L', 'T'): Q^T b
+  {
+    float aii = a[0]; a[0] = 1.f;
+    larf_left<4, 1>(a, 1, tau[0], b, 4);
+    a[0] = aii;
+    aii = a[1 + lda]; a[1 + lda] = 1.f;
+    larf_left<3, 1>(a + 1 + lda, 1, tau[1], b + 1, 4);
+    a[1 + lda] = aii;
+    aii = a[2 + 2 * lda]; a[2 + 2 * lda] = 1.f;
+    larf_left<2, 1>(a + 2 + 2 * lda, 1, tau[2], b + 2, 4);
+    a[2 + 2 * lda] = aii;
   }
   if (dbg) { for (int k = 0; k < 12; ++k) dbg[k] = a[k]; for (int k = 0; k < 3; ++k) dbg[12 + k] = tau[k]; for (int k = 0; k < 4; ++k) dbg[15 + k] = b[k]; }
   a[1] = a[2] = a[2 + lda] = 0.f;                                  // SLASET below the diagonal of R
   // SGEBD2 on the 3 x 3 R (lda = 4)
   float d[3], e[2], tauq[3], taup[3];
-  for (int i = 0; i < 3; ++i) {
-    larfg(3 - i, a[i + lda * i], a + (i + 1 < 3 ? i + 1 : 2) + lda * i, 1, tauq[i]);
-    d[i] = a[i + lda * i];
-    a[i + lda * i] = 1.f;
-    if (i < 2) larf_left(3 - i, 2 - i, a + i + lda * i, 1, tauq[i], a + i + lda * (i + 1), lda);
-    a[i + lda * i] = d[i];
-    if (i < 2) {
-      larfg(2 - i, a[i + lda * (i + 1)], a + i + lda * (i + 2 < 3 ? i + 2 : 2), lda, taup[i]);
-      e[i] = a[i + lda * (i + 1)];
-      a[i + lda * (i + 1)] = 1.f;
-      larf_right(2 - i, 2 - i, a + i + lda * (i + 1), lda, taup[i], a + (i + 1) + lda * (i + 1), lda);
-      a[i + lda * (i + 1)] = e[i];
-    } else taup[i] = 0.f;
+  {
+    // i = 1: the column below R(1,1) is zero -> tauq(1) = 0; the row reflector on R(1, 2:3)
+    larfg<3>(a[0], a + 1, 1, tauq[0]);
+    d[0] = a[0]; a[0] = 1.f;
+    larf_left<3, 2>(a, 1, tauq[0], a + lda, lda);
+    a[0] = d[0];
+    larfg<2>(a[lda], a + 2 * lda, lda, taup[0]);
+    e[0] = a[lda]; a[lda] = 1.f;
+    larf_right<2, 2>(a + lda, lda, taup[0], a + 1 + lda, lda);
+    a[lda] = e[0];
+    // i = 2
+    larfg<2>(a[1 + lda], a + 2 + lda, 1, tauq[1]);
+    d[1] = a[1 + lda]; a[1 + lda] = 1.f;
+    larf_left<2, 1>(a + 1 + lda, 1, tauq[1], a + 1 + 2 * lda, lda);
+    a[1 + lda] = d[1];
+    taup[1] = 0.f;                                                  // SLARFG on one entry
+    e[1] = a[1 + 2 * lda];
+    // i = 3
+    tauq[2] = 0.f; taup[2] = 0.f;
+    d[2] = a[2 + 2 * lda];
   }
-  // SORMBR('Q', 'L', 'T') = SORM2R with the tauq reflectors
-  for (int i = 0; i < 3; ++i) {
-    const float aii = a[i + lda * i];
-    a[i + lda * i] = 1.f;
-    larf_left(3 - i, 1, a + i + lda * i, 1, tauq[i], b + i, 4);
-    a[i + lda * i] = aii;
+  // SORMBR('Q', 'L', 'T') = SORM2R with the tauq reflectors (only tauq(2) can be non-zero; tauq(1) as SLARFG left it)
+  {
+    float aii = a[0]; a[0] = 1.f;
+    larf_left<3, 1>(a, 1, tauq[0], b, 4);
+    a[0] = aii;
+    aii = a[1 + lda]; a[1 + lda] = 1.f;
+    larf_left<2, 1>(a + 1 + lda, 1, tauq[1], b + 1, 4);
+    a[1 + lda] = aii;
   }
   if (dbg) { for (int k = 0; k < 12; ++k) dbg[20 + k] = a[k]; for (int k = 0; k < 3; ++k) { dbg[32 + k] = d[k]; dbg[37 + k] = tauq[k]; dbg[40 + k] = taup[k]; dbg[43 + k] = b[k]; } dbg[35] = e[0]; dbg[36] = e[1]; }
   // SLALSD('U', n = 3 <= smlsiz)
   const float rcnd = 1.1920929e-07f;                               // scipy passes cond = finfo(float32).eps
-  float orgnrm = 0.f;
-  for (int i = 0; i < 3; ++i) orgnrm = fmaxf(orgnrm, fabsf(d[i]));
-  for (int i = 0; i < 2; ++i) orgnrm = fmaxf(orgnrm, fabsf(e[i]));
+  const float orgnrm = fmaxf(fmaxf(fmaxf(fabsf(d[0]), fabsf(d[1])), fabsf(d[2])), fmaxf(fabsf(e[0]), fabsf(e[1])));
   int rank = 0;
   if (orgnrm == 0.f) { x[0] = x[1] = x[2] = 0.f; return 0; }
-  {
-    const float mul = lascl_mul(orgnrm, 1.f);
-    if (mul != 1.f) { for (int i = 0; i < 3; ++i) d[i] = d[i] * mul; for (int i = 0; i < 2; ++i) e[i] = e[i] * mul; }
-  }
+  const float unit = lascl_mul(orgnrm, 1.f);
+  if (unit != 1.f) { d[0] = d[0] * unit; d[1] = d[1] * unit; d[2] = d[2] * unit; e[0] = e[0] * unit; e[1] = e[1] * unit; }
   float vt[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
   if (bdsqr3(d, e, vt, b) != 0) { x[0] = x[1] = x[2] = 0.f; return -1; }
-  for (int i = 0; i < 3; ++i) {                                    // SLASDQ re-sorts what SBDSQR left in decreasing order into INCREASING order
-    int isub = i;
-    float sm = d[i];
-    for (int j = i + 1; j < 3; ++j)
-      if (d[j] < sm) { isub = j; sm = d[j]; }
-    if (isub != i) {
-      d[isub] = d[i]; d[i] = sm;
-      for (int k = 0; k < 3; ++k) { const float t = vt[isub + 3 * k]; vt[isub + 3 * k] = vt[i + 3 * k]; vt[i + 3 * k] = t; }
-      const float t = b[isub]; b[isub] = b[i]; b[i] = t;
-    }
+  {    // SLASDQ re-sorts what SBDSQR left in decreasing order into INCREASING order (selection sort, strict comparisons)
+    auto swap_rows = [&](int p, int q) {
+      const float td = d[p]; d[p] = d[q]; d[q] = td;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { const float t = vt[p + 3 * k]; vt[p + 3 * k] = vt[q + 3 * k]; vt[q + 3 * k] = t; }
+      const float tc = b[p]; b[p] = b[q]; b[q] = tc;
+    };
+    int isub = 0;
+    float sm = d[0];
+    if (d[1] < sm) { isub = 1; sm = d[1]; }
+    if (d[2] < sm) { isub = 2; sm = d[2]; }
+    if (isub == 1) swap_rows(0, 1); else if (isub == 2) swap_rows(0, 2);
+    if (d[2] < d[1]) swap_rows(1, 2);
   }
-  float dmax = 0.f;
-  for (int i = 0; i < 3; ++i) dmax = fmaxf(dmax, fabsf(d[i]));
+  const float dmax = fmaxf(fmaxf(fabsf(d[0]), fabsf(d[1])), fabsf(d[2]));
   const float tol = rcnd * dmax;
+#pragma unroll
   for (int i = 0; i < 3; ++i) {
     if (d[i] <= tol) b[i] = 0.f;
     else { const float mul = lascl_mul(d[i], 1.f); if (mul != 1.f) b[i] = b[i] * mul; ++rank; }
   }
   float y[3];
+#pragma unroll
   for (int i = 0; i < 3; ++i) y[i] = fmaf(vt[2 + 3 * i], b[2], fmaf(vt[1 + 3 * i], b[1], vt[0 + 3 * i] * b[0]));      // SGEMM('T', 'N', 3, 1, 3)
-  {
-    const float mul = lascl_mul(orgnrm, 1.f);
-    if (mul != 1.f) for (int i = 0; i < 3; ++i) y[i] = y[i] * mul;
-  }
-  for (int i = 0; i < 3; ++i) b[i] = y[i];
+  if (unit != 1.f) { y[0] = y[0] * unit; y[1] = y[1] * unit; y[2] = y[2] * unit; }
+  b[0] = y[0]; b[1] = y[1]; b[2] = y[2];
   if (dbg) for (int k = 0; k < 3; ++k) dbg[46 + k] = b[k];
   // SORMBR('P', 'L', 'N') = SORML2('L', 'T', 2, 1, 2) on b(2:3): reflectors taup(2) (= 0), then taup(1)
   {
-    const float aii = a[lda * 1];
-    a[lda * 1] = 1.f;
-    larf_left(2, 1, a + lda * 1, lda, taup[0], b + 1, 4);
-    a[lda * 1] = aii;
+    const float aii = a[lda];
+    a[lda] = 1.f;
+    larf_left<2, 1>(a + lda, lda, taup[0], b + 1, 4);
+    a[lda] = aii;
   }
   x[0] = b[0]; x[1] = b[1]; x[2] = b[2];
   return rank;
