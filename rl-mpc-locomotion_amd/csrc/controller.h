@@ -294,8 +294,38 @@ MPC_HD void ctrl_pre_legs(CtrlState &s, const RobotConst &rc, const float *dof, 
     s.pfoot[3 * i + 2] = s.foot_positions[3 * i + 2] + s.pos_z;
   }
 }
+// StateEstimator._compute_ground_normal_and_com_position without the CoM height (StateEstimator.py:120-143): the contact history takes the
+// positions of the feet that were in contact, the ground normal is the normalised least-squares solution of  history n = 1.
+MPC_HD void ground_normal_update(float *hist, float *normal, const float *contact_phase, const float *foot_positions) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  for (int i = 0; i < 4; ++i)
+    if (contact_phase[i] != 0.f)
+      for (int c = 0; c < 3; ++c) hist[3 * i + c] = foot_positions[3 * i + c];
+  // least squares H n = 1: scipy.linalg.lstsq on float32 = LAPACK SGELSD there, walked operation by operation here (gelsd43.h) --
+  // bit-identical to the reference's normal on every tick of the goldens
+  float n[3];
+  gelsd43::solve_ones(hist, n);
+  for (int pass = 0; pass < 2; ++pass) {           // normalised twice (StateEstimator.py:134,140)
+    // np.linalg.norm = sqrt(x.dot(x)); OpenBLAS' sdot rounds each product to float32, sums them in double and rounds once
+    const float nn = sqrtf((float)(((double)(n[0] * n[0]) + (double)(n[1] * n[1])) + (double)(n[2] * n[2])));
+    n[0] /= nn; n[1] /= nn; n[2] /= nn;
+    if (pass == 0 && n[2] < 0.f) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+  }
+  normal[0] = n[0]; normal[1] = n[1]; normal[2] = n[2];
+}
+// ... and the first-run initialisation of the history (ConvexMPCLocomotion.py:257-263 -> StateEstimator.py:99-101)
+MPC_HD void contact_history_init(float *hist, const float *foot_positions, double body_height) {
+  for (int i = 0; i < 4; ++i) {
+    hist[3 * i] = foot_positions[3 * i]; hist[3 * i + 1] = foot_positions[3 * i + 1];
+    hist[3 * i + 2] = (float)(-body_height);
+  }
+}
 MPC_HD void ctrl_pre_rest(CtrlState &s, const RobotConst &rc, const GaitTable &gt, const CtrlParams &cp,
-                          const float *est, const float *cmd, float *rec, int l0 = 0, int l1 = 4, bool lead = true) {
+                          const float *est, const float *cmd, float *rec, int l0 = 0, int l1 = 4, bool lead = true, bool do_normal = true) {
+  // do_normal = false: the contact history and the ground normal are somebody else's (ctrl_pre_fused_kernel: another wavefront updates them
+  // and writes the normal into the record)
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
@@ -310,10 +340,7 @@ MPC_HD void ctrl_pre_rest(CtrlState &s, const RobotConst &rc, const GaitTable &g
 
   if (s.first_run) {   // :257-263
     s.first_run = 0;
-    for (int i = 0; i < 4; ++i) {      // (the foot history of ALL legs: the ground-normal fit below reads it)
-      s.hist[3 * i] = s.foot_positions[3 * i]; s.hist[3 * i + 1] = s.foot_positions[3 * i + 1];
-      s.hist[3 * i + 2] = (float)(-rc.body_height);                     // StateEstimator.py:99-101
-    }
+    contact_history_init(s.hist, s.foot_positions, rc.body_height);      // (the foot history of ALL legs: the ground-normal fit below reads it)
     for (int i = l0; i < l1; ++i)
       for (int c = 0; c < 3; ++c) { s.p0[3 * i + c] = s.pfoot[3 * i + c]; s.pf[3 * i + c] = s.pfoot[3 * i + c]; }
   }
@@ -331,22 +358,7 @@ MPC_HD void ctrl_pre_rest(CtrlState &s, const RobotConst &rc, const GaitTable &g
       s.pos_z = acc / csum;
     }
   }
-  if (!cp.flat_ground) {   // _compute_ground_normal_and_com_position (StateEstimator.py:120-143)
-    for (int i = 0; i < 4; ++i)
-      if (s.contact_phase[i] != 0.f)
-        for (int c = 0; c < 3; ++c) s.hist[3 * i + c] = s.foot_positions[3 * i + c];
-    // least squares H n = 1: scipy.linalg.lstsq on float32 = LAPACK SGELSD there, walked operation by operation here (gelsd43.h) --
-    // bit-identical to the reference's normal on every tick of the goldens
-    float n[3];
-    gelsd43::solve_ones(s.hist, n);
-    for (int pass = 0; pass < 2; ++pass) {           // normalised twice (StateEstimator.py:134,140)
-      // np.linalg.norm = sqrt(x.dot(x)); OpenBLAS' sdot rounds each product to float32, sums them in double and rounds once
-      const float nn = sqrtf((float)(((double)(n[0] * n[0]) + (double)(n[1] * n[1])) + (double)(n[2] * n[2])));
-      n[0] /= nn; n[1] /= nn; n[2] /= nn;
-      if (pass == 0 && n[2] < 0.f) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
-    }
-    s.normal[0] = n[0]; s.normal[1] = n[1]; s.normal[2] = n[2];
-  }
+  if (!cp.flat_ground && do_normal) ground_normal_update(s.hist, s.normal, s.contact_phase, s.foot_positions);
 
   // foot placement (ConvexMPCLocomotion.py:270-311)
   const float swing_seg = (float)nseg - dur[0], stance_seg = dur[0];        // Gait.py:22-23
@@ -413,7 +425,8 @@ MPC_HD void ctrl_pre_rest(CtrlState &s, const RobotConst &rc, const GaitTable &g
       for (int k = 0; k < 3; ++k) {
         rec[IN_VEL + k] = vBody[k];
         rec[IN_RPY + k] = rpyBody[k];
-        rec[IN_NRM + k] = cp.flat_ground ? (k == 2 ? 1.f : 0.f) : s.normal[k];
+        if (cp.flat_ground) rec[IN_NRM + k] = k == 2 ? 1.f : 0.f;
+        else if (do_normal) rec[IN_NRM + k] = s.normal[k];
         rec[IN_ANG + k] = omegaBody[k];
       }
     }

@@ -14,7 +14,8 @@
 // is importable):  SNRM2 accumulates in double and rounds once;  SGEMV^T sums  m = 4, n = 2: (p0 + p1) + (p2 + p3);  m = 4, n = 1:
 // ((p0 + p1) + p2) + p3;  m = 3: fma(a2, x2, fma(a0, x0, a1 x1));  m = 2: fma(a0, x0, a1 x1);  SGER / SAXPY: a += (alpha y_j) x_i
 // as one fma;  SROT and SGEMM: see rot() / the VT^T product below.
-// Single precision throughout; compile WITHOUT floating-point contraction (the pragma below); fmaf only where the library fuses.
+// Single precision throughout; compile WITHOUT floating-point contraction -- the pragma in every function AND -ffp-contract=off for the translation unit
+// (csrc/Makefile: the pragma alone lets an fmaf whose multiplier constant-folds to 1 fuse with a neighbour on the device); fmaf only where the library fuses.
 #pragma once
 
 #include <math.h>

@@ -465,6 +465,92 @@ __global__ __launch_bounds__(kCtrlThreads) void ctrl_pre_kernel(int n, CtrlState
     active[r] = s.do_solve;
   }
 }
+// controller.run's first half as ONE kernel of three concurrent wavefronts per 16 robots (mpc_ctrl_run; mpc_ctrl_step, whose caller brings the
+// estimator outputs, keeps ctrl_pre_kernel):
+//   wave 0   the leg quads of ctrl_pre_kernel: leg kinematics, then -- after the barrier -- everything of ctrl_pre_rest but the ground-normal fit;
+//   wave 1   StateEstimator.update of the 16 robots, one lane each (estimator_kernel's work: no separate launch), handed over through LDS;
+//   wave 2   the contact history and the ground-normal fit (gelsd43.h: ~20 us of one dependent float32 chain per robot) from the foot positions
+//            wave 0 publishes, next to wave 0's foot placement / gait tables / record -- it writes the history, the normal and the record's normal.
+// Every value is computed by the same code as in the two-kernel form (bit-identical results); what changes is that three dependent chains run side by side.
+constexpr int kFusedRobots = 16;
+__device__ __forceinline__ void store_leg_fields_no_hist(CtrlState &d, const CtrlState &s, int leg) {
+  d.first_swing[leg] = s.first_swing[leg];
+  d.swing_time_remaining[leg] = s.swing_time_remaining[leg];
+  d.swing_times[leg] = s.swing_times[leg];
+  d.contact_phase[leg] = s.contact_phase[leg];
+  d.contact_states[leg] = s.contact_states[leg];
+  d.swing_states[leg] = s.swing_states[leg];
+  for (int c = 3 * leg; c < 3 * leg + 3; ++c) {
+    d.f_ff[c] = s.f_ff[c]; d.p0[c] = s.p0[c]; d.pf[c] = s.pf[c]; d.tp[c] = s.tp[c]; d.tv[c] = s.tv[c];
+    d.q[c] = s.q[c]; d.qd[c] = s.qd[c]; d.p[c] = s.p[c]; d.v[c] = s.v[c]; d.foot_positions[c] = s.foot_positions[c]; d.pfoot[c] = s.pfoot[c];
+  }
+  for (int c = 9 * leg; c < 9 * leg + 9; ++c) d.J[c] = s.J[c];
+}
+__global__ __launch_bounds__(3 * 64) void ctrl_pre_fused_kernel(int n, CtrlState *st, const RobotConst *rc, GaitTable gt, CtrlParams cp, const float *dof, const float *body,
+                                                               float *est_out, const float *cmd, float *rec, int *active) {
+  __shared__ float sh_est[kFusedRobots][kEstLen];
+  __shared__ float sh_fp[kFusedRobots][12];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r0 = blockIdx.x * kFusedRobots;
+  if (wave == 1) {
+    const int r = r0 + lane;
+    if (lane < kFusedRobots && r < n) {
+      const float nrm[3] = {st[r].normal[0], st[r].normal[1], st[r].normal[2]};       // the estimate of the previous tick (StateEstimator.py:88-92)
+      float e[kEstLen];
+      estimator_update(body + (size_t)r * 13, nrm, e);
+      for (int k = 0; k < kEstLen; ++k) { sh_est[lane][k] = e[k]; est_out[(size_t)r * kEstLen + k] = e[k]; }
+    }
+    __syncthreads();
+    return;
+  }
+  if (wave == 2) {
+    const int r = r0 + lane;
+    const bool on = lane < kFusedRobots && r < n && !cp.flat_ground;
+    float hist[12], cph[4], nrm[3];
+    int first_run = 0;
+    double body_height = 0.0;
+    if (on) {
+      for (int k = 0; k < 12; ++k) hist[k] = st[r].hist[k];
+      for (int k = 0; k < 4; ++k) cph[k] = st[r].contact_phase[k];
+      first_run = st[r].first_run;
+      body_height = rc[st[r].robot_type].body_height;
+    }
+    __builtin_amdgcn_s_waitcnt(kWaitVm0);      // (the loads of the state are complete before wave 0 may store to it: it stores after the barrier)
+    __syncthreads();
+    if (on) {
+      float fp[12];
+      for (int k = 0; k < 12; ++k) fp[k] = sh_fp[lane][k];
+      if (first_run) contact_history_init(hist, fp, body_height);
+      ground_normal_update(hist, nrm, cph, fp);
+      for (int k = 0; k < 12; ++k) st[r].hist[k] = hist[k];
+      for (int k = 0; k < 3; ++k) { st[r].normal[k] = nrm[k]; rec[(size_t)r * (56 + 4 * cp.horizon) + IN_NRM + k] = nrm[k]; }
+    }
+    return;
+  }
+  const int rl = lane >> 2, leg = lane & 3, r = r0 + rl;
+  const bool on = r < n;
+  CtrlState s;
+  if (on) {
+    s = st[r];
+    ctrl_pre_legs(s, rc[s.robot_type], dof + (size_t)r * 24, leg, leg + 1);
+    for (int c = 0; c < 3; ++c) sh_fp[rl][3 * leg + c] = c == 0 ? s.foot_positions[3 * leg] : (c == 1 ? s.foot_positions[3 * leg + 1] : s.foot_positions[3 * leg + 2]);
+  }
+  __builtin_amdgcn_s_waitcnt(kWaitVm0);
+  __syncthreads();
+  if (!on) return;
+  const RobotConst &k = rc[s.robot_type];
+  float e[kEstLen];
+  for (int c = 0; c < 12; ++c) s.foot_positions[c] = sh_fp[rl][c];
+  for (int c = 0; c < kEstLen; ++c) e[c] = sh_est[rl][c];
+  ctrl_pre_rest(s, k, gt, cp, e, cmd + (size_t)r * 16, rec + (size_t)r * (56 + 4 * cp.horizon), leg, leg + 1, leg == 0, false);
+  quad_reads_done();
+  if (cp.flat_ground) store_leg_fields(st[r], s, leg);      // (no fit on flat ground: the history is this wave's, set once at the first run)
+  else store_leg_fields_no_hist(st[r], s, leg);
+  if (leg == 0) {
+    st[r].iter = s.iter; st[r].first_run = s.first_run; st[r].pos_z = s.pos_z; st[r].posz_tick = s.posz_tick; st[r].do_solve = s.do_solve;
+    for (int c = 0; c < 3; ++c) st[r].vbody[c] = s.vbody[c];
+    active[r] = s.do_solve;
+  }
+}
 __global__ __launch_bounds__(kCtrlThreads) void estimator_kernel(int n, const CtrlState *st, const float *body, float *est) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
@@ -621,10 +707,9 @@ int mpc_ctrl_create(mpc_ctrl **out, int n, int horizon, double controller_dt, in
   return MPC_OK;
 }
 
-int mpc_ctrl_step(mpc_ctrl *c, const float *d_dof, const float *d_est, const float *d_cmd, float *d_torques, void *stream) {
-  if (!c || !d_dof || !d_est || !d_cmd || !d_torques) return fail(MPC_E_ARG, "mpc_ctrl_step: bad argument");
-  DeviceGuard guard_(c->solver->device);
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+// one tick: the pre kernel (with the caller's estimator outputs, or -- d_est null -- with StateEstimator.update from d_body fused in), the solver
+// launch when a robot is due, the post kernel
+static int ctrl_tick(mpc_ctrl *c, const float *d_dof, const float *d_est, const float *d_body, const float *d_cmd, float *d_torques, hipStream_t st) {
   const int n = c->n, blocks4 = (4 * n + kCtrlThreads - 1) / kCtrlThreads;      // (ctrl_pre / ctrl_post: one lane per leg)
   bool any_due = true;
   if (c->mirror_valid) {   // ConvexMPCLocomotion.run: iterationCounter += 1, MPC update when it is a multiple of iterationsBetweenMPC
@@ -632,7 +717,9 @@ int mpc_ctrl_step(mpc_ctrl *c, const float *d_dof, const float *d_est, const flo
     any_due = false;
     for (int r = 0; r < n; ++r) any_due |= (++c->h_iter[r] % c->cp.iters_between_mpc) == 0;
   }
-  hipLaunchKernelGGL(ctrl_pre_kernel, dim3(blocks4), dim3(kCtrlThreads), 0, st, n, c->d_state, c->d_rc, c->gt, c->cp, d_dof, d_est, d_cmd, c->d_rec, c->d_active);
+  if (d_est) hipLaunchKernelGGL(ctrl_pre_kernel, dim3(blocks4), dim3(kCtrlThreads), 0, st, n, c->d_state, c->d_rc, c->gt, c->cp, d_dof, d_est, d_cmd, c->d_rec, c->d_active);
+  else hipLaunchKernelGGL(ctrl_pre_fused_kernel, dim3((n + kFusedRobots - 1) / kFusedRobots), dim3(3 * 64), 0, st, n, c->d_state, c->d_rc, c->gt, c->cp, d_dof, d_body, c->d_est, d_cmd,
+                          c->d_rec, c->d_active);
   HIP_TRY(hipGetLastError());
   mpc_batch *b = c->solver;
   if (any_due) {
@@ -644,13 +731,17 @@ int mpc_ctrl_step(mpc_ctrl *c, const float *d_dof, const float *d_est, const flo
   return MPC_OK;
 }
 
+int mpc_ctrl_step(mpc_ctrl *c, const float *d_dof, const float *d_est, const float *d_cmd, float *d_torques, void *stream) {
+  if (!c || !d_dof || !d_est || !d_cmd || !d_torques) return fail(MPC_E_ARG, "mpc_ctrl_step: bad argument");
+  DeviceGuard guard_(c->solver->device);
+  return ctrl_tick(c, d_dof, d_est, nullptr, d_cmd, d_torques, reinterpret_cast<hipStream_t>(stream));
+}
+
 int mpc_ctrl_run(mpc_ctrl *c, const float *d_dof, const float *d_body, const float *d_cmd, float *d_torques, void *stream) {
   if (!c || !d_dof || !d_body || !d_cmd || !d_torques) return fail(MPC_E_ARG, "mpc_ctrl_run: bad argument");
   DeviceGuard guard_(c->solver->device);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(estimator_kernel, dim3((c->n + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, st, c->n, c->d_state, d_body, c->d_est);
-  HIP_TRY(hipGetLastError());
-  return mpc_ctrl_step(c, d_dof, c->d_est, d_cmd, d_torques, stream);
+  return ctrl_tick(c, d_dof, nullptr, d_body, d_cmd, d_torques, st);
 }
 
 int mpc_ctrl_reset(mpc_ctrl *c, const int *ids, int k, void *stream) {

@@ -198,6 +198,7 @@ __global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES
 #ifndef MPC_POLISH_MIN_WAVES
 #define MPC_POLISH_MIN_WAVES MPC_SOLVE_MIN_WAVES_WIDE
 #endif
+#if MPC_SPLIT_JOBS
 template <int H>
 __global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES : MPC_SOLVE_MIN_WAVES_WIDE)) void mpc_admm_jobs_kernel(
     const RobotModel *__restrict__ models, double *__restrict__ state, const double *__restrict__ qp, double *__restrict__ sc,
@@ -290,6 +291,7 @@ __global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES
     if (MPC_PROFILE_SUB == 8 && prof && threadIdx.x == 0) MPC_GST(prof + (size_t)e * kProfLen + 2, (long long)(sv.t_start - tf0));
   }
 }
+#endif
 
 // Workgroup -> robot order for the solve kernel of THIS launch: robots sorted by the shader cycles their previous solve took,
 // longest first.  Runs as one extra workgroup of the assembly kernel (blockIdx.x == 0), i.e. hidden behind the assembly.
@@ -387,13 +389,15 @@ int launch(const LaunchArgs &a) {
   else if (a.job_slots > 0) {   // persistent workgroups, ADMM and polish as separate jobs (h = 16: 2.68 -> 2.28 ms, h = 20: 3.36 -> 2.78 ms per 4096 robots)
     int slots = Cfg<H>::TW <= 64 || (H == 10 && MPC_SPLIT_H10) ? a.job_slots : a.job_slots / 2;         // (multi-wave workgroups: two per CU; the two-wave split of h = 10: four)
     if (slots < 1) slots = 1;
-    if (MPC_SPLIT_JOBS && Cfg<H>::TW > 64) {
+#if MPC_SPLIT_JOBS
+    if (Cfg<H>::TW > 64) {
       hipLaunchKernelGGL((mpc_admm_jobs_kernel<H>), dim3(a.n < slots ? a.n : slots), dim3(Cfg<H>::TW), 0, a.stream, a.models, a.state, a.qp, a.sc, a.forces, a.info, a.prof, a.order,
                          a.sched, a.ready, a.max_iter);
       const int pslots = MPC_POLISH_MIN_WAVES == 1 ? (slots + 1) / 2 : slots;
       hipLaunchKernelGGL((mpc_polish_jobs_kernel<H>), dim3(a.n < pslots ? a.n : pslots), dim3(Cfg<H>::TW), 0, a.stream, a.models, a.state, a.qp, a.sc, a.forces, a.info, a.prof, a.order,
                          a.sched, a.ready, a.max_iter);
     } else
+#endif
     hipLaunchKernelGGL((mpc_solve_jobs_kernel<H>), dim3(a.n < slots ? a.n : slots), dim3(Cfg<H>::TW), 0, a.stream, a.models, a.state, a.qp, a.sc, a.forces, a.info, a.prof, a.order,
                        a.sched, a.ready, a.max_iter);
   }

@@ -9,7 +9,7 @@
 set -u
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 MODE=${1:-full}
 mkdir -p $ROOT/gpurun_out
 cd $ROOT
@@ -30,3 +30,4 @@ for hc in "10:2" "16:4" "20:5"; do
   PMC_TAG=${TAG}_pmc_h$H PMC_FLAGS="--config $C --robots 4096" bash tools/pmc_passes.sh > gpurun_out/${TAG}_pmc_h$H.log 2>&1; tail -5 gpurun_out/${TAG}_pmc_h$H.log
 done
 timeout 900 python tools/parity_sweep.py > gpurun_out/${TAG}_parity_sweep.txt 2>&1; grep PARITY_JSON gpurun_out/${TAG}_parity_sweep.txt | sed 's/^PARITY_JSON //' > gpurun_out/${TAG}_parity_sweep.json; cut -c1-300 gpurun_out/${TAG}_parity_sweep.json
+timeout 600 python tools/controller_parity.py > gpurun_out/${TAG}_controller_parity.txt 2>&1; grep CONTROLLER_PARITY_JSON gpurun_out/${TAG}_controller_parity.txt | sed 's/^CONTROLLER_PARITY_JSON //' > gpurun_out/${TAG}_controller_parity.json; cut -c1-300 gpurun_out/${TAG}_controller_parity.json
