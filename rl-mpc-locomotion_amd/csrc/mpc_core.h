@@ -68,7 +68,8 @@ typedef double mpc_double2 __attribute__((ext_vector_type(2)));
 //   MPC_NT_H16 / MPC_NT_H20   dense-P tiles per thread of the prep kernel at h = 16 / 20
 //   MPC_PIN_MASK              live-range split points of the prep kernel's tile registers
 //   MPC_PROW_SKEW             1: pivot rows of the solve kernel 8 bytes off the 16-byte grid
-//   MPC_PART_ROWMAJOR         1: partial products of the solve kernel's tile mat-vec as [row][slot] (0: [slot][row])
+//   MPC_PART_ROWMAJOR_MAXT    the largest workgroup that keeps the partial products of the solve kernel's tile mat-vec as [row][slot] (else [slot][row]);
+//   MPC_PART_PAD              extra doubles per row of the [row][slot] layout
 //   MPC_QUAD_SCATTER          1: the per-step wrench sums as a quad reduce-scatter (0: all-sum of all six, then a select)
 //   MPC_GS_FORM               1: Shared::Gf holds G_f S_f^-1 and WThread::b holds S^-1 b (one 3 x 3 product less per ADMM iteration)
 #ifndef MPC_GS_FORM
@@ -83,8 +84,12 @@ typedef double mpc_double2 __attribute__((ext_vector_type(2)));
 #endif
 #define MPC_FOOT0(H, MTW) (((H) == 12 || (H) == 16 || ((H) == 10 && MPC_SPLIT_H10)) ? (((MTW) + 3) / 4) * 4 : 0)
 #endif
-#ifndef MPC_PART_ROWMAJOR
-#define MPC_PART_ROWMAJOR 1
+#ifndef MPC_PART_ROWMAJOR_MAXT
+#define MPC_PART_ROWMAJOR_MAXT 64
+#endif
+#define MPC_PART_ROWMAJOR(T) ((T) <= MPC_PART_ROWMAJOR_MAXT)
+#ifndef MPC_PART_PAD
+#define MPC_PART_PAD 0
 #endif
 #ifndef MPC_QUAD_SCATTER
 #define MPC_QUAD_SCATTER 1

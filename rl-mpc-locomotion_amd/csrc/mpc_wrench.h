@@ -191,7 +191,7 @@ struct Shared {
   using C = Cfg<H>;
   static constexpr int RW = ((C::NF + 1) & ~1);                         // row stride of the residual scratch
   static constexpr int NRED = 21;                                       // residual / certificate reductions (Solver::residuals)
-  static constexpr int PARTLEN_A0 = C::GW * C::NPW, PARTLEN_A1 = C::NW * ((C::GW + 1) & ~1);   // [slot][row] / [row][slot] (even row stride) partials
+  static constexpr int PARTLEN_A0 = C::GW * C::NPW, PARTLEN_A1 = C::NW * (((C::GW + 1) & ~1) + MPC_PART_PAD);   // [slot][row] / [row][slot] (even row stride) partials
   static constexpr int PARTLEN_A = PARTLEN_A0 > PARTLEN_A1 ? PARTLEN_A0 : PARTLEN_A1, PARTLEN_B = NRED * RW;
   static constexpr int PARTLEN_AB = PARTLEN_A > PARTLEN_B ? PARTLEN_A : PARTLEN_B, PARTLEN_C = MfmaSweepCfg<H>::on ? 16 * MfmaSweepCfg<H>::MP : 0;   // (C: sweep_all_mfma's stage, a tile row of the matrix)
   static constexpr int PARTLEN = PARTLEN_AB > PARTLEN_C ? PARTLEN_AB : PARTLEN_C;
@@ -431,39 +431,43 @@ struct Solver {
             ar[aa] += m * vc[bb];
             ac[bb] += m * vr[aa];
           }
-#if MPC_PART_ROWMAJOR
-        // [row][slot]: the G partials of a row are contiguous, and sum_parts fetches them as G / 2 ds_read_b128 (the [slot][row] layout
-        // costs the reader G ds_read_b64; the writer's stride-G stores pair up as ds_write2_b64 either way)
-        double *pd = s.part + (TS * t.ti) * GP + t.tj, *pt = s.part + (TS * t.tj) * GP + t.ti;
+        if constexpr (kPartRowMajor) {
+          // [row][slot]: the G partials of a row are contiguous, and sum_parts fetches them as G / 2 ds_read_b128 (the [slot][row] layout
+          // costs the reader G ds_read_b64; the writer's stride-G stores pair up as ds_write2_b64 either way)
+          double *pd = s.part + (TS * t.ti) * GP + t.tj, *pt = s.part + (TS * t.tj) * GP + t.ti;
 #pragma unroll
-        for (int aa = 0; aa < TS; ++aa) pd[aa * GP] = ar[aa];
-        if (!t.dia) {
+          for (int aa = 0; aa < TS; ++aa) pd[aa * GP] = ar[aa];
+          if (!t.dia) {
 #pragma unroll
-          for (int bb = 0; bb < TS; ++bb) pt[bb * GP] = ac[bb];
+            for (int bb = 0; bb < TS; ++bb) pt[bb * GP] = ac[bb];
+          }
+        } else {
+          double *pd = s.part + t.tj * NP + TS * t.ti, *pt = s.part + t.ti * NP + TS * t.tj;
+#pragma unroll
+          for (int aa = 0; aa < TS; ++aa) pd[aa] = ar[aa];
+          if (!t.dia) {
+#pragma unroll
+            for (int bb = 0; bb < TS; ++bb) pt[bb] = ac[bb];
+          }
         }
-#else
-        double *pd = s.part + t.tj * NP + TS * t.ti, *pt = s.part + t.ti * NP + TS * t.tj;
-#pragma unroll
-        for (int aa = 0; aa < TS; ++aa) pd[aa] = ar[aa];
-        if (!t.dia) {
-#pragma unroll
-          for (int bb = 0; bb < TS; ++bb) pt[bb] = ac[bb];
-        }
-#endif
       }
     });
   }
-  static constexpr int GP = (G + 1) & ~1;   // row stride of the [row][slot] layout: even, so that a row starts on a 16-byte boundary
+  // The partial products of the tile mat-vec in LDS: [row][slot] in the single-wavefront kernels (h <= 10), [slot][row] in the multi-wave ones --
+  // at G = 16 a row of the [row][slot] layout is 128 bytes, the readers' 16-byte loads of neighbouring rows fall on the same banks (38 % of
+  // the h = 16 kernel's LDS cycles were bank conflicts) and the plain layout is 6 % faster end to end (profiles/r05_ab_long_horizon_lds_layout.txt)
+  static constexpr bool kPartRowMajor = MPC_PART_ROWMAJOR(T);
+  static constexpr int GP = ((G + 1) & ~1) + MPC_PART_PAD;   // row stride of the [row][slot] layout: even, so that a row starts on a 16-byte boundary
   static_assert(NW * GP <= Sh::PARTLEN, "the partial products must fit Shared::part");
   static MPC_HD double sum_parts(const Sh &s, int row) {   // fixed pairwise order
     double v[GP];
-#if MPC_PART_ROWMAJOR
+    if constexpr (kPartRowMajor) {
 #pragma unroll
-    for (int k = 0; k < GP; k += 2) MPC_LDS_LOAD128(s.part + row * GP + k, v[k], v[k + 1]);
-#else
+      for (int k = 0; k < ((G + 1) & ~1); k += 2) MPC_LDS_LOAD128(s.part + row * GP + k, v[k], v[k + 1]);
+    } else {
 #pragma unroll
-    for (int k = 0; k < G; ++k) v[k] = MPC_LDS_LOAD64(s.part + k * NP + row);
-#endif
+      for (int k = 0; k < G; ++k) v[k] = MPC_LDS_LOAD64(s.part + k * NP + row);
+    }
 #pragma unroll
     for (int w = 1; w < G; w *= 2)
 #pragma unroll

@@ -38,3 +38,19 @@ def test_gelsd43_matches_scipy_live():
     x, _ = _solve(A)
     want = np.stack([linalg.lstsq(a, np.ones(4, dtype=np.float32))[0] for a in A])
     assert np.array_equal(x, want)
+
+
+@pytest.mark.gpu
+def test_gelsd43_on_the_device_matches_the_known_answers():
+    """The same header compiled for gfx950 (hipcc, -ffp-contract=off as csrc/Makefile compiles the controller) and run on the GPU over the
+    known-answer matrices: bit-identical to the reference's answers, with and without the stage records (tests/device/run_gelsd43_device.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not installed")
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "device", "run_gelsd43_device.py")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "device vs reference answers: 0 of" in out.stdout, out.stdout
+    assert "with / without the stage record: 0 entries differ" in out.stdout, out.stdout
