@@ -301,7 +301,7 @@ def test_full_size_properties_long_horizons(config, h, n):
     assert grf_relerr(fa[pick], fr, first_step_only=False).max() < GRF_RTOL
 
 
-@pytest.mark.parametrize("name", ["solver_h10_cfg3", "solver_h10_edge", "solver_h16_cfg4"])
+@pytest.mark.parametrize("name", ["solver_h10_cfg3", "solver_h10_edge", "solver_h16_cfg4", "solver_h20_cfg5"])
 def test_assembly_and_scaling_records_match_the_oracle(name):
     """the QP the prep kernel builds -- q, l, u, the cone block, and P through its wrench form
     P = BB^T Theta BB + alpha I (B6, th1, th2 of the QP record) -- against the oracle's restated mpc_osqp.cc assembly, element by
@@ -339,6 +339,14 @@ def test_assembly_and_scaling_records_match_the_oracle(name):
         np.testing.assert_allclose(sc[r, :N], st["D"], rtol=1e-11)
         np.testing.assert_allclose(sc[r, N:N + M], st["E"], rtol=1e-11)
         assert abs(sc[r, 2 * N + 3 * M + 60 * h] / st["c"] - 1) < 1e-11       # D[N] E[M] q_s[N] A_s[15 * 4 h] l_s[M] u_s[M] c 1/c job[2]
+        # ... and what the solve left for the next call (a13): OSQP's scaled iterates and rho.  This bounds the drift of the iteration against
+        # the vendored library -- the scaled cone block is formed as (a E) D from the final scalings here, ten per-pass roundings there
+        # (mpc_core.h: scaled_cone_entry) -- on top of the equal decisions: a few ulp in A_s stay a few 1e-9 in the iterates
+        mine = gpu.get_state()[r]
+        assert abs(mine[2 * N + 2 * M] / st["rho"] - 1) < 1e-6      # (an adopted rho is a ratio of residual norms: equal to ~1e-10, not bit for bit)
+        for name_, lo, hi in (("x", 0, N), ("z", N, N + M), ("y", N + M, N + 2 * M)):
+            ref_v = st[name_]
+            assert np.abs(mine[lo:hi] - ref_v).max() <= 2e-6 * max(np.abs(ref_v).max(), 1e-12), (name_, r)
 
 
 def test_non_solved_statuses_match_osqp():
