@@ -103,6 +103,42 @@ def test_emulated_full_run_matches_reference_python(name):
     assert compared.mean() >= 0.97                      # (one arccos sample early in a 48-tick golden of 9 robots costs 1 / 9 of it)
 
 
+class _Live(dict):
+    """a live run of the reference in the shape of a loaded golden"""
+    files = property(lambda self: list(self.keys()))
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("horizon,seed", [(10, 101), (16, 102), (20, 103)])
+def test_emulated_full_run_matches_the_live_reference(horizon, seed):
+    """Volume beyond the committed fixtures, where the reference tree is mounted (the build container): the reference Python itself is run
+    here -- 84 robots (seven gaits x three robot types x four), 24 ticks, sloped-ground estimate in the loop, horizonLength patched for
+    h = 16 / 20 exactly as for the goldens (tests/golden/make_golden_controller.py) -- and the host emulation of controller.run is held to it
+    like to a golden: ground normal bit-identical on every tick, torques inside TAU_RTOL wherever the estimator sample is the reference's."""
+    import os
+    import sys
+    if not os.path.isdir("/root/reference/MPC_Controller"):
+        pytest.skip("reference not mounted")
+    from tests.emu.emu import EmuLocomotion, estimator_update
+    argv, sys.argv = sys.argv, ["make_golden_controller"]
+    try:
+        from tests.golden import make_golden_controller as M
+        g = _Live(M.run_case(None, 84, 24, seed, False, horizon=horizon, gait_cycle=(0, 1, 2, 3, 5, 6, 7)))
+    finally:
+        sys.argv = argv
+    g = _Live({k: np.asarray(v) for k, v in g.items()})
+
+    def step(ctl, g, k):
+        prev = g["normal"][k - 1] if k else np.tile(np.array([0, 0, 1], np.float32), (g["body"].shape[1], 1))
+        tau = ctl.run(g["dof"][k], g["body"][k], g["cmd"][k])
+        return tau, estimator_update(g["body"][k], prev), ctl.estimate()[0]
+    errs, compared, normal_bad = _full_run(g, lambda g: EmuLocomotion(g["robot_type"], g["gait_id"], horizon=horizon, flat_ground=False), step)
+    print(f"live reference, h = {horizon}: compared {compared.mean():.4f} of {compared.size} samples, max torque error {errs.max():.2e}")
+    assert normal_bad == 0
+    assert errs.max() < TAU_RTOL
+    assert compared.mean() >= 0.97
+
+
 def test_gait_tables_match_reference_definition():
     """gait.py's tables against ConvexMPCLocomotion.py:30-56 (restated literally here)."""
     from rl_mpc_locomotion_amd.gait import GAIT_TABLE_10, gait_arrays, mpc_table
