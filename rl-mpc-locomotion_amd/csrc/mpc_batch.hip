@@ -486,8 +486,11 @@ __device__ __forceinline__ void store_leg_fields_no_hist(CtrlState &d, const Ctr
   }
   for (int c = 9 * leg; c < 9 * leg + 9; ++c) d.J[c] = s.J[c];
 }
+// WITH_POST: a tick on which the host knows that no robot is due for its MPC update (mpc_ctrl::mirror_valid) has no solver launch between the two halves,
+// so wave 0 goes straight on into ctrl_post (swing / stance commands, torque map) with the state it holds: one kernel per tick instead of two.
+template <bool WITH_POST>
 __global__ __launch_bounds__(3 * 64) void ctrl_pre_fused_kernel(int n, CtrlState *st, const RobotConst *rc, GaitTable gt, CtrlParams cp, const float *dof, const float *body,
-                                                               float *est_out, const float *cmd, float *rec, int *active) {
+                                                               float *est_out, const float *cmd, float *rec, int *active, float *torques) {
   __shared__ float sh_est[kFusedRobots][kEstLen];
   __shared__ float sh_fp[kFusedRobots][12];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r0 = blockIdx.x * kFusedRobots;
@@ -542,6 +545,7 @@ __global__ __launch_bounds__(3 * 64) void ctrl_pre_fused_kernel(int n, CtrlState
   for (int c = 0; c < 12; ++c) s.foot_positions[c] = sh_fp[rl][c];
   for (int c = 0; c < kEstLen; ++c) e[c] = sh_est[rl][c];
   ctrl_pre_rest(s, k, gt, cp, e, cmd + (size_t)r * 16, rec + (size_t)r * (56 + 4 * cp.horizon), leg, leg + 1, leg == 0, false);
+  if constexpr (WITH_POST) ctrl_post(s, k, nullptr, 0, torques + (size_t)r * 12, leg, leg + 1);      // (do_solve is 0 for every robot: no forces are read)
   quad_reads_done();
   if (cp.flat_ground) store_leg_fields(st[r], s, leg);      // (no fit on flat ground: the history is this wave's, set once at the first run)
   else store_leg_fields_no_hist(st[r], s, leg);
@@ -718,8 +722,14 @@ static int ctrl_tick(mpc_ctrl *c, const float *d_dof, const float *d_est, const 
     for (int r = 0; r < n; ++r) any_due |= (++c->h_iter[r] % c->cp.iters_between_mpc) == 0;
   }
   if (d_est) hipLaunchKernelGGL(ctrl_pre_kernel, dim3(blocks4), dim3(kCtrlThreads), 0, st, n, c->d_state, c->d_rc, c->gt, c->cp, d_dof, d_est, d_cmd, c->d_rec, c->d_active);
-  else hipLaunchKernelGGL(ctrl_pre_fused_kernel, dim3((n + kFusedRobots - 1) / kFusedRobots), dim3(3 * 64), 0, st, n, c->d_state, c->d_rc, c->gt, c->cp, d_dof, d_body, c->d_est, d_cmd,
-                          c->d_rec, c->d_active);
+  else if (!any_due) {      // nobody is due (host mirror): the whole tick is one kernel
+    hipLaunchKernelGGL(ctrl_pre_fused_kernel<true>, dim3((n + kFusedRobots - 1) / kFusedRobots), dim3(3 * 64), 0, st, n, c->d_state, c->d_rc, c->gt, c->cp, d_dof, d_body, c->d_est,
+                       d_cmd, c->d_rec, c->d_active, d_torques);
+    HIP_TRY(hipGetLastError());
+    return MPC_OK;
+  }
+  else hipLaunchKernelGGL(ctrl_pre_fused_kernel<false>, dim3((n + kFusedRobots - 1) / kFusedRobots), dim3(3 * 64), 0, st, n, c->d_state, c->d_rc, c->gt, c->cp, d_dof, d_body, c->d_est,
+                          d_cmd, c->d_rec, c->d_active, (float *)nullptr);
   HIP_TRY(hipGetLastError());
   mpc_batch *b = c->solver;
   if (any_due) {
