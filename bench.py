@@ -242,7 +242,7 @@ def run_leg_ctrl(cfg_id, n, h, K, W, dev, rank, world, dist, repeats=1, emulate=
         fa, fs = algorithmic_flops(h, contact, it, nf)
         flops += fs; asm_flops += fa
         exec_flops += executed_flops(h, it, nf)
-    return dict(wl=_Model(cs.robot_type, CTRL_DT, 1e-5), batches=recs, solver=ctl, block_s=np.array(block_s), elapsed=float(np.median(block_s)), prep_ms=prep_ms,
+    return dict(wl=_Model(cs.robot_type, CTRL_DT, 1e-5), batches=recs, solver=ctl, block_s=np.array(block_s), elapsed=float(np.median(block_s)), prep_ms=prep_ms, first_dof=host[W][0], robot_type=cs.robot_type,
                 solve_ms=solve_ms, info=info, first_forces=first_forces, flops_per_launch=flops / K, prep_flops_per_launch=asm_flops / K, exec_flops=exec_flops / K)
 
 
@@ -465,8 +465,9 @@ def main():
         # the same unit at the reference's own cadence (controller.run every 10 ms, MPC update on every 2nd call): two controller ticks per control step
         out["control_steps_per_s_incl_torque_map"] = out["control_loop"]["control_steps_per_s_incl_torque_map"]
     if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
-        out["cpu_baseline"] = cpu_baseline(m["wl"], m["batches"], W, h, gpu_first_forces=m["first_forces"])
+        out["cpu_baseline"] = cpu_baseline(m["wl"], m["batches"], W, h, gpu_first_forces=m["first_forces"], first_dof=m.get("first_dof"), robot_type=m.get("robot_type"))
         out["max_grf_err_vs_osqp"] = out["cpu_baseline"].pop("_gpu_err", None)
+        out["max_abs_dtau_vs_osqp_Nm"] = out["cpu_baseline"].pop("_gpu_dtau", None)      # the torque map J^T (f_gpu - f_osqp) of the first timed step, sampled robots
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
@@ -772,7 +773,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(wl, batches, W, h, sample=2048, steps=4, gpu_first_forces=None):
+def cpu_baseline(wl, batches, W, h, sample=2048, steps=4, gpu_first_forces=None, first_dof=None, robot_type=None):
     """The reference path (oracle/_ref: restated mpc_osqp.cc assembly + the vendored OSQP) timed on the
     host cores on a bounded sample of the same workload: the first `sample` robots, cold solve +
     `steps` timed warm solves (the same batches the GPU warmed up / timed on); all granted cores, then one core
@@ -791,11 +792,17 @@ def cpu_baseline(wl, batches, W, h, sample=2048, steps=4, gpu_first_forces=None)
         if s == 0:
             fr0 = fr.copy()
     dt = time.perf_counter() - t0
-    err = None
+    err = dtau_max = None
     if gpu_first_forces is not None:
         ok = ~np.isnan(fr0[:, 0])
         g = gpu_first_forces[:sample]
         err = float((np.abs(g[ok, :12] - fr0[ok, :12]).max(1) / np.maximum(np.abs(fr0[ok, :12]).max(1), 1.0)).max())
+        if first_dof is not None:      # "also report max-abs delta tau on the 12 torques": the stance legs' torque is J^T f_ff (LegController.py:108-132)
+            from rl_mpc_locomotion_amd.synthetic import leg_jacobian
+            J = leg_jacobian(np.asarray(first_dof)[:sample, :, 0].reshape(sample, 4, 3), np.asarray(robot_type)[:sample])
+            df = (g[:, :12] - fr0[:, :12]).reshape(sample, 4, 3)
+            dtau = np.einsum("nlij,nli->nlj", J, df)
+            dtau_max = float(np.abs(dtau[ok]).max())
     # one core: SURVEY 8(d)(i)
     s1 = max(64, sample // 8)
     ref1 = RefBatch(wl.mass[:s1], wl.inertia_diag[:s1], h, wl.dt_mpc, wl.alpha)
@@ -805,7 +812,7 @@ def cpu_baseline(wl, batches, W, h, sample=2048, steps=4, gpu_first_forces=None)
     for s in range(steps):
         ref1.solve(batches[W + s][:s1], nthreads=1)
     dt1 = time.perf_counter() - t1
-    out = {"_gpu_err": err, "value": sample * steps / dt, "unit": "control steps/s", "cores": cores, "kind": "reference",
+    out = {"_gpu_err": err, "_gpu_dtau": dtau_max, "value": sample * steps / dt, "unit": "control steps/s", "cores": cores, "kind": "reference",
            "sample": f"first {sample} robots of the workload, {W} warm-up + {steps} timed warm-started solves each, "
                      f"one OSQP workspace per robot, static partition over {cores} threads",
            "one_core": {"value": s1 * steps / dt1, "cores": 1, "sample": f"first {s1} robots, same sequence, one thread"}}

@@ -38,6 +38,30 @@ def leg_fk(q, robot_type):
     return p.astype(np.float32)
 
 
+def leg_jacobian(q, robot_type):
+    """[N,4,3,3] leg Jacobians, LegController.computeLegJacobianAndPosition (LegController.py:155-171): the torque map of
+    LegController.updateCommand is tau_leg = J^T (f_ff + ...) (LegController.py:108-132)."""
+    q = np.asarray(q, dtype=np.float64)
+    rt = np.asarray(robot_type)
+    dy = ROBOT_TABLE64[rt, COL_ABAD][:, None] * SIDE_SIGN[None, :].astype(np.float64)
+    dz1 = -ROBOT_TABLE64[rt, COL_HIP][:, None]
+    dz2 = -ROBOT_TABLE64[rt, COL_KNEE][:, None]
+    s1, s2, s3 = np.sin(q[..., 0]), np.sin(q[..., 1]), np.sin(q[..., 2])
+    c1, c2, c3 = np.cos(q[..., 0]), np.cos(q[..., 1]), np.cos(q[..., 2])
+    c23 = c2 * c3 - s2 * s3
+    s23 = s2 * c3 + c2 * s3
+    J = np.zeros(q.shape[:2] + (3, 3))
+    J[..., 1, 0] = -dy * s1 - dz2 * c1 * c23 - dz1 * c1 * c2
+    J[..., 2, 0] = -dz2 * s1 * c23 + dy * c1 - dz1 * c2 * s1
+    J[..., 0, 1] = dz2 * c23 + dz1 * c2
+    J[..., 1, 1] = dz2 * s1 * s23 + dz1 * s1 * s2
+    J[..., 2, 1] = -dz2 * c1 * s23 - dz1 * c1 * s2
+    J[..., 0, 2] = dz2 * c23
+    J[..., 1, 2] = dz2 * s1 * s23
+    J[..., 2, 2] = -dz2 * c1 * s23
+    return J
+
+
 def hip_locations(robot_type):
     """[N,4,3] float32 hip locations, Quadruped.getHipLocation (Quadruped.py:96-107)."""
     rt = np.asarray(robot_type)

@@ -162,7 +162,7 @@ def test_gait_and_fk_match_reference_modules():
     from MPC_Controller.common.Quadruped import Quadruped, RobotType as RefType
     from MPC_Controller.common.LegController import LegController
     from rl_mpc_locomotion_amd.gait import GAIT_TABLE_10, mpc_table
-    from rl_mpc_locomotion_amd.synthetic import leg_fk
+    from rl_mpc_locomotion_amd.synthetic import leg_fk, leg_jacobian
     for gid, (o, d) in GAIT_TABLE_10.items():
         g = OffsetDurationGait(10, np.array(o, dtype=np.float32), np.array(d, dtype=np.float32), "x")
         for it in range(0, 23):
@@ -176,6 +176,7 @@ def test_gait_and_fk_match_reference_modules():
             lc.datas[leg].q[:, 0] = q[leg]
             lc.computeLegJacobianAndPosition(leg)
             assert np.array_equal(lc.datas[leg].p[:, 0], leg_fk(q[None].astype(np.float32), [ours])[0, leg])
+            assert np.allclose(lc.datas[leg].J, leg_jacobian(q[None].astype(np.float32), [ours])[0, leg], atol=1e-6)      # (bench.py's torque-map error figure)
 
 
 @pytest.mark.gpu
