@@ -413,6 +413,11 @@ def main():
         "roofline": {"bound": "vector_fp64", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_parts": traffic_parts,
+                     # "and rocprof-measured HBM GB/s / 8 TB/s, side by side": the fabric-side bytes of a step over the step's two solver kernels
+                     "hbm": None if traffic is None else {"gb_per_s": traffic / ((prep_ms + solve_ms).mean() * 1e-3) / 1e9, "peak_gb_per_s": 8000.0,
+                                                           "frac": traffic / ((prep_ms + solve_ms).mean() * 1e-3) / 8e12,
+                                                           "algorithmic_gb_per_s": 47.7e6 * (n / 4096.0) / ((prep_ms + solve_ms).mean() * 1e-3) / 1e9,
+                                                           "note": "<< 1 by design (SURVEY 8d: the path is not HBM-bound); the bytes are an upper bound on HBM traffic (Infinity-Cache hits included)"},
                      "traffic_note": "HBM-side bytes per step, BOTH kernels (prep + solve), from rocprofv3 PMC (profiles/*_pmc_summary*_h10.json, measured offline on this command); "
                                      "algorithmic bytes per step: input 384 B + forces 960 B + state 2 x 5136 B per robot = 47.7 MB",
                      "note": "vector-FP bound, no MFMA / HBM roofline applies (SURVEY 8d): algorithmic flops (n_r formula, solve-kernel share) / "
