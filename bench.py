@@ -464,6 +464,7 @@ def main():
     if not args.no_control_loop and world == 1:      # secondary legs: single-GPU runs only
         out["control_loop"] = control_loop_leg(n, h, dev)
         out["control_loop_with_resets"] = control_loop_leg(n, h, dev, reset_every=37)
+        out["control_loop_mixed_phases"] = control_loop_leg(n, h, dev, reset_every=37, mixed=True)
         out["control_loop_exact"] = control_loop_leg(n, h, dev, solver="exact")      # the reference AS SHIPPED passes mpc.QPOASES (ConvexMPCLocomotion.py:108)
         out["control_loop_exact"]["note"] = "the same loop with the controllers' ConvexMpc objects in the exact-optimum mode (the reference's qpOASES branch, what its Python selects)"
         out["policy"] = policy_leg(n, dev)
@@ -700,12 +701,15 @@ def sharded_loop_leg(cfg_id, n_total, h, dev, dist, ticks=8, warm=3, emulate=Fal
     return out
 
 
-def control_loop_leg(n, h, dev, ticks=40, warm=10, reset_every=0, solver="osqp"):
+def control_loop_leg(n, h, dev, ticks=40, warm=10, reset_every=0, solver="osqp", mixed=False):
     """Secondary figure (NOT `value`): robot-ticks/s of the whole controller.run seam on device tensors --
     state estimator + leg kinematics + gait / foot placement + the MPC solve on every second tick (the
     reference's cadence, RobotRunnerMin.py:21-22) + swing / stance commands + joint torques.
     reset_every > 0: every that many ticks 1/64 of the robots are reset through a DEVICE tensor of indices, as VecTask.reset_idx does
-    (RL_Environment/tasks/aliengo.py:321-334) -- after which the robots' MPC phases are no longer aligned and every tick has solves due."""
+    (RL_Environment/tasks/aliengo.py:321-334) -- after which the robots' MPC phases are no longer aligned and every tick has solves due.
+    mixed: a random HALF of the robots is reset after an odd tick of the warm-up, so the two MPC phases hold ~n/2 robots each -- where a long training
+    run with resets at arbitrary steps ends up (the 1/64 case above is the unfavourable start of that drift: a 64-robot job list costs a tick one robot's whole
+    solve latency, a 2048-robot list costs it half a full launch)."""
     import torch
     from rl_mpc_locomotion_amd.locomotion import BatchedLocomotion
     from rl_mpc_locomotion_amd.synthetic import TickStream
@@ -718,6 +722,8 @@ def control_loop_leg(n, h, dev, ticks=40, warm=10, reset_every=0, solver="osqp")
         ctl.run(*ins[k])
         if reset_every and (k + 1) % 7 == 0:
             ctl.reset(ids[k])
+        if mixed and k == 4:
+            ctl.reset(torch.from_numpy(rng.choice(n, n // 2, replace=False).astype(np.int32)).to(dev))
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for k in range(warm, warm + ticks):
@@ -736,6 +742,8 @@ def control_loop_leg(n, h, dev, ticks=40, warm=10, reset_every=0, solver="osqp")
         out["reset_every_ticks"] = reset_every
         out["note"] = ("the same loop with reset(env_ids on the device) of n/64 robots every %d ticks (and a few during warm-up, so the robots' MPC phases "
                        "are mixed: solves are due on every tick)" % reset_every)
+    if mixed:
+        out["note"] += "; the two MPC phases hold ~half of the robots each (a random half was reset after an odd tick of the warm-up)"
     return out
 
 
