@@ -10,7 +10,7 @@
 //   (tauq(1) = tauq(3) = taup(2) = 0 by structure)  ->  SORM2R (Q_b^T b)  ->  SLALSD (n <= smlsiz: scale by the max-norm, SLASDQ =
 //   SBDSQR with VT and C = b followed by a re-sort into increasing order, threshold rcond * sigma_max, VT^T (c / sigma))  ->  SORML2 (P b).
 //
-// BLAS kernel facts pinned by experiment against the library (tests/test_gelsd43.py re-checks the end result against scipy when it
+// BLAS kernel facts pinned by experiment against the library (tools/gelsd43/pin.py, output: profiles/r05_gelsd43_pinning.txt; tests/test_gelsd43.py re-checks the end result against scipy when it
 // is importable):  SNRM2 accumulates in double and rounds once;  SGEMV^T sums  m = 4, n = 2: (p0 + p1) + (p2 + p3);  m = 4, n = 1:
 // ((p0 + p1) + p2) + p3;  m = 3: fma(a2, x2, fma(a0, x0, a1 x1));  m = 2: fma(a0, x0, a1 x1);  SGER / SAXPY: a += (alpha y_j) x_i
 // as one fma;  SROT and SGEMM: see rot() / the VT^T product below.
