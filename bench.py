@@ -13,7 +13,8 @@ specification.)
 
 Workloads (BASELINE.json configs):
   --config 2 (default, the configuration the metric is quoted on): 4096 Aliengo per GPU, trot, horizon 10, flat terrain; weak scaling.
-  --config 3: 4096 robots per GPU, {Go1, A1, Aliengo} mixed, trot / walk / bound, horizon 10; weak scaling.
+  --config 3: 4096 robots per GPU, {Go1, A1, Aliengo} mixed, trot / walk / bound CYCLING every 50 steps (use --steps > 40 to time a switch;
+              `secondary.config3` of the default run is 110 steps of it), horizon 10; weak scaling.
   --config 4: 32768 Aliengo in total, horizon 16, random terrain normals, sharded over the N ranks; strong scaling.
   --config 5: 65536 Aliengo in total, horizon 20, sharded over the N ranks; strong scaling.
 The K+W input batches are a seeded sequence: step 0 is the cold "osqp_setup" solve, the following ones advance the gait and
@@ -45,7 +46,7 @@ CONFIGS = {
     2: dict(h=10, robots_total=None, robots_per_gpu=4096, scaling="weak",
             what="Aliengo, trot, horizon=10, flat terrain (BASELINE configs[1])"),
     3: dict(h=10, robots_total=None, robots_per_gpu=4096, scaling="weak",
-            what="{Go1, A1, Aliengo} mixed, trot / walk / bound, horizon=10 (BASELINE configs[2])"),
+            what="{Go1, A1, Aliengo} mixed, trot / walk / bound cycling every 50 steps, horizon=10 (BASELINE configs[2])"),
     4: dict(h=16, robots_total=32768, robots_per_gpu=None, scaling="strong",
             what="Aliengo, horizon=16, random terrain normals, 32768 robots sharded over the ranks (BASELINE configs[3])"),
     5: dict(h=20, robots_total=65536, robots_per_gpu=None, scaling="strong",
@@ -148,6 +149,9 @@ class _EmulatedLocomotion:
     def set_iteration(self, it):
         self.e.set_iteration(it)
 
+    def set_gait(self, gait_id):
+        self.e.set_gait(gait_id.numpy() if hasattr(gait_id, "numpy") else gait_id)
+
     def run(self, dof, body, cmd):
         import torch
         return torch.from_numpy(self.e.run(dof.numpy(), body.numpy(), cmd.numpy()))
@@ -200,6 +204,9 @@ def run_leg_ctrl(cfg_id, n, h, K, W, dev, rank, world, dist, repeats=1, emulate=
         assert ctl.iterations_between_mpc == 1
         sync = lambda: torch.cuda.synchronize(dev)
     ctl.enable_timing()
+    # config 3: Parameters.cmpc_gait CYCLES Trot -> Walk -> Bound every 50 steps; the ids of every switch inside the sequence are resident in HBM
+    # before timing and handed over as device tensors (mpc_ctrl_set_gait_device: stream-ordered, no host round trip), inside the timed region when it falls there
+    gaits = {s: torch.from_numpy(cs.gait_at(s)).to(dev) for s in range(W + K) if s == 0 or cs.gait_switch_at(s)} if cs.gait_at(0) is not None else {}
     block_s, prep_ms, solve_ms = [], [], []
     for r in range(R + 1):                       # block R is the untimed replay
         replay = r == R
@@ -207,6 +214,8 @@ def run_leg_ctrl(cfg_id, n, h, K, W, dev, rank, world, dist, repeats=1, emulate=
         ctl.set_iteration(cs.iteration0)
         recs, infos, first_forces = [], [], None
         for s in range(W):
+            if s in gaits:
+                ctl.set_gait(gaits[s])
             ctl.run(*ins[s])
             if replay:
                 recs.append(ctl.solver_record())
@@ -216,6 +225,8 @@ def run_leg_ctrl(cfg_id, n, h, K, W, dev, rank, world, dist, repeats=1, emulate=
         sync()
         t0 = time.perf_counter()
         for s in range(K):
+            if W + s in gaits:
+                ctl.set_gait(gaits[W + s])
             ctl.run(*ins[W + s])
             if replay:
                 recs.append(ctl.solver_record()); infos.append(ctl.solver_info())
@@ -242,7 +253,7 @@ def run_leg_ctrl(cfg_id, n, h, K, W, dev, rank, world, dist, repeats=1, emulate=
         fa, fs = algorithmic_flops(h, contact, it, nf)
         flops += fs; asm_flops += fa
         exec_flops += executed_flops(h, it, nf)
-    return dict(wl=_Model(cs.robot_type, CTRL_DT, 1e-5), batches=recs, solver=ctl, block_s=np.array(block_s), elapsed=float(np.median(block_s)), prep_ms=prep_ms, first_dof=host[W][0], robot_type=cs.robot_type,
+    return dict(gait_switches_timed=sum(1 for s in gaits if s >= W and s > 0), wl=_Model(cs.robot_type, CTRL_DT, 1e-5), batches=recs, solver=ctl, block_s=np.array(block_s), elapsed=float(np.median(block_s)), prep_ms=prep_ms, first_dof=host[W][0], robot_type=cs.robot_type,
                 solve_ms=solve_ms, info=info, first_forces=first_forces, flops_per_launch=flops / K, prep_flops_per_launch=asm_flops / K, exec_flops=exec_flops / K)
 
 
@@ -525,9 +536,24 @@ def secondary_lines(dev, steps=5, warm=2):
     """Single-GPU lines of the other BASELINE configurations at their per-GPU shard sizes (config 3: 4096; config 4: 32768 / 8;
     config 5: 65536 / 8), so that the driver's N = 1 record carries them too.  Not `value`."""
     out = {}
+    # config 3 AS BASELINE STATES IT: three robot types, Trot / Walk / Bound cycling every 50 steps -- 110 timed controller.run steps after 10 warm-up steps, i.e.
+    # across the switches at steps 50 and 100 (parity of exactly this: tests/test_controller.py on controller_h10_cycling, minted from the unmodified reference)
+    m = run_leg_ctrl(3, 4096, 10, 110, 10, dev, 0, 1, None)
+    out["config3"] = {"robots": 4096, "horizon": 10, "steps": 110, "warmup": 10, "gait_switches_inside_the_timed_region": m["gait_switches_timed"], "seam": "ctrl",
+                      "control_steps_per_s": 4096 * 110 / m["elapsed"], "ms_per_step": m["elapsed"] / 110 * 1e3,
+                      "prep_kernel_ms": float(m["prep_ms"].mean()), "solve_kernel_ms": float(m["solve_ms"].mean()), "solved_fraction": float((m["info"][..., 1] == 1).mean()),
+                      "mean_admm_iters": float(m["info"][..., 0].mean()),
+                      "what": CONFIGS[3]["what"] + ": controller.run with every robot due, gait = (idx div 3 + step div 50) mod 3 over {TROT, WALK, BOUND} (SURVEY 8(d)), the "
+                              "ids of each switch handed over as a device tensor (mpc_ctrl_set_gait_device)"}
+    del m
     for cid, n in ((3, 4096), (4, 4096), (5, 8192)):
         h = CONFIGS[cid]["h"]
         m = run_leg(cid, n, h, steps, warm, dev, 0, 1, None)
+        if cid == 3:
+            out["config3_solver_seam"] = {"robots": n, "horizon": h, "steps": steps, "control_steps_per_s": n * steps / m["elapsed"], "ms_per_step": m["elapsed"] / steps * 1e3,
+                                          "what": "config 3's robot / gait mix through the bare compute_contact_forces batch (no controller, no gait switch)"}
+            del m
+            continue
         out[f"config{cid}"] = {"robots": n, "horizon": h, "steps": steps, "control_steps_per_s": n * steps / m["elapsed"],
                                "ms_per_step": m["elapsed"] / steps * 1e3, "prep_kernel_ms": float(m["prep_ms"].mean()),
                                "solve_kernel_ms": float(m["solve_ms"].mean()), "solved_fraction": float((m["info"][..., 1] == 1).mean()),

@@ -197,6 +197,11 @@ int mpc_ctrl_run(mpc_ctrl *c, const float *d_dof, const float *d_body, const flo
 int mpc_ctrl_reset(mpc_ctrl *c, const int *ids, int k, void *stream);      /* HOST ids; NULL = all */
 int mpc_ctrl_reset_device(mpc_ctrl *c, const int *d_ids, int k, void *stream);   /* DEVICE ids (env_ids tensor), stream-ordered */
 int mpc_ctrl_set_gait(mpc_ctrl *c, const int *gait_id, void *stream);       /* HOST [n] */
+/* ... the same from a DEVICE array [n] int32, stream-ordered, no host round trip: ConvexMPCLocomotion.run re-reads Parameters.cmpc_gait on EVERY
+ * tick (ConvexMPCLocomotion.py:224-244), so a gait switch may fall between any two controller.run calls (BASELINE configs[2]: Trot / Walk / Bound
+ * cycling every 50 steps); iterationCounter, firstSwing, swingTimeRemaining and the swing trajectories carry over.  An id outside the reference's
+ * dispatch (0, 1, 2, 3, 5, 6, 7) leaves that robot's gait unchanged. */
+int mpc_ctrl_set_gait_device(mpc_ctrl *c, const int *d_gait_id, void *stream);
 /* The QPSolverName argument of the controller's ConvexMpc objects (ConvexMPCLocomotion.py:102-108; the shipped Python passes QPOASES):
  * MPC_SOLVER_OSQP (default here: BASELINE's comparator) or MPC_SOLVER_EXACT, see mpc_batch_set_solver. */
 int mpc_ctrl_set_solver(mpc_ctrl *c, int solver);

@@ -14,7 +14,7 @@ SYMBOLS = [
     "mpc_batch_set_solver", "mpc_batch_set_max_iter", "mpc_batch_solve_f64", "mpc_batch_solve_f16", "mpc_batch_reset", "mpc_batch_reset_device", "mpc_batch_solve_host", "mpc_batch_solve_host_f64", "mpc_batch_size", "mpc_batch_horizon", "mpc_batch_device_bytes",
     "mpc_batch_state_len", "mpc_batch_get_state", "mpc_batch_set_state", "mpc_batch_qp_len", "mpc_batch_scale_len", "mpc_batch_get_qp", "mpc_batch_get_scale", "mpc_batch_get_profile", "mpc_batch_enable_timing",
     "mpc_batch_kernel_times", "mpc_last_error",
-    "mpc_ctrl_create", "mpc_ctrl_destroy", "mpc_ctrl_step", "mpc_ctrl_run", "mpc_ctrl_reset", "mpc_ctrl_reset_device", "mpc_ctrl_set_gait", "mpc_ctrl_set_solver", "mpc_ctrl_solver_info", "mpc_ctrl_solver_record", "mpc_ctrl_solver_forces", "mpc_ctrl_solver", "mpc_ctrl_set_iteration", "mpc_device_clock",
+    "mpc_ctrl_create", "mpc_ctrl_destroy", "mpc_ctrl_step", "mpc_ctrl_run", "mpc_ctrl_reset", "mpc_ctrl_reset_device", "mpc_ctrl_set_gait", "mpc_ctrl_set_gait_device", "mpc_ctrl_set_solver", "mpc_ctrl_solver_info", "mpc_ctrl_solver_record", "mpc_ctrl_solver_forces", "mpc_ctrl_solver", "mpc_ctrl_set_iteration", "mpc_device_clock",
     "mpc_ctrl_fsm_init", "mpc_ctrl_run_fsm", "mpc_ctrl_fsm_reset", "mpc_ctrl_fsm_reset_device", "mpc_ctrl_fsm_state",
     "mpc_policy_create", "mpc_policy_destroy", "mpc_policy_step", "mpc_policy_observations", "mpc_ctrl_estimate", "mpc_ctrl_update_estimate", "mpc_pack_commands",
 ]
@@ -70,6 +70,7 @@ def lib():
         L.mpc_ctrl_reset.argtypes = [vp, vp, ci, vp]; L.mpc_ctrl_reset.restype = ci
         L.mpc_ctrl_reset_device.argtypes = [vp, vp, ci, vp]; L.mpc_ctrl_reset_device.restype = ci
         L.mpc_ctrl_set_gait.argtypes = [vp, vp, vp]; L.mpc_ctrl_set_gait.restype = ci
+        L.mpc_ctrl_set_gait_device.argtypes = [vp, vp, vp]; L.mpc_ctrl_set_gait_device.restype = ci
         L.mpc_ctrl_set_solver.argtypes = [vp, ci]; L.mpc_ctrl_set_solver.restype = ci
         L.mpc_ctrl_solver_info.argtypes = [vp, vp]; L.mpc_ctrl_solver_info.restype = ci
         L.mpc_ctrl_solver_record.argtypes = [vp, vp]; L.mpc_ctrl_solver_record.restype = ci

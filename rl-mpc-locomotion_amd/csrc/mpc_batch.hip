@@ -221,7 +221,9 @@ int mpc_batch_set_solver(mpc_batch *b, int solver) {
   const bool exact = solver == MPC_SOLVER_EXACT;
   if (exact != b->exact && b->d_seed) {      // a working set left by an earlier stretch in the exact mode is not this stretch's
     DeviceGuard guard_(b->device);
+    HIP_TRY(hipDeviceSynchronize());      // (no stream argument here: solves in flight on any stream, non-blocking ones included, are over before the working sets go ...
     HIP_TRY(hipMemset(b->d_seed, 0, sizeof(int) * (size_t)b->n * 4 * b->h));
+    HIP_TRY(hipDeviceSynchronize());      // ... and the clear is complete before a solve launched right after on such a stream can read them)
   }
   b->exact = exact;
   return MPC_OK;
@@ -361,8 +363,10 @@ int mpc_batch_get_profile(mpc_batch *b, long long *h_prof) {
 int mpc_batch_set_state(mpc_batch *b, const double *h_state) {
   if (!b || !h_state) return fail(MPC_E_ARG, "mpc_batch_set_state: bad argument");
   DeviceGuard guard_(b->device);
+  HIP_TRY(hipDeviceSynchronize());      // (the null stream does not order against non-blocking streams: nothing may be in flight on the state ...
   HIP_TRY(hipMemcpy(b->d_state, h_state, sizeof(double) * (size_t)b->n * b->state_len, hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(b->d_seed, 0, sizeof(int) * (size_t)b->n * 4 * b->h));      // the working sets belonged to the state that was replaced
+  HIP_TRY(hipDeviceSynchronize());      // ... and both are complete before the caller's next launch on any stream)
   return MPC_OK;
 }
 
@@ -387,7 +391,7 @@ __global__ __launch_bounds__(kCtrlThreads) void ctrl_reset_kernel(int n, CtrlSta
 }
 __global__ void ctrl_set_gait_kernel(int n, CtrlState *st, const int *gait_id) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < n) st[r].gait_id = gait_id[r];
+  if (r < n && gait_id[r] >= 0 && gait_id[r] < kNumGaitIds) st[r].gait_id = gait_id[r];      // (an id outside the dispatch leaves the robot's gait as it is)
 }
 __global__ void ctrl_set_iter_kernel(int n, CtrlState *st, const int *iter) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -804,6 +808,14 @@ int mpc_ctrl_set_gait(mpc_ctrl *c, const int *gait_id, void *stream) {
   hipLaunchKernelGGL(ctrl_set_gait_kernel, dim3((c->n + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, st, c->n, c->d_state, c->d_gait);
   HIP_TRY(hipGetLastError());
   return MPC_OK;
+}
+
+int mpc_ctrl_set_gait_device(mpc_ctrl *c, const int *d_gait_id, void *stream) {
+  if (!c || !d_gait_id) return fail(MPC_E_ARG, "mpc_ctrl_set_gait_device: bad argument");
+  DeviceGuard guard_(c->solver->device);
+  hipLaunchKernelGGL(ctrl_set_gait_kernel, dim3((c->n + kCtrlThreads - 1) / kCtrlThreads), dim3(kCtrlThreads), 0, reinterpret_cast<hipStream_t>(stream), c->n, c->d_state, d_gait_id);
+  HIP_TRY(hipGetLastError());
+  return MPC_OK;      // (stream-ordered: no host round trip, no synchronisation)
 }
 
 int mpc_ctrl_set_iteration(mpc_ctrl *c, const int *iteration, void *stream) {

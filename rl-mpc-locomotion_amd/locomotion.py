@@ -121,13 +121,22 @@ class BatchedLocomotion:
         _lib.check(_lib.lib().mpc_ctrl_reset(self._handle, ids.ctypes.data, len(ids), stream), "mpc_ctrl_reset")
 
     def set_gait(self, gait_id):
+        """``Parameters.cmpc_gait`` (Parameters.py:17) per robot, effective from the next ``run`` -- which re-reads it on every tick like the
+        reference's (ConvexMPCLocomotion.py:224-244), so the gait may change DURING a run: iterationCounter, firstSwing, swingTimeRemaining and
+        the swing trajectories carry over.  A cuda int32 tensor [n] is taken as it is, stream-ordered (no host round trip, no synchronisation:
+        BASELINE configs[2] cycles Trot / Walk / Bound every 50 steps); a host array is validated, copied and waited for."""
         import torch
-        gi = np.ascontiguousarray(gait_id, dtype=np.int32)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        if hasattr(gait_id, "is_cuda") and gait_id.is_cuda:
+            if gait_id.dtype != torch.int32 or not gait_id.is_contiguous() or gait_id.numel() != self.n:
+                raise ValueError("gait_id on the device must be a contiguous int32 tensor with one entry per robot")
+            _lib.check(_lib.lib().mpc_ctrl_set_gait_device(self._handle, gait_id.data_ptr(), stream), "mpc_ctrl_set_gait_device")
+            return
+        gi = np.ascontiguousarray(gait_id.cpu().numpy() if hasattr(gait_id, "cpu") else gait_id, dtype=np.int32)
         if len(gi) != self.n:
             raise ValueError("gait_id must have one entry per robot")
-        stream = torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(_lib.lib().mpc_ctrl_set_gait(self._handle, gi.ctypes.data, stream), "mpc_ctrl_set_gait")
-        torch.cuda.current_stream(self.device).synchronize()
+        torch.cuda.current_stream(self.device).synchronize()      # (`gi` is a host buffer)
 
     # ---- control FSM (RobotRunnerFSM) --------------------------------------------------------------------
     PASSIVE, LOCOMOTION, RECOVERY_STAND = 0, 4, 6          # FSM_StateName (MPC_Controller/utils.py:26-30)

@@ -161,7 +161,26 @@ def perturb_workload(wl, seed, scale=0.05):
     return Workload(h, rec, wl.robot_type, wl.gait_id, it, wl.dt_mpc, wl.alpha)
 
 
-class TickStream:
+GAIT_CYCLE_STEPS = 50      # "gait = (idx div 3 + step div 50) mod 3 over {TROT, WALK, BOUND}"
+
+
+def config3_gait(n, step):
+    """Per-robot ``Parameters.cmpc_gait`` of BASELINE configs[2] at control step `step`: Trot / Walk / Bound CYCLING every 50 steps (the reference re-reads the
+    parameter on every tick, ConvexMPCLocomotion.py:224-244; ids TROT 0, WALK 6, BOUND 1, utils.py:17-24)."""
+    return np.array([0, 6, 1], dtype=np.int32)[(np.arange(n) // 3 + int(step) // GAIT_CYCLE_STEPS) % 3]
+
+
+class _GaitSchedule:
+    def gait_at(self, step):
+        """the gait ids controller.run must see at `step` (None: the gait of this configuration never changes)"""
+        return config3_gait(self.n, step) if self.config == 3 else None
+
+    def gait_switch_at(self, step):
+        """True when the ids of gait_at(step) differ from those of step - 1 (the caller hands them to set_gait before that step's run)"""
+        return self.config == 3 and step > 0 and step % GAIT_CYCLE_STEPS == 0
+
+
+class TickStream(_GaitSchedule):
     """Seeded, smooth open-loop (dof_states, body_states, commands) signals for N robots, shaped like the RL
     bridge's per-tick inputs (RL_Environment/tasks/aliengo.py:246-256).  Same construction as
     tests/golden/make_golden_controller.py, vectorised."""
@@ -171,10 +190,11 @@ class TickStream:
         idx = np.arange(n)
         if config == 3:
             self.robot_type = np.array([RobotType.GO1, RobotType.A1, RobotType.ALIENGO], dtype=np.int32)[idx % 3]
-            self.gait_id = np.array([0, 6, 1], dtype=np.int32)[(idx // 3) % 3]
+            self.gait_id = config3_gait(n, 0)
         else:
             self.robot_type = np.full(n, int(RobotType.ALIENGO), dtype=np.int32)
             self.gait_id = np.zeros(n, dtype=np.int32)
+        self.config = config
         self.n = n
         self.phase = rng.uniform(0, 2 * np.pi, (n, 21))
         self.amp = rng.uniform(0.02, 0.15, (n, 21))
@@ -206,7 +226,7 @@ class TickStream:
         return dof, body, cmd
 
 
-class ControlStepStream:
+class ControlStepStream(_GaitSchedule):
     """SURVEY.md 8(d)'s synthetic robot states at the BATCH seam -- (dof_states, body_states, commands) of ``controller.run``
     (RL_Environment/tasks/aliengo.py:246-256) instead of the 13 solver arguments: the same distributions as make_solver_workload
     (roll / pitch U(-0.15, 0.15), yaw U(-pi, pi), height H U(0.9, 1.05), omega U(-0.5, 0.5)^3, v (U(-1.5, 1.5), U(-0.5, 0.5), U(-0.1, 0.1)),
@@ -220,10 +240,11 @@ class ControlStepStream:
         idx = np.arange(n)
         if config == 3:
             self.robot_type = np.array([RobotType.GO1, RobotType.A1, RobotType.ALIENGO], dtype=np.int32)[idx % 3]
-            self.gait_id = np.array([0, 6, 1], dtype=np.int32)[(idx // 3) % 3]
+            self.gait_id = config3_gait(n, 0)
         else:
             self.robot_type = np.full(n, int(RobotType.ALIENGO), dtype=np.int32)
             self.gait_id = np.zeros(n, dtype=np.int32)
+        self.config = config
         self.n, self.h, self.seed = n, h, seed
         H = ROBOT_TABLE[self.robot_type, COL_HEIGHT]
         self.rpy0 = np.stack([rng.uniform(-0.15, 0.15, n), rng.uniform(-0.15, 0.15, n), rng.uniform(-np.pi, np.pi, n)], -1)

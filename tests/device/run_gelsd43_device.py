@@ -18,7 +18,7 @@ dbg = np.fromfile(os.path.join(d, "dbg.bin"), np.float32).reshape(n, 64)
 bad = (x != want).any(1)
 print("device vs reference answers: %d of %d matrices differ" % (bad.sum(), n))
 # host stage records
-subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "rl-mpc-locomotion_amd", "csrc"), "-x", "c++", "-", "-o", os.path.join(d, "h.so")], check=True, text=True,
+subprocess.run(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "rl-mpc-locomotion_amd", "csrc"), "-x", "c++", "-", "-o", os.path.join(d, "h.so")], check=True, text=True,
                input='#include "gelsd43.h"\nextern "C" void hs(int n, const float *A, float *x, float *dbg) { for (int i = 0; i < n; ++i) mpc::gelsd43::solve_ones(A + 12 * i, x + 3 * i, dbg + 64 * i); }\n')
 H = C.CDLL(os.path.join(d, "h.so"))
 hx = np.zeros((n, 3), np.float32); hd = np.zeros((n, 64), np.float32)

@@ -430,6 +430,10 @@ void emu_ctrl_reset(void *hnd, const int *ids, int k) {     // mpc_ctrl_reset: R
     std::fill(c.state.begin() + (size_t)r * sl, c.state.begin() + (size_t)(r + 1) * sl, 0.0);
   }
 }
+void emu_ctrl_set_gait(void *hnd, const int *gait) {     // mpc_ctrl_set_gait: Parameters.cmpc_gait, re-read by run() on every tick (ConvexMPCLocomotion.py:224)
+  EmuCtrl &c = *static_cast<EmuCtrl *>(hnd);
+  for (int r = 0; r < c.n; ++r) if (gait[r] >= 0 && gait[r] < kNumGaitIds) c.st[r].gait_id = gait[r];
+}
 void emu_ctrl_set_iteration(void *hnd, const int *it) { EmuCtrl &c = *static_cast<EmuCtrl *>(hnd); for (int r = 0; r < c.n; ++r) c.st[r].iter = it[r]; }
 void emu_ctrl_get(void *hnd, int *info, double *forces, float *rec) {
   EmuCtrl &c = *static_cast<EmuCtrl *>(hnd);

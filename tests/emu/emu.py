@@ -120,6 +120,12 @@ class EmuLocomotion:
         it = np.ascontiguousarray(it, dtype=np.int32)
         lib().emu_ctrl_set_iteration(self._h, it.ctypes.data_as(C.c_void_p))
 
+    def set_gait(self, gait_id):
+        gi = np.ascontiguousarray(gait_id, dtype=np.int32)
+        assert gi.shape == (self.n,)
+        lib().emu_ctrl_set_gait.argtypes = [C.c_void_p, C.c_void_p]
+        lib().emu_ctrl_set_gait(self._h, gi.ctypes.data_as(C.c_void_p))
+
     def solver_info(self):
         out = np.zeros((self.n, 8), np.int32)
         lib().emu_ctrl_get(self._h, out.ctypes.data_as(C.c_void_p), None, None)

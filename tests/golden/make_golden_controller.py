@@ -98,11 +98,22 @@ def inputs_for(robot, tick, rng_state):
     return dof, body, cmd
 
 
-def run_case(name, n, ticks, seed, flat_ground, horizon=10, gait_cycle=(0, 6, 1)):
+def cycling_schedule(n, ticks, gait_cycle=(0, 6, 1), period=50, period_alt=25, n_alt=0):
+    """gait = (idx div 3 + step div 50) mod 3 over {TROT, WALK, BOUND} -- the per-tick value of the process-global
+    ``Parameters.cmpc_gait`` (Parameters.py:17) that ``ConvexMPCLocomotion.run`` re-reads on every tick (:224).  The last `n_alt` robots switch every
+    `period_alt` ticks instead, so that switches also fall on ticks without an MPC update (odd iteration counters)."""
+    idx, k = np.arange(n)[None, :], np.arange(ticks)[:, None]
+    per = np.where(idx >= n - n_alt, period_alt, period)
+    return np.array(gait_cycle, dtype=np.int32)[(idx // 3 + k // per) % len(gait_cycle)]
+
+
+def run_case(name, n, ticks, seed, flat_ground, horizon=10, gait_cycle=(0, 6, 1), gait_sched=None):
+    """gait_sched [ticks, n]: ``Parameters.cmpc_gait`` of robot r at tick k (a gait switch DURING the run: iterationCounter, firstSwing,
+    swingTimeRemaining and the swing trajectories carry over, ConvexMPCLocomotion.py:224-244); None: the robot's gait never changes."""
     rng = np.random.default_rng(seed)
     Parameters.flat_ground = flat_ground
     robot_type = np.arange(n) % 3
-    gait_id = np.array(gait_cycle)[(np.arange(n) // 3) % len(gait_cycle)]
+    gait_id = np.array(gait_cycle)[(np.arange(n) // 3) % len(gait_cycle)] if gait_sched is None else np.asarray(gait_sched)[0]
     out = dict(robot_type=robot_type.astype(np.int32), gait_id=gait_id.astype(np.int32), flat_ground=int(flat_ground), ticks=ticks, horizon=int(horizon),
                dof=np.zeros((ticks, n, 12, 2), np.float32), body=np.zeros((ticks, n, 13), np.float32),
                cmd=np.zeros((ticks, n, 16), np.float32), est=np.zeros((ticks, n, 18), np.float32),
@@ -111,6 +122,8 @@ def run_case(name, n, ticks, seed, flat_ground, horizon=10, gait_cycle=(0, 6, 1)
                solved=np.zeros((ticks, n), np.int32),
                decisions=np.zeros((ticks, n, 4), np.int32),       # OSQP's (iterations, status, polish status, rho updates) of the tick's solve; zeros: no solve
                record=np.zeros((ticks, n, 56 + 4 * horizon), np.float32))   # the 13 arguments of the tick's compute_contact_forces call (layout.py)
+    if gait_sched is not None:
+        out["gait_sched"] = np.asarray(gait_sched, dtype=np.int32)
     for r in range(n):
         st = dict(phase=rng.uniform(0, 2 * np.pi, 21), amp=rng.uniform(0.02, 0.15, 21), yaw0=rng.uniform(-3, 3),
                   H=float(rng.uniform(0.25, 0.36)), v0=rng.uniform(-0.5, 0.5, 3) * np.array([1, 0.4, 0.1]),
@@ -123,6 +136,8 @@ def run_case(name, n, ticks, seed, flat_ground, horizon=10, gait_cycle=(0, 6, 1)
             patch_horizon(runner, horizon)
         for k in range(ticks):
             dof, body, cmd = inputs_for(r, k, st)
+            if gait_sched is not None:
+                Parameters.cmpc_gait = gait_parameter(int(gait_sched[k][r]))
             # RobotRunnerMin.run, split after StateEstimator.update to record the estimator outputs
             runner._desiredStateCommand.updateCommand(cmd)
             runner._legController.updateData(dof)
@@ -183,6 +198,10 @@ if __name__ == "__main__":
     # every gait of the reference's dispatch x the three robot types, ground normal from the estimator: 63 robots (7 gaits x 3 types x 3)
     if not only or "controller_h10_gaits" in only:
         run_case("controller_h10_gaits", 63, 44, 8, False, gait_cycle=(0, 1, 2, 3, 5, 6, 7))
+    # BASELINE configs[2] as SURVEY 8(d) writes it: three robot types, Parameters.cmpc_gait cycling TROT -> WALK -> BOUND every 50 ticks DURING the run
+    # (27 robots, 124 ticks: switches at ticks 50 and 100; the last 9 robots every 25 ticks, i.e. also on ticks without an MPC update)
+    if not only or "controller_h10_cycling" in only:
+        run_case("controller_h10_cycling", 27, 124, 13, False, gait_sched=cycling_schedule(27, 124, n_alt=9))
     # BASELINE configs[3] / [4]: the reference with horizonLength patched (module docstring)
     for case in (("controller_h16_slope", 18, 72, 9, False, 16), ("controller_h16_flat", 9, 40, 10, True, 16),
                  ("controller_h20_slope", 18, 88, 11, False, 20), ("controller_h20_flat", 9, 48, 12, True, 20)):

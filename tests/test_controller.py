@@ -260,6 +260,73 @@ def test_hip_full_run_as_shipped_matches_reference_python():
     assert errs.max() < TAU_RTOL, (float((errs < TAU_RTOL).mean()), float(errs.max()))
 
 
+# ---- BASELINE configs[2] as SURVEY 8(d) writes it: the gait changes DURING the run ----------------------------------------------------
+# controller_h10_cycling: 27 robots (3 types), Parameters.cmpc_gait cycling TROT -> WALK -> BOUND every 50 ticks (the last nine robots every 25: switches on
+# ticks with and without an MPC update), 124 ticks, minted from the unmodified reference (ConvexMPCLocomotion.py:224-244 re-reads the parameter on every tick).
+def _cycling_run(g, ctl, run, set_gait):
+    """controller.run over the golden with the gait schedule applied before each tick; returns what test_*_full_run compare, plus per-tick records / decisions."""
+    T, n = g["dof"].shape[:2]
+    sched = g["gait_sched"]
+    ok = np.ones(n, bool)
+    errs, compared, normal_bad, rec_bad, dec_bad, solves = [], np.zeros((T, n), bool), 0, 0, 0, 0
+    for k in range(T):
+        if k == 0 or (sched[k] != sched[k - 1]).any():
+            set_gait(ctl, sched[k])
+        tau, est, nrm, rec, dec = run(ctl, g, k)
+        ok &= (est == g["est"][k]).all(-1)
+        compared[k] = ok
+        errs.append(_relerr(tau, g["torque"][k])[ok])
+        normal_bad += int((nrm != g["normal"][k]).any(-1).sum())
+        due = g["solved"][k].astype(bool) & ok
+        if due.any():
+            solves += int(due.sum())
+            rec_bad += int((rec[due] != g["record"][k][due]).any(-1).sum())
+            dec_bad += int((dec[due, :4] != g["decisions"][k][due]).any(-1).sum())
+    return np.concatenate(errs), compared, normal_bad, rec_bad, dec_bad, solves
+
+
+def _check_cycling(name, out):
+    errs, compared, normal_bad, rec_bad, dec_bad, solves = out
+    print(f"{name}: compared {compared.mean():.4f} of the samples, {solves} solves, max torque error {errs.max():.2e}")
+    assert normal_bad == 0
+    assert rec_bad == 0          # every argument of every compute_contact_forces call bit-identical ACROSS the switches (contact tables of the new gait included)
+    assert dec_bad == 0          # ... and OSQP's decisions on every one of them
+    assert errs.max() < TAU_RTOL
+    assert compared.mean() >= 0.995
+    assert compared[101:].any()                                     # both switches (ticks 50 and 100) lie inside the compared stretch
+
+
+def test_emulated_gait_cycling_matches_reference_python():
+    from tests.emu.emu import EmuLocomotion, estimator_update
+    g = load_golden("controller_h10_cycling")
+    assert len(np.unique(g["gait_sched"][[0, 50, 100], 0])) == 3 and (g["gait_sched"][24] != g["gait_sched"][25]).any()      # TROT / WALK / BOUND; a switch before an odd tick
+
+    def run(ctl, g, k):
+        prev = g["normal"][k - 1] if k else np.tile(np.array([0, 0, 1], np.float32), (g["body"].shape[1], 1))
+        tau = ctl.run(g["dof"][k], g["body"][k], g["cmd"][k])
+        return tau, estimator_update(g["body"][k], prev), ctl.estimate()[0], ctl.solver_record(), ctl.solver_info()
+    ctl = EmuLocomotion(g["robot_type"], g["gait_id"], horizon=10, flat_ground=False)
+    _check_cycling("controller_h10_cycling (emulation)", _cycling_run(g, ctl, run, lambda c, gi: c.set_gait(gi)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_ids", [True, False])
+def test_hip_gait_cycling_matches_reference_python(device_ids):
+    """BASELINE configs[2] through controller.run on the GPU: the gait ids arrive as a DEVICE tensor (mpc_ctrl_set_gait_device, stream-ordered, no
+    synchronisation) or as a host array (mpc_ctrl_set_gait)."""
+    import torch
+    from rl_mpc_locomotion_amd.locomotion import BatchedLocomotion
+    g = load_golden("controller_h10_cycling")
+
+    def run(ctl, g, k):
+        tau = ctl.run(torch.from_numpy(g["dof"][k]).cuda(), torch.from_numpy(g["body"][k]).cuda(), torch.from_numpy(g["cmd"][k]).cuda())
+        est, nrm = ctl.estimate()
+        return tau.cpu().numpy(), est.cpu().numpy(), nrm.cpu().numpy(), ctl.solver_record(), ctl.solver_info()
+    ctl = BatchedLocomotion(g["robot_type"], g["gait_id"], horizon=10, flat_ground=False, device="cuda:0")
+    set_gait = (lambda c, gi: c.set_gait(torch.from_numpy(np.ascontiguousarray(gi)).cuda())) if device_ids else (lambda c, gi: c.set_gait(gi))
+    _check_cycling("controller_h10_cycling (hip)", _cycling_run(g, ctl, run, set_gait))
+
+
 @pytest.mark.gpu
 def test_hip_controller_reset_and_gait_switch():
     import torch
@@ -281,7 +348,9 @@ def test_hip_controller_reset_and_gait_switch():
         np.testing.assert_array_equal(again[k][[1, 3, 4, 5]], cont[6 + k][[1, 3, 4, 5]])
     a.set_gait(np.full(n, 1, dtype=np.int32))
     out = run(a, 6)
-    assert np.isfinite(out).all()
+    assert np.isfinite(out).all()      # (parity of a gait switch against the reference: test_hip_gait_cycling_matches_reference_python)
+    with pytest.raises(ValueError):
+        a.set_gait(torch.zeros(n, dtype=torch.int64, device="cuda:0"))
 
 
 @pytest.mark.gpu

@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 so = glob.glob(os.path.join(os.path.dirname(scipy.__file__), "..", "scipy.libs", "libscipy_openblas-*.so"))[0]
 L = C.CDLL(so)
 tmp = tempfile.mkdtemp()
-subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "rl-mpc-locomotion_amd", "csrc"), os.path.join(ROOT, "tools", "gelsd43", "harness.cpp"),
+subprocess.run(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "rl-mpc-locomotion_amd", "csrc"), os.path.join(ROOT, "tools", "gelsd43", "harness.cpp"),
                 "-o", os.path.join(tmp, "libh.so")], check=True)
 H = C.CDLL(os.path.join(tmp, "libh.so"))
 f32 = np.float32
