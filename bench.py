@@ -479,6 +479,12 @@ def main():
         out["control_loop_exact"] = control_loop_leg(n, h, dev, solver="exact")      # the reference AS SHIPPED passes mpc.QPOASES (ConvexMPCLocomotion.py:108)
         out["control_loop_exact"]["note"] = "the same loop with the controllers' ConvexMpc objects in the exact-optimum mode (the reference's qpOASES branch, what its Python selects)"
         out["policy"] = policy_leg(n, dev)
+        # what a training loop / the policy runner actually call (RL_Environment/tasks/aliengo.py:237-258, 321-334; robot_runner/RobotRunnerPolicy.py:62-92)
+        out["env_bridge_loop"] = env_bridge_loop_leg(n, h, dev)
+        out["env_bridge_loop"]["vs_control_loop"] = out["env_bridge_loop"]["robot_ticks_per_s"] / out["control_loop"]["robot_ticks_per_s"]
+        out["env_bridge_loop_with_resets"] = env_bridge_loop_leg(n, h, dev, reset_every=37)
+        out["env_bridge_loop_with_resets"]["vs_control_loop_with_resets"] = out["env_bridge_loop_with_resets"]["robot_ticks_per_s"] / out["control_loop_with_resets"]["robot_ticks_per_s"]
+        out["runner_policy_loop"] = runner_policy_loop_leg(n, h, dev)
         # the same unit at the reference's own cadence (controller.run every 10 ms, MPC update on every 2nd call): two controller ticks per control step
         out["control_steps_per_s_incl_torque_map"] = out["control_loop"]["control_steps_per_s_incl_torque_map"]
     if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
@@ -771,6 +777,79 @@ def control_loop_leg(n, h, dev, ticks=40, warm=10, reset_every=0, solver="osqp",
     if mixed:
         out["note"] += "; the two MPC phases hold ~half of the robots each (a random half was reset after an odd tick of the warm-up)"
     return out
+
+
+def env_bridge_loop_leg(n, h, dev, ticks=40, warm=10, reset_every=0):
+    """Secondary figure (NOT `value`): what an RL training loop calls per simulator step -- MpcEnvBridge.pre_physics_step(actions, dof_state, root_states, commands)
+    (RL_Environment/tasks/aliengo.py:237-258: rescale of the policy's actions, command record, controller.run for every env) and, with reset_every > 0,
+    reset_idx(env_ids on the device) of n/64 envs every that many ticks (:321-334).  Same tick stream and cadence as control_loop_leg (MPC on every 2nd tick), fresh
+    random actions per tick, everything resident in HBM."""
+    import torch
+    from rl_mpc_locomotion_amd.env_bridge import MpcEnvBridge
+    from rl_mpc_locomotion_amd.synthetic import TickStream
+    ts = TickStream(n, seed=4242, config=2)
+    br = MpcEnvBridge(ts.robot_type, ts.gait_id, horizon=h, device=dev)
+    rng = np.random.default_rng(6)
+    ins = []
+    for k in range(warm + ticks):
+        dof, body, cmd = ts.tick(k)
+        ins.append((torch.from_numpy(rng.uniform(-1, 1, (n, 12)).astype(np.float32)).to(dev), torch.from_numpy(dof.reshape(n * 12, 2)).to(dev),
+                    torch.from_numpy(body).to(dev), torch.from_numpy(np.ascontiguousarray(cmd[:, :3])).to(dev)))
+    ids = [torch.from_numpy(rng.choice(n, max(1, n // 64), replace=False).astype(np.int32)).to(dev) for _ in range(warm + ticks)]
+    for k in range(warm):
+        br.pre_physics_step(*ins[k])
+        if reset_every and (k + 1) % 7 == 0:
+            br.reset_idx(ids[k])
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(warm, warm + ticks):
+        br.pre_physics_step(*ins[k])
+        if reset_every and (k + 1) % reset_every == 0:
+            br.reset_idx(ids[k])
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    out = {"robot_ticks_per_s": n * ticks / dt, "ms_per_tick": dt / ticks * 1e3, "ticks": ticks, "mpc_every_n_ticks": 2,
+           "note": "MpcEnvBridge.pre_physics_step per tick: one fused rescale + pack kernel (actions * MPC_param_scale + MPC_param_const, command record), then controller.run"}
+    if reset_every:
+        out["reset_every_ticks"] = reset_every
+        out["note"] += "; reset_idx(device env_ids) of n/64 envs every %d ticks (and a few during warm-up: the MPC phases are mixed, compare control_loop_with_resets)" % reset_every
+    return out
+
+
+def runner_policy_loop_leg(n, h, dev, ticks=40, warm=10):
+    """Secondary figure (NOT `value`): the batched RobotRunnerPolicy.run (robot_runner/RobotRunnerPolicy.py:62-92) per tick -- StateEstimator.update, observations from
+    the fresh estimate and the previous weights, the 48-512-256-128-12 actor (random-init parameters of the reference architecture), command record, the control FSM in
+    LOCOMOTION (MPC on every 2nd tick) -- BatchedLocomotion.run_policy."""
+    import torch
+    from rl_mpc_locomotion_amd.locomotion import BatchedLocomotion
+    from rl_mpc_locomotion_amd.quadruped import ROBOT_TABLE64
+    from rl_mpc_locomotion_amd.synthetic import TickStream
+    from rl_mpc_locomotion_amd.weight_policy import WeightPolicy
+    rng = np.random.default_rng(99)
+    dims = [48, 512, 256, 128, 12]
+    layers = [((rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32), np.zeros(dims[i + 1], np.float32)) for i in range(4)]
+    pol = WeightPolicy(layers, device=dev)
+    ts = TickStream(n, seed=4242, config=2)
+    ctl = BatchedLocomotion(ts.robot_type, ts.gait_id, horizon=h, device=dev)
+    ctl.fsm_init(np.full(n, BatchedLocomotion.LOCOMOTION), operating_mode=1, check_safety=True)
+    req = torch.full((n,), BatchedLocomotion.LOCOMOTION, dtype=torch.int32, device=dev)
+    ins = []
+    for k in range(warm + ticks):
+        dof, body, cmd = ts.tick(k)
+        ins.append((torch.from_numpy(dof).to(dev), torch.from_numpy(body).to(dev), torch.from_numpy(np.ascontiguousarray(cmd[:, :3])).to(dev)))
+    w = torch.from_numpy(np.tile(ROBOT_TABLE64[0, 12:24].astype(np.float32), (n, 1))).to(dev)      # Quadruped._mpc_weights[:-1] (RobotRunnerPolicy.py:44)
+    for k in range(warm):
+        _, w = ctl.run_policy(pol, *ins[k], w, req)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(warm, warm + ticks):
+        _, w = ctl.run_policy(pol, *ins[k], w, req)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    return {"robot_ticks_per_s": n * ticks / dt, "ms_per_tick": dt / ticks * 1e3, "ticks": ticks, "mpc_every_n_ticks": 2,
+            "in_locomotion": float((ctl.fsm_state()[:, 0] == BatchedLocomotion.LOCOMOTION).mean()),
+            "note": "BatchedLocomotion.run_policy per tick: estimator, observations (straight from the controller's estimate), fused MLP on the fp32 MFMA pipe, command "
+                    "packing, fsm_pre, the solver kernels, fsm_post"}
 
 
 def policy_leg(n, dev, steps=50, warm=5):

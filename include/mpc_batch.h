@@ -283,6 +283,15 @@ int mpc_policy_observations(int n, const float *d_dof, const float *d_est, const
 int mpc_ctrl_update_estimate(mpc_ctrl *c, const float *d_body, void *stream);
 int mpc_ctrl_estimate(mpc_ctrl *c, float *d_est, float *d_ground_normal, void *stream);
 int mpc_pack_commands(int n, const float *d_cmd3, const float *d_weights12, float *d_cmd16, void *stream);
+/* VecTask.pre_physics_step's glue in ONE launch (RL_Environment/tasks/aliengo.py:237-251): actions_rescale = torch.mul(actions, MPC_param_scale).add(MPC_param_const)
+ * -- a float32 product then a float32 sum, bit for bit what torch's two kernels give -- packed with the commands into the [n, 16] record.  scale12 / const12: HOST [12]
+ * (MPC_Controller/Parameters.py:25-33). */
+int mpc_pack_commands_scaled(int n, const float *d_cmd3, const float *d_actions12, const float *scale12, const float *const12, float *d_cmd16, void *stream);
+/* RobotRunnerPolicy.run (robot_runner/RobotRunnerPolicy.py:62-92) without copies: the observations straight from the controller's own estimate -- what the last
+ * mpc_ctrl_update_estimate / mpc_ctrl_run wrote -- and its ground_normal_yaw (StateEstimator.py:99-143, the value of the previous controller tick, as there);
+ * then mpc_ctrl_run_fsm_estimated = mpc_ctrl_run_fsm minus its StateEstimator.update: the caller has run mpc_ctrl_update_estimate on the SAME d_body this tick. */
+int mpc_ctrl_policy_observations(mpc_ctrl *c, const float *d_dof, const float *d_cmd3, const float *d_prev_actions, const float *scales4, float *d_obs, void *stream);
+int mpc_ctrl_run_fsm_estimated(mpc_ctrl *c, const float *d_dof, const float *d_body, const float *d_cmd, const int *d_request, float *d_torques, void *stream);
 
 /* Shader clock of `device` under the solve kernel's own regime (one wave of dependent fp64 FMAs per SIMD on every CU) for about busy_ms
  * milliseconds: *ghz = shader cycles of one workgroup / HIP-event time of the launch, *ms (may be NULL) = that time.  Benchmarks record it next

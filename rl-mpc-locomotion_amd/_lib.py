@@ -16,7 +16,7 @@ SYMBOLS = [
     "mpc_batch_kernel_times", "mpc_last_error",
     "mpc_ctrl_create", "mpc_ctrl_destroy", "mpc_ctrl_step", "mpc_ctrl_run", "mpc_ctrl_reset", "mpc_ctrl_reset_device", "mpc_ctrl_set_gait", "mpc_ctrl_set_gait_device", "mpc_ctrl_set_solver", "mpc_ctrl_solver_info", "mpc_ctrl_solver_record", "mpc_ctrl_solver_forces", "mpc_ctrl_solver", "mpc_ctrl_set_iteration", "mpc_device_clock",
     "mpc_ctrl_fsm_init", "mpc_ctrl_run_fsm", "mpc_ctrl_fsm_reset", "mpc_ctrl_fsm_reset_device", "mpc_ctrl_fsm_state",
-    "mpc_policy_create", "mpc_policy_destroy", "mpc_policy_step", "mpc_policy_observations", "mpc_ctrl_estimate", "mpc_ctrl_update_estimate", "mpc_pack_commands",
+    "mpc_policy_create", "mpc_policy_destroy", "mpc_policy_step", "mpc_policy_observations", "mpc_ctrl_estimate", "mpc_ctrl_update_estimate", "mpc_pack_commands", "mpc_pack_commands_scaled", "mpc_ctrl_policy_observations", "mpc_ctrl_run_fsm_estimated",
 ]
 
 
@@ -90,6 +90,9 @@ def lib():
         L.mpc_ctrl_update_estimate.argtypes = [vp, vp, vp]; L.mpc_ctrl_update_estimate.restype = ci
         L.mpc_ctrl_estimate.argtypes = [vp, vp, vp, vp]; L.mpc_ctrl_estimate.restype = ci
         L.mpc_pack_commands.argtypes = [ci, vp, vp, vp, vp]; L.mpc_pack_commands.restype = ci
+        L.mpc_pack_commands_scaled.argtypes = [ci, vp, vp, vp, vp, vp, vp]; L.mpc_pack_commands_scaled.restype = ci
+        L.mpc_ctrl_policy_observations.argtypes = [vp, vp, vp, vp, vp, vp, vp]; L.mpc_ctrl_policy_observations.restype = ci
+        L.mpc_ctrl_run_fsm_estimated.argtypes = [vp, vp, vp, vp, vp, vp, vp]; L.mpc_ctrl_run_fsm_estimated.restype = ci
         L.mpc_last_error.argtypes = []; L.mpc_last_error.restype = C.c_char_p
         _LIB = L
     return _LIB

@@ -940,14 +940,14 @@ int mpc_ctrl_fsm_reset_device(mpc_ctrl *c, const int *d_ids, int k, void *stream
   return MPC_OK;      // (stream-ordered: no host round trip, no synchronisation)
 }
 
-int mpc_ctrl_run_fsm(mpc_ctrl *c, const float *d_dof, const float *d_body, const float *d_cmd, const int *d_request, float *d_torques, void *stream) {
+static int run_fsm(mpc_ctrl *c, const float *d_dof, const float *d_body, const float *d_cmd, const int *d_request, float *d_torques, void *stream, bool estimated) {
   if (!c || !d_dof || !d_body || !d_cmd || !d_request || !d_torques) return fail(MPC_E_ARG, "mpc_ctrl_run_fsm: bad argument");
   DeviceGuard guard_(c->solver->device);
   if (!c->d_fsm) return fail(MPC_E_ARG, "mpc_ctrl_run_fsm: call mpc_ctrl_fsm_init first");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int n = c->n, blocks = (n + kCtrlThreads - 1) / kCtrlThreads;
   mpc_batch *b = c->solver;
-  hipLaunchKernelGGL(estimator_kernel, dim3(blocks), dim3(kCtrlThreads), 0, st, n, c->d_state, d_body, c->d_est);
+  if (!estimated) hipLaunchKernelGGL(estimator_kernel, dim3(blocks), dim3(kCtrlThreads), 0, st, n, c->d_state, d_body, c->d_est);
   hipLaunchKernelGGL(fsm_pre_kernel, dim3(blocks), dim3(kCtrlThreads), 0, st, n, c->d_state, c->d_fsm, c->d_rc, c->gt, c->cp, c->fp, d_dof, d_body, c->d_est, d_cmd,
                      d_request, c->d_rec, c->d_active, b->d_state, b->state_len, b->d_seed, 4 * b->h);
   HIP_TRY(hipGetLastError());
@@ -956,6 +956,12 @@ int mpc_ctrl_run_fsm(mpc_ctrl *c, const float *d_dof, const float *d_body, const
   hipLaunchKernelGGL(fsm_post_kernel, dim3(blocks), dim3(kCtrlThreads), 0, st, n, c->d_state, c->d_fsm, c->d_rc, c->cp.horizon, c->d_forces, c->d_info, b->exact, d_torques);
   HIP_TRY(hipGetLastError());
   return MPC_OK;
+}
+int mpc_ctrl_run_fsm(mpc_ctrl *c, const float *d_dof, const float *d_body, const float *d_cmd, const int *d_request, float *d_torques, void *stream) {
+  return run_fsm(c, d_dof, d_body, d_cmd, d_request, d_torques, stream, false);
+}
+int mpc_ctrl_run_fsm_estimated(mpc_ctrl *c, const float *d_dof, const float *d_body, const float *d_cmd, const int *d_request, float *d_torques, void *stream) {
+  return run_fsm(c, d_dof, d_body, d_cmd, d_request, d_torques, stream, true);
 }
 
 int mpc_ctrl_fsm_state(mpc_ctrl *c, int *h_out) {
@@ -1056,8 +1062,27 @@ int mpc_policy_observations(int n, const float *d_dof, const float *d_est, const
                             const float *d_prev_actions, const float *scales4, float *d_obs, void *stream) {
   if (n <= 0 || !d_dof || !d_est || !d_normal || !d_cmd3 || !d_prev_actions || !scales4 || !d_obs)
     return fail(MPC_E_ARG, "mpc_policy_observations: bad argument");
-  hipLaunchKernelGGL(policy::observations_kernel, dim3((n * 48 + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, d_dof, d_est, d_normal,
+  hipLaunchKernelGGL(policy::observations_kernel, dim3((n * 48 + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, d_dof, d_est, d_normal, 3,
                      d_cmd3, d_prev_actions, scales4[0], scales4[1], scales4[2], scales4[3], d_obs);
+  HIP_TRY(hipGetLastError());
+  return MPC_OK;
+}
+
+int mpc_ctrl_policy_observations(mpc_ctrl *c, const float *d_dof, const float *d_cmd3, const float *d_prev_actions, const float *scales4, float *d_obs, void *stream) {
+  if (!c || !d_dof || !d_cmd3 || !d_prev_actions || !scales4 || !d_obs) return fail(MPC_E_ARG, "mpc_ctrl_policy_observations: bad argument");
+  DeviceGuard guard_(c->solver->device);
+  static_assert(sizeof(CtrlState) % sizeof(float) == 0, "the state records are read with a float stride");
+  hipLaunchKernelGGL(policy::observations_kernel, dim3((c->n * 48 + 255) / 256), dim3(256), 0, (hipStream_t)stream, c->n, d_dof, c->d_est, &c->d_state[0].normal[0],
+                     (int)(sizeof(CtrlState) / sizeof(float)), d_cmd3, d_prev_actions, scales4[0], scales4[1], scales4[2], scales4[3], d_obs);
+  HIP_TRY(hipGetLastError());
+  return MPC_OK;
+}
+
+int mpc_pack_commands_scaled(int n, const float *d_cmd3, const float *d_actions12, const float *scale12, const float *const12, float *d_cmd16, void *stream) {
+  if (n <= 0 || !d_cmd3 || !d_actions12 || !scale12 || !const12 || !d_cmd16) return fail(MPC_E_ARG, "mpc_pack_commands_scaled: bad argument");
+  policy::Rescale rs;
+  for (int k = 0; k < 12; ++k) { rs.scale[k] = scale12[k]; rs.shift[k] = const12[k]; }
+  hipLaunchKernelGGL(policy::pack_commands_scaled_kernel, dim3((n * 16 + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, d_cmd3, d_actions12, rs, d_cmd16);
   HIP_TRY(hipGetLastError());
   return MPC_OK;
 }

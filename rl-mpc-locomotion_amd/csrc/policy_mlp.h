@@ -144,7 +144,8 @@ inline size_t lds_bytes(const Net &net) {
 // WeightPolicy.compute_observations (:120-139): [vBody * lin, omegaBody * ang, -ground_normal_yaw, commands * (lin, lin, ang),
 // dof_pos * dps, dof_vel * dvs, previous actions]  (48 floats).  est = [vBody3, omegaBody3, rpy3, R9] as written by the
 // estimator kernel; dof = [12][2] (pos, vel); scales = {lin, ang, dof_pos, dof_vel}.
-__global__ void observations_kernel(int n, const float *__restrict__ dof, const float *__restrict__ est, const float *__restrict__ normal,
+// normal: ground_normal_yaw of robot r at normal[r * normal_stride + 0 .. 2] (3: a packed [n, 3] array; sizeof(CtrlState) / 4: the controller's own state records)
+__global__ void observations_kernel(int n, const float *__restrict__ dof, const float *__restrict__ est, const float *__restrict__ normal, int normal_stride,
                                     const float *__restrict__ cmd3, const float *__restrict__ prev, float lin, float ang, float dps, float dvs,
                                     float *__restrict__ obs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -153,7 +154,7 @@ __global__ void observations_kernel(int n, const float *__restrict__ dof, const 
   float v;
   if (k < 3) v = est[18 * r + k] * lin;
   else if (k < 6) v = est[18 * r + k] * ang;
-  else if (k < 9) v = -normal[3 * r + k - 6];
+  else if (k < 9) v = -normal[(size_t)normal_stride * r + k - 6];
   else if (k < 12) v = cmd3[3 * r + k - 9] * (k < 11 ? lin : ang);
   else if (k < 24) v = dof[24 * r + 2 * (k - 12)] * dps;
   else if (k < 36) v = dof[24 * r + 2 * (k - 24) + 1] * dvs;
@@ -167,6 +168,19 @@ __global__ void pack_commands_kernel(int n, const float *__restrict__ cmd3, cons
   if (i >= n * 16) return;
   const int r = i / 16, k = i - 16 * r;
   cmd16[i] = k < 3 ? cmd3[3 * r + k] : k < 15 ? w12[12 * r + k - 3] : 0.f;
+}
+
+// ... with the rescale of VecTask.pre_physics_step in front of it: actions_rescale = torch.mul(actions, MPC_param_scale).add(MPC_param_const)
+// (RL_Environment/tasks/aliengo.py:237-245) -- a float32 product, then a float32 sum, like torch's two kernels (no fused multiply-add)
+struct Rescale { float scale[12], shift[12]; };
+__global__ void pack_commands_scaled_kernel(int n, const float *__restrict__ cmd3, const float *__restrict__ act12, Rescale rs, float *__restrict__ cmd16) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * 16) return;
+  const int r = i / 16, k = i - 16 * r;
+  float v = 0.f;
+  if (k < 3) v = cmd3[3 * r + k];
+  else if (k < 15) v = __fadd_rn(__fmul_rn(act12[12 * r + k - 3], rs.scale[k - 3]), rs.shift[k - 3]);
+  cmd16[i] = v;
 }
 
 }  // namespace policy

@@ -151,9 +151,10 @@ class BatchedLocomotion:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(_lib.lib().mpc_ctrl_fsm_init(self._handle, cm.ctypes.data, int(operating_mode), int(bool(check_safety)), stream), "mpc_ctrl_fsm_init")
 
-    def run_fsm(self, dof_states, body_states, commands, request, torques=None):
+    def run_fsm(self, dof_states, body_states, commands, request, torques=None, estimated=False):
         """The batched ``RobotRunnerFSM.run(dof_states, body_states, commands)`` (robot_runner/RobotRunnerFSM.py:44-71);
-        ``request`` [N] cuda int32 is the control mode requested for each robot this tick."""
+        ``request`` [N] cuda int32 is the control mode requested for each robot this tick.  estimated: ``update_estimate(body_states)`` has been
+        called on the same body_states this tick (run_policy): StateEstimator.update is not run a second time."""
         import torch
         dof_states, body_states, commands = self._inputs(dof_states, body_states, commands)
         commands = self._full_commands(commands)
@@ -164,8 +165,8 @@ class BatchedLocomotion:
             raise ValueError("request must be a contiguous cuda int32 tensor with one entry per robot")
         torques = self.torques if torques is None else torques
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        _lib.check(_lib.lib().mpc_ctrl_run_fsm(self._handle, dof_states.data_ptr(), body_states.data_ptr(), commands.data_ptr(),
-                                               request.data_ptr(), torques.data_ptr(), stream), "mpc_ctrl_run_fsm")
+        fn = _lib.lib().mpc_ctrl_run_fsm_estimated if estimated else _lib.lib().mpc_ctrl_run_fsm
+        _lib.check(fn(self._handle, dof_states.data_ptr(), body_states.data_ptr(), commands.data_ptr(), request.data_ptr(), torques.data_ptr(), stream), "mpc_ctrl_run_fsm")
         return torques
 
     def fsm_reset(self, env_ids=None, control_mode=None):
@@ -204,10 +205,10 @@ class BatchedLocomotion:
         if body_states.dtype != torch.float32 or not body_states.is_cuda or not body_states.is_contiguous() or body_states.numel() != self.n * 13:
             raise ValueError("body_states must be a contiguous cuda float32 tensor with %d elements" % (self.n * 13))
         _lib.check(_lib.lib().mpc_ctrl_update_estimate(self._handle, body_states.data_ptr(), stream), "mpc_ctrl_update_estimate")
-        est, nrm = self.estimate()
-        obs = policy.compute_observations(dof_states, est, nrm, commands3, prev_weights)
+        # the observations straight from the controller's estimate and ground_normal_yaw (no copies), and the FSM tick without a second StateEstimator.update
+        obs = policy.observations_from(self, dof_states, commands3, prev_weights)
         weights = policy.step(obs)
-        return self.run_fsm(dof_states, body_states, policy.pack_commands(commands3, weights), request), weights
+        return self.run_fsm(dof_states, body_states, policy.pack_commands(commands3, weights), request, estimated=True), weights
 
     def estimate(self):
         """(est [n,18], ground_normal_yaw [n,3]) of the last ``run``: the StateEstimate the reference passes to

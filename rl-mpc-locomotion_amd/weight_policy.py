@@ -94,6 +94,19 @@ class WeightPolicy:
                    "mpc_policy_observations")
         return obs
 
+    def observations_from(self, ctl, dof_states, commands, actions):
+        """compute_observations with the StateEstimate taken where the controller keeps it (``ctl``: a BatchedLocomotion whose
+        ``update_estimate`` / ``run`` has just been called): RobotRunnerPolicy.run's ``compute_observations(dof_states, result, commands,
+        self.weights)`` (RobotRunnerPolicy.py:72-78) without copying the estimate out first."""
+        import torch
+        n = ctl.n
+        for name, t, k in (("dof_states", dof_states, 24), ("commands", commands, 3), ("actions", actions, 12)):
+            self._chk(name, t, n * k)
+        obs = torch.empty((n, 48), dtype=torch.float32, device=self.device)
+        _lib.check(_lib.lib().mpc_ctrl_policy_observations(ctl._handle, dof_states.data_ptr(), commands.data_ptr(), actions.data_ptr(), self._scales.ctypes.data,
+                                                           obs.data_ptr(), self._stream()), "mpc_ctrl_policy_observations")
+        return obs
+
     def pack_commands(self, commands, weights):
         """[n,3] velocity commands + [n,12] MPC weights -> the [n,16] command record of BatchedLocomotion.run/step."""
         import torch

@@ -354,6 +354,39 @@ def test_hip_controller_reset_and_gait_switch():
 
 
 @pytest.mark.gpu
+def test_env_bridge_equals_manual_composition():
+    """MpcEnvBridge.pre_physics_step (one fused rescale + pack kernel, then controller.run) against the composition it replaced -- torch.mul(...).add(...),
+    three slice copies into the command record, BatchedLocomotion.run (RL_Environment/tasks/aliengo.py:237-258 statement by statement): torques bit-identical
+    on every tick, device-side reset_idx included."""
+    import torch
+    from rl_mpc_locomotion_amd.env_bridge import MpcEnvBridge
+    from rl_mpc_locomotion_amd.locomotion import BatchedLocomotion
+    from rl_mpc_locomotion_amd.synthetic import TickStream
+    from rl_mpc_locomotion_amd.weight_policy import MPC_PARAM_CONST, MPC_PARAM_SCALE
+    n = 96
+    ts = TickStream(n, seed=31, config=3)
+    br = MpcEnvBridge(ts.robot_type, ts.gait_id, horizon=10, flat_ground=False)
+    ctl = BatchedLocomotion(ts.robot_type, ts.gait_id, horizon=10, flat_ground=False)
+    scale = torch.tensor(MPC_PARAM_SCALE, dtype=torch.float, device="cuda"); const = torch.tensor(MPC_PARAM_CONST, dtype=torch.float, device="cuda")
+    rng = np.random.default_rng(3)
+    cmd16 = torch.zeros((n, 16), dtype=torch.float32, device="cuda")
+    for k in range(14):
+        dof, body, cmd = ts.tick(k)
+        actions = torch.from_numpy(rng.uniform(-1, 1, (n, 12)).astype(np.float32)).cuda()
+        commands = torch.from_numpy(np.ascontiguousarray(cmd[:, :3])).cuda()
+        dof_t, body_t = torch.from_numpy(dof.reshape(n * 12, 2)).cuda(), torch.from_numpy(body).cuda()
+        a = br.pre_physics_step(actions, dof_t, body_t, commands).clone()
+        actions_rescale = torch.mul(actions, scale).add(const)
+        cmd16[:, 0:3] = commands; cmd16[:, 3:15] = actions_rescale; cmd16[:, 15] = 0.0
+        b = ctl.run(dof_t.reshape(n, 12, 2).contiguous(), body_t, cmd16)
+        assert torch.equal(a, b), k
+        assert torch.equal(br._cmd, cmd16)
+        if k == 6:
+            ids = torch.tensor([3, 17, 40], dtype=torch.int32, device="cuda")
+            br.reset_idx(ids); ctl.reset(ids)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("task", ["aliengo", "a1", "go1"])
 def test_env_bridge_matches_reference_glue(task):
     """MpcEnvBridge against the reference's own pre_physics_step / reset_idx of all three task files (RL_Environment/tasks/aliengo.py,

@@ -179,6 +179,40 @@ def test_gpu_runner_policy_loop():
     assert (loco.fsm_state()[:, 0] == BatchedLocomotion.LOCOMOTION).all()
 
 
+@pytest.mark.gpu
+def test_gpu_runner_policy_equals_its_unfused_composition():
+    """run_policy (observations straight from the controller's estimate, the FSM tick without a second StateEstimator.update) against the composition it
+    replaced -- update_estimate, estimate() copies, compute_observations, step, pack_commands, run_fsm with its own estimator pass: weights and torques
+    bit-identical on every tick."""
+    import torch
+    import rl_mpc_locomotion_amd  # noqa: F401
+    from rl_mpc_locomotion_amd import _lib
+    from rl_mpc_locomotion_amd.locomotion import BatchedLocomotion
+    from rl_mpc_locomotion_amd.quadruped import ROBOT_TABLE64
+    from rl_mpc_locomotion_amd.synthetic import TickStream
+    g, sd = _gold()
+    pol = _policy(sd)
+    n = 64
+    ts = TickStream(n, seed=13, config=3)
+    a = BatchedLocomotion(ts.robot_type, ts.gait_id, horizon=10)
+    b = BatchedLocomotion(ts.robot_type, ts.gait_id, horizon=10)
+    for c in (a, b):
+        c.fsm_init(np.full(n, BatchedLocomotion.LOCOMOTION), operating_mode=1, check_safety=True)
+    req = torch.full((n,), BatchedLocomotion.LOCOMOTION, dtype=torch.int32, device="cuda")
+    wa = wb = torch.from_numpy(np.tile(ROBOT_TABLE64[0, 12:24].astype(np.float32), (n, 1))).cuda()
+    for tick in range(8):
+        dof, body, cmd16 = ts.tick(tick)
+        dof_t, body_t, cmd3 = torch.from_numpy(dof).cuda(), torch.from_numpy(body).cuda(), torch.from_numpy(np.ascontiguousarray(cmd16[:, :3])).cuda()
+        ta, wa = a.run_policy(pol, dof_t, body_t, cmd3, wa, req)
+        ta = ta.clone()
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().mpc_ctrl_update_estimate(b._handle, body_t.data_ptr(), stream), "mpc_ctrl_update_estimate")
+        est, nrm = b.estimate()
+        wb = pol.step(pol.compute_observations(dof_t, est, nrm, cmd3, wb))
+        tb = b.run_fsm(dof_t, body_t, pol.pack_commands(cmd3, wb), req)
+        assert torch.equal(wa, wb) and torch.equal(ta, tb), tick
+
+
 # ------------------------------------------------------------------- pinned by the reference's own code
 RUNNER_GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "runner_policy_h10.npz")
 
