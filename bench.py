@@ -782,18 +782,20 @@ def control_loop_leg(n, h, dev, ticks=40, warm=10, reset_every=0, solver="osqp",
 def env_bridge_loop_leg(n, h, dev, ticks=40, warm=10, reset_every=0):
     """Secondary figure (NOT `value`): what an RL training loop calls per simulator step -- MpcEnvBridge.pre_physics_step(actions, dof_state, root_states, commands)
     (RL_Environment/tasks/aliengo.py:237-258: rescale of the policy's actions, command record, controller.run for every env) and, with reset_every > 0,
-    reset_idx(env_ids on the device) of n/64 envs every that many ticks (:321-334).  Same tick stream and cadence as control_loop_leg (MPC on every 2nd tick), fresh
-    random actions per tick, everything resident in HBM."""
+    reset_idx(env_ids on the device) of n/64 envs every that many ticks (:321-334).  Same tick stream and cadence as control_loop_leg (MPC on every 2nd tick); the
+    actions are the ones whose rescale gives control_loop_leg's weights (so the two legs solve the same problems and differ by the glue only), everything resident in HBM."""
     import torch
     from rl_mpc_locomotion_amd.env_bridge import MpcEnvBridge
     from rl_mpc_locomotion_amd.synthetic import TickStream
     ts = TickStream(n, seed=4242, config=2)
     br = MpcEnvBridge(ts.robot_type, ts.gait_id, horizon=h, device=dev)
-    rng = np.random.default_rng(6)
+    from rl_mpc_locomotion_amd.weight_policy import MPC_PARAM_CONST, MPC_PARAM_SCALE
+    rng = np.random.default_rng(5)
+    actions = torch.from_numpy(((ts.w - np.array(MPC_PARAM_CONST, np.float32)) / np.array(MPC_PARAM_SCALE, np.float32)).astype(np.float32)).to(dev)
     ins = []
     for k in range(warm + ticks):
         dof, body, cmd = ts.tick(k)
-        ins.append((torch.from_numpy(rng.uniform(-1, 1, (n, 12)).astype(np.float32)).to(dev), torch.from_numpy(dof.reshape(n * 12, 2)).to(dev),
+        ins.append((actions, torch.from_numpy(dof.reshape(n * 12, 2)).to(dev),
                     torch.from_numpy(body).to(dev), torch.from_numpy(np.ascontiguousarray(cmd[:, :3])).to(dev)))
     ids = [torch.from_numpy(rng.choice(n, max(1, n // 64), replace=False).astype(np.int32)).to(dev) for _ in range(warm + ticks)]
     for k in range(warm):

@@ -71,18 +71,11 @@ typedef double mpc_double2 __attribute__((ext_vector_type(2)));
 //   MPC_PART_ROWMAJOR_MAXT    the largest workgroup that keeps the partial products of the solve kernel's tile mat-vec as [row][slot] (else [slot][row]);
 //   MPC_PART_PAD              extra doubles per row of the [row][slot] layout
 //   MPC_QUAD_SCATTER          1: the per-step wrench sums as a quad reduce-scatter (0: all-sum of all six, then a select)
-//   MPC_GS_FORM               1: Shared::Gf holds G_f S_f^-1 and WThread::b holds S^-1 b (one 3 x 3 product less per ADMM iteration)
-#ifndef MPC_GS_FORM
-#define MPC_GS_FORM 1
-#endif
 #ifndef MPC_SHARE_ROLE_REGS       // tile and foot state of a solve-kernel thread in the same registers where the roles are different threads
 #define MPC_SHARE_ROLE_REGS 1
 #endif
 #ifndef MPC_FOOT0                 // first foot lane of the solve kernel's workgroup for horizon H with MTW tile lanes
-#ifndef MPC_SPLIT_H10             // 1: also at h = 10 tile lanes and foot lanes are different threads (a 128-thread workgroup: a tile wave and a foot wave; experiment)
-#define MPC_SPLIT_H10 0
-#endif
-#define MPC_FOOT0(H, MTW) (((H) == 12 || (H) == 16 || ((H) == 10 && MPC_SPLIT_H10)) ? (((MTW) + 3) / 4) * 4 : 0)
+#define MPC_FOOT0(H, MTW) (((H) == 12 || (H) == 16) ? (((MTW) + 3) / 4) * 4 : 0)
 #endif
 #ifndef MPC_PART_ROWMAJOR_MAXT
 #define MPC_PART_ROWMAJOR_MAXT 64

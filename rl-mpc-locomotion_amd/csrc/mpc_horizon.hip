@@ -189,110 +189,6 @@ __global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES
   }
 }
 
-// The same two job loops as two kernels of one stream (MPC_SPLIT_JOBS; the long horizons): the register allocation of each is its own -- the
-// ADMM loop is not allocated for the polish's state and the polish not for the iteration's -- at the price of the polish jobs no longer
-// filling the tail of the ADMM jobs (the second kernel starts when the first has ended).
-#ifndef MPC_SPLIT_JOBS
-#define MPC_SPLIT_JOBS 0
-#endif
-#ifndef MPC_POLISH_MIN_WAVES
-#define MPC_POLISH_MIN_WAVES MPC_SOLVE_MIN_WAVES_WIDE
-#endif
-#if MPC_SPLIT_JOBS
-template <int H>
-__global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES : MPC_SOLVE_MIN_WAVES_WIDE)) void mpc_admm_jobs_kernel(
-    const RobotModel *__restrict__ models, double *__restrict__ state, const double *__restrict__ qp, double *__restrict__ sc,
-    double *__restrict__ forces, int *__restrict__ info, long long *__restrict__ prof, const int *__restrict__ order, int *__restrict__ sched,
-    int *__restrict__ ready, int max_iter) {
-  __shared__ __attribute__((aligned(16))) Shared<H> sh;
-  __shared__ int job;
-  using C = Cfg<H>;
-  using Ex = DeviceExec<WThread<H>, (C::TW <= 64)>;
-  WThread<H> th;
-  th.init(threadIdx.x);
-  Ex ex{th};
-  const int njobs = sched[kSchedJobs];
-  auto solver = [&](int robot) {
-    return Solver<H, Ex>{ex, sh, models[robot], state + (size_t)robot * state_len<H>(), qp + (size_t)robot * C::QP_LEN, sc + (size_t)robot * C::SC_LEN,
-                         forces + (size_t)robot * C::N, info + (size_t)robot * kInfoLen, prof ? prof + (size_t)robot * kProfLen : nullptr};
-  };
-  for (;;) {     // ---- ADMM jobs, in the dispatch order of order_block
-    [[maybe_unused]] const long long tf0 = MPC_CLOCK();
-    ex.par([&](WThread<H> &t) { if (t.tid == 0) job = atomicAdd(&sched[kSchedNext], 1); });
-    const int idx = job;
-    ex.par([](WThread<H> &) {});     // (everybody has read `job` before thread 0 overwrites it)
-    if (idx >= njobs) break;
-    const int robot = order[idx];
-#pragma unroll
-    for (int j = 0; j < C::TE; ++j) th.Mx[j] = 0;
-    bool pol;
-    {
-      Solver<H, Ex> sv = solver(robot);
-      sv.max_iter = max_iter;
-      sv.jobrec = sc + (size_t)robot * C::SC_LEN + C::SC_JOB;
-      pol = sv.admm_job();
-      if (MPC_PROFILE_SUB == 8 && prof && threadIdx.x == 0) MPC_GST(prof + (size_t)robot * kProfLen + 1, (long long)(sv.t_start - tf0));
-    }
-    // The job's results are device-coherent stores (MPC_GST: sc1, write-through), so they need no L2 write-back -- only to have COMPLETED
-    // before the entry is published.  That wait is spelled out: every thread waits for its own stores (s_waitcnt vmcnt(0)), the phase
-    // boundary below (barrier / single-wave order) joins the threads, then thread 0 publishes.  The workgroup-scope release fence is
-    // there for the COMPILER's ordering only; the memory model does not let it synchronise two workgroups, and nothing may depend on
-    // how it happens to be lowered (tests/test_isa_budget.py checks the s_waitcnt on the ISA of every instantiation).
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(kWaitVm0);
-    ex.par([](WThread<H> &) {});
-    ex.par([&](WThread<H> &t) {
-      if (t.tid == 0) {
-        const int pos = atomicAdd(&sched[kSchedTail], 1);
-        __hip_atomic_store(&ready[pos], pol ? robot : -2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    });
-  }
-}
-template <int H>
-__global__ __launch_bounds__(Cfg<H>::TW, (Cfg<H>::TW <= 64 ? MPC_SOLVE_MIN_WAVES : MPC_POLISH_MIN_WAVES)) void mpc_polish_jobs_kernel(
-    const RobotModel *__restrict__ models, double *__restrict__ state, const double *__restrict__ qp, double *__restrict__ sc,
-    double *__restrict__ forces, int *__restrict__ info, long long *__restrict__ prof, const int *__restrict__ order, int *__restrict__ sched,
-    int *__restrict__ ready, int max_iter) {
-  __shared__ __attribute__((aligned(16))) Shared<H> sh;
-  __shared__ int job;
-  using C = Cfg<H>;
-  using Ex = DeviceExec<WThread<H>, (C::TW <= 64)>;
-  WThread<H> th;
-  th.init(threadIdx.x);
-  Ex ex{th};
-  const int njobs = sched[kSchedJobs];
-  auto solver = [&](int robot) {
-    return Solver<H, Ex>{ex, sh, models[robot], state + (size_t)robot * state_len<H>(), qp + (size_t)robot * C::QP_LEN, sc + (size_t)robot * C::SC_LEN,
-                         forces + (size_t)robot * C::N, info + (size_t)robot * kInfoLen, prof ? prof + (size_t)robot * kProfLen : nullptr};
-  };
-  for (;;) {     // ---- polish jobs, in completion order of the ADMM parts
-    [[maybe_unused]] const long long tf0 = MPC_CLOCK();
-    ex.par([&](WThread<H> &t) {
-      if (t.tid == 0) {
-        const int pos = atomicAdd(&sched[kSchedHead], 1);
-        int e = -2;
-        if (pos < njobs) {
-          while ((e = __hip_atomic_load(&ready[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == -1) __builtin_amdgcn_s_sleep(32);
-        } else e = -3;
-        job = e;
-      }
-    });
-    const int e = job;
-    ex.par([](WThread<H> &) {});
-    if (e == -3) break;
-    if (e < 0) continue;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // (the ADMM job's results are read with device-coherent loads, MPC_GLD: no L2 invalidate)
-#pragma unroll
-    for (int j = 0; j < C::TE; ++j) th.Mx[j] = 0;
-    Solver<H, Ex> sv = solver(e);
-    sv.jobrec = sc + (size_t)e * C::SC_LEN + C::SC_JOB;
-    sv.polish_job();
-    if (MPC_PROFILE_SUB == 8 && prof && threadIdx.x == 0) MPC_GST(prof + (size_t)e * kProfLen + 2, (long long)(sv.t_start - tf0));
-  }
-}
-#endif
-
 // Workgroup -> robot order for the solve kernel of THIS launch: robots sorted by the shader cycles their previous solve took,
 // longest first.  Runs as one extra workgroup of the assembly kernel (blockIdx.x == 0), i.e. hidden behind the assembly.
 // Warm-started robots repeat their iteration counts from step to step, and solve times differ 3x between a 25-iteration
@@ -387,17 +283,8 @@ int launch(const LaunchArgs &a) {
                        a.max_iter);
   }
   else if (a.job_slots > 0) {   // persistent workgroups, ADMM and polish as separate jobs (h = 16: 2.68 -> 2.28 ms, h = 20: 3.36 -> 2.78 ms per 4096 robots)
-    int slots = Cfg<H>::TW <= 64 || (H == 10 && MPC_SPLIT_H10) ? a.job_slots : a.job_slots / 2;         // (multi-wave workgroups: two per CU; the two-wave split of h = 10: four)
+    int slots = Cfg<H>::TW <= 64 ? a.job_slots : a.job_slots / 2;         // (multi-wave workgroups: two per CU)
     if (slots < 1) slots = 1;
-#if MPC_SPLIT_JOBS
-    if (Cfg<H>::TW > 64) {
-      hipLaunchKernelGGL((mpc_admm_jobs_kernel<H>), dim3(a.n < slots ? a.n : slots), dim3(Cfg<H>::TW), 0, a.stream, a.models, a.state, a.qp, a.sc, a.forces, a.info, a.prof, a.order,
-                         a.sched, a.ready, a.max_iter);
-      const int pslots = MPC_POLISH_MIN_WAVES == 1 ? (slots + 1) / 2 : slots;
-      hipLaunchKernelGGL((mpc_polish_jobs_kernel<H>), dim3(a.n < pslots ? a.n : pslots), dim3(Cfg<H>::TW), 0, a.stream, a.models, a.state, a.qp, a.sc, a.forces, a.info, a.prof, a.order,
-                         a.sched, a.ready, a.max_iter);
-    } else
-#endif
     hipLaunchKernelGGL((mpc_solve_jobs_kernel<H>), dim3(a.n < slots ? a.n : slots), dim3(Cfg<H>::TW), 0, a.stream, a.models, a.state, a.qp, a.sc, a.forces, a.info, a.prof, a.order,
                        a.sched, a.ready, a.max_iter);
   }

@@ -63,21 +63,6 @@ struct RoleRegs<TE, true> {
   };
 };
 
-// The symmetric sweep of the multi-wave workgroups on the matrix pipe (Solver::sweep_all_mfma): which horizons use it.  None: measured at h = 16
-// (profiles/r04_ab_long_horizon_sweep.txt) it loses -- 72 more registers per lane at the 256-register cap, and even spill-free (one wave per SIMD) a block of
-// four pivots costs 2.7 k cycles where the one-pivot form spends 4 x 0.9 k shared between two robots.  -DMPC_MFMA_SWEEP\(H\)=\(\(H\)==16\) builds it.
-#ifndef MPC_MFMA_SWEEP
-#define MPC_MFMA_SWEEP(H) 0
-#endif
-// its geometry: the 6h x 6h matrix as MT x MT tiles of 16 x 16 (padded with the identity), a WR x WC grid of wavefronts, TR x TC tiles per wavefront
-template <int H>
-struct MfmaSweepCfg {
-  static constexpr int NW = 6 * H, T = Cfg<H>::TW, MT = (NW + 15) / 16, MP = 16 * MT, W = T / 64;
-  static constexpr int WC = W >= 4 ? 2 : 1, WR = W / WC;
-  static constexpr int TR = (MT + WR - 1) / WR, TC = (MT + WC - 1) / WC, TPW = TR * TC;
-  static constexpr bool on = MPC_MFMA_SWEEP(H) && T % 64 == 0 && WR * WC == W;
-};
-
 template <int H>
 struct WThread : RoleRegs<Cfg<H>::TE, (Cfg<H>::FOOT0 != 0 && MPC_SHARE_ROLE_REGS)> {
   using C = Cfg<H>;
@@ -101,8 +86,6 @@ struct WThread : RoleRegs<Cfg<H>::TE, (Cfg<H>::FOOT0 != 0 && MPC_SHARE_ROLE_REGS
   int gidx;                                      //   their index result
   static constexpr int kGaccT = C::TW <= 64 ? 3 : 0;      //   seed_inverse_mfma: up to 3 x 3 tiles of 16 x 16 (single-wavefront workgroups only)
   double gacc[kGaccT ? 4 * kGaccT * kGaccT : 1], gz[kGaccT ? kGaccT : 1], gnr[kGaccT ? kGaccT : 1];      //   my four elements of each tile; my element of L^-1 A_K,J / B^-1 A_K,J per tile column
-  double macc[MfmaSweepCfg<H>::on ? 4 * MfmaSweepCfg<H>::TPW : 1];             // sweep_all_mfma: my four elements of each of my wavefront's 16 x 16 tiles
-  double mz[MfmaSweepCfg<H>::on ? MfmaSweepCfg<H>::TR + MfmaSweepCfg<H>::TC : 1];   //   my element of the two operands per tile row / tile column
   double pG[9], pC[9], pu0[3], pg[3], pr[3], pt[3], pxN[3], pPu[3], pw[3];
   double pQ[18], pR[21], pv[3], pn[6];           // orthogonalisation of the step's wrench columns (polish)
   double xp[3], zp[5], yp[5];
@@ -182,9 +165,6 @@ struct GiShared {
 #ifndef MPC_SEED_LAMBDA           // ... and one whose multiplier is below this fraction of the largest is dropped as not (clearly) active
 #define MPC_SEED_LAMBDA 1e-6
 #endif
-#ifndef MPC_SPLIT_RANGES
-#define MPC_SPLIT_RANGES 0   // (measured on the ISA: no help at present)
-#endif
 #define MPC_V alignas(16) double
 template <int H>
 struct Shared {
@@ -193,8 +173,7 @@ struct Shared {
   static constexpr int NRED = 21;                                       // residual / certificate reductions (Solver::residuals)
   static constexpr int PARTLEN_A0 = C::GW * C::NPW, PARTLEN_A1 = C::NW * (((C::GW + 1) & ~1) + MPC_PART_PAD);   // [slot][row] / [row][slot] (even row stride) partials
   static constexpr int PARTLEN_A = PARTLEN_A0 > PARTLEN_A1 ? PARTLEN_A0 : PARTLEN_A1, PARTLEN_B = NRED * RW;
-  static constexpr int PARTLEN_AB = PARTLEN_A > PARTLEN_B ? PARTLEN_A : PARTLEN_B, PARTLEN_C = MfmaSweepCfg<H>::on ? 16 * MfmaSweepCfg<H>::MP : 0;   // (C: sweep_all_mfma's stage, a tile row of the matrix)
-  static constexpr int PARTLEN = PARTLEN_AB > PARTLEN_C ? PARTLEN_AB : PARTLEN_C;
+  static constexpr int PARTLEN = PARTLEN_A > PARTLEN_B ? PARTLEN_A : PARTLEN_B;
   MPC_V B6[72]; MPC_V th1[36]; MPC_V th2[8];
   double c, cinv, rho, calpha;
   double rho3[4], rinv3[4];                             // rho and 1 / rho of a loose / inequality / equality row (index type + 1)
@@ -724,17 +703,12 @@ struct Solver {
         double w[18], gf[18];
         foot_w(t, w);
         mul_tk(t, w, gf);
-#if MPC_GS_FORM
         // G_f X_f is what the iteration uses:  x~ = X b - (G X)^T y_w,  the wrench of the next right-hand side = (G X) b
         double hs[18];
 #pragma unroll
         for (int r = 0; r < 6; ++r) sym3_mul(xs(t), gf + 3 * r, hs + 3 * r);
 #pragma unroll
         for (int k = 0; k < 18; ++k) s.Gf[pidx(k, t.fid)] = hs[k];
-#else
-#pragma unroll
-        for (int k = 0; k < 18; ++k) s.Gf[pidx(k, t.fid)] = gf[k];
-#endif
       }
     });
     factor_tail();
@@ -792,29 +766,9 @@ struct Solver {
       }
     });
     lap(6);
-    split_ranges();
     sweep_all();
-    split_ranges();
     ex.par([&](Th &t) { if (t.tid == 0) s.nfact++; });
     lap(7);
-  }
-  // A register-allocation hint, no code (multi-wave workgroups, which run at a 256-register cap): every value that lives across the
-  // sweep passes through an empty asm, which ends its live range and starts a new one.  Without such split points the allocator treats
-  // a foot lane's iterate as one range over the whole solve and, once the sweep is over budget, spills inside its loop; with them the
-  // foot state is spilled once before the sweep and reloaded once after it.
-  MPC_HD void split_ranges() {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (T > 64 && MPC_SPLIT_RANGES) {
-      Th &t = ex.th;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) { MPC_LAUNDER(t.x[k]); MPC_LAUNDER(t.q[k]); }
-#pragma unroll
-      for (int k = 0; k < 5; ++k) { MPC_LAUNDER(t.z[k]); MPC_LAUNDER(t.y[k]); }
-#pragma unroll
-      for (int k = 0; k < 6; ++k) MPC_LAUNDER(t.Si[k]);
-      MPC_LAUNDER(t.dlq[0]); MPC_LAUNDER(t.dlq[1]);
-    }
-#endif
   }
   MPC_HD void factor() {
     ex.par([&](Th &t) {
@@ -854,7 +808,6 @@ struct Solver {
   static constexpr bool kPairSweep = MPC_PAIR_SWEEP(T);
   MPC_HD void sweep_all() {
     static_assert(TS % 2 == 0, "pairs must not straddle tiles");
-    if constexpr (MS::on) { sweep_all_mfma(); return; }
     if constexpr (!kPairSweep) { sweep_all_single(); return; }
     int buf = 0;
     ex.par([&](Th &t) { if (t.mact) publish<0>(t, 0, 0); });
@@ -945,165 +898,6 @@ struct Solver {
     }
   }
 
-  // ---- the same sweep in blocks of FOUR pivots on v_mfma_f64_16x16x4_f64 (multi-wave workgroups).  One pivot per phase costs the long horizons a
-  // publish -> barrier -> fetch round trip per pivot (6h of them, ~900 cycles each at h = 16 for ~250 of arithmetic).  Per block K of four pivots, with
-  // A_KK = L D L^T:   A <- A - U B U^T,  B = A_KK^-1 = L^-T D^-1 L^-1,  U = A_:,K with A_KK - I in the rows of K
-  // -- the generic update again does everything: A_iK B on the block's columns, B A_Kj on its rows, 2 I - B on the block itself (see above).  The matrix is
-  // held as 16 x 16 tiles in the instruction's accumulator layout (lane l: rows (l >> 4) + 4 r, column l & 15), BOTH triangles, a TR x TC block of tiles
-  // per wavefront: the four pivot rows of a tile are register (pivot / 4) % 4 of every lane -- the B-operand layout -- and, by symmetry, the A operand of
-  // the mirrored block, so a tile's update is one instruction:  acc(I, J) += (-D^-1 L^-1 R_I)^T-as-A x (L^-1 R_J)-as-B  with R the four published rows.
-  // Every lane factors the 4 x 4 pivot block itself (L D L^T: four reciprocals, no square root).  One barrier per block; 6h / 4 blocks.
-  // The tile lanes' 6 x 6 register tiles (what the iteration's products use) go to this layout and back through LDS, sixteen matrix rows at a time.
-  using MS = MfmaSweepCfg<H>;
-  MPC_HD double *mrows(int b) { return s.part + (b & 1) * 4 * MS::MP; }
-  template <int A>
-  MPC_HD void mfma_publish(int kt, int b) {
-    double *R = mrows(b);
-    ex.par([&](Th &t) {
-      const int w = t.tid >> 6, l = t.tid & 63, k = l >> 4, cl = l & 15, wr = w / MS::WC, wc = w % MS::WC;
-      static_for<MS::TR>([&](auto a_) {
-        const int I = wr * MS::TR + a_.value;
-        if (I == kt) {
-          static_for<MS::TC>([&](auto b_) {
-            const int J = wc * MS::TC + b_.value;
-            if (J < MS::MT) {
-              double v = t.macc[(a_.value * MS::TC + b_.value) * 4 + A];
-              if (I == J && cl == 4 * A + k) v -= 1.0;
-              R[k * MS::MP + 16 * J + cl] = v;
-            }
-          });
-        }
-      });
-    });
-  }
-  template <int A>
-  MPC_HD void mfma_steps(int kt, int &buf) {
-    if constexpr (A < 4) {
-      if (16 * kt + 4 * A < NW) {      // (beyond: the identity padding)
-        mfma_step<A>(kt, buf);
-        buf ^= 1;
-      }
-      mfma_steps<A + 1>(kt, buf);
-    }
-  }
-  template <int A>
-  MPC_HD void mfma_step(int kt, int buf) {
-    const double *R = mrows(buf);
-    const int p0 = 16 * kt + 4 * A;
-    ex.seq([&](Th &t) {
-      const int w = t.tid >> 6, l = t.tid & 63, k = l >> 4, cl = l & 15, wr = w / MS::WC, wc = w % MS::WC;
-      const double p00 = R[p0] + 1.0, p10 = R[MS::MP + p0], p11 = R[MS::MP + p0 + 1] + 1.0, p20 = R[2 * MS::MP + p0], p21 = R[2 * MS::MP + p0 + 1],
-                   p22 = R[2 * MS::MP + p0 + 2] + 1.0, p30 = R[3 * MS::MP + p0], p31 = R[3 * MS::MP + p0 + 1], p32 = R[3 * MS::MP + p0 + 2], p33 = R[3 * MS::MP + p0 + 3] + 1.0;
-      const double i0 = fast_recip(p00);
-      const double l10 = p10 * i0, l20 = p20 * i0, l30 = p30 * i0;
-      const double d1 = p11 - l10 * p10, i1 = fast_recip(d1);
-      const double u21 = p21 - l20 * p10, u31 = p31 - l30 * p10;
-      const double l21 = u21 * i1, l31 = u31 * i1;
-      const double d2 = (p22 - l20 * p20) - l21 * u21, i2 = fast_recip(d2);
-      const double u32 = (p32 - l30 * p20) - l31 * u21;
-      const double l32 = u32 * i2;
-      const double d3 = ((p33 - l30 * p30) - l31 * u31) - l32 * u32, i3 = fast_recip(d3);
-      if (t.tid == 0 && !(p00 > 0 && d1 > 0 && d2 > 0 && d3 > 0)) s.bad = 1;     // not positive definite
-      // L^-1 (unit lower), my row k of it, my pivot's 1 / d
-      const double m10 = -l10, m21 = -l21, m32 = -l32;
-      const double m20 = l21 * l10 - l20, m31 = l32 * l21 - l31;
-      const double m30 = -(l30 + l31 * m10 + l32 * m20);
-      const double c0 = k == 0 ? 1.0 : (k == 1 ? m10 : (k == 2 ? m20 : m30));
-      const double c1 = k == 0 ? 0.0 : (k == 1 ? 1.0 : (k == 2 ? m21 : m31));
-      const double c2 = k <= 1 ? 0.0 : (k == 2 ? 1.0 : m32);
-      const double c3 = k == 3 ? 1.0 : 0.0;
-      const double dk = k == 0 ? i0 : (k == 1 ? i1 : (k == 2 ? i2 : i3));
-      auto col = [&](int J) {
-        const int q = 16 * (J < MS::MT ? J : 0) + cl;
-        return ((c0 * R[q] + c1 * R[MS::MP + q]) + c2 * R[2 * MS::MP + q]) + c3 * R[3 * MS::MP + q];
-      };
-      static_for<MS::TR>([&](auto a_) { t.mz[a_.value] = -(dk * col(wr * MS::TR + a_.value)); });
-      static_for<MS::TC>([&](auto b_) { t.mz[MS::TR + b_.value] = col(wc * MS::TC + b_.value); });
-    });
-    static_for<MS::TPW>([&](auto ij) {
-      constexpr int a_ = ij.value / MS::TC, b_ = ij.value % MS::TC;
-      constexpr int off = 4 * ij.value;
-      ex.mfma16([](Th &t) { return t.mz[a_]; }, [](Th &t) { return t.mz[MS::TR + b_]; }, [](Th &t) { return t.macc + off; });
-    });
-    // the next block's rows (their tiles have just been updated)
-    constexpr int AN = (A + 1) % 4;
-    const int ktn = A + 1 < 4 ? kt : kt + 1;
-    if (16 * ktn + 4 * AN < NW) mfma_publish<AN>(ktn, buf ^ 1);
-  }
-  MPC_HD void sweep_all_mfma() {
-    static_assert(!MS::on || 16 * MS::MP <= Sh::PARTLEN, "a tile row of the matrix must fit Shared::part");
-    double *const chunk = s.part;
-    for (int c = 0; c < MS::MT; ++c) {      // in: sixteen matrix rows at a time
-      ex.par([&](Th &t) {
-        if (t.mact) {
-#pragma unroll
-          for (int a = 0; a < TS; ++a)
-#pragma unroll
-            for (int b = 0; b < TS; ++b) {
-              const int r = TS * t.ti + a, q = TS * t.tj + b;
-              const double v = t.Mx[a * TS + b];
-              if ((r >> 4) == c) chunk[(r & 15) * MS::MP + q] = v;
-              if (!t.dia && (q >> 4) == c) chunk[(q & 15) * MS::MP + r] = v;
-            }
-        }
-        if constexpr (MS::MP > NW) {      // the identity padding
-          for (int i = t.tid; i < 16 * MS::MP; i += T) {
-            const int r = 16 * c + i / MS::MP, q = i % MS::MP;
-            if (r >= NW || q >= NW) chunk[i] = r == q ? 1.0 : 0.0;
-          }
-        }
-      });
-      ex.par([&](Th &t) {
-        const int w = t.tid >> 6, l = t.tid & 63, k = l >> 4, cl = l & 15, wr = w / MS::WC, wc = w % MS::WC;
-        static_for<MS::TR>([&](auto a_) {
-          if (wr * MS::TR + a_.value == c) {
-            static_for<MS::TC>([&](auto b_) {
-              const int J = wc * MS::TC + b_.value;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) t.macc[(a_.value * MS::TC + b_.value) * 4 + r] = J < MS::MT ? chunk[(k + 4 * r) * MS::MP + 16 * J + cl] : 0.0;
-            });
-          }
-        });
-      });
-    }
-    MPC_SUBLAP(10, 1);
-    int buf = 0;
-    mfma_publish<0>(0, 0);
-    for (int kt = 0; kt < MS::MT; ++kt) mfma_steps<0>(kt, buf);
-    ex.par([](Th &) {});      // (the last block's rows are read until here; the stage is rewritten below)
-    MPC_SUBLAP(10, 2);
-    for (int c = 0; c < MS::MT; ++c) {      // out
-      ex.par([&](Th &t) {
-        const int w = t.tid >> 6, l = t.tid & 63, k = l >> 4, cl = l & 15, wr = w / MS::WC, wc = w % MS::WC;
-        static_for<MS::TR>([&](auto a_) {
-          if (wr * MS::TR + a_.value == c) {
-            static_for<MS::TC>([&](auto b_) {
-              const int J = wc * MS::TC + b_.value;
-              if (J < MS::MT) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) chunk[(k + 4 * r) * MS::MP + 16 * J + cl] = t.macc[(a_.value * MS::TC + b_.value) * 4 + r];
-              }
-            });
-          }
-        });
-      });
-      ex.par([&](Th &t) {
-        // (every thread, whether it holds a tile or not: an unconditional definition, so that the tiles are dead registers during the blocks)
-        const int ti = t.mact ? t.ti : 0, tj = t.mact ? t.tj : 0;
-#pragma unroll
-        for (int a = 0; a < TS; ++a) {
-          const int r = TS * ti + a;
-#pragma unroll
-          for (int b = 0; b < TS; ++b) {
-            const double v = chunk[(r & 15) * MS::MP + TS * tj + b];
-            t.Mx[a * TS + b] = (r >> 4) == c ? v : (c == 0 ? 0.0 : t.Mx[a * TS + b]);
-          }
-        }
-      });
-    }
-    MPC_SUBLAP(10, 3);
-  }
-
   // ---- the one-pivot form of the same sweep (the multi-wave kernels of the long horizons: at their 256-register cap the pair form's
   // two extra 6-vectors go to scratch inside the loop -- measured h = 16 2.35 -> 2.72 ms, h = 20 2.83 -> 3.11 ms per 4096 robots).
   // Per step k:  p = a_kk;  a_ij -= a_ik a_kj / p;  a_ik -> a_ik / p;  a_kk -> -1/p (+2, as above).  The published row carries
@@ -1181,15 +975,9 @@ struct Solver {
     for (int r = 0; r < 5; ++r) tm[r] = rho_at(t, r) * t.z[r] - t.y[r];
     at_mul(a, tm, acc);
 #pragma unroll
-#if MPC_GS_FORM
     for (int c = 0; c < 3; ++c) v[c] = kSigma * t.x[c] - t.q[c] + acc[c];
     sym3_mul(t.Si, v, t.b);       // t.b holds S^-1 b
     put_g(t, v);                  // (G S^-1) b
-#else
-    for (int c = 0; c < 3; ++c) t.b[c] = kSigma * t.x[c] - t.q[c] + acc[c];
-    sym3_mul(t.Si, t.b, v);
-    put_g(t, v);
-#endif
   }
   MPC_HD void admm_prepare() {
     ex.seq([&](Th &t) { if (t.foot) foot_rhs(t); });
@@ -1233,15 +1021,8 @@ struct Solver {
           double wy = 0;
 #pragma unroll
           for (int r = 0; r < 6; ++r) wy += gf[3 * r + c] * t.w6[r];
-#if MPC_GS_FORM
           t.xt[c] = t.b[c] - wy;      // S^-1 b - (G S^-1)^T y_w
-#else
-          tt[c] = t.b[c] - wy;
-#endif
         }
-#if !MPC_GS_FORM
-        sym3_mul(t.Si, tt, t.xt);
-#endif
         a_mul(a, t.xt, zt);
         if constexpr (!kBatchLoads) foot_bounds(t, lo, up);
 #pragma unroll
@@ -1262,17 +1043,9 @@ struct Solver {
           const double xn = kAlphaRelax * t.xt[c] + (1.0 - kAlphaRelax) * t.x[c];
           if constexpr (LAST) s.dxy[pidx(c, t.fid)] = xn - t.x[c];
           t.x[c] = xn;
-#if MPC_GS_FORM
           v[c] = kSigma * xn - t.q[c] + acc[c];
-#else
-          t.b[c] = kSigma * xn - t.q[c] + acc[c];
-#endif
         }
-#if MPC_GS_FORM
         sym3_mul(t.Si, v, t.b);
-#else
-        sym3_mul(t.Si, t.b, v);
-#endif
 #pragma unroll
         for (int r = 0; r < 6; ++r) t.w6[r] = gf[3 * r] * v[0] + gf[3 * r + 1] * v[1] + gf[3 * r + 2] * v[2];
       }

@@ -242,12 +242,8 @@ static void ksolve_one(const RobotModel &mdl, const float *in, double rho, const
       double v[3];
       for (int c = 0; c < 3; ++c) t.b[c] = b[3 * t.fid + c];
       Solver<H, Ex>::sym3_mul(t.Si, t.b, v);
-#if MPC_GS_FORM
       for (int c = 0; c < 3; ++c) t.xt[c] = v[c];      // S^-1 b
       sv.put_g(t, t.b);                                // Gf holds G S^-1
-#else
-      sv.put_g(t, v);
-#endif
     }
   });
   sv.template product<Solver<H, Ex>::kHeld>();
@@ -255,12 +251,7 @@ static void ksolve_one(const RobotModel &mdl, const float *in, double rho, const
     if (t.foot) {
       double wy[3], tt[3], o[3];
       sv.get_g(t, wy);
-#if MPC_GS_FORM
       for (int c = 0; c < 3; ++c) o[c] = t.xt[c] - wy[c];      // x~ = S^-1 b - (G S^-1)^T y
-#else
-      for (int c = 0; c < 3; ++c) tt[c] = t.b[c] - wy[c];
-      Solver<H, Ex>::sym3_mul(t.Si, tt, o);
-#endif
       for (int c = 0; c < 3; ++c) xt[3 * t.fid + c] = o[c];
     }
   });
