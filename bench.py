@@ -946,7 +946,13 @@ def python_tick_baseline(ticks=200):
     """the real Python path of BASELINE configs[0] -- one Aliengo, RobotRunnerMin.run, trot, h = 10 -- timed per tick with
     the oracle behind the reference's mpc_osqp seam.  Only where the reference tree is present (not on the GPU boxes)."""
     if not os.path.isdir("/root/reference/MPC_Controller"):
-        return None
+        # the GPU boxes have no reference tree: quote the record taken in the build container (profiles/r06_python_tick.json, which says where it was measured)
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", "r06_python_tick.json")))
+            rec["quoted_from"] = "profiles/r06_python_tick.json (measured in the build container, not on this box's host cores)"
+            return rec
+        except (OSError, ValueError):
+            return None
     try:
         sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
         import make_golden_controller as mg
