@@ -293,6 +293,29 @@ int mpc_pack_commands_scaled(int n, const float *d_cmd3, const float *d_actions1
 int mpc_ctrl_policy_observations(mpc_ctrl *c, const float *d_dof, const float *d_cmd3, const float *d_prev_actions, const float *scales4, float *d_obs, void *stream);
 int mpc_ctrl_run_fsm_estimated(mpc_ctrl *c, const float *d_dof, const float *d_body, const float *d_cmd, const int *d_request, float *d_torques, void *stream);
 
+/* ---- the optional torque exchange of an env batch that spans the GPUs of a node, as one-shot direct peer writes ------------------------
+ *
+ * robots shard over the GPUs with NO data-path collective; only a consumer that wants every robot's torques on every device needs an
+ * exchange of [n_local, 12] float32 per rank (24.6 KB per GPU at 4096 robots: latency-bound on xGMI).  sharding.ShardedLocomotion issues it
+ * either as an RCCL all-gather (torch.distributed) or through these entry points: every rank owns a receive region for the whole batch (fine-grained
+ * device memory, two parities), exported as a hipIpc handle; mpc_peer_put is ONE kernel that stores the rank's rows into every rank's region and then
+ * raises its epoch flag there (system-scope release); mpc_peer_wait ONE kernel that watches the local flags of all ranks (system-scope acquire; bounded:
+ * a rank that never arrives costs a timeout count, not a hang).  Both are stream-ordered, nothing synchronises the host.
+ *   Protocol per tick: put(k) ... wait(k) copies the whole batch of epoch k into the caller's buffer.  A rank must wait(k) before it puts k + 1, which
+ *   bounds every rank's lead to one epoch -- what makes two parities enough.
+ *   The handles (MPC_PEER_HANDLE_BYTES each, ranks in order) travel by whatever the host has (torch.distributed.all_gather_object).
+ * There is no reference counterpart (the reference is one process); UNMEASURED across GPUs -- the tests run two processes on one GPU and a one-rank group. */
+#define MPC_PEER_HANDLE_BYTES 64
+typedef struct mpc_peer mpc_peer;
+int mpc_peer_create(mpc_peer **out, int rank, int world, int n_rows_total, int row_bytes);      /* on the calling thread's current HIP device */
+int mpc_peer_handle(mpc_peer *p, void *handle64);
+int mpc_peer_connect(mpc_peer *p, const void *handles /* [world][MPC_PEER_HANDLE_BYTES], own entry ignored; NULL when world == 1 */);
+int mpc_peer_put(mpc_peer *p, const void *d_local, int row_lo, int n_rows, void *stream);
+int mpc_peer_wait(mpc_peer *p, void *d_out /* [n_rows_total, row_bytes] of the last put's epoch, or NULL: wait only */, void *stream);
+int mpc_peer_timeouts(mpc_peer *p, int *count);      /* synchronises; wait kernels that gave up (2 s) so far */
+void mpc_peer_destroy(mpc_peer *p);
+const char *mpc_peer_last_error(void);
+
 /* Shader clock of `device` under the solve kernel's own regime (one wave of dependent fp64 FMAs per SIMD on every CU) for about busy_ms
  * milliseconds: *ghz = shader cycles of one workgroup / HIP-event time of the launch, *ms (may be NULL) = that time.  Benchmarks record it next
  * to their numbers: boxes of one pool differ by 10 % in the clock they sustain. */

@@ -17,6 +17,7 @@ SYMBOLS = [
     "mpc_ctrl_create", "mpc_ctrl_destroy", "mpc_ctrl_step", "mpc_ctrl_run", "mpc_ctrl_reset", "mpc_ctrl_reset_device", "mpc_ctrl_set_gait", "mpc_ctrl_set_gait_device", "mpc_ctrl_set_solver", "mpc_ctrl_solver_info", "mpc_ctrl_solver_record", "mpc_ctrl_solver_forces", "mpc_ctrl_solver", "mpc_ctrl_set_iteration", "mpc_device_clock",
     "mpc_ctrl_fsm_init", "mpc_ctrl_run_fsm", "mpc_ctrl_fsm_reset", "mpc_ctrl_fsm_reset_device", "mpc_ctrl_fsm_state",
     "mpc_policy_create", "mpc_policy_destroy", "mpc_policy_step", "mpc_policy_observations", "mpc_ctrl_estimate", "mpc_ctrl_update_estimate", "mpc_pack_commands", "mpc_pack_commands_scaled", "mpc_ctrl_policy_observations", "mpc_ctrl_run_fsm_estimated",
+    "mpc_peer_create", "mpc_peer_handle", "mpc_peer_connect", "mpc_peer_put", "mpc_peer_wait", "mpc_peer_timeouts", "mpc_peer_destroy", "mpc_peer_last_error",
 ]
 
 
@@ -93,6 +94,14 @@ def lib():
         L.mpc_pack_commands_scaled.argtypes = [ci, vp, vp, vp, vp, vp, vp]; L.mpc_pack_commands_scaled.restype = ci
         L.mpc_ctrl_policy_observations.argtypes = [vp, vp, vp, vp, vp, vp, vp]; L.mpc_ctrl_policy_observations.restype = ci
         L.mpc_ctrl_run_fsm_estimated.argtypes = [vp, vp, vp, vp, vp, vp, vp]; L.mpc_ctrl_run_fsm_estimated.restype = ci
+        L.mpc_peer_create.argtypes = [C.POINTER(vp), ci, ci, ci, ci]; L.mpc_peer_create.restype = ci
+        L.mpc_peer_handle.argtypes = [vp, vp]; L.mpc_peer_handle.restype = ci
+        L.mpc_peer_connect.argtypes = [vp, vp]; L.mpc_peer_connect.restype = ci
+        L.mpc_peer_put.argtypes = [vp, vp, ci, ci, vp]; L.mpc_peer_put.restype = ci
+        L.mpc_peer_wait.argtypes = [vp, vp, vp]; L.mpc_peer_wait.restype = ci
+        L.mpc_peer_timeouts.argtypes = [vp, vp]; L.mpc_peer_timeouts.restype = ci
+        L.mpc_peer_destroy.argtypes = [vp]; L.mpc_peer_destroy.restype = None
+        L.mpc_peer_last_error.argtypes = []; L.mpc_peer_last_error.restype = C.c_char_p
         L.mpc_last_error.argtypes = []; L.mpc_last_error.restype = C.c_char_p
         _LIB = L
     return _LIB

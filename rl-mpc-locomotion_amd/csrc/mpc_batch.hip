@@ -506,6 +506,7 @@ __global__ __launch_bounds__(3 * 64) void ctrl_pre_fused_kernel(int n, CtrlState
       estimator_update(body + (size_t)r * 13, nrm, e);
       for (int k = 0; k < kEstLen; ++k) { sh_est[lane][k] = e[k]; est_out[(size_t)r * kEstLen + k] = e[k]; }
     }
+    __builtin_amdgcn_s_waitcnt(kWaitVm0);      // (like waves 0 and 2: this wave's loads of the state -- the previous tick's normal -- have arrived before wave 2 may overwrite it)
     __syncthreads();
     return;
   }
@@ -513,12 +514,13 @@ __global__ __launch_bounds__(3 * 64) void ctrl_pre_fused_kernel(int n, CtrlState
     const int r = r0 + lane;
     const bool on = lane < kFusedRobots && r < n && !cp.flat_ground;
     float hist[12], cph[4], nrm[3];
-    int first_run = 0;
+    int first_run = 0, due = 0;
     double body_height = 0.0;
     if (on) {
       for (int k = 0; k < 12; ++k) hist[k] = st[r].hist[k];
       for (int k = 0; k < 4; ++k) cph[k] = st[r].contact_phase[k];
       first_run = st[r].first_run;
+      due = ((st[r].iter + 1) % cp.iters_between_mpc) == 0;      // ctrl_pre_rest's do_solve of this tick: iterationCounter += 1, then the test (wave 0 stores the counter after the barrier)
       body_height = rc[st[r].robot_type].body_height;
     }
     __builtin_amdgcn_s_waitcnt(kWaitVm0);      // (the loads of the state are complete before wave 0 may store to it: it stores after the barrier)
@@ -529,7 +531,9 @@ __global__ __launch_bounds__(3 * 64) void ctrl_pre_fused_kernel(int n, CtrlState
       if (first_run) contact_history_init(hist, fp, body_height);
       ground_normal_update(hist, nrm, cph, fp);
       for (int k = 0; k < 12; ++k) st[r].hist[k] = hist[k];
-      for (int k = 0; k < 3; ++k) { st[r].normal[k] = nrm[k]; rec[(size_t)r * (56 + 4 * cp.horizon) + IN_NRM + k] = nrm[k]; }
+      for (int k = 0; k < 3; ++k) st[r].normal[k] = nrm[k];
+      if (due)      // the solver record is written on MPC ticks only, like the two-kernel path's (controller.h ctrl_pre_rest)
+        for (int k = 0; k < 3; ++k) rec[(size_t)r * (56 + 4 * cp.horizon) + IN_NRM + k] = nrm[k];
     }
     return;
   }

@@ -84,6 +84,7 @@ typedef double mpc_double2 __attribute__((ext_vector_type(2)));
 #ifndef MPC_PART_PAD
 #define MPC_PART_PAD 0
 #endif
+static_assert(MPC_PART_PAD % 2 == 0, "MPC_PART_PAD must be even: a row of the [row][slot] partial products starts on a 16-byte boundary (MPC_LDS_LOAD128 in sum_parts)");
 #ifndef MPC_QUAD_SCATTER
 #define MPC_QUAD_SCATTER 1
 #endif

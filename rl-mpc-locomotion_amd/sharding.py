@@ -51,6 +51,74 @@ def max_over_ranks(seconds: float, device, group=None) -> float:
     return float(t.item())
 
 
+class PeerExchange:
+    """The same exchange as one-shot direct peer writes (include/mpc_batch.h mpc_peer_*; SURVEY.md 5 recommends it for a 24 KB message): every rank's
+    rows go straight into every rank's receive region over xGMI in ONE kernel, flags instead of a collective.  The hipIpc handles travel once, at
+    construction, through torch.distributed.all_gather_object (any backend).  put(local) / wait() -> [n_total, width] are stream-ordered on the current
+    stream; a rank must wait() for an exchange before it starts the next one.  UNMEASURED across GPUs (tests: two processes on one GPU, a one-rank group)."""
+
+    def __init__(self, n_total, lo, n_local, width=12, group=None, device=None):
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        from . import _lib
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.n_total, self.lo, self.n_local, self.width = int(n_total), int(lo), int(n_local), int(width)
+        if (self.lo * self.width * 4) % 16:
+            raise ValueError("PeerExchange: a rank's block must start on a 16-byte boundary of the batch (lo * width * 4 bytes)")
+        with torch.cuda.device(self.device):
+            self._h = C.c_void_p()
+            self._check(_lib.lib().mpc_peer_create(C.byref(self._h), self.rank, self.world, self.n_total, self.width * 4), "mpc_peer_create")
+            mine = (C.c_ubyte * 64)()
+            self._check(_lib.lib().mpc_peer_handle(self._h, C.cast(mine, C.c_void_p)), "mpc_peer_handle")
+            handles = [None] * self.world
+            if self.world > 1:
+                dist.all_gather_object(handles, bytes(mine), group=group)
+                blob = (C.c_ubyte * (64 * self.world)).from_buffer_copy(b"".join(handles))
+                self._check(_lib.lib().mpc_peer_connect(self._h, C.cast(blob, C.c_void_p)), "mpc_peer_connect")
+            else:
+                self._check(_lib.lib().mpc_peer_connect(self._h, None), "mpc_peer_connect")
+        if self.world > 1:
+            dist.barrier(group=group)      # every rank has opened every region before anybody writes
+
+    @staticmethod
+    def _check(rc, what):
+        from . import _lib
+        if rc != 0:
+            raise _lib.MpcLibraryError(f"{what} failed ({rc}): {_lib.lib().mpc_peer_last_error().decode()}")
+
+    def put(self, local):
+        import torch
+        from . import _lib
+        if local.dtype != torch.float32 or not local.is_cuda or not local.is_contiguous() or local.numel() != self.n_local * self.width:
+            raise ValueError("PeerExchange.put: a contiguous cuda float32 [n_local, width] tensor")
+        self._check(_lib.lib().mpc_peer_put(self._h, local.data_ptr(), self.lo, self.n_local, torch.cuda.current_stream(self.device).cuda_stream), "mpc_peer_put")
+
+    def wait(self):
+        import torch
+        from . import _lib
+        out = torch.empty((self.n_total, self.width), dtype=torch.float32, device=self.device)
+        self._check(_lib.lib().mpc_peer_wait(self._h, out.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream), "mpc_peer_wait")
+        return out
+
+    def timeouts(self):
+        import ctypes as C
+        from . import _lib
+        n = C.c_int(0)
+        self._check(_lib.lib().mpc_peer_timeouts(self._h, C.addressof(n)), "mpc_peer_timeouts")
+        return n.value
+
+    def __del__(self):
+        from . import _lib
+        h = getattr(self, "_h", None)
+        if h and _lib is not None and _lib._LIB is not None:
+            _lib._LIB.mpc_peer_destroy(h)
+            self._h = None
+
+
 class ShardedLocomotion:
     """One env batch of `n_total` robots over the ranks of a node (one process per GPU, `torch.distributed` initialised by
     the caller): this rank owns the contiguous block [lo, hi) of robot indices and their persistent state -- warm starts, gait counters,
@@ -68,7 +136,9 @@ class ShardedLocomotion:
     `controller_factory(robot_type, gait_id, **kw)` builds the per-rank controller (default BatchedLocomotion on this rank's GPU; the CPU tests pass
     the host emulation and run over gloo)."""
 
-    def __init__(self, robot_type, gait_id, horizon=10, group=None, device=None, controller_factory=None, **kw):
+    def __init__(self, robot_type, gait_id, horizon=10, group=None, device=None, controller_factory=None, exchange="rccl", **kw):
+        """exchange: "rccl" -- torch.distributed's all_gather_into_tensor (RCCL on GPUs, gloo in the CPU tests) -- or "peer": one-shot direct peer writes
+        (PeerExchange; GPUs only), behind the same start_gather() / torques_all()."""
         import numpy as np
         import torch
         import torch.distributed as dist
@@ -92,6 +162,14 @@ class ShardedLocomotion:
         self._all = torch.zeros((self.world * mx, 12), dtype=torch.float32, device=self.device)
         self._work = None
         self._tau = None
+        if exchange not in ("rccl", "peer"):
+            raise ValueError("exchange must be 'rccl' or 'peer'")
+        self._peer = None
+        if exchange == "peer":
+            if self.device.type != "cuda":
+                raise ValueError("exchange='peer' needs GPUs (hipIpc peer writes)")
+            self._peer = PeerExchange(self.n_total, self.lo, self.n_local, 12, group=group, device=self.device)
+            self._peer_pending = False
 
     def _mine(self, t):
         """a [n_total, ...] batch tensor -> this rank's block; a [n_local, ...] tensor passes through"""
@@ -112,11 +190,25 @@ class ShardedLocomotion:
         import torch.distributed as dist
         if self._tau is None:
             raise RuntimeError("ShardedLocomotion.start_gather: run() first")
+        if self._peer is not None:
+            if self._peer_pending:                                               # (a rank waits for an exchange before it starts the next one: PeerExchange)
+                self._peer.wait()
+            self._side.wait_stream(torch.cuda.current_stream(self.device))      # the torques of this tick are complete
+            with torch.cuda.stream(self._side):
+                self._peer.put(self._tau)                                        # reads the controller's buffer on the side stream ...
+            torch.cuda.current_stream(self.device).wait_stream(self._side)      # ... before the next tick's ctrl_post may overwrite it (the put is one short kernel)
+            self._peer_pending = True
+            return
         if self.world == 1 and not dist.is_initialized():
             self._all[: self.n_local].copy_(self._tau)
             return
-        if self._side is not None and self._work is not None:
-            torch.cuda.current_stream(self.device).wait_stream(self._side)        # a gather nobody read yet still sends from the staging buffer
+        if self._work is not None:
+            # a gather nobody read yet still sends from the staging buffer: an async collective runs on the backend's own stream (RCCL) or thread (gloo), so only
+            # work.wait() orders the next write of the buffer behind it (wait_stream on the side stream does not)
+            self._work.wait()
+            self._work = None
+            if self._side is not None:
+                torch.cuda.current_stream(self.device).wait_stream(self._side)
         self._stage[: self.n_local].copy_(self._tau)                             # ordered before the next run() by the stream itself
         if self._side is not None:
             self._side.wait_stream(torch.cuda.current_stream(self.device))      # the snapshot is complete
@@ -129,6 +221,11 @@ class ShardedLocomotion:
         """[n_total, 12] on this rank's device, a fresh tensor (the next gather reuses the receive buffer): waits for the gather started last
         (the current stream waits; the host does not block on a GPU)."""
         import torch
+        if self._peer is not None:
+            if not self._peer_pending:
+                raise RuntimeError("ShardedLocomotion.torques_all: start_gather() first")
+            self._peer_pending = False
+            return self._peer.wait()                                             # a fresh [n_total, 12] tensor, filled on the current stream once every rank's flag is up
         if self._work is not None:
             self._work.wait()
             self._work = None

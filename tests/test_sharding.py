@@ -259,6 +259,73 @@ def test_sharded_locomotion_single_gpu_equals_batched():
     assert float(b.abs().max()) > 1.0
 
 
+# ---- the exchange as one-shot direct peer writes (sharding.PeerExchange, include/mpc_batch.h mpc_peer_*) ------------------------------------------------
+def _peer_worker(rank, world, port, n_total, ticks, out_dir, devices):
+    """`world` processes; rank r on GPU devices[r] (the 1-GPU boxes: every rank on GPU 0 -- the hipIpc handles, the flags and the double buffering are the
+    real ones, only the link is not xGMI).  The host side (handle exchange, barriers) runs over gloo: RCCL refuses two ranks on one device."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(devices[rank])
+    dev = torch.device(f"cuda:{devices[rank]}")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rl_mpc_locomotion_amd.sharding import ShardedLocomotion
+    ts, ins = _tick_inputs(n_total, ticks)
+    sl = ShardedLocomotion(ts.robot_type, ts.gait_id, horizon=10, device=dev, exchange="peer")
+    outs, prev = [], None
+    for k in range(ticks):
+        if k == 3:
+            sl.reset(torch.tensor([0, n_total - 1, n_total // 2], dtype=torch.int32, device=dev))    # global ids on the device
+        if prev is not None:
+            outs.append(sl.torques_all().cpu().numpy().copy())        # last tick's exchange, read after this tick's inputs were staged
+        sl.run(*(a.to(dev) for a in ins[k]))
+        sl.start_gather()
+        prev = k
+    outs.append(sl.torques_all().cpu().numpy().copy())
+    assert sl._peer.timeouts() == 0
+    np.save(os.path.join(out_dir, f"peer{rank}.npy"), np.stack(outs))
+    dist.barrier()
+    del sl
+    dist.destroy_process_group()
+
+
+def _peer_reference(n_total, ticks):
+    from rl_mpc_locomotion_amd.locomotion import BatchedLocomotion
+    ts, ins = _tick_inputs(n_total, ticks)
+    one = BatchedLocomotion(ts.robot_type, ts.gait_id, horizon=10, device="cuda:0")
+    ref = []
+    for k in range(ticks):
+        if k == 3:
+            one.reset(np.array([0, n_total - 1, n_total // 2], dtype=np.int32))
+        ref.append(one.run(*(a.cuda() for a in ins[k])).cpu().numpy().copy())
+    return np.stack(ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2])
+def test_peer_write_exchange_between_processes_of_one_gpu(tmp_path, world):
+    """ShardedLocomotion(exchange="peer") -- hipIpc receive regions, one put kernel, one wait kernel, two parities -- in the documented overlap pattern,
+    against one BatchedLocomotion of the whole batch: bit-identical torques on every rank, no wait kernel timed out.  world = 2: two PROCESSES sharing
+    GPU 0 (what a 1-GPU box can execute of the cross-process path); world = 1: the degenerate group.  n_total = 16 puts rank 1's block on a 16-byte boundary."""
+    n_total, ticks, port = 16, 6, _free_port()
+    mp.spawn(_peer_worker, args=(world, port, n_total, ticks, str(tmp_path), [0] * world), nprocs=world, join=True)
+    ref = _peer_reference(n_total, ticks)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"peer{r}.npy"), ref), f"rank {r}"
+
+
+@pytest.mark.gpu
+def test_peer_write_exchange_two_gpus(tmp_path):
+    """The same across two GPUs (xGMI peer writes): needs two visible devices (1-GPU boxes skip) -- so far unmeasured on hardware."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    n_total, ticks, port = 16, 6, _free_port()
+    mp.spawn(_peer_worker, args=(2, port, n_total, ticks, str(tmp_path), [0, 1]), nprocs=2, join=True)
+    ref = _peer_reference(n_total, ticks)
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"peer{r}.npy"), ref), f"rank {r}"
+
+
 def _sharded_nccl_worker(rank, world, port, n_total, ticks, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
