@@ -102,6 +102,9 @@ def parse_args():
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps each; `value` is the MEDIAN block (one block of ~20 steps is an 18 ms sample)")
     ap.add_argument("--robots-total", type=int, default=None, help="(strong-scaling configurations: overrides the total that is sharded over the ranks)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the N > 1 launch (nccl = RCCL; gloo only with --emulate)")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "peer", "both"],
+                    help="N > 1: which torque exchange the separately reported gather leg times -- the RCCL all-gather (default), the one-shot direct peer writes "
+                         "(sharding.PeerExchange: hipIpc + flags; unmeasured across GPUs, hence opt-in), or both for an A/B")
     ap.add_argument("--emulate", action="store_true",
                     help="CPU dry run of this script's control flow (self-launch, sharding, barriers, gather leg, rank-0 JSON) with the host emulation of the "
                          "kernels (tests/emu) standing in for the HIP library: for tests/test_bench_multirank.py, the numbers mean nothing")
@@ -378,6 +381,8 @@ def main():
     m = leg(args.config, n, h, K, W, dev, rank, world, dist, repeats=args.repeats, emulate=args.emulate)
     clock1 = device_state(local_rank, smi=False) if not args.emulate and rank == 0 else None
     gather = all_gather_leg(n, n_total, dev, dist) if dist is not None else None
+    if dist is not None and args.exchange in ("peer", "both") and not args.emulate:
+        gather["peer_write"] = peer_write_leg(n, n_total, rank, world, dev, dist)
     if dist is not None and seam == "ctrl":
         gather["sharded_loop"] = sharded_loop_leg(args.config, n_total, h, dev, dist, emulate=args.emulate)
 
@@ -655,6 +660,34 @@ def all_gather_leg(n, n_total, dev, dist, reps=50, warm=5):
     ok = bool(tuple(out.shape) == (n_total, 12))
     return {"ms": ms, "bytes_per_rank": n * 48, "robots_total": n_total, "shape_ok": ok,
             "note": "one all_gather_into_tensor of [n_local, 12] float32 per rank over RCCL / xGMI on a side stream; latency-bound"}
+
+
+def peer_write_leg(n, n_total, rank, world, dev, dist, reps=50, warm=5):
+    """--exchange peer | both: the same exchange as one-shot direct peer writes (sharding.PeerExchange), timed like all_gather_leg: put + wait per repetition on a side
+    stream, HIP events on that stream, max over ranks.  Equal shards only (a block must start on a 16-byte boundary of the batch)."""
+    import torch
+    from rl_mpc_locomotion_amd.sharding import PeerExchange, max_over_ranks
+    try:
+        px = PeerExchange(n_total, rank * n, n, 12, device=dev)
+        local = torch.randn((n, 12), dtype=torch.float32, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize(dev)
+        with torch.cuda.stream(side):
+            for _ in range(warm):
+                px.put(local); out = px.wait()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(side)
+            for _ in range(reps):
+                px.put(local); out = px.wait()
+            e1.record(side)
+        side.synchronize()
+        ms = max_over_ranks(e0.elapsed_time(e1) / reps, dev)
+        ok = bool(torch.equal(out[rank * n:(rank + 1) * n], local)) and px.timeouts() == 0
+        dist.barrier()
+        return {"ms": ms, "bytes_per_rank": n * 48, "own_block_ok_and_no_timeouts": ok,
+                "note": "one put kernel (this rank's rows into every rank's receive region + epoch flag) and one wait kernel (flags of all ranks, copy out) per exchange"}
+    except Exception as e:      # never fail the bench line on the optional variant
+        return {"error": repr(e)[:300]}
 
 
 def sharded_loop_leg(cfg_id, n_total, h, dev, dist, ticks=8, warm=3, emulate=False):
