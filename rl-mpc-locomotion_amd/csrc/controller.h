@@ -20,6 +20,7 @@
 
 #include "mpc_core.h"
 #include "gelsd43.h"
+#include "svml_acosf.h"
 
 namespace mpc {
 
@@ -202,13 +203,13 @@ MPC_HD void estimator_update(const float *body, const float *normal, float *est)
     }
   }
   // quat_to_rpy (:120-133) -- only the yaw of the world-frame rpy is used
-  const float yaw = round_to_half(atan2f(2.f * (x * y + w * z), w * w + x * x - y * y - z * z));
+  const float yaw = round_to_half(svml_atan2f(2.f * (x * y + w * z), w * w + x * x - y * y - z * z));      // np.arctan2 on float32 = SVML's routine (svml_acosf.h)
   const double th = (double)yaw;
   const float cz = round_to_half_d(cos(th)), sz = round_to_half_d(sin(th));
   const float ZT[9] = {cz, -sz, 0.f, sz, cz, 0.f, 0.f, 0.f, 1.f};          // world_R_yaw_frame^T
   // get_rot_from_normals / axis_angle_to_rot (:88-107), axis un-normalised, zz term uses k1*k1 (as written there)
   const float k0 = 0.f * normal[2] - 1.f * normal[1], k1 = 1.f * normal[0] - 0.f * normal[2], k2 = 0.f * normal[1] - 0.f * normal[0];
-  const float theta = acosf((0.f * normal[0] + 0.f * normal[1]) + 1.f * normal[2]);
+  const float theta = svml_acosf((0.f * normal[0] + 0.f * normal[1]) + 1.f * normal[2]);      // np.arccos on float32 = SVML's routine, bit for bit (svml_acosf.h)
   const float c_t = (float)cos((double)theta), s_t = (float)sin((double)theta), v_t = (float)(1.0 - cos((double)theta));
   float E[9];   // R_axis_angle as listed (= yaw_R_ground_frame^T)
   E[0] = round_to_half(k0 * k0 * v_t + c_t); E[1] = round_to_half(k0 * k1 * v_t - k2 * s_t); E[2] = round_to_half(k0 * k2 * v_t + k1 * s_t);
@@ -566,7 +567,7 @@ MPC_HD void world_roll_pitch(const float *body, float *roll, float *pitch) {
 #pragma clang fp contract(off)
 #endif
   const float x = body[3], y = body[4], z = body[5], w = body[6];
-  *roll = round_to_half(atan2f(2.f * (y * z + w * x), w * w - x * x - y * y + z * z));
+  *roll = round_to_half(svml_atan2f(2.f * (y * z + w * x), w * w - x * x - y * y + z * z));
   *pitch = round_to_half_d(asin(fmin((double)(-2.f * (x * z - w * y)), 0.99999)));
 }
 

@@ -17,11 +17,11 @@ GOLDENS_H10 = ["controller_h10_flat", "controller_h10_slope", "controller_h10_co
 # BASELINE configs[3] / [4] -- the reference with horizonLength patched (tests/golden/make_golden_controller.py says how)
 GOLDENS_NEW = ["controller_h10_gaits", "controller_h16_flat", "controller_h16_slope", "controller_h20_flat", "controller_h20_slope"]
 GOLDENS = GOLDENS_H10 + GOLDENS_NEW
-# One operation of StateEstimator.update is not reproducible: np.arccos on float32 (orientation_tools.py:93) is numpy's AVX-512 SVML
-# kernel, seeded by the vrsqrt14ps instruction -- up to 2 ulp from libm's / OCML's acosf.  The angle's cos / sin are rounded to float16
-# right after, so it shows in about 4 of 10 000 estimator samples (a float16 ulp in ground_R_body_frame).  The tests below count those
-# samples and leave a robot out of the torque comparison from such a tick on; everything else is held to TAU_RTOL.
-EST_MISMATCH_FRAC = 2e-3
+# Every operation of StateEstimator.update is reproduced, numpy's float32 transcendentals included: on the AVX-512 machine that minted the goldens np.arccos
+# (orientation_tools.py:94) and np.arctan2 (quat_to_rpy, :120-133) on float32 are Intel SVML's __svml_acosf16 / __svml_atan2f16, restated in csrc/svml_acosf.h and checked
+# against numpy on every float32 of [-1, 1] and on 1.3 G pairs (tools/acosf/pin.py, profiles/r06_acosf_pinning.txt).  Until round 5 those calls went through libm's / OCML's
+# acosf / atan2f (up to 2 ulp away: 3 of the 11 512 estimator samples of the goldens differed after the float16 rounding of the yaw -- rounds 4-5 blamed the arccos; it
+# was the arctan2 -- and the tests let such a robot leave the torque comparison); now EVERY sample of every golden is compared: the bookkeeping must find compared == 1.0.
 
 
 def _relerr(a, b):
@@ -55,22 +55,19 @@ def test_emulated_controller_matches_reference_python(name):
 def test_emulated_estimator_matches_reference_python(name):
     """StateEstimator.update restated with explicit float16/float32 semantics: every output -- the float16 ones (rpyBody,
     ground_R_body_frame) and the float32 ones (vBody, omegaBody, numpy's float16 @ float32 product through OpenBLAS) -- bit-identical
-    to the reference's, except for the np.arccos samples counted above."""
+    to the reference's on every sample of every golden."""
     from tests.emu.emu import estimator_update
     g = load_golden(name)
     T, n = g["body"].shape[:2]
     est = estimator_update(g["body"].reshape(T * n, 13), _normal_prev(g).reshape(T * n, 3)).reshape(T, n, 18)
     bad = (est != g["est"]).any(-1)
     print(f"{name}: {int(bad.sum())} of {T * n} estimator samples differ")
-    if name in GOLDENS_H10:
-        assert not bad.any()
-    assert bad.sum() <= max(1, EST_MISMATCH_FRAC * T * n)
-    assert np.array_equal(est[..., :6], g["est"][..., :6])          # vBody, omegaBody do not pass through the arccos
+    assert not bad.any()
 
 
 def _full_run(g, make_ctl, est_of):
     """controller.run over a golden: returns (torque errors of the compared samples, compared [T, n], ticks x robots whose ground normal is not
-    bit-identical to the reference's).  A robot leaves the comparison at its first estimator sample that differs from the reference's."""
+    bit-identical to the reference's).  A robot would leave the comparison at an estimator sample that differs from the reference's: the callers assert that none does."""
     T, n = g["dof"].shape[:2]
     ctl = make_ctl(g)
     ok = np.ones(n, bool)
@@ -88,7 +85,7 @@ def _full_run(g, make_ctl, est_of):
 @pytest.mark.parametrize("name", GOLDENS)
 def test_emulated_full_run_matches_reference_python(name):
     """The whole controller.run seam (estimator + ground-normal fit + controller + solve) on the host emulation: ground normal bit-identical
-    on every tick, torques inside TAU_RTOL wherever the estimator sample is the reference's (all but the counted arccos samples)."""
+    and every estimator sample bit-identical on every tick, torques inside TAU_RTOL."""
     from tests.emu.emu import EmuLocomotion, estimator_update
 
     def step(ctl, g, k):
@@ -100,7 +97,7 @@ def test_emulated_full_run_matches_reference_python(name):
     print(f"{name}: compared {compared.mean():.4f} of the samples, max torque error {errs.max():.2e}")
     assert normal_bad == 0
     assert errs.max() < TAU_RTOL
-    assert compared.mean() >= 0.97                      # (one arccos sample early in a 48-tick golden of 9 robots costs 1 / 9 of it)
+    assert compared.mean() == 1.0                       # no estimator sample differs from the reference's any more (svml_acosf.h)
 
 
 class _Live(dict):
@@ -114,7 +111,7 @@ def test_emulated_full_run_matches_the_live_reference(horizon, seed):
     """Volume beyond the committed fixtures, where the reference tree is mounted (the build container): the reference Python itself is run
     here -- 84 robots (seven gaits x three robot types x four), 24 ticks, sloped-ground estimate in the loop, horizonLength patched for
     h = 16 / 20 exactly as for the goldens (tests/golden/make_golden_controller.py) -- and the host emulation of controller.run is held to it
-    like to a golden: ground normal bit-identical on every tick, torques inside TAU_RTOL wherever the estimator sample is the reference's."""
+    like to a golden: ground normal and estimator outputs bit-identical on every tick, torques inside TAU_RTOL."""
     import os
     import sys
     if not os.path.isdir("/root/reference/MPC_Controller"):
@@ -136,7 +133,7 @@ def test_emulated_full_run_matches_the_live_reference(horizon, seed):
     print(f"live reference, h = {horizon}: compared {compared.mean():.4f} of {compared.size} samples, max torque error {errs.max():.2e}")
     assert normal_bad == 0
     assert errs.max() < TAU_RTOL
-    assert compared.mean() >= 0.97
+    assert compared.mean() == 1.0
 
 
 def test_gait_tables_match_reference_definition():
@@ -224,8 +221,7 @@ def test_estimator_matmul_rule_matches_numpy():
 def test_hip_full_run_matches_reference_python(name):
     """The complete controller.run seam (estimator + ground-normal fit + controller + solve) on the GPU against the reference's torques,
     horizons 10, 16 and 20, all seven gaits: the ground normal bit-identical on every tick (gelsd43.h on the device), every compared
-    (tick, robot) sample inside TAU_RTOL; a robot leaves the comparison at an estimator sample that differs from the reference's (the
-    np.arccos samples, EST_MISMATCH_FRAC) -- the compared fraction is printed and asserted."""
+    (tick, robot) sample inside TAU_RTOL, every estimator sample bit-identical (compared fraction asserted to be 1.0)."""
     import torch
     from rl_mpc_locomotion_amd.locomotion import BatchedLocomotion
 
@@ -238,7 +234,7 @@ def test_hip_full_run_matches_reference_python(name):
     print(f"{name}: compared {compared.mean():.4f} of the samples, max torque error {errs.max():.2e}")
     assert normal_bad == 0
     assert errs.max() < TAU_RTOL, (float((errs < TAU_RTOL).mean()), float(errs.max()))
-    assert compared.mean() >= 0.97
+    assert compared.mean() == 1.0
 
 
 @pytest.mark.gpu
@@ -292,8 +288,8 @@ def _check_cycling(name, out):
     assert rec_bad == 0          # every argument of every compute_contact_forces call bit-identical ACROSS the switches (contact tables of the new gait included)
     assert dec_bad == 0          # ... and OSQP's decisions on every one of them
     assert errs.max() < TAU_RTOL
-    assert compared.mean() >= 0.995
-    assert compared[101:].any()                                     # both switches (ticks 50 and 100) lie inside the compared stretch
+    assert compared.mean() == 1.0
+    assert compared[101:].all()                                     # both switches (ticks 50 and 100) lie inside the compared stretch
 
 
 def test_emulated_gait_cycling_matches_reference_python():
@@ -417,12 +413,12 @@ def test_env_bridge_matches_reference_glue(task):
     # The torques hinge on OSQP's discrete decisions (a polish accepted there and rejected here moves the forces by 1e-2), and those on every
     # bit of the solver's arguments.  With the ground-normal fit walked in LAPACK's own arithmetic (gelsd43.h) the arguments are the
     # reference's: observed on all three tasks, every robot's decisions equal the reference's on every solve (agree fraction 1.0) and the
-    # torques are within 3.2e-7.  A robot that took another decision (an np.arccos sample, see EST_MISMATCH_FRAC) would be left out from there
-    # to its next reset; the fraction of samples compared is printed and must be (nearly) all of them.
+    # torques are within 3.2e-7.  With the estimator's float32 arccos / arctan2 restated too (svml_acosf.h) nothing is left that could make a robot take another
+    # decision: the bookkeeping must find every sample compared.
     frac = counted / (T * n)
     print(f"bridge_{task}: decisions agree on {frac:.4f} of the (tick, robot) samples, max torque error {np.max(errs):.2e}")
     assert np.max(errs) < TAU_RTOL, np.max(errs)
-    assert frac >= 0.97, (counted, T * n)
+    assert frac == 1.0, (counted, T * n)
 
 
 @pytest.mark.gpu
