@@ -2,7 +2,7 @@
 # After tools/gpu/final.sh (through gpurun): copy the round's artefacts from gpurun_out/ to profiles/ and condense the PMC passes.
 set -e
 cd "$(dirname "$0")/.."
-TAG=${TAG:-r05}
+TAG=${TAG:-r06}
 for f in bench_n1.json kernel_stats_bench_steps10.csv kernel_stats_config4_4096xh16.csv kernel_stats_config5_4096xh20.csv exact_mode_sweep.json parity_sweep.json controller_parity.json; do cp gpurun_out/${TAG}_$f profiles/${TAG}_$f; done
 for h in 10 16 20; do
   d=$(mktemp -d)

@@ -1,6 +1,6 @@
 """Parity figures of the controller.run seam on the GPU against the goldens minted from the reference Python (tests/golden/controller_*.npz,
-bridge_*.npz): per golden the number of (tick, robot) samples, how many estimator samples differ from the reference's bit for bit (the np.arccos
-samples, tests/test_controller.py), on how many ticks the ground normal differs (expected: none), which fraction of the samples is compared and the
+bridge_*.npz): per golden the number of (tick, robot) samples, how many estimator samples differ from the reference's bit for bit (none since round 6:
+csrc/svml_acosf.h), on how many ticks the ground normal differs (expected: none), which fraction of the samples is compared and the
 largest torque error among them; through the step seam (golden estimator outputs) whether every compute_contact_forces argument record and every
 OSQP decision equals the reference's.  Prints one line: CONTROLLER_PARITY_JSON {...}   (copied to profiles/ by the caller)."""
 import json
@@ -15,7 +15,7 @@ import rl_mpc_locomotion_amd  # noqa: E402,F401
 from rl_mpc_locomotion_amd.locomotion import BatchedLocomotion  # noqa: E402
 from rl_mpc_locomotion_amd.env_bridge import MpcEnvBridge  # noqa: E402
 from tests.helpers import load_golden  # noqa: E402
-from tests.test_controller import GOLDENS, _relerr, _horizon, _full_run  # noqa: E402
+from tests.test_controller import GOLDENS, _relerr, _horizon, _full_run, _cycling_run  # noqa: E402
 
 out = {}
 for name in GOLDENS:
@@ -50,6 +50,22 @@ for name in GOLDENS:
     rec["step_seam"] = dict(max_torque_rel_err=worst, solves=solves, argument_records_bit_identical=rec_same, osqp_decisions_equal=dec_same)
     out[name] = rec
     print(name, json.dumps(rec), flush=True)
+# BASELINE configs[2] as stated: the gait changes DURING the run (controller_h10_cycling: TROT / WALK / BOUND every 50 ticks, set through a device tensor)
+g = load_golden("controller_h10_cycling")
+
+
+def run_c(ctl, g, k):
+    tau = ctl.run(torch.from_numpy(g["dof"][k]).cuda(), torch.from_numpy(g["body"][k]).cuda(), torch.from_numpy(g["cmd"][k]).cuda())
+    est, nrm = ctl.estimate()
+    return tau.cpu().numpy(), est.cpu().numpy(), nrm.cpu().numpy(), ctl.solver_record(), ctl.solver_info()
+
+
+ctl = BatchedLocomotion(g["robot_type"], g["gait_id"], horizon=10, flat_ground=False, device="cuda:0")
+errs, compared, normal_bad, rec_bad, dec_bad, solves = _cycling_run(g, ctl, run_c, lambda c, gi: c.set_gait(torch.from_numpy(np.ascontiguousarray(gi)).cuda()))
+out["controller_h10_cycling"] = dict(horizon=10, robots=int(g["dof"].shape[1]), ticks=int(g["dof"].shape[0]), samples=int(compared.size), gait_switches="every 50 ticks (the last nine robots: every 25)",
+                                     compared_fraction=float(compared.mean()), ground_normal_samples_not_bit_identical=normal_bad, solves=solves,
+                                     argument_records_not_bit_identical=rec_bad, osqp_decisions_not_equal=dec_bad, max_torque_rel_err_compared=float(errs.max()))
+print("controller_h10_cycling", json.dumps(out["controller_h10_cycling"]), flush=True)
 for task in ("aliengo", "a1", "go1"):
     g = load_golden("bridge_h10_" + task)
     T, n = g["actions"].shape[:2]

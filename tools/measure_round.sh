@@ -9,7 +9,7 @@
 set -u
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
-TAG=${TAG:-r05}
+TAG=${TAG:-r06}
 MODE=${1:-full}
 mkdir -p $ROOT/gpurun_out
 cd $ROOT
