@@ -501,7 +501,7 @@ def main():
         dist.destroy_process_group()
 
 
-TRAFFIC_PROFILE = "r05"      # profiles/r05_pmc_summary_h10.json + ..._prep_h10.json: the PMC passes that `roofline.traffic` quotes
+TRAFFIC_PROFILE = "r06"      # profiles/r06_pmc_summary_h10.json + ..._prep_h10.json: the PMC passes that `roofline.traffic` quotes
 
 
 def traffic_from_profile():

@@ -18,7 +18,7 @@ d = json.load(open(f"profiles/{TAG}_parity_sweep.json"))
 print("parity", sum(v["solves"] for v in d.values()), "solves, mismatches", sum(v["decision_mismatch"] for v in d.values()), "max rel err", max(v["max_rel_err"] for v in d.values()))
 d = json.load(open(f"profiles/{TAG}_bench_n1.json")); r = d["roofline"]
 print("value", round(d["value"]), "ms/step", round(d["ms_per_step"], 4), "solve", round(r["kernel_ms"], 4), "prep", round(r["prep_kernel_ms"], 4), "frac", round(r["frac"], 5), "traffic MB", r["traffic"] and round(r["traffic"] / 1e6, 1))
-for k, v in d["secondary"].items(): print(" ", k, round(v["ms_per_step"], 3), round(v["prep_kernel_ms"], 3), round(v.get("solve_kernel_ms", v.get("solve_kernels_ms")), 3), round(v["control_steps_per_s"]))
+for k, v in d["secondary"].items(): print(" ", k, round(v["ms_per_step"], 3), round(v.get("prep_kernel_ms", 0), 3), round(v.get("solve_kernel_ms", v.get("solve_kernels_ms", 0)), 3), round(v["control_steps_per_s"]))
 print("  clock", d["device_state"]["before"]["shader_clock_ghz"], d["device_state"]["after"]["shader_clock_ghz"])
 print("  control loop", round(d["control_loop"]["ms_per_tick"], 4), round(d["control_loop"]["robot_ticks_per_s"]), "| with resets", round(d["control_loop_with_resets"]["ms_per_tick"], 4), round(d["control_loop_with_resets"]["robot_ticks_per_s"]), "| incl. torque map", round(d["control_steps_per_s_incl_torque_map"]))
 for h in (10, 16, 20):
