@@ -21,7 +21,8 @@ static const char *kSymbols[] = {
     "mpc_ctrl_step", "mpc_ctrl_run", "mpc_ctrl_reset", "mpc_ctrl_reset_device", "mpc_ctrl_set_gait", "mpc_ctrl_set_solver", "mpc_ctrl_solver_info", "mpc_ctrl_solver_record", "mpc_ctrl_solver_forces", "mpc_ctrl_solver", "mpc_ctrl_set_iteration", "mpc_device_clock", "mpc_ctrl_fsm_init",
     "mpc_ctrl_run_fsm", "mpc_ctrl_fsm_reset", "mpc_ctrl_fsm_reset_device", "mpc_ctrl_fsm_state", "mpc_policy_create",
     "mpc_policy_destroy", "mpc_policy_step", "mpc_policy_observations", "mpc_ctrl_estimate", "mpc_ctrl_update_estimate",
-    "mpc_pack_commands"};
+    "mpc_pack_commands", "mpc_ctrl_set_gait_device", "mpc_pack_commands_scaled", "mpc_ctrl_policy_observations", "mpc_ctrl_run_fsm_estimated",
+    "mpc_peer_create", "mpc_peer_handle", "mpc_peer_connect", "mpc_peer_put", "mpc_peer_wait", "mpc_peer_timeouts", "mpc_peer_destroy", "mpc_peer_last_error"};
 
 typedef int (*create_fn)(mpc_batch **, int, int, double, double, const double *, const double *);
 typedef int (*solve_host_fn)(mpc_batch *, const float *, double *, int *);
