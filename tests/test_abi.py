@@ -56,3 +56,35 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "oracle/" not in txt.replace("oracle/README", ""), f
+
+
+def test_new_entry_points_reject_bad_arguments_without_a_gpu():
+    """Round 6's entry points (mpc_ctrl_set_gait_device, mpc_pack_commands_scaled, mpc_ctrl_policy_observations, mpc_ctrl_run_fsm_estimated, mpc_peer_*) validate
+    their arguments before they touch the device: MPC_E_ARG (-1) and a message, on a box without a GPU too."""
+    L = _lib.lib()
+    MPC_E_ARG = -1
+    z = ctypes.c_void_p(0)
+    assert L.mpc_ctrl_set_gait_device(z, z, z) == MPC_E_ARG and b"mpc_ctrl_set_gait_device" in L.mpc_last_error()
+    assert L.mpc_pack_commands_scaled(0, z, z, z, z, z, z) == MPC_E_ARG and b"mpc_pack_commands_scaled" in L.mpc_last_error()
+    assert L.mpc_ctrl_policy_observations(z, z, z, z, z, z, z) == MPC_E_ARG
+    assert L.mpc_ctrl_run_fsm_estimated(z, z, z, z, z, z, z) == MPC_E_ARG
+    h = ctypes.c_void_p()
+    assert L.mpc_peer_create(ctypes.byref(h), 3, 2, 16, 48) == MPC_E_ARG and b"mpc_peer_create" in L.mpc_peer_last_error()      # rank outside the group
+    assert L.mpc_peer_create(ctypes.byref(h), 0, 17, 16, 48) == MPC_E_ARG                                                        # more than 16 ranks
+    assert L.mpc_peer_put(z, z, 0, 0, z) == MPC_E_ARG and L.mpc_peer_wait(z, z, z) == MPC_E_ARG and L.mpc_peer_timeouts(z, z) == MPC_E_ARG
+    L.mpc_peer_destroy(z)      # a null handle is ignored
+
+
+def test_sharded_locomotion_rejects_the_peer_exchange_without_gpus():
+    import numpy as np
+    from rl_mpc_locomotion_amd.sharding import ShardedLocomotion
+
+    class Ctl:      # stands for the per-rank controller of the CPU tests
+        device = "cpu"
+
+        def __init__(self, robot_type, gait_id, horizon=10):
+            pass
+    with pytest.raises(ValueError):
+        ShardedLocomotion(np.zeros(4, np.int32), np.zeros(4, np.int32), controller_factory=Ctl, exchange="peer")
+    with pytest.raises(ValueError):
+        ShardedLocomotion(np.zeros(4, np.int32), np.zeros(4, np.int32), controller_factory=Ctl, exchange="carrier pigeon")
